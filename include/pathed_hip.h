@@ -1,0 +1,246 @@
+/*
+ * pathed_hip.h — C ABI of the MI355X path-tracing integrator (libpathed_hip.so).
+ *
+ * This is the drop-in boundary for ONE hot path of chellmuth/pathed: the per-pixel
+ * radiance loop  Integrator::run -> SampleIntegrator::sampleImage/samplePixel ->
+ * PathTracer::L / direct  (reference src/integrator.cpp:19-106,
+ * src/sample_integrator.cpp:10-113, src/path_tracer.cpp:19-216) together with the
+ * ray queries it makes through Scene (reference src/scene.cpp:91-223, 355-381,
+ * 446-502), which the reference forwards to Embree (rtcIntersect1 / rtcOccluded1).
+ *
+ * The reference has no FFI: its plug-in surface is the C++ virtual class
+ * `Integrator` (reference include/integrator.h:16-55) chosen by the "integrator"
+ * string of job.json (reference src/job.cpp:65-97).  A GPU integrator subclasses
+ * `Integrator`, overrides run(), and calls the functions below.  The binding a
+ * reference maintainer would add is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain C, no exceptions cross the boundary; every call returns 0 on success
+ *     or a negative PATHED_E_* code, message via pathed_hip_last_error()
+ *     (reference error behaviour: throw "Unimplemented" / std::runtime_error /
+ *     exit(1), src/job.cpp:96, src/scene_parser.cpp:665, src/glass.cpp:69-72).
+ *   - caller owns every array in PathedSceneDesc; scene_create copies what it needs.
+ *   - a PathedScene is used by one host thread at a time; render calls block.
+ *   - all arithmetic is IEEE fp32; indices are int32/uint32.
+ */
+#ifndef PATHED_HIP_H
+#define PATHED_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PATHED_ABI_VERSION 1
+
+/* error codes */
+#define PATHED_OK            0
+#define PATHED_E_INVALID    -1   /* bad argument / malformed scene description   */
+#define PATHED_E_DEVICE     -2   /* HIP runtime error (message has the HIP text)  */
+#define PATHED_E_NO_DEVICE  -3   /* no usable gfx950 device                        */
+#define PATHED_E_UNSUPPORTED -4  /* feature outside the hot-path scope             */
+#define PATHED_E_NOMEM      -5
+
+/* material kinds — reference Material subclasses on the hot path
+ * (src/lambertian.cpp, src/oren_nayar.cpp, src/microfacet.cpp + src/beckmann.cpp,
+ *  src/plastic.cpp, src/glass.cpp, src/mirror.cpp) */
+#define PATHED_MAT_LAMBERTIAN 0
+#define PATHED_MAT_OREN_NAYAR 1
+#define PATHED_MAT_MICROFACET 2
+#define PATHED_MAT_PLASTIC    3
+#define PATHED_MAT_GLASS      4
+#define PATHED_MAT_MIRROR     5
+
+/* Lambertian albedo source (reference include/albedo.h, src/checkerboard.cpp:9-20) */
+#define PATHED_ALBEDO_CONSTANT     0
+#define PATHED_ALBEDO_CHECKERBOARD 1
+
+/* microfacet distribution (reference src/scene_parser.cpp:669-683) */
+#define PATHED_DIST_BECKMANN 0
+
+/* geometry kinds in model order (reference src/scene_parser.cpp:251-291) */
+#define PATHED_GEOM_MESH   0
+#define PATHED_GEOM_SPHERE 1
+
+/* Camera — reference Camera ctor arguments (src/camera.cpp:13-30), as parsed by
+ * src/scene_parser.cpp:146-158.  vertical_fov is already in radians. */
+typedef struct PathedCamera {
+    float origin[3];
+    float target[3];
+    float up[3];
+    float vertical_fov;      /* radians */
+    int32_t width;           /* job.json "width"  (reference include/job.h:24) */
+    int32_t height;          /* job.json "height" (reference include/job.h:25) */
+    int32_t flip_handedness; /* scene "sensor.flipHandedness"                  */
+} PathedCamera;
+
+/* One BSDF.  Only the fields of `type` are read.
+ * emit != 0 makes every surface with this material an area light
+ * (reference src/scene_parser.cpp:173-183). */
+typedef struct PathedMaterial {
+    int32_t type;            /* PATHED_MAT_*                                   */
+    int32_t albedo_type;     /* PATHED_ALBEDO_* (Lambertian / Plastic diffuse) */
+    float diffuse[3];        /* Lambertian, OrenNayar, Plastic                 */
+    float emit[3];           /* Material::emit()                               */
+    float checker_on[3];     /* Checkerboard onColor                           */
+    float checker_off[3];    /* Checkerboard offColor                          */
+    float checker_res[2];    /* Checkerboard resolution (u, v)                 */
+    float sigma;             /* OrenNayar sigma (A, B derived as oren_nayar.cpp:11-18) */
+    float alpha;             /* Beckmann alpha                                 */
+    float ior;               /* Glass ior (reference default 1.4, glass.cpp:16-18) */
+    int32_t distribution;    /* PATHED_DIST_*                                  */
+} PathedMaterial;
+
+/* Sphere — reference Sphere (src/sphere.cpp).  The reference intersects the
+ * TRANSFORMED centre (sphere.cpp:30-35) but samples the UNTRANSFORMED m_center
+ * (sphere.cpp:77-128); both are carried so that quirk is reproducible. */
+typedef struct PathedSphere {
+    float center_world[3];
+    float radius;
+    float center_sample[3];
+    int32_t material;
+} PathedSphere;
+
+/* One entry per model of the scene JSON, in file order (= Embree geomID order,
+ * reference src/rtc_manager.cpp:12-27).  Light order follows it
+ * (reference src/scene_parser.cpp:173-183). */
+typedef struct PathedGeom {
+    int32_t type;   /* PATHED_GEOM_*                                            */
+    int32_t first;  /* MESH: first triangle index; SPHERE: index into spheres  */
+    int32_t count;  /* MESH: triangle count;       SPHERE: 1                   */
+} PathedGeom;
+
+/* Environment light — reference EnvironmentLight (src/environment_light.cpp).
+ * rgba is the float RGBA image LoadEXR returns (row 0 = theta 0), map_to_world /
+ * world_to_map are the 4x4 row-major matrices parseTransform builds
+ * (src/scene_parser.cpp:690-793). */
+typedef struct PathedEnvLight {
+    int32_t width;
+    int32_t height;
+    const float *rgba;        /* 4*width*height                                 */
+    float scale;
+    float map_to_world[16];
+    float world_to_map[16];
+} PathedEnvLight;
+
+/* Flat scene description: what the reference hands Embree
+ * (src/geometry_parser.cpp:12-96: vertex / index / uv / normal buffers per mesh)
+ * plus its material, light and camera objects. */
+typedef struct PathedSceneDesc {
+    uint32_t abi_version;     /* PATHED_ABI_VERSION                             */
+
+    PathedCamera camera;
+
+    /* triangle soup, all meshes concatenated in geom order */
+    uint32_t n_vertices;
+    const float *positions;   /* 3*n_vertices, world space                      */
+    const float *normals;     /* 3*n_vertices, zero vector = "no normal"        */
+    const float *uvs;         /* 2*n_vertices                                   */
+    uint32_t n_triangles;
+    const uint32_t *indices;  /* 3*n_triangles, into the vertex arrays          */
+    const int32_t *tri_material; /* n_triangles, index into materials           */
+
+    uint32_t n_spheres;
+    const PathedSphere *spheres;
+
+    uint32_t n_geoms;
+    const PathedGeom *geoms;
+
+    uint32_t n_materials;
+    const PathedMaterial *materials;
+
+    const PathedEnvLight *env; /* NULL = no environment light                   */
+} PathedSceneDesc;
+
+typedef struct PathedScene PathedScene;   /* opaque; owns all device memory     */
+
+/* Counters filled by the instrumented ("stats") variants of the kernels and by the
+ * timed renders; see DESIGN.md "Algorithmic bytes". */
+typedef struct PathedStats {
+    uint64_t camera_samples;       /* paths started                              */
+    uint64_t closest_rays;         /* closest-hit queries traced                 */
+    uint64_t shadow_rays;          /* any-hit queries traced                     */
+    uint64_t nodes_visited;        /* child boxes tested (32 B each) — stats mode */
+    uint64_t tris_tested;          /* triangles tested (48 B each)  — stats mode */
+    uint64_t dropped_samples;      /* non-finite samples dropped                 */
+    uint64_t iterations;           /* wavefront iterations launched              */
+    double   trace_ms;             /* HIP-event time inside the trace kernel     */
+    double   shade_ms;             /* HIP-event time inside the shade kernel     */
+    uint64_t trace_launches;
+    uint64_t bvh_nodes;            /* inner nodes (64 B each)                    */
+    uint64_t bvh_bytes;            /* nodes + leaf triangles resident in HBM     */
+    uint32_t bvh_max_depth;
+    uint32_t scene_in_lds;         /* 1 if the trace kernel stages the BVH in LDS */
+} PathedStats;
+
+/* ---- life cycle ---------------------------------------------------------- */
+
+/* Select the device this process renders on (one process per GPU).
+ * Replaces the reference's rtcNewDevice / rtcNewScene (app/main.cpp:46-52). */
+int pathed_hip_init(int device_id);
+
+/* Flatten + upload once: leaf-ordered 48-B triangles, flattened BVH2 (64-B nodes),
+ * spheres, material table, light table, env map + CDFs, camera.
+ * Replaces rtcCommitScene (reference src/scene.cpp:39) and the light list
+ * construction (src/scene_parser.cpp:173-190). */
+int pathed_hip_scene_create(const PathedSceneDesc *desc, PathedScene **out);
+void pathed_hip_scene_destroy(PathedScene *scene);
+
+/* ---- the hot path -------------------------------------------------------- */
+
+/* Render camera samples [spp_begin, spp_begin+spp_count) of every pixel and ADD
+ * the per-pixel radiance sums into accum_rgb_sum (host memory, 3*W*H floats,
+ * index 3*(row*W+col)+c, row 0 = bottom scanline) — exactly what
+ * SampleIntegrator::sampleImage does to radianceLookup, spp_count times
+ * (reference src/sample_integrator.cpp:61-63, src/integrator.cpp:42-51).
+ * Bounce window as BounceController (reference src/bounce_controller.cpp:14-25);
+ * last_bounce = -1 means unbounded in the reference and is rejected here
+ * (PATHED_E_UNSUPPORTED) unless the scene is open; see DESIGN.md. */
+int pathed_hip_render(PathedScene *scene, uint64_t seed,
+                      uint32_t spp_begin, uint32_t spp_count,
+                      int start_bounce, int last_bounce,
+                      float *accum_rgb_sum);
+
+/* Same, but the sum buffer is DEVICE memory owned by the caller (e.g. a torch
+ * tensor) and the work is enqueued on `stream` (a hipStream_t, NULL = default
+ * stream).  The per-pixel sum CONTINUES from the buffer's current contents in
+ * sample order, so successive calls are bit-identical to one long call.
+ * Returns after the work has been enqueued AND completed on the device only if
+ * `blocking` != 0. */
+int pathed_hip_render_device(PathedScene *scene, uint64_t seed,
+                             uint32_t spp_begin, uint32_t spp_count,
+                             int start_bounce, int last_bounce,
+                             float *d_accum_rgb_sum, void *stream, int blocking);
+
+/* Test hook onto the intersector that stands in for Embree.
+ * rays: n * 8 floats (ox,oy,oz,tnear, dx,dy,dz,tfar), host memory.
+ * any_hit == 0: closest hit (rtcIntersect1, reference src/scene.cpp:91-117):
+ *               hits = n * 4 x 32-bit (t, u, v as float; prim as int32, -1 = miss;
+ *               prim < n_triangles: triangle, else sphere n_triangles+i).
+ * any_hit != 0: occlusion (rtcOccluded1, reference src/scene.cpp:355-381):
+ *               hits = n * int32 (1 = occluded). */
+int pathed_hip_trace(PathedScene *scene, const float *rays, size_t n,
+                     int any_hit, void *hits);
+
+/* Enable/disable the counting variants of the trace kernel (nodes_visited /
+ * tris_tested).  Off by default: the timed path never counts. */
+int pathed_hip_set_stats_mode(PathedScene *scene, int enabled);
+int pathed_hip_get_stats(PathedScene *scene, PathedStats *out);
+int pathed_hip_reset_stats(PathedScene *scene);
+
+/* Export the flattened BVH so a checker can walk the SAME tree
+ * (nodes: 16 floats per node; tris: 12 floats per leaf triangle, 4th/8th/12th
+ * lanes carry prim id / padding).  Pass NULL to query sizes. */
+int pathed_hip_scene_export_bvh(PathedScene *scene,
+                                float *nodes, size_t *n_nodes,
+                                float *tris, size_t *n_tris);
+
+const char *pathed_hip_last_error(void);
+const char *pathed_hip_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PATHED_HIP_H */

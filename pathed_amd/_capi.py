@@ -1,0 +1,217 @@
+"""ctypes view of include/pathed_hip.h and of the host library's loader entry points.
+
+Plumbing only: the structs mirror the C header field for field; nothing here computes.
+The HIP library is mandatory for the product path — `load_hip()` raises if it is
+missing instead of falling back to anything.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+REPO_ROOT = os.path.dirname(_HERE)
+LIB_DIR = os.path.join(_HERE, "lib")
+
+PATHED_ABI_VERSION = 1
+
+MAT_LAMBERTIAN, MAT_OREN_NAYAR, MAT_MICROFACET, MAT_PLASTIC, MAT_GLASS, MAT_MIRROR = range(6)
+ALBEDO_CONSTANT, ALBEDO_CHECKERBOARD = 0, 1
+GEOM_MESH, GEOM_SPHERE = 0, 1
+
+
+class PathedCamera(C.Structure):
+    _fields_ = [
+        ("origin", C.c_float * 3),
+        ("target", C.c_float * 3),
+        ("up", C.c_float * 3),
+        ("vertical_fov", C.c_float),
+        ("width", C.c_int32),
+        ("height", C.c_int32),
+        ("flip_handedness", C.c_int32),
+    ]
+
+
+class PathedMaterial(C.Structure):
+    _fields_ = [
+        ("type", C.c_int32),
+        ("albedo_type", C.c_int32),
+        ("diffuse", C.c_float * 3),
+        ("emit", C.c_float * 3),
+        ("checker_on", C.c_float * 3),
+        ("checker_off", C.c_float * 3),
+        ("checker_res", C.c_float * 2),
+        ("sigma", C.c_float),
+        ("alpha", C.c_float),
+        ("ior", C.c_float),
+        ("distribution", C.c_int32),
+    ]
+
+
+class PathedSphere(C.Structure):
+    _fields_ = [
+        ("center_world", C.c_float * 3),
+        ("radius", C.c_float),
+        ("center_sample", C.c_float * 3),
+        ("material", C.c_int32),
+    ]
+
+
+class PathedGeom(C.Structure):
+    _fields_ = [("type", C.c_int32), ("first", C.c_int32), ("count", C.c_int32)]
+
+
+class PathedEnvLight(C.Structure):
+    _fields_ = [
+        ("width", C.c_int32),
+        ("height", C.c_int32),
+        ("rgba", C.POINTER(C.c_float)),
+        ("scale", C.c_float),
+        ("map_to_world", C.c_float * 16),
+        ("world_to_map", C.c_float * 16),
+    ]
+
+
+class PathedSceneDesc(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_uint32),
+        ("camera", PathedCamera),
+        ("n_vertices", C.c_uint32),
+        ("positions", C.POINTER(C.c_float)),
+        ("normals", C.POINTER(C.c_float)),
+        ("uvs", C.POINTER(C.c_float)),
+        ("n_triangles", C.c_uint32),
+        ("indices", C.POINTER(C.c_uint32)),
+        ("tri_material", C.POINTER(C.c_int32)),
+        ("n_spheres", C.c_uint32),
+        ("spheres", C.POINTER(PathedSphere)),
+        ("n_geoms", C.c_uint32),
+        ("geoms", C.POINTER(PathedGeom)),
+        ("n_materials", C.c_uint32),
+        ("materials", C.POINTER(PathedMaterial)),
+        ("env", C.POINTER(PathedEnvLight)),
+    ]
+
+
+class PathedStats(C.Structure):
+    _fields_ = [
+        ("camera_samples", C.c_uint64),
+        ("closest_rays", C.c_uint64),
+        ("shadow_rays", C.c_uint64),
+        ("nodes_visited", C.c_uint64),
+        ("tris_tested", C.c_uint64),
+        ("dropped_samples", C.c_uint64),
+        ("iterations", C.c_uint64),
+        ("trace_ms", C.c_double),
+        ("shade_ms", C.c_double),
+        ("trace_launches", C.c_uint64),
+        ("bvh_nodes", C.c_uint64),
+        ("bvh_bytes", C.c_uint64),
+        ("bvh_max_depth", C.c_uint32),
+        ("scene_in_lds", C.c_uint32),
+    ]
+
+
+# every symbol include/pathed_hip.h declares; tests check that the library exports all
+HIP_SYMBOLS = [
+    "pathed_hip_init",
+    "pathed_hip_scene_create",
+    "pathed_hip_scene_destroy",
+    "pathed_hip_render",
+    "pathed_hip_render_device",
+    "pathed_hip_trace",
+    "pathed_hip_set_stats_mode",
+    "pathed_hip_get_stats",
+    "pathed_hip_reset_stats",
+    "pathed_hip_scene_export_bvh",
+    "pathed_hip_last_error",
+    "pathed_hip_version",
+]
+
+_hip = None
+_host = None
+
+
+class PathedLibraryMissing(RuntimeError):
+    pass
+
+
+def hip_library_path():
+    return os.path.join(LIB_DIR, "libpathed_hip.so")
+
+
+def host_library_path():
+    return os.path.join(LIB_DIR, "libpathed_host.so")
+
+
+def load_hip():
+    """Load libpathed_hip.so and declare its prototypes. No fallback exists."""
+    global _hip
+    if _hip is not None:
+        return _hip
+    path = hip_library_path()
+    if not os.path.exists(path):
+        raise PathedLibraryMissing(
+            "%s not found: build it with `make hip` (python -c 'import __graft_entry__ as g; g.build()')" % path
+        )
+    lib = C.CDLL(path, mode=C.RTLD_GLOBAL)
+    vp = C.c_void_p
+    lib.pathed_hip_init.argtypes = [C.c_int]
+    lib.pathed_hip_init.restype = C.c_int
+    lib.pathed_hip_scene_create.argtypes = [C.POINTER(PathedSceneDesc), C.POINTER(vp)]
+    lib.pathed_hip_scene_create.restype = C.c_int
+    lib.pathed_hip_scene_destroy.argtypes = [vp]
+    lib.pathed_hip_scene_destroy.restype = None
+    lib.pathed_hip_render.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.POINTER(C.c_float)]
+    lib.pathed_hip_render.restype = C.c_int
+    lib.pathed_hip_render_device.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, C.c_int, vp, vp, C.c_int]
+    lib.pathed_hip_render_device.restype = C.c_int
+    lib.pathed_hip_trace.argtypes = [vp, C.POINTER(C.c_float), C.c_size_t, C.c_int, vp]
+    lib.pathed_hip_trace.restype = C.c_int
+    lib.pathed_hip_set_stats_mode.argtypes = [vp, C.c_int]
+    lib.pathed_hip_set_stats_mode.restype = C.c_int
+    lib.pathed_hip_get_stats.argtypes = [vp, C.POINTER(PathedStats)]
+    lib.pathed_hip_get_stats.restype = C.c_int
+    lib.pathed_hip_reset_stats.argtypes = [vp]
+    lib.pathed_hip_reset_stats.restype = C.c_int
+    lib.pathed_hip_scene_export_bvh.argtypes = [
+        vp, C.POINTER(C.c_float), C.POINTER(C.c_size_t), C.POINTER(C.c_float), C.POINTER(C.c_size_t)
+    ]
+    lib.pathed_hip_scene_export_bvh.restype = C.c_int
+    lib.pathed_hip_last_error.argtypes = []
+    lib.pathed_hip_last_error.restype = C.c_char_p
+    lib.pathed_hip_version.argtypes = []
+    lib.pathed_hip_version.restype = C.c_char_p
+    _hip = lib
+    return lib
+
+
+def load_host():
+    """Load libpathed_host.so (scene readers, job runner)."""
+    global _host
+    if _host is not None:
+        return _host
+    path = host_library_path()
+    if not os.path.exists(path):
+        raise PathedLibraryMissing("%s not found: build it with `make host`" % path)
+    # libpathed_host.so links against libpathed_hip.so; make sure it resolves in-tree
+    if os.path.exists(hip_library_path()):
+        load_hip()
+    lib = C.CDLL(path)
+    lib.pathed_host_load_scene.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_char_p]
+    lib.pathed_host_load_scene.restype = C.c_void_p
+    lib.pathed_host_scene_desc.argtypes = [C.c_void_p]
+    lib.pathed_host_scene_desc.restype = C.POINTER(PathedSceneDesc)
+    lib.pathed_host_free_scene.argtypes = [C.c_void_p]
+    lib.pathed_host_free_scene.restype = None
+    lib.pathed_host_last_error.argtypes = []
+    lib.pathed_host_last_error.restype = C.c_char_p
+    if hasattr(lib, "pathed_host_run_job"):
+        lib.pathed_host_run_job.argtypes = [C.c_char_p, C.c_char_p]
+        lib.pathed_host_run_job.restype = C.c_int
+    if hasattr(lib, "pathed_host_write_exr_float_rgba"):
+        lib.pathed_host_write_exr_float_rgba.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_float)]
+        lib.pathed_host_write_exr_float_rgba.restype = C.c_int
+    if hasattr(lib, "pathed_host_read_exr_rgba"):
+        lib.pathed_host_read_exr_rgba.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_float), C.c_size_t]
+        lib.pathed_host_read_exr_rgba.restype = C.c_int
+    _host = lib
+    return lib

@@ -1,0 +1,407 @@
+#include "exr.h"
+
+#include <zlib.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <fstream>
+#include <map>
+
+namespace pathed {
+
+unsigned short floatToHalf(float value)
+{
+    uint32_t bits;
+    std::memcpy(&bits, &value, 4);
+    const uint32_t sign = (bits >> 16) & 0x8000u;
+    const int32_t exponent = (int32_t)((bits >> 23) & 0xFF) - 127 + 15;
+    uint32_t mantissa = bits & 0x7FFFFFu;
+
+    if (((bits >> 23) & 0xFF) == 0xFF) {  // inf / nan
+        return (unsigned short)(sign | 0x7C00u | (mantissa ? 0x200u : 0u));
+    }
+    if (exponent >= 31) { return (unsigned short)(sign | 0x7C00u); }  // overflow -> inf
+    if (exponent <= 0) {
+        if (exponent < -10) { return (unsigned short)sign; }  // underflow -> 0
+        mantissa |= 0x800000u;
+        const int shift = 14 - exponent;
+        uint32_t half = mantissa >> shift;
+        const uint32_t remainder = mantissa & ((1u << shift) - 1u);
+        const uint32_t halfway = 1u << (shift - 1);
+        if (remainder > halfway || (remainder == halfway && (half & 1u))) { half++; }
+        return (unsigned short)(sign | half);
+    }
+    uint32_t half = ((uint32_t)exponent << 10) | (mantissa >> 13);
+    const uint32_t remainder = mantissa & 0x1FFFu;
+    if (remainder > 0x1000u || (remainder == 0x1000u && (half & 1u))) { half++; }
+    return (unsigned short)(sign | half);
+}
+
+float halfToFloat(unsigned short half)
+{
+    const uint32_t sign = ((uint32_t)half & 0x8000u) << 16;
+    uint32_t exponent = (half >> 10) & 0x1Fu;
+    uint32_t mantissa = half & 0x3FFu;
+    uint32_t bits;
+    if (exponent == 0) {
+        if (mantissa == 0) {
+            bits = sign;
+        } else {
+            exponent = 127 - 15 + 1;
+            while (!(mantissa & 0x400u)) { mantissa <<= 1; exponent--; }
+            mantissa &= 0x3FFu;
+            bits = sign | (exponent << 23) | (mantissa << 13);
+        }
+    } else if (exponent == 31) {
+        bits = sign | 0x7F800000u | (mantissa << 13);
+    } else {
+        bits = sign | ((exponent + 127 - 15) << 23) | (mantissa << 13);
+    }
+    float value;
+    std::memcpy(&value, &bits, 4);
+    return value;
+}
+
+namespace {
+
+void putBytes(std::vector<unsigned char> &out, const void *data, size_t size)
+{
+    const unsigned char *bytes = (const unsigned char *)data;
+    out.insert(out.end(), bytes, bytes + size);
+}
+
+void putString(std::vector<unsigned char> &out, const char *text)
+{
+    putBytes(out, text, std::strlen(text) + 1);
+}
+
+void putInt(std::vector<unsigned char> &out, int32_t value) { putBytes(out, &value, 4); }
+void putFloat(std::vector<unsigned char> &out, float value) { putBytes(out, &value, 4); }
+
+void putAttribute(
+    std::vector<unsigned char> &out,
+    const char *name, const char *type,
+    const std::vector<unsigned char> &value
+) {
+    putString(out, name);
+    putString(out, type);
+    putInt(out, (int32_t)value.size());
+    putBytes(out, value.data(), value.size());
+}
+
+struct ChannelSpec {
+    const char *name;
+    int pixelType;  // 1 = HALF, 2 = FLOAT
+    const float *plane;
+    int stride;     // floats between consecutive pixels of the plane
+};
+
+bool writeScanlineExr(
+    const std::string &path,
+    int width, int height,
+    const std::vector<ChannelSpec> &channels,  // must be in alphabetical order
+    std::string *error
+) {
+    std::vector<unsigned char> out;
+    const unsigned char magic[4] = { 0x76, 0x2f, 0x31, 0x01 };
+    putBytes(out, magic, 4);
+    const unsigned char version[4] = { 2, 0, 0, 0 };
+    putBytes(out, version, 4);
+
+    {
+        std::vector<unsigned char> chlist;
+        for (const ChannelSpec &channel : channels) {
+            putString(chlist, channel.name);
+            putInt(chlist, channel.pixelType);
+            const unsigned char linearAndReserved[4] = { 0, 0, 0, 0 };
+            putBytes(chlist, linearAndReserved, 4);
+            putInt(chlist, 1);
+            putInt(chlist, 1);
+        }
+        chlist.push_back(0);
+        putAttribute(out, "channels", "chlist", chlist);
+    }
+    putAttribute(out, "compression", "compression", { 0 });
+    {
+        std::vector<unsigned char> box;
+        putInt(box, 0); putInt(box, 0); putInt(box, width - 1); putInt(box, height - 1);
+        putAttribute(out, "dataWindow", "box2i", box);
+        putAttribute(out, "displayWindow", "box2i", box);
+    }
+    putAttribute(out, "lineOrder", "lineOrder", { 0 });
+    {
+        std::vector<unsigned char> one;
+        putFloat(one, 1.f);
+        putAttribute(out, "pixelAspectRatio", "float", one);
+        std::vector<unsigned char> center;
+        putFloat(center, 0.f); putFloat(center, 0.f);
+        putAttribute(out, "screenWindowCenter", "v2f", center);
+        putAttribute(out, "screenWindowWidth", "float", one);
+    }
+    out.push_back(0);
+
+    size_t bytesPerLine = 0;
+    for (const ChannelSpec &channel : channels) {
+        bytesPerLine += (size_t)width * (channel.pixelType == 1 ? 2 : 4);
+    }
+
+    const size_t tableStart = out.size();
+    const size_t dataStart = tableStart + (size_t)height * 8;
+    for (int y = 0; y < height; y++) {
+        uint64_t offset = dataStart + (uint64_t)y * (8 + bytesPerLine);
+        putBytes(out, &offset, 8);
+    }
+
+    out.reserve(dataStart + (size_t)height * (8 + bytesPerLine));
+    std::vector<unsigned short> halfLine((size_t)width);
+    std::vector<float> floatLine((size_t)width);
+    for (int y = 0; y < height; y++) {
+        putInt(out, y);
+        putInt(out, (int32_t)bytesPerLine);
+        for (const ChannelSpec &channel : channels) {
+            const float *row = channel.plane + (size_t)y * width * channel.stride;
+            if (channel.pixelType == 1) {
+                for (int x = 0; x < width; x++) { halfLine[x] = floatToHalf(row[(size_t)x * channel.stride]); }
+                putBytes(out, halfLine.data(), (size_t)width * 2);
+            } else {
+                for (int x = 0; x < width; x++) { floatLine[x] = row[(size_t)x * channel.stride]; }
+                putBytes(out, floatLine.data(), (size_t)width * 4);
+            }
+        }
+    }
+
+    std::ofstream file(path, std::ios::binary);
+    if (!file) {
+        if (error) { *error = "cannot open " + path + " for writing"; }
+        return false;
+    }
+    file.write((const char *)out.data(), (std::streamsize)out.size());
+    return (bool)file;
+}
+
+}  // namespace
+
+bool writeExrHalfBGR(
+    const std::string &path,
+    int width, int height,
+    const float *r, const float *g, const float *b,
+    std::string *error
+) {
+    std::vector<ChannelSpec> channels = {
+        { "B", 1, b, 1 },
+        { "G", 1, g, 1 },
+        { "R", 1, r, 1 },
+    };
+    return writeScanlineExr(path, width, height, channels, error);
+}
+
+bool writeExrFloatRGBA(
+    const std::string &path,
+    int width, int height,
+    const float *rgba,
+    std::string *error
+) {
+    std::vector<ChannelSpec> channels = {
+        { "A", 2, rgba + 3, 4 },
+        { "B", 2, rgba + 2, 4 },
+        { "G", 2, rgba + 1, 4 },
+        { "R", 2, rgba + 0, 4 },
+    };
+    return writeScanlineExr(path, width, height, channels, error);
+}
+
+namespace {
+
+struct Reader {
+    const std::vector<unsigned char> &data;
+    size_t pos = 0;
+    bool ok = true;
+
+    explicit Reader(const std::vector<unsigned char> &d) : data(d) {}
+
+    bool take(void *out, size_t size)
+    {
+        if (pos + size > data.size()) { ok = false; return false; }
+        std::memcpy(out, data.data() + pos, size);
+        pos += size;
+        return true;
+    }
+
+    std::string takeString()
+    {
+        std::string s;
+        while (pos < data.size() && data[pos] != 0) { s += (char)data[pos++]; }
+        if (pos >= data.size()) { ok = false; return s; }
+        pos++;
+        return s;
+    }
+};
+
+struct ChannelInfo {
+    std::string name;
+    int pixelType;
+};
+
+}  // namespace
+
+bool readExrRGBA(
+    const std::string &path,
+    int *width, int *height,
+    std::vector<float> *rgba,
+    std::string *error
+) {
+    auto fail = [&](const std::string &what) {
+        if (error) { *error = "exr " + path + ": " + what; }
+        return false;
+    };
+
+    std::ifstream file(path, std::ios::binary);
+    if (!file) { return fail("cannot open"); }
+    std::vector<unsigned char> data((std::istreambuf_iterator<char>(file)), std::istreambuf_iterator<char>());
+
+    Reader reader(data);
+    unsigned char magic[4];
+    unsigned char version[4];
+    if (!reader.take(magic, 4) || !reader.take(version, 4)) { return fail("truncated"); }
+    if (magic[0] != 0x76 || magic[1] != 0x2f || magic[2] != 0x31 || magic[3] != 0x01) { return fail("bad magic"); }
+    if (version[1] & 0x02) { return fail("tiled files unsupported"); }
+    if (version[1] & 0x18) { return fail("deep / multipart files unsupported"); }
+
+    std::vector<ChannelInfo> channels;
+    int compression = -1;
+    int32_t window[4] = { 0, 0, -1, -1 };
+    int lineOrder = 0;
+
+    while (reader.ok) {
+        std::string name = reader.takeString();
+        if (name.empty()) { break; }
+        std::string type = reader.takeString();
+        int32_t size = 0;
+        reader.take(&size, 4);
+        if (!reader.ok || size < 0 || reader.pos + (size_t)size > data.size()) { return fail("bad attribute"); }
+        const size_t valueStart = reader.pos;
+        if (name == "channels") {
+            Reader sub(data);
+            sub.pos = valueStart;
+            while (sub.pos < valueStart + (size_t)size) {
+                std::string channelName = sub.takeString();
+                if (channelName.empty()) { break; }
+                int32_t pixelType = 0;
+                unsigned char skip[4];
+                int32_t xs = 0, ys = 0;
+                sub.take(&pixelType, 4);
+                sub.take(skip, 4);
+                sub.take(&xs, 4);
+                sub.take(&ys, 4);
+                if (xs != 1 || ys != 1) { return fail("subsampled channels unsupported"); }
+                channels.push_back({ channelName, pixelType });
+            }
+        } else if (name == "compression") {
+            compression = data[valueStart];
+        } else if (name == "dataWindow") {
+            std::memcpy(window, data.data() + valueStart, 16);
+        } else if (name == "lineOrder") {
+            lineOrder = data[valueStart];
+        }
+        reader.pos = valueStart + (size_t)size;
+    }
+    if (!reader.ok) { return fail("truncated header"); }
+    if (channels.empty()) { return fail("no channels"); }
+    if (compression != 0 && compression != 2 && compression != 3) {
+        return fail("compression type " + std::to_string(compression) + " unsupported (NONE/ZIPS/ZIP only)");
+    }
+    (void)lineOrder;
+
+    const int w = window[2] - window[0] + 1;
+    const int h = window[3] - window[1] + 1;
+    if (w <= 0 || h <= 0) { return fail("bad data window"); }
+
+    size_t bytesPerLine = 0;
+    for (const ChannelInfo &channel : channels) {
+        if (channel.pixelType != 1 && channel.pixelType != 2) { return fail("UINT channels unsupported"); }
+        bytesPerLine += (size_t)w * (channel.pixelType == 1 ? 2 : 4);
+    }
+
+    const int linesPerBlock = (compression == 3) ? 16 : 1;
+    const int blockCount = (h + linesPerBlock - 1) / linesPerBlock;
+
+    std::vector<uint64_t> offsets((size_t)blockCount);
+    if (!reader.take(offsets.data(), (size_t)blockCount * 8)) { return fail("truncated offset table"); }
+
+    rgba->assign((size_t)4 * w * h, 0.f);
+    for (size_t i = 0; i < (size_t)w * h; i++) { (*rgba)[4 * i + 3] = 1.f; }
+
+    std::vector<unsigned char> raw;
+    std::vector<unsigned char> scratch;
+    for (int block = 0; block < blockCount; block++) {
+        size_t pos = (size_t)offsets[(size_t)block];
+        if (pos + 8 > data.size()) { return fail("bad block offset"); }
+        int32_t y, size;
+        std::memcpy(&y, data.data() + pos, 4);
+        std::memcpy(&size, data.data() + pos + 4, 4);
+        pos += 8;
+        if (size < 0 || pos + (size_t)size > data.size()) { return fail("bad block size"); }
+
+        const int firstLine = y - window[1];
+        const int lines = std::min(linesPerBlock, h - firstLine);
+        if (firstLine < 0 || lines <= 0) { return fail("bad block y"); }
+        const size_t expected = bytesPerLine * (size_t)lines;
+
+        if (compression == 0 || (size_t)size == expected) {
+            raw.assign(data.begin() + (long)pos, data.begin() + (long)(pos + (size_t)size));
+            if (raw.size() != expected) { return fail("bad uncompressed block"); }
+        } else {
+            scratch.resize(expected);
+            uLongf destLength = (uLongf)expected;
+            int code = uncompress(scratch.data(), &destLength, data.data() + pos, (uLong)size);
+            if (code != Z_OK || destLength != expected) { return fail("zlib failure"); }
+            // undo the predictor ...
+            for (size_t i = 1; i < expected; i++) {
+                scratch[i] = (unsigned char)(scratch[i - 1] + scratch[i] - 128);
+            }
+            // ... and the even/odd byte split
+            raw.resize(expected);
+            const size_t half = (expected + 1) / 2;
+            size_t a = 0, b = half;
+            for (size_t i = 0; i < expected; ) {
+                raw[i++] = scratch[a++];
+                if (i < expected) { raw[i++] = scratch[b++]; }
+            }
+        }
+
+        size_t cursor = 0;
+        for (int line = 0; line < lines; line++) {
+            const int row = firstLine + line;
+            for (const ChannelInfo &channel : channels) {
+                int component = -1;
+                if (channel.name == "R") { component = 0; }
+                else if (channel.name == "G") { component = 1; }
+                else if (channel.name == "B") { component = 2; }
+                else if (channel.name == "A") { component = 3; }
+                else if (channel.name == "Y" && channels.size() == 1) { component = 4; }
+                for (int x = 0; x < w; x++) {
+                    float value;
+                    if (channel.pixelType == 1) {
+                        unsigned short half;
+                        std::memcpy(&half, raw.data() + cursor, 2);
+                        cursor += 2;
+                        value = halfToFloat(half);
+                    } else {
+                        std::memcpy(&value, raw.data() + cursor, 4);
+                        cursor += 4;
+                    }
+                    float *pixel = rgba->data() + 4 * ((size_t)row * w + x);
+                    if (component == 4) { pixel[0] = pixel[1] = pixel[2] = value; }
+                    else if (component >= 0) { pixel[component] = value; }
+                }
+            }
+        }
+    }
+
+    *width = w;
+    *height = h;
+    return true;
+}
+
+}  // namespace pathed

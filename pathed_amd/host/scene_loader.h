@@ -1,0 +1,59 @@
+// Scene JSON / OBJ / MTL / PLY / quad / sphere readers producing the flat
+// PathedSceneDesc the C ABI consumes.
+//
+// The reference builds an object graph whose BSDF parameters are private and whose
+// per-vertex attributes live only in Embree buffers, so a drop-in
+// has to read the same files itself.  Format rules followed here:
+//   scene JSON   reference src/scene_parser.cpp:140-200, 251-291, 574-667, 690-850
+//   OBJ          reference src/obj_parser.cpp:50-515
+//   MTL          reference src/mtl_parser.cpp:40-113
+//   PLY          reference src/ply_parser.cpp:29-151
+//   quad         reference src/quad.cpp:7-151
+//   sphere       reference src/sphere.cpp:16-48, src/scene_parser.cpp:484-512
+#pragma once
+
+#include "pathed_hip.h"
+
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace pathed {
+
+struct FlatScene {
+    PathedCamera camera;
+
+    std::vector<float> positions;
+    std::vector<float> normals;
+    std::vector<float> uvs;
+    std::vector<uint32_t> indices;
+    std::vector<int32_t> triMaterial;
+
+    std::vector<PathedSphere> spheres;
+    std::vector<PathedGeom> geoms;
+    std::vector<PathedMaterial> materials;
+
+    bool hasEnv = false;
+    PathedEnvLight env;
+    std::vector<float> envData;
+
+    // valid as long as this FlatScene is alive and unmodified
+    PathedSceneDesc desc() const;
+};
+
+struct SceneLoadError : std::runtime_error {
+    explicit SceneLoadError(const std::string &what) : std::runtime_error(what) {}
+};
+
+// assetRoot plays the role of the reference's working directory after its
+// chdir("..") (app/main.cpp:60): every filename inside the scene is relative to it.
+FlatScene loadScene(
+    const std::string &scenePath,
+    int width, int height,
+    const std::string &assetRoot
+);
+
+PathedMaterial makeLambertian(const float diffuse[3], const float emit[3]);
+
+}  // namespace pathed
