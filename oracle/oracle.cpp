@@ -1493,6 +1493,7 @@ struct OracleSceneImpl {
     Color directSampleLights(const Intersection &isect, const Material &material, Rng &random, Counters *counters) const
     {
         if (isDelta(material)) { return col(0.f); }
+        if (lights.empty()) { return col(0.f); } /* the reference would index an empty vector */
 
         const LightSample lightSample = sampleDirectLights(isect.point, random);
 

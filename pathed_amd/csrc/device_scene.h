@@ -1,0 +1,94 @@
+// Device-resident scene: flat arrays in HBM, uploaded once by pathed_hip_scene_create.
+#pragma once
+
+#include "vecmath.h"
+
+#include <cstdint>
+
+namespace pathed {
+
+// material table entry (80 B), staged in LDS by the shade kernel
+struct DMaterial {
+    int type;
+    int albedoType;
+    float orenA, orenB;      // OrenNayar A, B (reference src/oren_nayar.cpp:11-18)
+    float diffuse[3];
+    float alpha;
+    float emit[3];
+    float ior;
+    float checkerOn[3];
+    float checkerResU;
+    float checkerOff[3];
+    float checkerResV;
+};
+
+// per-triangle shading record, indexed by ORIGINAL primitive id (128 B = 8 x float4):
+//   q0 = (p0, material)  q1 = (p1, uv0.u)  q2 = (p2, uv0.v)
+//   q3 = (n0, uv1.u)     q4 = (n1, uv1.v)  q5 = (n2, uv2.u)  q6 = (uv2.v, -, -, -)  q7 = pad
+static const int kTriShadeQuads = 8;
+
+struct DSphere {
+    float centerWorld[3];
+    float radius;
+    float centerSample[3];
+    int material;
+};
+
+struct DLight {
+    int kind;   // 0 triangle, 1 sphere, 2 environment
+    int index;  // triangle prim id / sphere index
+};
+
+struct DCamera {
+    float origin[3];
+    float m[9];        // cameraToWorld rotation rows (reference lookAt, src/transform.cpp:138-164)
+    float filmHeight;  // 2 * tanf(fov / 2) * zNear          (src/camera.cpp:34)
+    float filmWidth;   // filmHeight * resX / resY            (src/camera.cpp:35)
+    int resX, resY;
+};
+
+struct DEnv {
+    int width, height;
+    const float4 *rgba;        // width*height texels
+    const float *thetaCdf;     // height
+    const float *phiCdf;       // height*width, row-major
+    const int *phiEmpty;       // height flags: 1 = the row has zero weight
+    int thetaEmpty;
+    float scale;
+    float mapToWorld[9];       // 3x3 part, row-major (the reference applies it to directions only)
+    float worldToMap[9];
+};
+
+struct DScene {
+    DCamera camera;
+
+    // intersector
+    const float4 *nodes;       // 4 x float4 per inner node
+    const float4 *leafTris;    // 3 x float4 per leaf-ordered triangle: (v0, prim) (e1, -) (e2, -)
+    int nNodes;
+    int nTris;
+    const DSphere *spheres;
+    int nSpheres;
+
+    // shading
+    const float4 *triShade;    // kTriShadeQuads x float4 per original primitive
+    const DMaterial *materials;
+    int nMaterials;
+    const DLight *lights;
+    int nLights;
+    int hasEnv;
+    DEnv env;
+};
+
+// path state word (rayD.w)
+static const int kStBounceMask = 0xFFFF;
+static const int kStEligible = 1 << 16;   // the vertex wants the BSDF-sampling MIS term
+static const int kStDelta = 1 << 17;      // the vertex BSDF is a delta lobe
+static const int kStContinue = 1 << 18;   // the path may continue past this ray
+static const int kStDone = 1 << 30;       // slot has no ray in flight
+
+// ray interval of Scene::testIntersect (reference src/scene.cpp:102-103)
+#define PATHED_TNEAR 1e-3f
+#define PATHED_TFAR 1e5f
+
+}  // namespace pathed

@@ -1,0 +1,644 @@
+// The wavefront path-tracing kernels (gfx950).
+//
+// One path SLOT per pixel; a slot renders its pixel's samples one after another
+// ("path regeneration"), so every lane stays busy until the sample budget is spent and
+// the per-pixel sum is accumulated in sample order exactly like the reference's wave
+// loop (src/integrator.cpp:42-51, src/sample_integrator.cpp:61-63).
+//
+// Per iteration, two launches on one stream:
+//   k_trace  persistent waves pull 64-ray batches from [slot rays | shadow queue]
+//            closest hit  -> hit[slot]               (Scene::testIntersect's rtcIntersect1)
+//            any hit      -> pend[slot] = 0 if occluded (Scene::testOcclusion's rtcOccluded1)
+//   k_shade  one lane per slot: finishes the previous vertex's BSDF-sampling MIS term with
+//            the new hit, updates throughput, samples the BSDF and one light at the new
+//            vertex (PathTracer::L / direct / directSampleLights / directSampleBSDF,
+//            src/path_tracer.cpp:19-216), emits the next ray and a compacted shadow ray,
+//            or terminates the sample, accumulates it and regenerates a camera ray.
+// State is SoA-of-float4 in HBM so a wave reads 1 KiB contiguous per stream.
+#pragma once
+
+#include "shading.h"
+#include "trace.h"
+
+namespace pathed {
+
+static const int kBlock = 256;
+static const int kMaxLdsMaterials = 96;  // 96 x 80 B = 7.5 KiB of LDS
+
+// counters[] layout (unsigned int)
+static const int kCtrShadowCount = 0;  // [0],[1] double-buffered shadow-queue tails
+static const int kCtrCursor = 2;       // [2],[3] double-buffered persistent-trace cursors
+static const int kCtrRemaining = 4;    // slots that still have samples to render
+static const int kCtrCount = 8;
+
+// stats[] layout (unsigned long long)
+static const int kStatSamples = 0;
+static const int kStatClosest = 1;
+static const int kStatShadow = 2;
+static const int kStatBoxes = 3;
+static const int kStatTris = 4;
+static const int kStatDropped = 5;
+static const int kStatCount = 8;
+
+struct PathState {
+    float4 *rayO;   // origin.xyz, bits(material of a directly visible emitter, or -1)
+    float4 *rayD;   // direction.xyz, bits(state word)
+    float4 *hit;    // t, u, v, bits(prim)
+    float4 *mod;    // modulation.rgb, pdf of the pending BSDF sample
+    float4 *thr;    // throughput.rgb of the pending BSDF sample, |n_s . wi|
+    float4 *res;    // result.rgb, bits(sample index)
+    float4 *pend;   // light-sampling term of the pending vertex (zeroed if occluded)
+    float4 *shO;    // shadow queue: origin.xyz, tfar
+    float4 *shD;    // shadow queue: direction.xyz, bits(slot)
+};
+
+struct RenderParams {
+    DScene scene;
+    PathState state;
+    unsigned int *counters;
+    unsigned long long *stats;
+    float *accum;          // 3*W*H radiance sums, index 3*(row*W+col)+c
+    int nSlots;
+    int nSlotsPadded;      // multiple of 64
+    uint32_t seedLo, seedHi;
+    uint32_t sppBegin, sppEnd;
+    int startBounce, lastBounce;
+    int parity;            // iteration & 1
+};
+
+// BounceController, reference src/bounce_controller.cpp:14-25
+__device__ inline bool checkDone(int lastBounce, int bounce)
+{
+    if (lastBounce == -1) { return false; }
+    return bounce > lastBounce;
+}
+
+__device__ inline bool checkCounts(int startBounce, int lastBounce, int bounce)
+{
+    if (startBounce > bounce) { return false; }
+    return !checkDone(lastBounce, bounce);
+}
+
+// ------------------------------------------------------------------------- trace
+
+template <int STACK, bool LDS_SCENE, bool COUNT>
+__global__ __launch_bounds__(kBlock) void k_trace(RenderParams p)
+{
+    extern __shared__ float4 ldsRaw[];
+    int *stackBase = reinterpret_cast<int *>(ldsRaw);
+    int *stack = stackBase + threadIdx.x;
+
+    TraceGeometry geometry;
+    geometry.nodes = p.scene.nodes;
+    geometry.tris = p.scene.leafTris;
+    geometry.nNodes = p.scene.nNodes;
+    geometry.nTris = p.scene.nTris;
+    geometry.spheres = p.scene.spheres;
+    geometry.nSpheres = p.scene.nSpheres;
+
+    if (LDS_SCENE) {
+        // small scenes: the whole BVH + leaf triangles are staged in LDS once per block
+        float4 *ldsNodes = ldsRaw + (STACK * kBlock) / 4;
+        float4 *ldsTris = ldsNodes + 4 * p.scene.nNodes;
+        for (int i = threadIdx.x; i < 4 * p.scene.nNodes; i += kBlock) { ldsNodes[i] = p.scene.nodes[i]; }
+        for (int i = threadIdx.x; i < 3 * p.scene.nTris; i += kBlock) { ldsTris[i] = p.scene.leafTris[i]; }
+        __syncthreads();
+        geometry.nodes = ldsNodes;
+        geometry.tris = ldsTris;
+    }
+
+    const int parity = p.parity;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { p.counters[kCtrShadowCount + (parity ^ 1)] = 0; }
+
+    const unsigned int shadowCount = p.counters[kCtrShadowCount + parity];
+    const unsigned int total = (unsigned int)p.nSlotsPadded + shadowCount;
+    const int lane = threadIdx.x & 63;
+
+    TraceCounters counters;
+    counters.boxes = 0;
+    counters.tris = 0;
+    unsigned int closestRays = 0, shadowRays = 0;
+
+    // persistent loop: every wave reaches the exit because the cursor only grows
+    while (true) {
+        unsigned int base = 0;
+        if (lane == 0) { base = atomicAdd(&p.counters[kCtrCursor + parity], 64u); }
+        base = __shfl(base, 0);
+        if (base >= total) { break; }
+
+        const unsigned int item = base + lane;
+        if (base < (unsigned int)p.nSlotsPadded) {
+            if (item < (unsigned int)p.nSlots) {
+                const float4 rd = p.state.rayD[item];
+                if (!(floatAsInt(rd.w) & kStDone)) {
+                    const float4 ro = p.state.rayO[item];
+                    RayHit hit;
+                    traverse<false, COUNT, kBlock>(
+                        geometry, stack, STACK,
+                        v3(ro.x, ro.y, ro.z), v3(rd.x, rd.y, rd.z), PATHED_TNEAR, PATHED_TFAR,
+                        &hit, &counters);
+                    p.state.hit[item] = make_float4(hit.t, hit.u, hit.v, intAsFloat(hit.prim));
+                    if (COUNT) { closestRays++; }
+                }
+            }
+        } else {
+            const unsigned int q = item - (unsigned int)p.nSlotsPadded;
+            if (q < shadowCount) {
+                const float4 so = p.state.shO[q];
+                const float4 sd = p.state.shD[q];
+                RayHit hit;
+                const bool occluded = traverse<true, COUNT, kBlock>(
+                    geometry, stack, STACK,
+                    v3(so.x, so.y, so.z), v3(sd.x, sd.y, sd.z), PATHED_TNEAR, so.w,
+                    &hit, &counters);
+                if (occluded) { p.state.pend[floatAsInt(sd.w)] = make_float4(0.f, 0.f, 0.f, 0.f); }
+                if (COUNT) { shadowRays++; }
+            }
+        }
+    }
+
+    if (COUNT) {
+        atomicAdd(&p.stats[kStatBoxes], (unsigned long long)counters.boxes);
+        atomicAdd(&p.stats[kStatTris], (unsigned long long)counters.tris);
+        atomicAdd(&p.stats[kStatClosest], (unsigned long long)closestRays);
+        atomicAdd(&p.stats[kStatShadow], (unsigned long long)shadowRays);
+    }
+}
+
+// test hook kernel behind pathed_hip_trace: plain grid, arbitrary ray intervals
+template <int STACK>
+__global__ __launch_bounds__(kBlock) void k_trace_rays(
+    DScene scene, const float4 *rays, int n, int anyHit, float4 *hitsOut, int *occludedOut
+) {
+    extern __shared__ float4 ldsRaw[];
+    int *stack = reinterpret_cast<int *>(ldsRaw) + threadIdx.x;
+
+    TraceGeometry geometry;
+    geometry.nodes = scene.nodes;
+    geometry.tris = scene.leafTris;
+    geometry.nNodes = scene.nNodes;
+    geometry.nTris = scene.nTris;
+    geometry.spheres = scene.spheres;
+    geometry.nSpheres = scene.nSpheres;
+
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) { return; }
+    const float4 ro = rays[2 * i + 0];
+    const float4 rd = rays[2 * i + 1];
+    RayHit hit;
+    hit.t = 0.f; hit.u = 0.f; hit.v = 0.f; hit.prim = -1;
+    TraceCounters counters;
+    if (anyHit) {
+        const bool occluded = traverse<true, false, kBlock>(
+            geometry, stack, STACK, v3(ro.x, ro.y, ro.z), v3(rd.x, rd.y, rd.z), ro.w, rd.w, &hit, &counters);
+        occludedOut[i] = occluded ? 1 : 0;
+    } else {
+        const bool found = traverse<false, false, kBlock>(
+            geometry, stack, STACK, v3(ro.x, ro.y, ro.z), v3(rd.x, rd.y, rd.z), ro.w, rd.w, &hit, &counters);
+        if (!found) { hit.t = 0.f; hit.u = 0.f; hit.v = 0.f; hit.prim = -1; }
+        hitsOut[i] = make_float4(hit.t, hit.u, hit.v, intAsFloat(hit.prim));
+    }
+}
+
+// ------------------------------------------------------------------------- shade
+
+struct TriShade {
+    V3 p0, p1, p2;
+    int material;
+};
+
+__device__ inline TriShade loadTriCorners(const DScene &scene, int prim)
+{
+    const float4 *q = scene.triShade + (size_t)kTriShadeQuads * prim;
+    const float4 q0 = q[0], q1 = q[1], q2 = q[2];
+    TriShade tri;
+    tri.p0 = v3(q0.x, q0.y, q0.z);
+    tri.p1 = v3(q1.x, q1.y, q1.z);
+    tri.p2 = v3(q2.x, q2.y, q2.z);
+    tri.material = floatAsInt(q0.w);
+    return tri;
+}
+
+// Scene::testIntersect's record construction, reference src/scene.cpp:121-218
+__device__ inline Isect makeIsect(const DScene &scene, V3 o, V3 d, float4 h)
+{
+    const float t = h.x, u = h.y, v = h.z;
+    const int prim = floatAsInt(h.w);
+
+    V3 geometricNormal;
+    V3 shadingNormal = v3(0.f, 0.f, 0.f);
+    float uvU = 0.f, uvV = 0.f;
+    int material;
+
+    if (prim < scene.nTris) {
+        const float4 *q = scene.triShade + (size_t)kTriShadeQuads * prim;
+        const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4], q5 = q[5], q6 = q[6];
+        const V3 p0 = v3(q0.x, q0.y, q0.z), p1 = v3(q1.x, q1.y, q1.z), p2 = v3(q2.x, q2.y, q2.z);
+        const float w = 1.f - u - v;
+        // rtcInterpolate0 with weights (1-u-v, u, v): uv slot 0, normal slot 1
+        uvU = fmaf(w, q1.w, fmaf(u, q3.w, v * q5.w));
+        uvV = fmaf(w, q2.w, fmaf(u, q4.w, v * q6.x));
+        shadingNormal = v3(
+            fmaf(w, q3.x, fmaf(u, q4.x, v * q5.x)),
+            fmaf(w, q3.y, fmaf(u, q4.y, v * q5.y)),
+            fmaf(w, q3.z, fmaf(u, q4.z, v * q5.z)));
+        geometricNormal = normalized(xcross(p1 - p0, p2 - p0));  // Ng = (v1-v0) x (v2-v0)
+        material = floatAsInt(q0.w);
+    } else {
+        const DSphere sphere = scene.spheres[prim - scene.nTris];
+        const V3 point = o + d * t;
+        geometricNormal = normalized(point - v3(sphere.centerWorld[0], sphere.centerWorld[1], sphere.centerWorld[2]));
+        material = sphere.material;
+    }
+
+    if (length(shadingNormal) == 0.f) { shadingNormal = geometricNormal; }
+
+    Isect isect;
+    isect.point = o + d * t;  // Ray::at, src/ray.cpp:9-12
+    isect.wo = -d;
+    isect.normal = geometricNormal;
+    isect.shadingNormal = normalized(shadingNormal);
+    isect.u = uvU;
+    isect.v = uvV;
+    isect.material = material;
+    isect.prim = prim;
+    isect.frame = normalToWorldSpace(isect.shadingNormal, isect.wo);
+    return isect;
+}
+
+// Scene::lightsPDF, src/scene.cpp:469-484
+__device__ inline float lightsPDF(const DScene &scene, V3 referencePoint, const Isect &lightIsect)
+{
+    float measurePDF;
+    if (lightIsect.prim < scene.nTris) {
+        const TriShade tri = loadTriCorners(scene, lightIsect.prim);
+        measurePDF = trianglePdfSolidAngle(tri.p0, tri.p1, tri.p2, lightIsect.point, referencePoint);
+    } else {
+        const DSphere sphere = scene.spheres[lightIsect.prim - scene.nTris];
+        measurePDF = spherePdfSolidAngle(
+            v3(sphere.centerSample[0], sphere.centerSample[1], sphere.centerSample[2]), sphere.radius, referencePoint);
+    }
+    return measurePDF / scene.nLights;
+}
+
+// Scene::environmentL, src/scene.cpp:486-492
+__device__ inline Rgb environmentL(const DScene &scene, V3 direction)
+{
+    if (scene.hasEnv) { return envEmit(scene.env, -direction); }
+    return rgb(0.f);
+}
+
+struct ShadowRequest {
+    bool push;
+    V3 origin, direction;
+    float tfar;
+};
+
+// PathTracer::directSampleLights, src/path_tracer.cpp:113-165, up to (not including) the
+// occlusion query: returns the contribution assuming visibility and the shadow ray to test.
+template <typename MaterialTable>
+__device__ inline Rgb sampleLightsTerm(
+    const DScene &scene, const MaterialTable &materials,
+    const Isect &isect, const DMaterial &material, Rng &random, ShadowRequest *shadow
+) {
+    shadow->push = false;
+    if (isDelta(material)) { return rgb(0.f); }
+    if (scene.nLights == 0) { return rgb(0.f); }
+
+    // Scene::sampleDirectLights, src/scene.cpp:446-467
+    const int lightCount = scene.nLights;
+    int lightIndex = (int)floorf(random.next() * lightCount);
+    lightIndex = imin(lightIndex, lightCount - 1);
+    const DLight light = scene.lights[lightIndex];
+
+    SurfaceSample surfaceSample;
+    int lightMaterial = 0;
+    if (light.kind == 0) {
+        const TriShade tri = loadTriCorners(scene, light.index);
+        surfaceSample = triangleSample(tri.p0, tri.p1, tri.p2, random);
+        lightMaterial = tri.material;
+    } else if (light.kind == 1) {
+        const DSphere sphere = scene.spheres[light.index];
+        surfaceSample = sphereSample(
+            v3(sphere.centerSample[0], sphere.centerSample[1], sphere.centerSample[2]), sphere.radius, isect.point, random);
+        lightMaterial = sphere.material;
+    } else {
+        surfaceSample = envSample(scene.env, isect.point, random);
+    }
+    const float lightChoicePDF = 1.f / lightCount;
+    const float invPDF = surfaceSample.invPDF * (1.f / lightChoicePDF);
+
+    const V3 lightDirection = surfaceSample.point - isect.point;
+    const V3 wiWorld = normalized(lightDirection);
+
+    if (dot(surfaceSample.normal, wiWorld) >= 0.f) { return rgb(0.f); }  // back of the light
+
+    const float lightDistance = length(lightDirection);
+
+    // LightSample::solidAnglePDF, include/scene.h:66-80
+    float pdf;
+    if (surfaceSample.solidAngle) {
+        pdf = 1.f / invPDF;
+    } else {
+        const V3 lightWoForPdf = -normalized(lightDirection);
+        const float distance2 = lightDistance * lightDistance;
+        const float projectedArea = smax(0.f, dot(surfaceSample.normal, lightWoForPdf));
+        pdf = (1.f / invPDF) * distance2 / projectedArea;
+    }
+
+    float brdfPDF;
+    const Rgb f = materialF(material, isect, wiWorld, &brdfPDF);
+    const float lightWeight = (1 * pdf) / (1 * pdf + 1 * brdfPDF);  // include/mis.h:4-7
+
+    const V3 lightWo = -normalized(lightDirection);
+    Rgb emitted;
+    if (light.kind == 2) { emitted = envEmit(scene.env, lightWo); }
+    else { emitted = matEmit(materials[lightMaterial]); }
+
+    // Scene::testOcclusion's interval, src/scene.cpp:366-367
+    shadow->push = true;
+    shadow->origin = isect.point;
+    shadow->direction = wiWorld;
+    shadow->tfar = lightDistance - 1e-3f;
+
+    return emitted
+        * lightWeight
+        * f
+        * fabsf(dot(isect.shadingNormal, wiWorld))
+        / pdf;
+}
+
+// Camera::generateRay(int,int), src/camera.cpp:49-55, for (slot = pixel, sample)
+__device__ inline void startSample(const RenderParams &p, int slot, uint32_t sample, float4 *rayO, float4 *rayD)
+{
+    const int width = p.scene.camera.resX;
+    const int row = slot / width;
+    const int col = slot - row * width;
+    Rng random;
+    makeKey(((uint64_t)p.seedHi << 32) | p.seedLo, (uint32_t)slot, sample, &random.k0, &random.k1);
+    random.dimension = 0;
+    const float jitterX = random.next() - 0.5f;
+    const float jitterY = random.next() - 0.5f;
+    V3 origin, direction;
+    cameraRay(p.scene.camera, row + jitterY, col + jitterX, &origin, &direction);
+    *rayO = make_float4(origin.x, origin.y, origin.z, intAsFloat(-1));
+    *rayD = make_float4(direction.x, direction.y, direction.z, intAsFloat(0));
+}
+
+__global__ __launch_bounds__(kBlock) void k_init(RenderParams p)
+{
+    const int slot = blockIdx.x * kBlock + threadIdx.x;
+    if (slot == 0) {
+        for (int i = 0; i < kCtrCount; i++) { p.counters[i] = 0; }
+        p.counters[kCtrRemaining] = (p.sppEnd > p.sppBegin) ? (unsigned int)p.nSlots : 0u;
+    }
+    if (slot >= p.nSlots) { return; }
+    float4 rayO, rayD;
+    if (p.sppEnd > p.sppBegin) {
+        startSample(p, slot, p.sppBegin, &rayO, &rayD);
+    } else {
+        rayO = make_float4(0.f, 0.f, 0.f, intAsFloat(-1));
+        rayD = make_float4(0.f, 0.f, 0.f, intAsFloat(kStDone));
+    }
+    p.state.rayO[slot] = rayO;
+    p.state.rayD[slot] = rayD;
+    p.state.res[slot] = make_float4(0.f, 0.f, 0.f, intAsFloat((int)p.sppBegin));
+    p.state.mod[slot] = make_float4(1.f, 1.f, 1.f, 1.f);
+    p.state.thr[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
+    p.state.pend[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+template <bool LDS_MATERIALS>
+struct MaterialAccess {
+    const DMaterial *table;
+    __device__ inline const DMaterial &operator[](int index) const { return table[index]; }
+};
+
+template <bool LDS_MATERIALS>
+__global__ __launch_bounds__(kBlock) void k_shade(RenderParams p)
+{
+    __shared__ DMaterial ldsMaterials[LDS_MATERIALS ? kMaxLdsMaterials : 1];
+
+    MaterialAccess<LDS_MATERIALS> materials;
+    if (LDS_MATERIALS) {
+        // material parameters staged in LDS: every lane indexes them by its own hit
+        const int words = p.scene.nMaterials * (int)(sizeof(DMaterial) / 4);
+        const int *source = reinterpret_cast<const int *>(p.scene.materials);
+        int *target = reinterpret_cast<int *>(ldsMaterials);
+        for (int i = threadIdx.x; i < words; i += kBlock) { target[i] = source[i]; }
+        __syncthreads();
+        materials.table = ldsMaterials;
+    } else {
+        materials.table = p.scene.materials;
+    }
+
+    const int slot = blockIdx.x * kBlock + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int parity = p.parity;
+    if (slot == 0) { p.counters[kCtrCursor + (parity ^ 1)] = 0; }
+
+    const DScene &scene = p.scene;
+
+    bool active = slot < p.nSlots;
+    float4 rd = make_float4(0.f, 0.f, 0.f, 0.f);
+    int st = kStDone;
+    if (active) {
+        rd = p.state.rayD[slot];
+        st = floatAsInt(rd.w);
+        active = !(st & kStDone);
+    }
+
+    ShadowRequest shadow;
+    shadow.push = false;
+    shadow.origin = v3(0.f, 0.f, 0.f);
+    shadow.direction = v3(0.f, 0.f, 0.f);
+    shadow.tfar = 0.f;
+
+    if (active) {
+        const float4 ro = p.state.rayO[slot];
+        const float4 h = p.state.hit[slot];
+        const float4 resIn = p.state.res[slot];
+
+        const V3 o = v3(ro.x, ro.y, ro.z);
+        const V3 d = v3(rd.x, rd.y, rd.z);
+        const int rayBounce = st & kStBounceMask;  // vertex that spawned this ray, 0 = camera
+        const bool miss = floatAsInt(h.w) < 0;
+        uint32_t sample = (uint32_t)floatAsInt(resIn.w);
+        int firstEmitMaterial = floatAsInt(ro.w);
+
+        Rgb result = rgb(resIn.x, resIn.y, resIn.z);
+        Rgb modulation = rgb(1.f);
+
+        bool finished = false;
+        Rgb color = rgb(0.f);
+
+        bool haveVertex = false;  // a new surface vertex to process this iteration
+        Isect isect;
+        int vertex = rayBounce + 1;
+
+        if (rayBounce == 0) {
+            // SampleIntegrator::samplePixel, src/sample_integrator.cpp:18-59
+            if (miss) {
+                color = rgb(0.f) + environmentL(scene, d);
+                finished = true;
+            } else {
+                isect = makeIsect(scene, o, d, h);
+                firstEmitMaterial = -1;
+                if (checkCounts(p.startBounce, p.lastBounce, 0)) {
+                    const Rgb emit = matEmit(materials[isect.material]);
+                    const bool backside = dot(isect.normal, isect.wo) < 0.f;
+                    if (!isBlack(emit) && !backside) { firstEmitMaterial = isect.material; }
+                }
+                result = rgb(0.f);
+                haveVertex = true;
+            }
+        } else {
+            // the ray left vertex `rayBounce` along its BSDF sample
+            const float4 modIn = p.state.mod[slot];
+            const float4 thrIn = p.state.thr[slot];
+            modulation = rgb(modIn.x, modIn.y, modIn.z);
+            const float bsdfPdf = modIn.w;
+            const Rgb throughput = rgb(thrIn.x, thrIn.y, thrIn.z);
+            const float cosTheta = thrIn.w;
+
+            if (!miss) { isect = makeIsect(scene, o, d, h); }
+
+            if (st & kStEligible) {
+                // PathTracer::directSampleBSDF, src/path_tracer.cpp:167-216
+                const float4 pendIn = p.state.pend[slot];
+                Rgb bsdfTerm = rgb(0.f);
+                if (!miss) {
+                    const Rgb emit = matEmit(materials[isect.material]);
+                    if (!isBlack(emit) && dot(isect.wo, isect.shadingNormal) >= 0.f) {
+                        const float lightPDF = lightsPDF(scene, o, isect);
+                        const float brdfWeight = (st & kStDelta)
+                            ? 1.f
+                            : (1 * bsdfPdf) / (1 * bsdfPdf + 1 * lightPDF);
+                        bsdfTerm = emit * brdfWeight * throughput * cosTheta / bsdfPdf;
+                    }
+                } else {
+                    const Rgb environmentLight = environmentL(scene, d);
+                    if (!isBlack(environmentLight)) {
+                        // Scene::environmentPDF, src/scene.cpp:494-502
+                        const float lightPDF = envEmitPDF(scene.env, d) / scene.nLights;
+                        const float brdfWeight = (st & kStDelta)
+                            ? 1.f
+                            : (1 * bsdfPdf) / (1 * bsdfPdf + 1 * lightPDF);
+                        bsdfTerm = environmentLight * brdfWeight * throughput * cosTheta / bsdfPdf;
+                    }
+                }
+                const Rgb Ld = rgb(pendIn.x, pendIn.y, pendIn.z) + bsdfTerm;
+                if (rayBounce == 1) { result = Ld; }
+                else { result = result + Ld * modulation; }
+            }
+
+            // PathTracer::L loop body, src/path_tracer.cpp:41-58
+            if (!(st & kStContinue) || miss) {
+                finished = true;
+            } else {
+                const float invPDF = 1.f / bsdfPdf;
+                modulation = modulation * (throughput * cosTheta * invPDF);
+                if (isBlack(modulation)) { finished = true; }
+                else { haveVertex = true; }
+            }
+            if (finished) {
+                Rgb first = rgb(0.f);
+                if (firstEmitMaterial >= 0) { first = first + matEmit(materials[firstEmitMaterial]); }
+                color = first + result;
+            }
+        }
+
+        float4 outRayO = ro, outRayD = rd;
+        float4 outMod = make_float4(modulation.r, modulation.g, modulation.b, 1.f);
+        float4 outThr = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 outPend = make_float4(0.f, 0.f, 0.f, 0.f);
+
+        if (haveVertex) {
+            // PathTracer::L: sample the BSDF, then direct(), src/path_tracer.cpp:30-36, 60-73
+            const DMaterial &material = materials[isect.material];
+
+            Rng random;
+            makeKey(((uint64_t)p.seedHi << 32) | p.seedLo, (uint32_t)slot, sample, &random.k0, &random.k1);
+            random.dimension = vertexBase(vertex);
+            const BSDFSample bsdfSample = materialSample(material, isect, random);
+
+            const bool counts = checkCounts(p.startBounce, p.lastBounce, vertex);
+            const bool emissive = !isBlack(matEmit(material));
+            const bool wantDirect = counts && !emissive;  // direct() returns 0 on emitters (:86-90)
+            const bool wantContinue = !checkDone(p.lastBounce, vertex + 1);
+
+            Rgb lightTerm = rgb(0.f);
+            if (wantDirect) {
+                random.dimension = vertexBase(vertex) + 3;
+                lightTerm = sampleLightsTerm(scene, materials, isect, material, random, &shadow);
+            }
+
+            if (!wantDirect && !wantContinue) {
+                finished = true;
+                Rgb first = rgb(0.f);
+                if (firstEmitMaterial >= 0) { first = first + matEmit(materials[firstEmitMaterial]); }
+                color = first + result;
+                shadow.push = false;
+            } else {
+                int nextState = vertex;
+                if (wantDirect) { nextState |= kStEligible; }
+                if (isDelta(material)) { nextState |= kStDelta; }
+                if (wantContinue) { nextState |= kStContinue; }
+                outRayO = make_float4(isect.point.x, isect.point.y, isect.point.z, intAsFloat(firstEmitMaterial));
+                outRayD = make_float4(bsdfSample.wiWorld.x, bsdfSample.wiWorld.y, bsdfSample.wiWorld.z, intAsFloat(nextState));
+                outMod.w = bsdfSample.pdf;
+                outThr = make_float4(
+                    bsdfSample.throughput.r, bsdfSample.throughput.g, bsdfSample.throughput.b,
+                    fabsf(dot(isect.shadingNormal, bsdfSample.wiWorld)));
+                outPend = make_float4(lightTerm.r, lightTerm.g, lightTerm.b, 0.f);
+            }
+        }
+
+        float4 outRes = make_float4(result.r, result.g, result.b, intAsFloat((int)sample));
+
+        if (finished) {
+            // radianceLookup += color, src/sample_integrator.cpp:61-63; non-finite samples dropped
+            const bool finite = isfinite(color.r) && isfinite(color.g) && isfinite(color.b);
+            if (finite) {
+                float *pixel = p.accum + 3 * (size_t)slot;
+                pixel[0] += color.r;
+                pixel[1] += color.g;
+                pixel[2] += color.b;
+            } else {
+                atomicAdd(&p.stats[kStatDropped], 1ull);
+            }
+            sample++;
+            if (sample < p.sppEnd) {
+                startSample(p, slot, sample, &outRayO, &outRayD);
+            } else {
+                outRayD.w = intAsFloat(kStDone);
+                atomicSub(&p.counters[kCtrRemaining], 1u);
+            }
+            outRes = make_float4(0.f, 0.f, 0.f, intAsFloat((int)sample));
+            outMod = make_float4(1.f, 1.f, 1.f, 1.f);
+        }
+
+        p.state.rayO[slot] = outRayO;
+        p.state.rayD[slot] = outRayD;
+        p.state.mod[slot] = outMod;
+        p.state.thr[slot] = outThr;
+        p.state.res[slot] = outRes;
+        p.state.pend[slot] = outPend;
+    }
+
+    // shadow-ray stream compaction: wave ballot + prefix popcount, one atomic per wave
+    const unsigned long long mask = __ballot(shadow.push);
+    if (mask != 0ull) {
+        unsigned int base = 0;
+        const int leader = __ffsll((long long)mask) - 1;
+        if (lane == leader) { base = atomicAdd(&p.counters[kCtrShadowCount + (parity ^ 1)], (unsigned int)__popcll(mask)); }
+        base = __shfl(base, leader);
+        if (shadow.push) {
+            const unsigned int index = base + (unsigned int)__popcll(mask & ((1ull << lane) - 1ull));
+            p.state.shO[index] = make_float4(shadow.origin.x, shadow.origin.y, shadow.origin.z, shadow.tfar);
+            p.state.shD[index] = make_float4(shadow.direction.x, shadow.direction.y, shadow.direction.z, intAsFloat(slot));
+        }
+    }
+}
+
+}  // namespace pathed

@@ -1,0 +1,789 @@
+// libpathed_hip.so — implementation of include/pathed_hip.h.
+// Host side: scene flattening (BVH, shading records, light table, env CDFs), upload,
+// the wavefront iteration loop, HIP-event timing and statistics.
+#include "pathed_hip.h"
+
+#include "bvh_build.h"
+#include "kernels.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace pathed;
+
+namespace {
+
+thread_local std::string g_error;
+int g_device = -1;
+
+int fail(int code, const std::string &message)
+{
+    g_error = message;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t status_ = (expr);                                                       \
+        if (status_ != hipSuccess) {                                                       \
+            return fail(PATHED_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(status_)); \
+        }                                                                                  \
+    } while (0)
+
+template <typename T>
+struct DeviceBuffer {
+    T *ptr = nullptr;
+    size_t count = 0;
+
+    hipError_t allocate(size_t n)
+    {
+        release();
+        count = n;
+        if (n == 0) { return hipSuccess; }
+        return hipMalloc((void **)&ptr, n * sizeof(T));
+    }
+
+    hipError_t upload(const std::vector<T> &host)
+    {
+        hipError_t status = allocate(host.size());
+        if (status != hipSuccess || host.empty()) { return status; }
+        return hipMemcpy(ptr, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice);
+    }
+
+    void release()
+    {
+        if (ptr) { (void)hipFree(ptr); }
+        ptr = nullptr;
+        count = 0;
+    }
+};
+
+struct EventRing {
+    static const int kPairs = 512;
+    hipEvent_t start[kPairs];
+    hipEvent_t stop[kPairs];
+    bool used[kPairs];
+    int next = 0;
+    bool created = false;
+    double totalMs = 0.0;
+    unsigned long long launches = 0;
+
+    hipError_t create()
+    {
+        if (created) { return hipSuccess; }
+        for (int i = 0; i < kPairs; i++) {
+            hipError_t status = hipEventCreate(&start[i]);
+            if (status != hipSuccess) { return status; }
+            status = hipEventCreate(&stop[i]);
+            if (status != hipSuccess) { return status; }
+            used[i] = false;
+        }
+        created = true;
+        return hipSuccess;
+    }
+
+    void harvest(int i)
+    {
+        if (!used[i]) { return; }
+        float ms = 0.f;
+        (void)hipEventSynchronize(stop[i]);
+        if (hipEventElapsedTime(&ms, start[i], stop[i]) == hipSuccess) {
+            totalMs += ms;
+            launches++;
+        }
+        used[i] = false;
+    }
+
+    int acquire()
+    {
+        const int i = next;
+        next = (next + 1) % kPairs;
+        harvest(i);
+        used[i] = true;
+        return i;
+    }
+
+    void harvestAll()
+    {
+        if (!created) { return; }
+        for (int i = 0; i < kPairs; i++) { harvest(i); }
+    }
+
+    void destroy()
+    {
+        if (!created) { return; }
+        for (int i = 0; i < kPairs; i++) {
+            (void)hipEventDestroy(start[i]);
+            (void)hipEventDestroy(stop[i]);
+        }
+        created = false;
+    }
+};
+
+}  // namespace
+
+struct PathedScene {
+    DScene device;
+    int width = 0, height = 0;
+
+    // host copies kept for export / introspection
+    FlatBvh bvh;
+
+    DeviceBuffer<float4> nodes, leafTris, triShade, envRgba;
+    DeviceBuffer<DSphere> spheres;
+    DeviceBuffer<DMaterial> materials;
+    DeviceBuffer<DLight> lights;
+    DeviceBuffer<float> thetaCdf, phiCdf;
+    DeviceBuffer<int> phiEmpty;
+
+    // render state, allocated on first use
+    int nSlots = 0, nSlotsPadded = 0;
+    DeviceBuffer<float4> rayO, rayD, hit, mod, thr, res, pend, shO, shD;
+    DeviceBuffer<unsigned int> counters;
+    DeviceBuffer<unsigned long long> stats;
+    unsigned int *hostRemaining = nullptr;  // pinned
+
+    int stackDepth = 8;
+    bool sceneInLds = false;
+    size_t traceLdsBytes = 0;
+    int traceGrid = 0;
+    int computeUnits = 256;
+
+    bool countMode = false;
+    bool timeKernels = false;
+    EventRing traceEvents, shadeEvents;
+    unsigned long long iterations = 0;
+    unsigned long long cameraSamples = 0;
+
+    ~PathedScene()
+    {
+        nodes.release(); leafTris.release(); triShade.release(); envRgba.release();
+        spheres.release(); materials.release(); lights.release();
+        thetaCdf.release(); phiCdf.release(); phiEmpty.release();
+        rayO.release(); rayD.release(); hit.release(); mod.release(); thr.release();
+        res.release(); pend.release(); shO.release(); shD.release();
+        counters.release(); stats.release();
+        if (hostRemaining) { (void)hipHostFree(hostRemaining); }
+        traceEvents.destroy();
+        shadeEvents.destroy();
+    }
+};
+
+namespace {
+
+V3 hv(const float *p) { return v3(p[0], p[1], p[2]); }
+
+// lookAt, reference src/transform.cpp:138-164
+void buildCamera(const PathedCamera &desc, DCamera *camera)
+{
+    const V3 source = hv(desc.origin);
+    const V3 target = hv(desc.target);
+    const V3 up = hv(desc.up);
+
+    const V3 direction = normalized(source - target);
+    const V3 xAxis = normalized(cross(normalized(up), direction));
+    const V3 yAxis = cross(direction, xAxis);
+    const float sign = desc.flip_handedness ? -1.f : 1.f;
+
+    camera->m[0] = sign * xAxis.x; camera->m[1] = yAxis.x; camera->m[2] = direction.x;
+    camera->m[3] = sign * xAxis.y; camera->m[4] = yAxis.y; camera->m[5] = direction.y;
+    camera->m[6] = sign * xAxis.z; camera->m[7] = yAxis.z; camera->m[8] = direction.z;
+    camera->origin[0] = source.x; camera->origin[1] = source.y; camera->origin[2] = source.z;
+
+    // src/camera.cpp:34-35
+    const float zNear = 0.01f;
+    camera->filmHeight = 2 * tanf(desc.vertical_fov / 2) * zNear;
+    camera->filmWidth = camera->filmHeight * desc.width / desc.height;
+    camera->resX = desc.width;
+    camera->resY = desc.height;
+}
+
+DMaterial buildMaterial(const PathedMaterial &m)
+{
+    DMaterial out;
+    std::memset(&out, 0, sizeof out);
+    out.type = m.type;
+    out.albedoType = m.albedo_type;
+    // OrenNayar ctor, reference src/oren_nayar.cpp:11-18
+    const float sigma2 = m.sigma * m.sigma;
+    out.orenA = 1.f - (sigma2 / (2.f * (sigma2 + 0.33f)));
+    out.orenB = (0.45f * sigma2) / (sigma2 + 0.09f);
+    for (int i = 0; i < 3; i++) {
+        out.diffuse[i] = m.diffuse[i];
+        // only Lambertian carries emission through the reference's parser
+        // (src/scene_parser.cpp:574-667: every other ctor passes Color(0))
+        out.emit[i] = (m.type == PATHED_MAT_LAMBERTIAN) ? m.emit[i] : 0.f;
+        out.checkerOn[i] = m.checker_on[i];
+        out.checkerOff[i] = m.checker_off[i];
+    }
+    out.alpha = m.alpha;
+    out.ior = m.ior;
+    out.checkerResU = m.checker_res[0];
+    out.checkerResV = m.checker_res[1];
+    return out;
+}
+
+bool emits(const DMaterial &m) { return !(m.emit[0] == 0.f && m.emit[1] == 0.f && m.emit[2] == 0.f); }
+
+// Distribution ctor, reference src/distribution.cpp:6-33 (sequential float accumulation)
+bool buildCdf(const float *values, size_t size, float *cdf)
+{
+    float sum = 0.f;
+    for (size_t i = 0; i < size; i++) { sum += values[i]; cdf[i] = 0.f; }
+    if (sum == 0.f) { return true; }  // empty
+    for (size_t i = 0; i < size; i++) {
+        cdf[i] = values[i] / sum;
+        if (i > 0) { cdf[i] += cdf[i - 1]; }
+    }
+    cdf[size - 1] = 1.f;
+    return false;
+}
+
+int validate(const PathedSceneDesc *desc)
+{
+    if (!desc) { return fail(PATHED_E_INVALID, "scene description is null"); }
+    if (desc->abi_version != PATHED_ABI_VERSION) { return fail(PATHED_E_INVALID, "abi_version mismatch"); }
+    if (desc->camera.width <= 0 || desc->camera.height <= 0) { return fail(PATHED_E_INVALID, "camera resolution must be positive"); }
+    if ((uint64_t)desc->camera.width * (uint64_t)desc->camera.height > (1ull << 28)) { return fail(PATHED_E_INVALID, "image too large"); }
+    if (desc->n_triangles && (!desc->positions || !desc->indices || !desc->tri_material || !desc->normals || !desc->uvs)) {
+        return fail(PATHED_E_INVALID, "triangle arrays missing");
+    }
+    if (desc->n_spheres && !desc->spheres) { return fail(PATHED_E_INVALID, "sphere array missing"); }
+    if (desc->n_geoms && !desc->geoms) { return fail(PATHED_E_INVALID, "geom array missing"); }
+    if (desc->n_materials == 0 || !desc->materials) { return fail(PATHED_E_INVALID, "scene needs at least one material"); }
+    for (uint32_t i = 0; i < desc->n_triangles; i++) {
+        for (int k = 0; k < 3; k++) {
+            if (desc->indices[3 * i + k] >= desc->n_vertices) { return fail(PATHED_E_INVALID, "vertex index out of range"); }
+        }
+        if (desc->tri_material[i] < 0 || (uint32_t)desc->tri_material[i] >= desc->n_materials) {
+            return fail(PATHED_E_INVALID, "triangle material index out of range");
+        }
+    }
+    for (uint32_t i = 0; i < desc->n_spheres; i++) {
+        if (desc->spheres[i].material < 0 || (uint32_t)desc->spheres[i].material >= desc->n_materials) {
+            return fail(PATHED_E_INVALID, "sphere material index out of range");
+        }
+    }
+    for (uint32_t i = 0; i < desc->n_materials; i++) {
+        const int type = desc->materials[i].type;
+        if (type < PATHED_MAT_LAMBERTIAN || type > PATHED_MAT_MIRROR) { return fail(PATHED_E_UNSUPPORTED, "unknown material type"); }
+        if ((type == PATHED_MAT_MICROFACET || type == PATHED_MAT_PLASTIC) && desc->materials[i].distribution != PATHED_DIST_BECKMANN) {
+            return fail(PATHED_E_UNSUPPORTED, "only the Beckmann distribution is in scope");
+        }
+    }
+    for (uint32_t i = 0; i < desc->n_geoms; i++) {
+        const PathedGeom &geom = desc->geoms[i];
+        if (geom.type == PATHED_GEOM_MESH) {
+            if (geom.first < 0 || geom.count < 0 || (uint64_t)geom.first + (uint64_t)geom.count > desc->n_triangles) {
+                return fail(PATHED_E_INVALID, "mesh geom range out of bounds");
+            }
+        } else if (geom.type == PATHED_GEOM_SPHERE) {
+            if (geom.first < 0 || (uint32_t)geom.first >= desc->n_spheres) { return fail(PATHED_E_INVALID, "sphere geom out of bounds"); }
+        } else {
+            return fail(PATHED_E_INVALID, "unknown geom type");
+        }
+    }
+    if (desc->env) {
+        if (desc->env->width <= 0 || desc->env->height <= 0 || !desc->env->rgba) { return fail(PATHED_E_INVALID, "environment map missing"); }
+    }
+    return PATHED_OK;
+}
+
+int ensureRenderState(PathedScene *scene)
+{
+    const int nSlots = scene->width * scene->height;
+    if (scene->nSlots == nSlots && scene->rayO.ptr) { return PATHED_OK; }
+    scene->nSlots = nSlots;
+    scene->nSlotsPadded = (nSlots + 63) / 64 * 64;
+    const size_t n = (size_t)scene->nSlotsPadded;
+    HIP_TRY(scene->rayO.allocate(n));
+    HIP_TRY(scene->rayD.allocate(n));
+    HIP_TRY(scene->hit.allocate(n));
+    HIP_TRY(scene->mod.allocate(n));
+    HIP_TRY(scene->thr.allocate(n));
+    HIP_TRY(scene->res.allocate(n));
+    HIP_TRY(scene->pend.allocate(n));
+    HIP_TRY(scene->shO.allocate(n));
+    HIP_TRY(scene->shD.allocate(n));
+    HIP_TRY(scene->counters.allocate(kCtrCount));
+    if (!scene->stats.ptr) {
+        HIP_TRY(scene->stats.allocate(kStatCount));
+        HIP_TRY(hipMemset(scene->stats.ptr, 0, kStatCount * sizeof(unsigned long long)));
+    }
+    if (!scene->hostRemaining) {
+        HIP_TRY(hipHostMalloc((void **)&scene->hostRemaining, 64 * sizeof(unsigned int), hipHostMallocDefault));
+    }
+    return PATHED_OK;
+}
+
+template <int STACK>
+void launchTraceStack(PathedScene *scene, const RenderParams &params, hipStream_t stream)
+{
+    const dim3 grid((unsigned)scene->traceGrid), block(kBlock);
+    const size_t lds = scene->traceLdsBytes;
+    if (scene->sceneInLds) {
+        if (scene->countMode) { hipLaunchKernelGGL((k_trace<STACK, true, true>), grid, block, lds, stream, params); }
+        else { hipLaunchKernelGGL((k_trace<STACK, true, false>), grid, block, lds, stream, params); }
+    } else {
+        if (scene->countMode) { hipLaunchKernelGGL((k_trace<STACK, false, true>), grid, block, lds, stream, params); }
+        else { hipLaunchKernelGGL((k_trace<STACK, false, false>), grid, block, lds, stream, params); }
+    }
+}
+
+void launchTrace(PathedScene *scene, const RenderParams &params, hipStream_t stream)
+{
+    switch (scene->stackDepth) {
+    case 8: launchTraceStack<8>(scene, params, stream); break;
+    case 16: launchTraceStack<16>(scene, params, stream); break;
+    case 32: launchTraceStack<32>(scene, params, stream); break;
+    default: launchTraceStack<64>(scene, params, stream); break;
+    }
+}
+
+void launchShade(PathedScene *scene, const RenderParams &params, hipStream_t stream)
+{
+    const dim3 grid((unsigned)((scene->nSlots + kBlock - 1) / kBlock)), block(kBlock);
+    if (scene->device.nMaterials <= kMaxLdsMaterials) {
+        hipLaunchKernelGGL((k_shade<true>), grid, block, 0, stream, params);
+    } else {
+        hipLaunchKernelGGL((k_shade<false>), grid, block, 0, stream, params);
+    }
+}
+
+void configureTrace(PathedScene *scene)
+{
+    const int depth = scene->bvh.maxDepth + 1;
+    scene->stackDepth = depth <= 8 ? 8 : depth <= 16 ? 16 : depth <= 32 ? 32 : 64;
+
+    const size_t stackBytes = (size_t)scene->stackDepth * kBlock * sizeof(int);
+    const size_t sceneBytes = (size_t)scene->device.nNodes * 64 + (size_t)scene->device.nTris * 48;
+    // stage the BVH in LDS when it is small enough to leave >= 4 blocks per CU
+    scene->sceneInLds = scene->device.nNodes > 0 && (stackBytes + sceneBytes) <= 36 * 1024;
+    scene->traceLdsBytes = stackBytes + (scene->sceneInLds ? sceneBytes : 0);
+
+    int blocksPerCu = (int)((160 * 1024) / (scene->traceLdsBytes ? scene->traceLdsBytes : 1));
+    if (blocksPerCu > 8) { blocksPerCu = 8; }
+    if (blocksPerCu < 1) { blocksPerCu = 1; }
+    scene->traceGrid = scene->computeUnits * blocksPerCu;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *pathed_hip_last_error(void) { return g_error.c_str(); }
+
+const char *pathed_hip_version(void) { return "pathed_hip 0.1.0 (gfx950, abi 1)"; }
+
+int pathed_hip_init(int device_id)
+{
+    int count = 0;
+    hipError_t status = hipGetDeviceCount(&count);
+    if (status != hipSuccess || count == 0) {
+        return fail(PATHED_E_NO_DEVICE, std::string("no HIP device: ") + hipGetErrorString(status));
+    }
+    if (device_id < 0 || device_id >= count) { return fail(PATHED_E_INVALID, "device id out of range"); }
+    HIP_TRY(hipSetDevice(device_id));
+    g_device = device_id;
+    return PATHED_OK;
+}
+
+int pathed_hip_scene_create(const PathedSceneDesc *desc, PathedScene **out)
+{
+    if (!out) { return fail(PATHED_E_INVALID, "out pointer is null"); }
+    *out = nullptr;
+    int code = validate(desc);
+    if (code != PATHED_OK) { return code; }
+    if (g_device < 0) {
+        code = pathed_hip_init(0);
+        if (code != PATHED_OK) { return code; }
+    }
+
+    PathedScene *scene = new PathedScene();
+    std::memset(&scene->device, 0, sizeof scene->device);
+    scene->width = desc->camera.width;
+    scene->height = desc->camera.height;
+
+    hipDeviceProp_t properties;
+    if (hipGetDeviceProperties(&properties, g_device) == hipSuccess) {
+        scene->computeUnits = properties.multiProcessorCount > 0 ? properties.multiProcessorCount : 256;
+    }
+
+    DScene &d = scene->device;
+    buildCamera(desc->camera, &d.camera);
+
+    // materials
+    std::vector<DMaterial> materials(desc->n_materials);
+    for (uint32_t i = 0; i < desc->n_materials; i++) { materials[i] = buildMaterial(desc->materials[i]); }
+
+    // per-triangle shading records, original primitive order
+    std::vector<float4> triShade((size_t)kTriShadeQuads * desc->n_triangles);
+    for (uint32_t i = 0; i < desc->n_triangles; i++) {
+        const uint32_t i0 = desc->indices[3 * i + 0], i1 = desc->indices[3 * i + 1], i2 = desc->indices[3 * i + 2];
+        const float *p0 = desc->positions + 3 * i0, *p1 = desc->positions + 3 * i1, *p2 = desc->positions + 3 * i2;
+        const float *n0 = desc->normals + 3 * i0, *n1 = desc->normals + 3 * i1, *n2 = desc->normals + 3 * i2;
+        const float *t0 = desc->uvs + 2 * i0, *t1 = desc->uvs + 2 * i1, *t2 = desc->uvs + 2 * i2;
+        float4 *q = triShade.data() + (size_t)kTriShadeQuads * i;
+        int material = desc->tri_material[i];
+        float materialBits;
+        std::memcpy(&materialBits, &material, 4);
+        q[0] = make_float4(p0[0], p0[1], p0[2], materialBits);
+        q[1] = make_float4(p1[0], p1[1], p1[2], t0[0]);
+        q[2] = make_float4(p2[0], p2[1], p2[2], t0[1]);
+        q[3] = make_float4(n0[0], n0[1], n0[2], t1[0]);
+        q[4] = make_float4(n1[0], n1[1], n1[2], t1[1]);
+        q[5] = make_float4(n2[0], n2[1], n2[2], t2[0]);
+        q[6] = make_float4(t2[1], 0.f, 0.f, 0.f);
+        q[7] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+
+    std::vector<DSphere> spheres(desc->n_spheres);
+    for (uint32_t i = 0; i < desc->n_spheres; i++) {
+        const PathedSphere &s = desc->spheres[i];
+        for (int k = 0; k < 3; k++) {
+            spheres[i].centerWorld[k] = s.center_world[k];
+            spheres[i].centerSample[k] = s.center_sample[k];
+        }
+        spheres[i].radius = s.radius;
+        spheres[i].material = s.material;
+    }
+
+    // lights: emissive surfaces in model order, environment light last
+    // (reference src/scene_parser.cpp:173-190)
+    std::vector<DLight> lights;
+    for (uint32_t g = 0; g < desc->n_geoms; g++) {
+        const PathedGeom &geom = desc->geoms[g];
+        if (geom.type == PATHED_GEOM_MESH) {
+            for (int i = 0; i < geom.count; i++) {
+                const int tri = geom.first + i;
+                if (emits(materials[(size_t)desc->tri_material[tri]])) { lights.push_back({ 0, tri }); }
+            }
+        } else if (emits(materials[(size_t)desc->spheres[geom.first].material])) {
+            lights.push_back({ 1, geom.first });
+        }
+    }
+
+    // environment light: EnvironmentLight ctor, reference src/environment_light.cpp:14-53
+    std::vector<float4> envRgba;
+    std::vector<float> thetaCdf, phiCdf;
+    std::vector<int> phiEmpty;
+    if (desc->env) {
+        const PathedEnvLight &env = *desc->env;
+        const size_t texels = (size_t)env.width * env.height;
+        envRgba.resize(texels);
+        std::vector<float> luminance(texels, 0.f);
+        for (size_t i = 0; i < texels; i++) {
+            envRgba[i] = make_float4(env.rgba[4 * i], env.rgba[4 * i + 1], env.rgba[4 * i + 2], env.rgba[4 * i + 3]);
+            luminance[i] += env.rgba[4 * i + 0];
+            luminance[i] += env.rgba[4 * i + 1];
+            luminance[i] += env.rgba[4 * i + 2];
+        }
+        thetaCdf.resize((size_t)env.height);
+        phiCdf.resize(texels);
+        phiEmpty.resize((size_t)env.height);
+        std::vector<float> thetaData((size_t)env.height, 0.f);
+        for (int row = 0; row < env.height; row++) {
+            float thetaSum = 0.f;
+            for (int col = 0; col < env.width; col++) { thetaSum += luminance[(size_t)row * env.width + col]; }
+            phiEmpty[(size_t)row] = buildCdf(&luminance[(size_t)row * env.width], (size_t)env.width, &phiCdf[(size_t)row * env.width]) ? 1 : 0;
+            thetaData[(size_t)row] = thetaSum;
+        }
+        d.env.thetaEmpty = buildCdf(thetaData.data(), (size_t)env.height, thetaCdf.data()) ? 1 : 0;
+        d.env.width = env.width;
+        d.env.height = env.height;
+        d.env.scale = env.scale;
+        for (int r = 0; r < 3; r++) {
+            for (int c = 0; c < 3; c++) {
+                d.env.mapToWorld[3 * r + c] = env.map_to_world[4 * r + c];
+                d.env.worldToMap[3 * r + c] = env.world_to_map[4 * r + c];
+            }
+        }
+        d.hasEnv = 1;
+        lights.push_back({ 2, 0 });
+    }
+
+    scene->bvh = buildBvh(desc->positions, desc->indices, desc->n_triangles);
+
+    auto fail_cleanup = [&](hipError_t status, const char *what) {
+        delete scene;
+        return fail(PATHED_E_DEVICE, std::string(what) + ": " + hipGetErrorString(status));
+    };
+
+    hipError_t status;
+    {
+        std::vector<float4> nodes(scene->bvh.nodes.size() / 4), tris(scene->bvh.leafTris.size() / 4);
+        std::memcpy(nodes.data(), scene->bvh.nodes.data(), scene->bvh.nodes.size() * sizeof(float));
+        std::memcpy(tris.data(), scene->bvh.leafTris.data(), scene->bvh.leafTris.size() * sizeof(float));
+        if ((status = scene->nodes.upload(nodes)) != hipSuccess) { return fail_cleanup(status, "upload nodes"); }
+        if ((status = scene->leafTris.upload(tris)) != hipSuccess) { return fail_cleanup(status, "upload triangles"); }
+    }
+    if ((status = scene->triShade.upload(triShade)) != hipSuccess) { return fail_cleanup(status, "upload shading records"); }
+    if ((status = scene->spheres.upload(spheres)) != hipSuccess) { return fail_cleanup(status, "upload spheres"); }
+    if ((status = scene->materials.upload(materials)) != hipSuccess) { return fail_cleanup(status, "upload materials"); }
+    if ((status = scene->lights.upload(lights)) != hipSuccess) { return fail_cleanup(status, "upload lights"); }
+    if ((status = scene->envRgba.upload(envRgba)) != hipSuccess) { return fail_cleanup(status, "upload env map"); }
+    if ((status = scene->thetaCdf.upload(thetaCdf)) != hipSuccess) { return fail_cleanup(status, "upload env cdf"); }
+    if ((status = scene->phiCdf.upload(phiCdf)) != hipSuccess) { return fail_cleanup(status, "upload env cdf"); }
+    if ((status = scene->phiEmpty.upload(phiEmpty)) != hipSuccess) { return fail_cleanup(status, "upload env cdf"); }
+
+    d.nodes = scene->nodes.ptr;
+    d.leafTris = scene->leafTris.ptr;
+    d.nNodes = scene->bvh.nodeCount;
+    d.nTris = (int)desc->n_triangles;
+    d.spheres = scene->spheres.ptr;
+    d.nSpheres = (int)desc->n_spheres;
+    d.triShade = scene->triShade.ptr;
+    d.materials = scene->materials.ptr;
+    d.nMaterials = (int)desc->n_materials;
+    d.lights = scene->lights.ptr;
+    d.nLights = (int)lights.size();
+    d.env.rgba = scene->envRgba.ptr;
+    d.env.thetaCdf = scene->thetaCdf.ptr;
+    d.env.phiCdf = scene->phiCdf.ptr;
+    d.env.phiEmpty = scene->phiEmpty.ptr;
+
+    configureTrace(scene);
+    *out = scene;
+    return PATHED_OK;
+}
+
+void pathed_hip_scene_destroy(PathedScene *scene)
+{
+    delete scene;
+}
+
+int pathed_hip_render_device(PathedScene *scene, uint64_t seed,
+                             uint32_t spp_begin, uint32_t spp_count,
+                             int start_bounce, int last_bounce,
+                             float *d_accum_rgb_sum, void *stream_handle, int blocking)
+{
+    (void)blocking;  // the iteration loop polls a device counter, so the call always completes
+    if (!scene || !d_accum_rgb_sum) { return fail(PATHED_E_INVALID, "null scene or accumulation buffer"); }
+    if (start_bounce < 0 || (last_bounce != -1 && start_bounce > last_bounce)) {
+        return fail(PATHED_E_INVALID, "bounce window: need 0 <= startBounce <= lastBounce (or lastBounce == -1)");
+    }
+    if (spp_count == 0) { return PATHED_OK; }
+    if ((uint64_t)spp_begin + spp_count > 0x7fffffffull) { return fail(PATHED_E_INVALID, "sample index overflow"); }
+
+    int code = ensureRenderState(scene);
+    if (code != PATHED_OK) { return code; }
+    if (scene->timeKernels) {
+        HIP_TRY(scene->traceEvents.create());
+        HIP_TRY(scene->shadeEvents.create());
+    }
+
+    hipStream_t stream = (hipStream_t)stream_handle;
+
+    RenderParams params;
+    params.scene = scene->device;
+    params.state.rayO = scene->rayO.ptr;
+    params.state.rayD = scene->rayD.ptr;
+    params.state.hit = scene->hit.ptr;
+    params.state.mod = scene->mod.ptr;
+    params.state.thr = scene->thr.ptr;
+    params.state.res = scene->res.ptr;
+    params.state.pend = scene->pend.ptr;
+    params.state.shO = scene->shO.ptr;
+    params.state.shD = scene->shD.ptr;
+    params.counters = scene->counters.ptr;
+    params.stats = scene->stats.ptr;
+    params.accum = d_accum_rgb_sum;
+    params.nSlots = scene->nSlots;
+    params.nSlotsPadded = scene->nSlotsPadded;
+    params.seedLo = (uint32_t)seed;
+    params.seedHi = (uint32_t)(seed >> 32);
+    params.sppBegin = spp_begin;
+    params.sppEnd = spp_begin + spp_count;
+    params.startBounce = start_bounce;
+    params.lastBounce = last_bounce;
+    params.parity = 0;
+
+    const dim3 slotGrid((unsigned)((scene->nSlots + kBlock - 1) / kBlock)), block(kBlock);
+    hipLaunchKernelGGL(k_init, slotGrid, block, 0, stream, params);
+
+    // Iterate until every slot has rendered its samples.  `remaining` is polled with a
+    // lag of one chunk so the GPU never waits for the host.
+    const int chunk = 8;
+    const int ringSize = 64;
+    hipEvent_t pollEvents[2];
+    HIP_TRY(hipEventCreateWithFlags(&pollEvents[0], hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&pollEvents[1], hipEventDisableTiming));
+    unsigned long long iteration = 0;
+    int pollIndex = 0;
+    bool havePending = false;
+    bool done = false;
+    while (!done) {
+        for (int k = 0; k < chunk; k++) {
+            params.parity = (int)(iteration & 1);
+            if (scene->timeKernels) {
+                const int e = scene->traceEvents.acquire();
+                (void)hipEventRecord(scene->traceEvents.start[e], stream);
+                launchTrace(scene, params, stream);
+                (void)hipEventRecord(scene->traceEvents.stop[e], stream);
+                const int s = scene->shadeEvents.acquire();
+                (void)hipEventRecord(scene->shadeEvents.start[s], stream);
+                launchShade(scene, params, stream);
+                (void)hipEventRecord(scene->shadeEvents.stop[s], stream);
+            } else {
+                launchTrace(scene, params, stream);
+                launchShade(scene, params, stream);
+            }
+            iteration++;
+        }
+        const int slotIndex = pollIndex % ringSize;
+        HIP_TRY(hipMemcpyAsync(scene->hostRemaining + slotIndex, scene->counters.ptr + kCtrRemaining,
+                               sizeof(unsigned int), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipEventRecord(pollEvents[pollIndex & 1], stream));
+        if (havePending) {
+            const int previous = pollIndex - 1;
+            HIP_TRY(hipEventSynchronize(pollEvents[previous & 1]));
+            if (scene->hostRemaining[previous % ringSize] == 0) { done = true; }
+        }
+        havePending = true;
+        pollIndex++;
+    }
+    HIP_TRY(hipStreamSynchronize(stream));
+    (void)hipEventDestroy(pollEvents[0]);
+    (void)hipEventDestroy(pollEvents[1]);
+    HIP_TRY(hipGetLastError());
+
+    scene->iterations += iteration;
+    scene->cameraSamples += (unsigned long long)spp_count * (unsigned long long)scene->nSlots;
+    if (scene->timeKernels) {
+        scene->traceEvents.harvestAll();
+        scene->shadeEvents.harvestAll();
+    }
+    return PATHED_OK;
+}
+
+int pathed_hip_render(PathedScene *scene, uint64_t seed,
+                      uint32_t spp_begin, uint32_t spp_count,
+                      int start_bounce, int last_bounce,
+                      float *accum_rgb_sum)
+{
+    if (!scene || !accum_rgb_sum) { return fail(PATHED_E_INVALID, "null scene or accumulation buffer"); }
+    const size_t count = (size_t)3 * scene->width * scene->height;
+    float *deviceAccum = nullptr;
+    HIP_TRY(hipMalloc((void **)&deviceAccum, count * sizeof(float)));
+    hipError_t status = hipMemset(deviceAccum, 0, count * sizeof(float));
+    if (status != hipSuccess) { (void)hipFree(deviceAccum); return fail(PATHED_E_DEVICE, hipGetErrorString(status)); }
+
+    const int code = pathed_hip_render_device(scene, seed, spp_begin, spp_count, start_bounce, last_bounce, deviceAccum, nullptr, 1);
+    if (code != PATHED_OK) { (void)hipFree(deviceAccum); return code; }
+
+    std::vector<float> host(count);
+    status = hipMemcpy(host.data(), deviceAccum, count * sizeof(float), hipMemcpyDeviceToHost);
+    (void)hipFree(deviceAccum);
+    if (status != hipSuccess) { return fail(PATHED_E_DEVICE, hipGetErrorString(status)); }
+    for (size_t i = 0; i < count; i++) { accum_rgb_sum[i] += host[i]; }
+    return PATHED_OK;
+}
+
+int pathed_hip_trace(PathedScene *scene, const float *rays, size_t n, int any_hit, void *hits)
+{
+    if (!scene) { return fail(PATHED_E_INVALID, "null scene"); }
+    if (n == 0) { return PATHED_OK; }
+    if (!rays || !hits) { return fail(PATHED_E_INVALID, "null ray or hit buffer"); }
+    if (n > (size_t)1 << 28) { return fail(PATHED_E_INVALID, "too many rays in one call"); }
+
+    float4 *deviceRays = nullptr;
+    float4 *deviceHits = nullptr;
+    int *deviceOccluded = nullptr;
+    HIP_TRY(hipMalloc((void **)&deviceRays, n * 2 * sizeof(float4)));
+    hipError_t status = hipMemcpy(deviceRays, rays, n * 8 * sizeof(float), hipMemcpyHostToDevice);
+    if (status == hipSuccess) {
+        status = any_hit ? hipMalloc((void **)&deviceOccluded, n * sizeof(int)) : hipMalloc((void **)&deviceHits, n * sizeof(float4));
+    }
+    if (status == hipSuccess) {
+        const dim3 grid((unsigned)((n + kBlock - 1) / kBlock)), block(kBlock);
+        const size_t lds = (size_t)scene->stackDepth * kBlock * sizeof(int);
+        switch (scene->stackDepth) {
+        case 8: hipLaunchKernelGGL((k_trace_rays<8>), grid, block, lds, 0, scene->device, deviceRays, (int)n, any_hit, deviceHits, deviceOccluded); break;
+        case 16: hipLaunchKernelGGL((k_trace_rays<16>), grid, block, lds, 0, scene->device, deviceRays, (int)n, any_hit, deviceHits, deviceOccluded); break;
+        case 32: hipLaunchKernelGGL((k_trace_rays<32>), grid, block, lds, 0, scene->device, deviceRays, (int)n, any_hit, deviceHits, deviceOccluded); break;
+        default: hipLaunchKernelGGL((k_trace_rays<64>), grid, block, lds, 0, scene->device, deviceRays, (int)n, any_hit, deviceHits, deviceOccluded); break;
+        }
+        status = hipDeviceSynchronize();
+    }
+    if (status == hipSuccess) {
+        status = any_hit
+            ? hipMemcpy(hits, deviceOccluded, n * sizeof(int), hipMemcpyDeviceToHost)
+            : hipMemcpy(hits, deviceHits, n * sizeof(float4), hipMemcpyDeviceToHost);
+    }
+    (void)hipFree(deviceRays);
+    if (deviceHits) { (void)hipFree(deviceHits); }
+    if (deviceOccluded) { (void)hipFree(deviceOccluded); }
+    if (status != hipSuccess) { return fail(PATHED_E_DEVICE, hipGetErrorString(status)); }
+    return PATHED_OK;
+}
+
+int pathed_hip_set_stats_mode(PathedScene *scene, int enabled)
+{
+    if (!scene) { return fail(PATHED_E_INVALID, "null scene"); }
+    scene->countMode = (enabled & 1) != 0;   // bit 0: count child boxes / triangles tested
+    scene->timeKernels = (enabled & 2) != 0; // bit 1: HIP-event timing of every trace / shade launch
+    return PATHED_OK;
+}
+
+int pathed_hip_reset_stats(PathedScene *scene)
+{
+    if (!scene) { return fail(PATHED_E_INVALID, "null scene"); }
+    if (scene->stats.ptr) { HIP_TRY(hipMemset(scene->stats.ptr, 0, kStatCount * sizeof(unsigned long long))); }
+    scene->iterations = 0;
+    scene->cameraSamples = 0;
+    scene->traceEvents.totalMs = 0.0;
+    scene->traceEvents.launches = 0;
+    scene->shadeEvents.totalMs = 0.0;
+    scene->shadeEvents.launches = 0;
+    return PATHED_OK;
+}
+
+int pathed_hip_get_stats(PathedScene *scene, PathedStats *out)
+{
+    if (!scene || !out) { return fail(PATHED_E_INVALID, "null argument"); }
+    std::memset(out, 0, sizeof *out);
+    unsigned long long device[kStatCount] = { 0 };
+    if (scene->stats.ptr) {
+        HIP_TRY(hipMemcpy(device, scene->stats.ptr, sizeof device, hipMemcpyDeviceToHost));
+    }
+    out->camera_samples = scene->cameraSamples;
+    out->closest_rays = device[kStatClosest];
+    out->shadow_rays = device[kStatShadow];
+    out->nodes_visited = device[kStatBoxes];
+    out->tris_tested = device[kStatTris];
+    out->dropped_samples = device[kStatDropped];
+    out->iterations = scene->iterations;
+    out->trace_ms = scene->traceEvents.totalMs;
+    out->shade_ms = scene->shadeEvents.totalMs;
+    out->trace_launches = scene->traceEvents.launches;
+    out->bvh_nodes = (uint64_t)scene->bvh.nodeCount;
+    out->bvh_bytes = (uint64_t)scene->bvh.nodeCount * 64 + (uint64_t)scene->device.nTris * 48;
+    out->bvh_max_depth = (uint32_t)scene->bvh.maxDepth;
+    out->scene_in_lds = scene->sceneInLds ? 1u : 0u;
+    return PATHED_OK;
+}
+
+int pathed_hip_scene_export_bvh(PathedScene *scene, float *nodes, size_t *n_nodes, float *tris, size_t *n_tris)
+{
+    if (!scene || !n_nodes || !n_tris) { return fail(PATHED_E_INVALID, "null argument"); }
+    const size_t nodeCount = (size_t)scene->bvh.nodeCount;
+    const size_t triCount = scene->bvh.leafTris.size() / 12;
+    if (nodes) {
+        if (*n_nodes < nodeCount) { return fail(PATHED_E_INVALID, "node buffer too small"); }
+        std::memcpy(nodes, scene->bvh.nodes.data(), nodeCount * 16 * sizeof(float));
+    }
+    if (tris) {
+        if (*n_tris < triCount) { return fail(PATHED_E_INVALID, "triangle buffer too small"); }
+        std::memcpy(tris, scene->bvh.leafTris.data(), triCount * 12 * sizeof(float));
+    }
+    *n_nodes = nodeCount;
+    *n_tris = triCount;
+    return PATHED_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,781 @@
+// Device shading library: frames, samplers, BSDFs, light sampling, environment map.
+//
+// Each function states the reference code it follows (chellmuth/pathed, file:line).
+// Arithmetic keeps the reference's operation order in fp32; the few expressions the
+// reference evaluates in double because M_PI is a double constant are evaluated in
+// fp32 (DESIGN.md "Arithmetic contract").  Branch structure is written for a SIMT
+// wave: short bodies are predicated, material dispatch is a switch the caller can
+// make wave-uniform by sorting.
+#pragma once
+
+#include "device_scene.h"
+
+namespace pathed {
+
+#define PATHED_INV_PI 0.3183098861837907f   /* include/util.h:10 */
+#define PATHED_PI 3.14159265358979323846f   /* M_PI narrowed to fp32 */
+#define PATHED_TWO_PI 6.283185307179586f    /* include/util.h:11 */
+
+// ---------------------------------------------------------------------------- rng
+// Counter-based stream u(seed, pixel, sample, dimension); replaces the reference's
+// shared, unseedable mt19937 (src/random_generator.cpp:4-6).  Two bijective 32-bit
+// mixers keyed by pixel and sample, so no two (pixel, sample) pairs share a stream.
+
+__host__ __device__ inline uint32_t mix32(uint32_t x)
+{
+    x ^= x >> 16; x *= 0x7feb352du;
+    x ^= x >> 15; x *= 0x846ca68bu;
+    x ^= x >> 16;
+    return x;
+}
+
+struct Rng {
+    uint32_t k0, k1;
+    uint32_t dimension;
+
+    __device__ inline float next()
+    {
+        const uint32_t bits = mix32(k0 + mix32(k1 + dimension * 0x9e3779b9u));
+        dimension++;
+        // 24 bits scaled into [0, 1 - 2^-23): the range of the reference generator
+        return (float)(bits >> 8) * 5.9604638e-08f;
+    }
+};
+
+__host__ __device__ inline void makeKey(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t *k0, uint32_t *k1)
+{
+    *k0 = mix32(pixel ^ mix32((uint32_t)seed));
+    *k1 = mix32(sample ^ mix32((uint32_t)(seed >> 32) ^ 0x9e3779b9u));
+}
+
+// dimension layout: [0,1] pixel jitter (X first, src/camera.cpp:51-52);
+// vertex k >= 1 owns 8 dimensions from 2 + 8(k-1): +0..2 BSDF, +3 light choice, +4,+5 light
+__device__ inline uint32_t vertexBase(int vertex) { return 2u + 8u * (uint32_t)(vertex - 1); }
+
+// ------------------------------------------------------------------------- frames
+
+struct Frame {
+    V3 xAxis, normal, zAxis;  // columns of tangentToWorld
+};
+
+// src/transform.cpp:201-219
+__device__ inline Frame normalToWorldSpace1(V3 normal)
+{
+    V3 xAxis;
+    if (fabsf(normal.x) > fabsf(normal.y)) {
+        xAxis = normalized(v3(-normal.z, 0.f, normal.x));
+    } else {
+        xAxis = normalized(v3(0.f, -normal.z, normal.y));
+    }
+    Frame frame;
+    frame.xAxis = xAxis;
+    frame.normal = normal;
+    frame.zAxis = cross(normal, xAxis);
+    return frame;
+}
+
+// src/transform.cpp:182-199
+__device__ inline Frame normalToWorldSpace(V3 normal, V3 rayDirection)
+{
+    if (normal == rayDirection) { return normalToWorldSpace1(normal); }
+    Frame frame;
+    frame.xAxis = normalized(cross(normal, rayDirection));
+    frame.normal = normal;
+    frame.zAxis = normalized(cross(normal, frame.xAxis));
+    return frame;
+}
+
+// Transform::apply(Vector3), src/transform.cpp:90-102, rows (x.i, n.i, z.i)
+__device__ inline V3 toWorld(const Frame &f, V3 l)
+{
+    return v3(
+        f.xAxis.x * l.x + f.normal.x * l.y + f.zAxis.x * l.z,
+        f.xAxis.y * l.x + f.normal.y * l.y + f.zAxis.y * l.z,
+        f.xAxis.z * l.x + f.normal.z * l.y + f.zAxis.z * l.z);
+}
+
+__device__ inline V3 toLocal(const Frame &f, V3 w)
+{
+    return v3(
+        f.xAxis.x * w.x + f.xAxis.y * w.y + f.xAxis.z * w.z,
+        f.normal.x * w.x + f.normal.y * w.y + f.normal.z * w.z,
+        f.zAxis.x * w.x + f.zAxis.y * w.y + f.zAxis.z * w.z);
+}
+
+// include/intersection.h:13-56 (hit only; the kernels never build a miss record)
+struct Isect {
+    V3 point;
+    V3 wo;
+    V3 normal;
+    V3 shadingNormal;
+    float u, v;
+    int material;
+    int prim;
+    Frame frame;
+};
+
+// ---------------------------------------------------- tangent-frame trigonometry
+// include/tangent_frame.h:12-107, include/trig.h
+
+__device__ inline float tfCos2Theta(V3 v) { return v.y * v.y; }
+__device__ inline float tfSinTheta(V3 v) { return sqrtf(smax(0.f, 1.f - tfCos2Theta(v))); }
+__device__ inline float tfSin2Theta(V3 v) { return 1.f - tfCos2Theta(v); }
+__device__ inline float tfTanTheta(V3 v) { return tfSinTheta(v) / v.y; }
+__device__ inline float tfTan2Theta(V3 v) { return tfSin2Theta(v) / tfCos2Theta(v); }
+
+__device__ inline V3 tfClamp(V3 v)
+{
+    const float max = 0.9999f;
+    if (v.x >= max) { return v3(1.f, 0.f, 0.f); }
+    if (v.y >= max) { return v3(0.f, 1.f, 0.f); }
+    if (v.z >= max) { return v3(0.f, 0.f, 1.f); }
+    if (v.x <= -max) { return v3(-1.f, 0.f, 0.f); }
+    if (v.y <= -max) { return v3(0.f, -1.f, 0.f); }
+    if (v.z <= -max) { return v3(0.f, 0.f, -1.f); }
+    return v;
+}
+
+__device__ inline float tfCosPhi(V3 v)
+{
+    const float sinTheta = tfSinTheta(v);
+    if (sinTheta == 0.f) { return 1.f; }
+    return clampf(v.x / sinTheta, -1.f, 1.f);
+}
+
+__device__ inline float tfSinPhi(V3 v)
+{
+    const V3 clamped = tfClamp(v);
+    const float sinTheta = tfSinTheta(clamped);
+    if (sinTheta == 0.f) { return 0.f; }
+    return clampf(clamped.z / sinTheta, -1.f, 1.f);
+}
+
+__device__ inline float tfCos2Phi(V3 v) { const float c = tfCosPhi(v); return c * c; }
+__device__ inline float tfSin2Phi(V3 v) { const float s = tfSinPhi(v); return s * s; }
+
+__device__ inline float sinFromCos(float cosTheta)
+{
+    const float sin2Theta = 1.f - (cosTheta * cosTheta);
+    return sqrtf(smax(0.f, sin2Theta));
+}
+
+// ----------------------------------------------------------------------- samplers
+
+// src/monte_carlo.cpp:24-41
+__device__ inline V3 cosineSampleHemisphere(Rng &random)
+{
+    const float xi1 = random.next();
+    const float r = sqrtf(xi1);
+    const float phi = PATHED_TWO_PI * random.next();
+    const float x = r * cosf(phi);
+    const float z = r * sinf(phi);
+    const float y = sqrtf(1.f - xi1);
+    return v3(x, y, z);
+}
+
+__device__ inline float cosineHemispherePdf(V3 v) { return v.y * PATHED_INV_PI; }
+
+// src/coordinate.cpp:7-18
+__device__ inline void cartesianToSpherical(V3 cartesian, float *phi, float *theta)
+{
+    float p = atan2f(cartesian.z, cartesian.x);
+    if (p < 0.f) { p += PATHED_TWO_PI; }
+    if (p == PATHED_TWO_PI) { p = 0.f; }
+    *phi = p;
+    *theta = acosf(clampf(cartesian.y, -1.f, 1.f));
+}
+
+// src/coordinate.cpp:25-32
+__device__ inline V3 sphericalToCartesian(float phi, float cosTheta, float sinTheta)
+{
+    const float y = cosTheta;
+    const float x = sinTheta * cosf(phi);
+    const float z = sinTheta * sinf(phi);
+    return v3(x, y, z);
+}
+
+// ---------------------------------------------------------------- fresnel / snell
+
+// src/fresnel.cpp:30-64, src/snell.cpp:51-57
+__device__ inline float dielectricReflectance(float cosThetaIncident, float etaIncident, float etaTransmitted)
+{
+    const float sinThetaTransmitted =
+        (etaIncident / etaTransmitted) * sqrtf(smax(0.f, 1.f - cosThetaIncident * cosThetaIncident));
+    if (sinThetaTransmitted > 1.f) { return 1.f; }
+
+    const float cosThetaTransmitted = sqrtf(smax(0.f, 1.f - sinThetaTransmitted * sinThetaTransmitted));
+
+    const float rParallel =
+        (etaTransmitted * cosThetaIncident - etaIncident * cosThetaTransmitted)
+        / (etaTransmitted * cosThetaIncident + etaIncident * cosThetaTransmitted);
+    const float rPerpendicular =
+        (etaIncident * cosThetaIncident - etaTransmitted * cosThetaTransmitted)
+        / (etaIncident * cosThetaIncident + etaTransmitted * cosThetaTransmitted);
+
+    return 0.5f * (rParallel * rParallel + rPerpendicular * rPerpendicular);
+}
+
+// src/snell.cpp:9-37
+__device__ inline bool snellRefract(V3 incidentLocal, V3 *transmittedLocal, float etaIncident, float etaTransmitted)
+{
+    V3 normal = v3(0.f, 1.f, 0.f);
+    if (incidentLocal.y < 0.f) { normal = normal * -1.f; }
+
+    const V3 wIncidentPerpendicular = incidentLocal - (normal * dot(incidentLocal, normal));
+    const V3 wTransmittedPerpendicular = -wIncidentPerpendicular * (etaIncident / etaTransmitted);
+
+    const float perpendicularLength = length(wTransmittedPerpendicular);
+    const float transmittedPerpendicularLength2 = perpendicularLength * perpendicularLength;
+    const float wTransmittedParallelLength = sqrtf(smax(0.f, 1.f - transmittedPerpendicularLength2));
+    const V3 wTransmittedParallel = normal * -wTransmittedParallelLength;
+
+    const float cosThetaIncident = incidentLocal.y;
+    const float sin2ThetaIncident = smax(0.f, 1.f - (cosThetaIncident * cosThetaIncident));
+    const float eta2 = (etaIncident / etaTransmitted) * (etaIncident / etaTransmitted);
+    const float sin2ThetaTransmitted = eta2 * sin2ThetaIncident;
+
+    *transmittedLocal = normalized(wTransmittedParallel + wTransmittedPerpendicular);
+
+    return !(sin2ThetaTransmitted >= 1.f);
+}
+
+// ---------------------------------------------------------------------- materials
+
+struct BSDFSample {
+    V3 wiWorld;
+    float pdf;
+    Rgb throughput;
+};
+
+__device__ inline Rgb matDiffuse(const DMaterial &m) { return rgb(m.diffuse[0], m.diffuse[1], m.diffuse[2]); }
+__device__ inline Rgb matEmit(const DMaterial &m) { return rgb(m.emit[0], m.emit[1], m.emit[2]); }
+
+__device__ inline bool isDelta(const DMaterial &m)
+{
+    return m.type == PATHED_MAT_GLASS || m.type == PATHED_MAT_MIRROR;
+}
+
+// src/checkerboard.cpp:9-20
+__device__ inline Rgb checkerboardLookup(const DMaterial &m, const Isect &isect)
+{
+    const int uIndex = (int)floorf(isect.u * m.checkerResU);
+    const int vIndex = (int)floorf(isect.v * m.checkerResV);
+    if (uIndex % 2 == vIndex % 2) { return rgb(m.checkerOn[0], m.checkerOn[1], m.checkerOn[2]); }
+    return rgb(m.checkerOff[0], m.checkerOff[1], m.checkerOff[2]);
+}
+
+// src/lambertian.cpp:16-40
+__device__ inline Rgb lambertianF(const DMaterial &m, const Isect &isect, V3 wiWorld, float *pdf)
+{
+    if (dot(isect.wo, isect.shadingNormal) < 0.f) { *pdf = 0.f; return rgb(0.f); }
+    if (dot(wiWorld, isect.shadingNormal) < 0.f) { *pdf = 0.f; return rgb(0.f); }
+
+    const V3 wi = normalized(toLocal(isect.frame, wiWorld));
+    *pdf = cosineHemispherePdf(wi);
+
+    if (m.albedoType == PATHED_ALBEDO_CHECKERBOARD) { return checkerboardLookup(m, isect) / PATHED_PI; }
+    return matDiffuse(m) / PATHED_PI;
+}
+
+// src/lambertian.cpp:42-58
+__device__ inline BSDFSample lambertianSample(const DMaterial &m, const Isect &isect, Rng &random)
+{
+    const V3 localSample = cosineSampleHemisphere(random);
+    const V3 worldSample = toWorld(isect.frame, localSample);
+    BSDFSample sample;
+    sample.wiWorld = worldSample;
+    sample.pdf = cosineHemispherePdf(localSample);
+    float ignored;
+    sample.throughput = lambertianF(m, isect, worldSample, &ignored);
+    return sample;
+}
+
+// src/oren_nayar.cpp:20-67 (pdf = 1, not 0, on the rejected configurations)
+__device__ inline Rgb orenNayarF(const DMaterial &m, const Isect &isect, V3 wiWorld, float *pdf)
+{
+    if (dot(isect.normal, isect.wo) < 0.f) { *pdf = 1.f; return rgb(0.f); }
+    if (dot(isect.shadingNormal, isect.wo) < 0.f) { *pdf = 1.f; return rgb(0.f); }
+
+    const V3 localWo = normalized(toLocal(isect.frame, isect.wo));
+    const V3 localWi = normalized(toLocal(isect.frame, wiWorld));
+
+    if (localWo.y < 0.f) { *pdf = 1.f; return rgb(0.f); }
+    if (localWi.y < 0.f) { *pdf = 1.f; return rgb(0.f); }
+
+    float phiI, thetaI, phiO, thetaO;
+    cartesianToSpherical(localWi, &phiI, &thetaI);
+    cartesianToSpherical(localWo, &phiO, &thetaO);
+
+    const float alpha = smax(thetaI, thetaO);
+    const float beta = smin(thetaI, thetaO);
+
+    *pdf = cosineHemispherePdf(localWi);
+
+    const float throughput = PATHED_INV_PI * (
+        m.orenA
+        + m.orenB * smax(0.f, cosf(phiI - phiO))
+            * sinf(alpha)
+            * tanf(beta));
+
+    return matDiffuse(m) * throughput;
+}
+
+// src/oren_nayar.cpp:69-85
+__device__ inline BSDFSample orenNayarSample(const DMaterial &m, const Isect &isect, Rng &random)
+{
+    const V3 localSample = cosineSampleHemisphere(random);
+    const V3 worldSample = toWorld(isect.frame, localSample);
+    BSDFSample sample;
+    sample.wiWorld = worldSample;
+    sample.pdf = cosineHemispherePdf(localSample);
+    float ignored;
+    sample.throughput = orenNayarF(m, isect, worldSample, &ignored);
+    return sample;
+}
+
+// src/beckmann.cpp:50-69, including the TangentFrame::clamp asymmetry between cosPhi
+// and sinPhi (include/tangent_frame.h:79-102), which changes D near the pole
+__device__ inline float beckmannD(float alpha, V3 wh)
+{
+    const float tan2Theta = tfTan2Theta(wh);
+    if (isinf(tan2Theta)) { return 0.f; }
+
+    const float cos2Theta = tfCos2Theta(wh);
+    const float cos4Theta = cos2Theta * cos2Theta;
+    const float alpha2 = alpha * alpha;
+
+    const float numerator = expf(
+        -tan2Theta * (
+            (tfCos2Phi(wh) / alpha2)
+            + (tfSin2Phi(wh) / alpha2)));
+    const float denominator = PATHED_PI * alpha2 * cos4Theta;
+
+    return numerator / denominator;
+}
+
+// src/beckmann.cpp:45-48
+__device__ inline float beckmannPdf(float alpha, V3 wh) { return beckmannD(alpha, wh) * fabsf(wh.y); }
+
+// src/beckmann.cpp:71-86
+__device__ inline float beckmannLambda(float alphaX, float alphaY, V3 w)
+{
+    const float absTanTheta = fabsf(tfTanTheta(w));
+    if (isinf(absTanTheta)) { return 0.f; }
+
+    const float alpha = sqrtf(tfCos2Phi(w) * alphaX * alphaX + tfSin2Phi(w) * alphaY * alphaY);
+    const float a = 1.f / (alpha * absTanTheta);
+    if (a >= 1.6f) { return 0.f; }
+
+    return (1 - 1.259f * a + 0.396f * a * a) / (3.535f * a + 2.181f * a * a);
+}
+
+// src/beckmann.cpp:88-94
+__device__ inline float beckmannG(float alpha, V3 wo, V3 wi)
+{
+    return 1.f / (1.f + beckmannLambda(alpha, alpha, wo) + beckmannLambda(alpha, alpha, wi));
+}
+
+// src/beckmann.cpp:13-43: phi is drawn first, then the tan^2 variate
+__device__ inline V3 beckmannSampleWh(float alpha, Rng &random)
+{
+    const float phi = random.next() * PATHED_PI * 2.f;
+
+    const float xi = random.next();
+    float logXi = logf(xi);
+    if (isinf(logXi)) { logXi = 0.f; }
+    const float tan2Theta = -alpha * alpha * logXi;
+
+    const float cosTheta = 1.f / sqrtf(1.f + tan2Theta);
+    const float sinTheta = sinFromCos(cosTheta);
+    return sphericalToCartesian(phi, cosTheta, sinTheta);
+}
+
+// src/microfacet.cpp:12-57 (Fresnel eta hard-coded to 1.5 at :41)
+__device__ inline Rgb microfacetF(const DMaterial &m, const Isect &isect, V3 wiWorld, float *pdf)
+{
+    const V3 wo = normalized(toLocal(isect.frame, isect.wo));
+    const V3 wi = normalized(toLocal(isect.frame, wiWorld));
+
+    if (dot(isect.wo, isect.shadingNormal) < 0.f) { *pdf = 0.f; return rgb(0.f); }
+    if (dot(wiWorld, isect.shadingNormal) < 0.f) { *pdf = 0.f; return rgb(0.f); }
+
+    const float cosThetaO = fabsf(wo.y);
+    const float cosThetaI = fabsf(wi.y);
+    const V3 wh = normalized(wo + wi);
+
+    *pdf = beckmannPdf(m.alpha, wh) / (4.f * dot(wo, wh));
+
+    if (cosThetaO == 0.f || cosThetaI == 0.f) { return rgb(0.f); }
+    if (wh.x == 0.f && wh.y == 0.f && wh.z == 0.f) { return rgb(0.f); }
+
+    const float cosThetaIncident = clampf(dot(wi, wh), 0.f, 1.f);
+    const float fresnel = dielectricReflectance(cosThetaIncident, 1.f, 1.5f);
+    const float distribution = beckmannD(m.alpha, wh);
+    const float masking = beckmannG(m.alpha, wo, wi);
+    const Rgb albedo = rgb(1.f);
+
+    return albedo * distribution * masking * fresnel / (4 * cosThetaI * cosThetaO);
+}
+
+// src/microfacet.cpp:59-78
+__device__ inline BSDFSample microfacetSample(const DMaterial &m, const Isect &isect, Rng &random)
+{
+    const V3 wo = toLocal(isect.frame, isect.wo);
+    const V3 wh = beckmannSampleWh(m.alpha, random);
+    const V3 wi = reflect(wo, wh);
+    const V3 wiWorld = toWorld(isect.frame, wi);
+
+    BSDFSample sample;
+    sample.wiWorld = wiWorld;
+    sample.pdf = beckmannPdf(m.alpha, wh) / (4.f * dot(wo, wh));
+    float ignored;
+    sample.throughput = microfacetF(m, isect, wiWorld, &ignored);
+    return sample;
+}
+
+// src/plastic.cpp:19-33
+__device__ inline Rgb plasticF(const DMaterial &m, const Isect &isect, V3 wiWorld, float *pdf)
+{
+    float lambertianPDF, microfacetPDF;
+    const Rgb f = lambertianF(m, isect, wiWorld, &lambertianPDF) + microfacetF(m, isect, wiWorld, &microfacetPDF);
+    *pdf = (lambertianPDF + microfacetPDF) / 2.f;
+    return f;
+}
+
+// src/plastic.cpp:35-66
+__device__ inline BSDFSample plasticSample(const DMaterial &m, const Isect &isect, Rng &random)
+{
+    const float xi = random.next();
+    BSDFSample sample;
+    float otherPDF;
+    Rgb otherThroughput;
+    if (xi > 0.5f) {
+        sample = lambertianSample(m, isect, random);
+        otherThroughput = microfacetF(m, isect, sample.wiWorld, &otherPDF);
+    } else {
+        sample = microfacetSample(m, isect, random);
+        otherThroughput = lambertianF(m, isect, sample.wiWorld, &otherPDF);
+    }
+    BSDFSample out;
+    out.wiWorld = sample.wiWorld;
+    out.pdf = (sample.pdf + otherPDF) / 2.f;
+    out.throughput = sample.throughput + otherThroughput;
+    return out;
+}
+
+// src/glass.cpp:30-85.  Where the reference exit(1)s (refraction branch taken although
+// Snell::refract reported total internal reflection — a rounding corner) the direction
+// refract() produced is used.
+__device__ inline BSDFSample glassSample(const DMaterial &m, const Isect &isect, Rng &random)
+{
+    const V3 localWo = toLocal(isect.frame, isect.wo);
+    V3 localWi = v3(0.f, 0.f, 0.f);
+
+    float etaIncident = 1.f;
+    float etaTransmitted = m.ior;
+    if (localWo.y < 0.f) {
+        const float swap = etaIncident;
+        etaIncident = etaTransmitted;
+        etaTransmitted = swap;
+    }
+
+    snellRefract(localWo, &localWi, etaIncident, etaTransmitted);
+
+    const float fresnelReflectance = dielectricReflectance(fabsf(localWo.y), etaIncident, etaTransmitted);
+
+    BSDFSample sample;
+    if (random.next() < fresnelReflectance) {
+        localWi = reflect(localWo, v3(0.f, 1.f, 0.f));
+        sample.wiWorld = toWorld(isect.frame, localWi);
+        sample.pdf = fresnelReflectance;
+        sample.throughput = rgb(fresnelReflectance / fabsf(localWi.y));
+    } else {
+        const float fresnelTransmittance = 1.f - fresnelReflectance;
+        sample.wiWorld = toWorld(isect.frame, localWi);
+        sample.pdf = fresnelTransmittance;
+        sample.throughput = rgb(fresnelTransmittance / fabsf(localWi.y));
+    }
+    return sample;
+}
+
+// src/mirror.cpp:21-37
+__device__ inline BSDFSample mirrorSample(const Isect &isect)
+{
+    const V3 localWo = toLocal(isect.frame, isect.wo);
+    const V3 localWi = reflect(localWo, v3(0.f, 1.f, 0.f));
+    BSDFSample sample;
+    sample.wiWorld = toWorld(isect.frame, localWi);
+    sample.pdf = 1.f;
+    sample.throughput = rgb(smax(0.f, 1.f / localWi.y));
+    return sample;
+}
+
+__device__ inline Rgb materialF(const DMaterial &m, const Isect &isect, V3 wiWorld, float *pdf)
+{
+    switch (m.type) {
+    case PATHED_MAT_LAMBERTIAN: return lambertianF(m, isect, wiWorld, pdf);
+    case PATHED_MAT_OREN_NAYAR: return orenNayarF(m, isect, wiWorld, pdf);
+    case PATHED_MAT_MICROFACET: return microfacetF(m, isect, wiWorld, pdf);
+    case PATHED_MAT_PLASTIC: return plasticF(m, isect, wiWorld, pdf);
+    default: *pdf = 0.f; return rgb(0.f);  // src/glass.cpp:20-28, src/mirror.cpp:11-19
+    }
+}
+
+__device__ inline BSDFSample materialSample(const DMaterial &m, const Isect &isect, Rng &random)
+{
+    switch (m.type) {
+    case PATHED_MAT_LAMBERTIAN: return lambertianSample(m, isect, random);
+    case PATHED_MAT_OREN_NAYAR: return orenNayarSample(m, isect, random);
+    case PATHED_MAT_MICROFACET: return microfacetSample(m, isect, random);
+    case PATHED_MAT_PLASTIC: return plasticSample(m, isect, random);
+    case PATHED_MAT_GLASS: return glassSample(m, isect, random);
+    default: return mirrorSample(isect);
+    }
+}
+
+// ------------------------------------------------------------------------- shapes
+
+struct SurfaceSample {
+    V3 point;
+    V3 normal;
+    float invPDF;
+    int solidAngle;  // Measure::SolidAngle (1) or Measure::Area (0)
+};
+
+// src/triangle.cpp:64-71
+__device__ inline float triangleArea(V3 p0, V3 p1, V3 p2)
+{
+    const V3 e1 = p1 - p0;
+    const V3 e2 = p2 - p0;
+    return fabsf(length(cross(e1, e2)) / 2.f);
+}
+
+// src/triangle.cpp:16-38
+__device__ inline SurfaceSample triangleSample(V3 p0, V3 p1, V3 p2, Rng &random)
+{
+    const float r1 = random.next();
+    const float r2 = random.next();
+
+    const float a = 1.f - sqrtf(r1);
+    const float b = sqrtf(r1) * (1.f - r2);
+    const float c = 1.f - a - b;
+
+    SurfaceSample sample;
+    sample.point = p0 * a + p1 * b + p2 * c;
+    sample.normal = normalized(cross(p1 - p0, p2 - p0));
+    sample.invPDF = triangleArea(p0, p1, p2);
+    sample.solidAngle = 0;
+    return sample;
+}
+
+// include/measure.h:13-28
+__device__ inline float areaToSolidAngle(float areaPDF, V3 referencePoint, V3 surfacePoint, V3 surfaceNormal)
+{
+    const V3 surfaceDirection = referencePoint - surfacePoint;
+    const V3 surfaceWo = normalized(surfaceDirection);
+    const float distance = length(surfaceDirection);
+    const float distance2 = distance * distance;
+    const float projectedArea = smax(0.f, dot(surfaceNormal, surfaceWo));
+    return areaPDF * distance2 / projectedArea;
+}
+
+// src/triangle.cpp:48-62
+__device__ inline float trianglePdfSolidAngle(V3 p0, V3 p1, V3 p2, V3 point, V3 referencePoint)
+{
+    const float areaPDF = 1.f / triangleArea(p0, p1, p2);
+    const V3 normal = normalized(cross(p1 - p0, p2 - p0));
+    return areaToSolidAngle(areaPDF, referencePoint, point, normal);
+}
+
+__device__ inline float uniformConePdf(float cosThetaMax)
+{
+    return 1.f / (2.f * PATHED_PI * (1.f - cosThetaMax));
+}
+
+// src/sphere.cpp:54-70
+__device__ inline SurfaceSample sphereSampleArea(V3 center, float radius, Rng &random)
+{
+    const float z = 1 - 2 * random.next();
+    const float r = sqrtf(fmaxf(0, 1 - z * z));
+    const float phi = 2 * PATHED_PI * random.next();
+    const V3 v = v3(r * cosf(phi), r * sinf(phi), z);
+
+    SurfaceSample sample;
+    sample.point = center + v * radius;
+    sample.normal = normalized(v);
+    sample.invPDF = 4 * PATHED_PI * radius * radius;
+    sample.solidAngle = 0;
+    return sample;
+}
+
+// src/sphere.cpp:77-128 (samples about the UNTRANSFORMED centre, as the reference does)
+__device__ inline SurfaceSample sphereSample(V3 center, float radius, V3 referencePoint, Rng &random)
+{
+    const float centerDistance = length(center - referencePoint);
+    const float centerDistance2 = centerDistance * centerDistance;
+    if (centerDistance <= radius) { return sphereSampleArea(center, radius, random); }
+
+    const float radius2 = radius * radius;
+    const float sin2ThetaMax = radius * radius / centerDistance2;
+    const float cosThetaMax = sqrtf(smax(0.f, 1.f - sin2ThetaMax));
+
+    const float xi1 = random.next();
+    const float cosTheta = (1.f - xi1) + xi1 * cosThetaMax;
+    const float phi = random.next() * 2.f * PATHED_PI;
+
+    const float sinTheta = sinFromCos(cosTheta);
+    const float sideOppositeTheta = centerDistance * sinTheta;
+    const float sideHelper = sqrtf(smax(0.f, radius * radius - sideOppositeTheta * sideOppositeTheta));
+    const float sampleDistance = centerDistance * cosTheta - sideHelper;
+    const float sampleDistance2 = sampleDistance * sampleDistance;
+
+    const float cosAlpha = clampf(
+        (centerDistance2 + radius2 - sampleDistance2) / (2.f * radius * centerDistance),
+        0.f, 1.f);
+    const float sinAlpha = sinFromCos(cosAlpha);
+
+    const V3 localSample = sphericalToCartesian(phi, cosAlpha, sinAlpha);
+    const Frame localToWorld = normalToWorldSpace1(normalized(referencePoint - center));
+    const V3 worldSample = normalized(toWorld(localToWorld, localSample));
+
+    SurfaceSample sample;
+    sample.point = center + worldSample * radius;
+    sample.normal = normalized(worldSample);
+    sample.invPDF = 1.f / uniformConePdf(cosThetaMax);
+    sample.solidAngle = 1;
+    return sample;
+}
+
+// src/sphere.cpp:130-147 (inside the sphere the reference returns the AREA pdf)
+__device__ inline float spherePdfSolidAngle(V3 center, float radius, V3 referencePoint)
+{
+    const float centerDistance = length(center - referencePoint);
+    const float centerDistance2 = centerDistance * centerDistance;
+    if (centerDistance <= radius) { return 1.f / (4 * PATHED_PI * radius * radius); }
+
+    const float sin2ThetaMax = radius * radius / centerDistance2;
+    const float cosThetaMax = sqrtf(smax(0.f, 1.f - sin2ThetaMax));
+    return uniformConePdf(cosThetaMax);
+}
+
+// -------------------------------------------------------------- environment light
+
+__device__ inline V3 apply3x3(const float *m, V3 v)
+{
+    return v3(
+        m[0] * v.x + m[1] * v.y + m[2] * v.z,
+        m[3] * v.x + m[4] * v.y + m[5] * v.z,
+        m[6] * v.x + m[7] * v.y + m[8] * v.z);
+}
+
+// Distribution::sample, src/distribution.cpp:35-53: the reference scans linearly for the
+// first i with xi <= cdf[i]; the CDF is non-decreasing, so a lower-bound binary search
+// returns the same i.
+__device__ inline int cdfSample(const float *cdf, int size, int empty, float xi, float *pdf)
+{
+    if (empty) { *pdf = 0.f; return 0; }
+    int lo = 0, hi = size - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (xi <= cdf[mid]) { hi = mid; } else { lo = mid + 1; }
+    }
+    if (!(xi <= cdf[lo])) { *pdf = 0.f; return size - 1; }
+    *pdf = (lo > 0) ? cdf[lo] - cdf[lo - 1] : cdf[lo];
+    return lo;
+}
+
+// Distribution::pdf, src/distribution.cpp:55-64
+__device__ inline float cdfPdf(const float *cdf, int empty, int index)
+{
+    if (empty) { return 0.f; }
+    if (index == 0) { return cdf[0]; }
+    return cdf[index] - cdf[index - 1];
+}
+
+// EnvironmentLight::emit(lightWo), src/environment_light.cpp:60-80
+__device__ inline Rgb envEmit(const DEnv &env, V3 lightWo)
+{
+    const V3 direction = -lightWo;
+    float phi, theta;
+    cartesianToSpherical(normalized(apply3x3(env.worldToMap, direction)), &phi, &theta);
+
+    const float phiCanonical = clampf(phi / PATHED_TWO_PI, 0.f, 1.f);
+    const float thetaCanonical = clampf(theta / PATHED_PI, 0.f, 1.f);
+
+    const int phiStep = imin((int)floorf(env.width * phiCanonical), env.width - 1);
+    const int thetaStep = imin((int)floorf(env.height * thetaCanonical), env.height - 1);
+
+    const float4 texel = env.rgba[(size_t)thetaStep * env.width + phiStep];
+    return rgb(texel.x, texel.y, texel.z) * env.scale;
+}
+
+// EnvironmentLight::sample, src/environment_light.cpp:82-105
+__device__ inline SurfaceSample envSample(const DEnv &env, V3 point, Rng &random)
+{
+    float thetaPDF, phiPDF;
+    const int thetaStep = cdfSample(env.thetaCdf, env.height, env.thetaEmpty, random.next(), &thetaPDF);
+    const int phiStep = cdfSample(
+        env.phiCdf + (size_t)thetaStep * env.width, env.width, env.phiEmpty[thetaStep], random.next(), &phiPDF);
+
+    const float phiCanonical = (phiStep + 0.5f) / env.width;
+    const float thetaCanonical = (thetaStep + 0.5f) / env.height;
+
+    const float phi = phiCanonical * PATHED_TWO_PI;
+    const float theta = thetaCanonical * PATHED_PI;
+
+    const float pdf = thetaPDF * phiPDF * env.width * env.height / (sinf(theta) * PATHED_TWO_PI * PATHED_PI);
+
+    const V3 direction = apply3x3(env.mapToWorld, sphericalToCartesian(phi, cosf(theta), sinf(theta)));
+
+    SurfaceSample out;
+    out.point = point + direction * 10000.f;
+    out.normal = direction * -1.f;
+    out.invPDF = 1.f / pdf;
+    out.solidAngle = 1;
+    return out;
+}
+
+// EnvironmentLight::emitPDF, src/environment_light.cpp:117-138
+__device__ inline float envEmitPDF(const DEnv &env, V3 direction)
+{
+    float phi, theta;
+    cartesianToSpherical(apply3x3(env.worldToMap, direction), &phi, &theta);
+
+    const float phiCanonical = phi / PATHED_TWO_PI;
+    const float thetaCanonical = theta / PATHED_PI;
+
+    const int phiStep = imin((int)floorf(phiCanonical * env.width), env.width - 1);
+    const int thetaStep = imin((int)floorf(thetaCanonical * env.height), env.height - 1);
+
+    const float thetaPDF = cdfPdf(env.thetaCdf, env.thetaEmpty, thetaStep);
+    const float phiPDF = cdfPdf(env.phiCdf + (size_t)thetaStep * env.width, env.phiEmpty[thetaStep], phiStep);
+
+    return thetaPDF * phiPDF * env.width * env.height / (sinf(theta) * PATHED_TWO_PI * PATHED_PI);
+}
+
+// ------------------------------------------------------------------------- camera
+
+// Camera::generateRay(float,float), src/camera.cpp:32-47 (film size precomputed on the host)
+__device__ inline void cameraRay(const DCamera &camera, float row, float col, V3 *origin, V3 *direction)
+{
+    const float zNear = 0.01f;
+    const float width = camera.filmWidth;
+    const float height = camera.filmHeight;
+
+    const V3 local = normalized(v3(
+        width * (col + 0.5f) / camera.resX - width / 2.f,
+        height * (row + 0.5f) / camera.resY - height / 2.f,
+        -zNear));
+
+    const float *m = camera.m;
+    *origin = v3(
+        m[0] * 0.f + m[1] * 0.f + m[2] * 0.f + camera.origin[0],
+        m[3] * 0.f + m[4] * 0.f + m[5] * 0.f + camera.origin[1],
+        m[6] * 0.f + m[7] * 0.f + m[8] * 0.f + camera.origin[2]);
+    *direction = v3(
+        m[0] * local.x + m[1] * local.y + m[2] * local.z,
+        m[3] * local.x + m[4] * local.y + m[5] * local.z,
+        m[6] * local.x + m[7] * local.y + m[8] * local.z);
+}
+
+}  // namespace pathed

@@ -1,0 +1,165 @@
+"""Python mirror of the reference's Integrator plug-in surface for the GPU path.
+
+Reference: include/integrator.h:16-55 (`Integrator::run(image, scene, callback, quit)`),
+src/integrator.cpp:19-106 (wave loop, sum -> mean, power-of-two checkpoints) and
+src/job.cpp:65-97 (the "integrator" string factory).  The C++ twin of this file is
+pathed_amd/host/integrator.{h,cpp}; both sit directly on include/pathed_hip.h.
+
+Everything computed here happens inside libpathed_hip.so; if that library (or a GPU)
+is missing the calls raise — there is no CPU fallback in the product path.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+
+
+class PathedError(RuntimeError):
+    pass
+
+
+def _check(lib, code, what):
+    if code != 0:
+        raise PathedError("%s failed (%d): %s" % (what, code, lib.pathed_hip_last_error().decode()))
+
+
+class HipScene:
+    """A scene uploaded to one GPU (PathedScene handle)."""
+
+    def __init__(self, desc_pointer, device=None):
+        self._lib = _capi.load_hip()
+        if device is not None:
+            _check(self._lib, self._lib.pathed_hip_init(int(device)), "pathed_hip_init")
+        handle = C.c_void_p()
+        _check(self._lib, self._lib.pathed_hip_scene_create(desc_pointer, C.byref(handle)), "pathed_hip_scene_create")
+        self._handle = handle
+        self.width = int(desc_pointer.contents.camera.width)
+        self.height = int(desc_pointer.contents.camera.height)
+
+    def close(self):
+        if getattr(self, "_handle", None):
+            self._lib.pathed_hip_scene_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def render(self, seed, spp_begin, spp_count, start_bounce, last_bounce, accum=None):
+        """radianceLookup += ... for samples [spp_begin, spp_begin+spp_count); host buffer (H, W, 3)."""
+        if accum is None:
+            accum = np.zeros((self.height, self.width, 3), dtype=np.float32)
+        assert accum.dtype == np.float32 and accum.flags["C_CONTIGUOUS"] and accum.size == 3 * self.width * self.height
+        code = self._lib.pathed_hip_render(
+            self._handle, C.c_uint64(seed), spp_begin, spp_count, start_bounce, last_bounce,
+            accum.ctypes.data_as(C.POINTER(C.c_float)))
+        _check(self._lib, code, "pathed_hip_render")
+        return accum
+
+    def render_device(self, seed, spp_begin, spp_count, start_bounce, last_bounce, device_pointer, stream=0):
+        """Same, into caller-owned device memory (e.g. tensor.data_ptr()) on `stream`."""
+        code = self._lib.pathed_hip_render_device(
+            self._handle, C.c_uint64(seed), spp_begin, spp_count, start_bounce, last_bounce,
+            C.c_void_p(device_pointer), C.c_void_p(stream), 1)
+        _check(self._lib, code, "pathed_hip_render_device")
+
+    def trace(self, rays, any_hit=False):
+        rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 8)
+        n = rays.shape[0]
+        out = np.zeros(n, dtype=np.int32) if any_hit else np.zeros((n, 4), dtype=np.float32)
+        code = self._lib.pathed_hip_trace(
+            self._handle, rays.ctypes.data_as(C.POINTER(C.c_float)), n, 1 if any_hit else 0,
+            out.ctypes.data_as(C.c_void_p))
+        _check(self._lib, code, "pathed_hip_trace")
+        return out
+
+    def set_stats_mode(self, count=False, time_kernels=False):
+        mode = (1 if count else 0) | (2 if time_kernels else 0)
+        _check(self._lib, self._lib.pathed_hip_set_stats_mode(self._handle, mode), "pathed_hip_set_stats_mode")
+
+    def reset_stats(self):
+        _check(self._lib, self._lib.pathed_hip_reset_stats(self._handle), "pathed_hip_reset_stats")
+
+    def stats(self):
+        stats = _capi.PathedStats()
+        _check(self._lib, self._lib.pathed_hip_get_stats(self._handle, C.byref(stats)), "pathed_hip_get_stats")
+        return {name: getattr(stats, name) for name, _ in _capi.PathedStats._fields_}
+
+    def export_bvh(self):
+        n_nodes, n_tris = C.c_size_t(0), C.c_size_t(0)
+        _check(self._lib, self._lib.pathed_hip_scene_export_bvh(self._handle, None, C.byref(n_nodes), None, C.byref(n_tris)),
+               "pathed_hip_scene_export_bvh")
+        nodes = np.zeros((n_nodes.value, 16), dtype=np.float32)
+        tris = np.zeros((n_tris.value, 12), dtype=np.float32)
+        _check(self._lib, self._lib.pathed_hip_scene_export_bvh(
+            self._handle, nodes.ctypes.data_as(C.POINTER(C.c_float)), C.byref(n_nodes),
+            tris.ctypes.data_as(C.POINTER(C.c_float)), C.byref(n_tris)), "pathed_hip_scene_export_bvh")
+        return nodes, tris
+
+
+class BounceController:
+    """reference src/bounce_controller.cpp:5-25"""
+
+    def __init__(self, start_bounce, last_bounce):
+        assert start_bounce >= 0
+        assert last_bounce == -1 or start_bounce <= last_bounce
+        self.start_bounce = start_bounce
+        self.last_bounce = last_bounce
+
+    def check_done(self, bounce):
+        if self.last_bounce == -1:
+            return False
+        return bounce > self.last_bounce
+
+    def check_counts(self, bounce):
+        if self.start_bounce > bounce:
+            return False
+        return not self.check_done(bounce)
+
+
+class PathTracer:
+    """GPU stand-in for the reference's PathTracer integrator.
+
+    `run(image, scene, callback, quit)` keeps the reference's contract: `image` receives
+    sum/(i+1) after every batch, checkpoints are reported at power-of-two sample counts.
+    Instead of one wave per call it renders `spp_per_launch` samples per launch (the
+    reference's PDFIntegrator also overrides run()).
+    """
+
+    def __init__(self, bounce_controller, spp=1, seed=1, spp_per_launch=64):
+        self.bounce_controller = bounce_controller
+        self.spp = spp
+        self.seed = seed
+        self.spp_per_launch = spp_per_launch
+
+    def run(self, image, scene, callback=None, quit_flag=None):
+        """image: float32 (H, W, 3) array that receives the running mean; scene: HipScene."""
+        radiance_lookup = np.zeros((scene.height, scene.width, 3), dtype=np.float32)
+        done = 0
+        while done < self.spp:
+            # stop at the next power of two so checkpoints land exactly where the reference writes them
+            next_power = 1
+            while next_power <= done:
+                next_power *= 2
+            count = min(self.spp_per_launch, self.spp - done, next_power - done)
+            scene.render(self.seed, done, count, self.bounce_controller.start_bounce,
+                         self.bounce_controller.last_bounce, radiance_lookup)
+            done += count
+            np.divide(radiance_lookup, np.float32(done), out=image)
+            if callback is not None:
+                callback(done, (done & (done - 1)) == 0)
+            if quit_flag is not None and quit_flag():
+                return
+        return image
+
+
+def integrator_from_job(job, **kwargs):
+    """reference Job::integrator(), src/job.cpp:65-97 — only the hot-path integrator exists here."""
+    name = job["integrator"]
+    if name in ("PathTracer", "DataParallelIntegrator"):
+        return PathTracer(BounceController(job["startBounce"], job["lastBounce"]),
+                          spp=job["spp"] if job["spp"] > 0 else 9999999, **kwargs)
+    raise PathedError("Unimplemented")
