@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Msamples/s of the GPU PathTracer on scenes/cornell.json, 1024x1024.
+
+A "step" renders `--spp-per-step` camera samples (default 64) for every pixel through the C ABI
+(pathed_hip_render_device) into a device-resident radiance-sum buffer; 64 steps are the
+4096-spp configuration BASELINE.json quotes.  With N ranks each rank renders its own,
+disjoint range of sample indices (weak scaling: per-GPU work is fixed) and the sums are
+reduced to rank 0 over RCCL once, inside the timed region.
+
+Prints ONE JSON line on rank 0 (contract in the task statement), including
+  roofline      algorithmic bytes of the BVH-traversal kernel / its HIP-event time
+  cpu_baseline  the CPU oracle (a port of the reference estimator; the reference binary
+                cannot be built) timed on the host cores, bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO_ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO_ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse_args():
+    parser = argparse.ArgumentParser()
+    parser.add_argument("--gpus", type=int, default=1)
+    parser.add_argument("--steps", type=int, default=64)
+    parser.add_argument("--warmup", type=int, default=2)
+    parser.add_argument("--spp-per-step", type=int, default=64)
+    parser.add_argument("--width", type=int, default=1024)
+    parser.add_argument("--height", type=int, default=1024)
+    parser.add_argument("--scene", default="scenes/cornell.json")
+    parser.add_argument("--last-bounce", type=int, default=10)
+    parser.add_argument("--seed", type=int, default=1)
+    parser.add_argument("--no-cpu-baseline", action="store_true")
+    parser.add_argument("--no-kernel-timing", action="store_true",
+                        help="skip the HIP-event timing of every trace launch (roofline.achieved becomes null)")
+    return parser.parse_args()
+
+
+def algorithmic_bytes(stats):
+    """per ray 32 B of ray + S_hit (16 closest / 4 any-hit) + 32 B per child box
+    tested + 48 B per leaf triangle tested."""
+    return (48 * stats["closest_rays"] + 36 * stats["shadow_rays"]
+            + 32 * stats["nodes_visited"] + 48 * stats["tris_tested"])
+
+
+def cpu_baseline(scene, args):
+    """Time the CPU oracle on the same workload at reduced spp (rate is spp-independent)."""
+    sys.path.insert(0, os.path.join(REPO_ROOT, "tests"))
+    import oracle_lib  # the checker; used here only as the reported CPU baseline
+
+    cores = os.cpu_count() or 1
+    oracle = oracle_lib.OracleScene(scene.desc)
+    t0 = time.perf_counter()
+    oracle.render(args.width, args.height, args.seed, 0, 1, 0, args.last_bounce, threads=cores)
+    one = time.perf_counter() - t0
+    spp = max(1, min(64, int(15.0 / max(one, 1e-3))))
+    t0 = time.perf_counter()
+    oracle.render(args.width, args.height, args.seed, 1, spp, 0, args.last_bounce, threads=cores)
+    elapsed = time.perf_counter() - t0
+    samples = args.width * args.height * spp
+    return {
+        "value": samples / elapsed / 1e6,
+        "unit": "Msamples/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": "%s %dx%d, %d spp, lastBounce %d, OpenMP over rows, %.1f s" % (
+            args.scene, args.width, args.height, spp, args.last_bounce, elapsed),
+    }
+
+
+def main():
+    args = parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world_size > 1
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    from pathed_amd.integrator import HipScene
+    from pathed_amd.scene import LoadedScene
+
+    scene = LoadedScene(args.scene, args.width, args.height)
+    gpu = HipScene(scene.desc, device=local_rank)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    accum = torch.zeros((args.height, args.width, 3), dtype=torch.float32, device="cuda")
+    spp = args.spp_per_step
+    # rank r owns sample indices [r * (W+K) * spp, (r+1) * (W+K) * spp): disjoint streams
+    base = rank * (args.warmup + args.steps) * spp
+
+    def step(index):
+        gpu.render_device(args.seed, base + index * spp, spp, 0, args.last_bounce, accum.data_ptr(), stream)
+
+    # one untimed, counting pass over the first step's samples: exact ray / box / triangle counts
+    per_step_stats = None
+    if rank == 0:
+        gpu.set_stats_mode(count=True)
+        gpu.reset_stats()
+        scratch = torch.zeros_like(accum)
+        gpu.render_device(args.seed, base + args.warmup * spp, spp, 0, args.last_bounce, scratch.data_ptr(), stream)
+        torch.cuda.synchronize()
+        per_step_stats = gpu.stats()
+        del scratch
+    gpu.set_stats_mode(count=False)
+
+    for index in range(args.warmup):
+        step(index)
+    accum.zero_()
+
+    gpu.set_stats_mode(count=False, time_kernels=not args.no_kernel_timing)
+    gpu.reset_stats()
+
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for index in range(args.steps):
+        step(args.warmup + index)
+    if distributed:
+        # the path's one exchange step: per-GPU radiance sums -> rank 0 (RCCL reduce over xGMI)
+        dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+
+    if distributed:
+        slowest = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(slowest, op=dist.ReduceOp.MAX)
+        elapsed = float(slowest.item())
+
+    timed_stats = gpu.stats()
+
+    if rank == 0:
+        samples_per_rank = args.width * args.height * spp * args.steps
+        total_samples = samples_per_rank * world_size
+        value = total_samples / elapsed / 1e6
+
+        roofline = None
+        if per_step_stats is not None:
+            bytes_per_step = algorithmic_bytes(per_step_stats)
+            launches = timed_stats["trace_launches"]
+            trace_ms = timed_stats["trace_ms"]
+            total_bytes = bytes_per_step * args.steps
+            achieved = (total_bytes / (trace_ms * 1e-3) / 1e9) if trace_ms > 0 else None
+            traffic = None
+            traffic_path = os.path.join(REPO_ROOT, "profiles", "hbm_traffic.json")
+            if os.path.exists(traffic_path):
+                with open(traffic_path) as handle:
+                    traffic = json.load(handle).get("trace_hbm_bytes_per_launch")
+            roofline = {
+                "bound": "hbm",
+                "kernel": "k_trace (BVH traversal + triangle/sphere intersect, closest + any-hit)",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
+                "traffic": traffic,
+                "algorithmic_bytes_per_launch": (total_bytes / launches) if launches else None,
+                "algorithmic_bytes_per_sample": bytes_per_step / (args.width * args.height * spp),
+                "avg_launch_ms": (trace_ms / launches) if launches else None,
+                "launches": launches,
+                "rays_per_sample": (per_step_stats["closest_rays"] + per_step_stats["shadow_rays"])
+                / (args.width * args.height * spp),
+                "bvh_resident": "LDS" if per_step_stats["scene_in_lds"] else "HBM",
+                "trace_ms_total": trace_ms,
+                "shade_ms_total": timed_stats["shade_ms"],
+            }
+
+        baseline = None
+        if not args.no_cpu_baseline:
+            baseline = cpu_baseline(scene, args)
+
+        mean = (accum / float(spp * args.steps * world_size)).mean(dim=(0, 1)).tolist()
+        line = {
+            "metric": "Msamples/s (pixels x spp / s), PathTracer radiance loop",
+            "value": value,
+            "unit": "Msamples/s",
+            "n_gpus": world_size,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic camera samples on scenes/cornell.json (the reference's own scene file)",
+            "config": {
+                "workload": "%s %dx%d, %d spp per step x %d steps per GPU (4096-spp config = 64 steps), "
+                            "Lambertian, bounces 0..%d, seed %d" % (
+                                args.scene, args.width, args.height, spp, args.steps, args.last_bounce, args.seed),
+                "spp_per_step": spp,
+                "samples_per_gpu": samples_per_rank,
+                "parallelism": "spp sharded over %d GPU(s), one RCCL reduce of 3*W*H fp32" % world_size,
+            },
+            "roofline": roofline,
+            "cpu_baseline": baseline,
+            "image_mean_rgb": mean,
+            "dropped_samples": timed_stats["dropped_samples"],
+        }
+        print(json.dumps(line), flush=True)
+
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

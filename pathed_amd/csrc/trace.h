@@ -101,7 +101,14 @@ __device__ inline bool traverse(
     int bestPrim = -1;
     float bestU = 0.f, bestV = 0.f;
 
-    const V3 invD = v3(1.f / d.x, 1.f / d.y, 1.f / d.z);
+    // 1/d clamped to a large FINITE value: with +-inf the one-fma slab form computes
+    // inf - inf = NaN for axis-parallel rays.  3e30 x coordinate stays below FLT_MAX for
+    // |coordinate| < 1e8 and still orders every slab plane correctly.
+    const float kHuge = 3e30f;
+    const V3 invD = v3(
+        fminf(fmaxf(1.f / d.x, -kHuge), kHuge),
+        fminf(fmaxf(1.f / d.y, -kHuge), kHuge),
+        fminf(fmaxf(1.f / d.z, -kHuge), kHuge));
     const V3 oInvD = v3(o.x * invD.x, o.y * invD.y, o.z * invD.z);
 
     if (g.nNodes > 0) {

@@ -47,3 +47,85 @@ void pathed_host_free_scene(void *handle)
 }
 
 }  // extern "C"
+
+// ---- job runner (shared by the `pathed` executable and the Python harness) ----------
+
+#include "exr.h"
+#include "integrator.h"
+#include "job.h"
+
+#include <iostream>
+#include <thread>
+
+int runJob(const std::string &jobPath, const std::string &assetRootOverride)
+{
+    using namespace pathed;
+    try {
+        Job job(jobPath);
+        job.init();
+
+        const int width = job.width();
+        const int height = job.height();
+        Image image(width, height, job.outputDirectory());
+
+        const std::string assetRoot = !assetRootOverride.empty() ? assetRootOverride : job.assetRoot();
+        Scene scene(loadScene(job.scene(), width, height, assetRoot), job.gpu());
+
+        std::shared_ptr<Integrator> integrator = job.integrator();
+        integrator->configure(job.spp(), job.seed(), job.sppPerLaunch(), job.outputDirectory());
+
+        // the reference renders on a dedicated thread while the UI owns the main thread
+        // (app/main.cpp:98); kept so `quit` and the Image lock behave the same
+        bool quit = false;
+        std::string failure;
+        std::thread renderThread([&]() {
+            try {
+                integrator->run(image, scene, [](RenderStatus) {}, &quit);
+            } catch (const std::exception &error) {
+                failure = error.what();
+            }
+        });
+        renderThread.join();
+        if (!failure.empty()) { throw std::runtime_error(failure); }
+        return 0;
+    } catch (const std::exception &error) {
+        g_hostError = error.what();
+        std::cerr << "pathed: " << error.what() << std::endl;
+        return 1;
+    }
+}
+
+extern "C" {
+
+int pathed_host_run_job(const char *jobPath, const char *assetRoot)
+{
+    return runJob(jobPath ? jobPath : "job.json", assetRoot ? assetRoot : "");
+}
+
+int pathed_host_write_exr_float_rgba(const char *path, int width, int height, const float *rgba)
+{
+    std::string error;
+    if (!pathed::writeExrFloatRGBA(path, width, height, rgba, &error)) {
+        g_hostError = error;
+        return 1;
+    }
+    return 0;
+}
+
+// capacity = number of floats `rgba` can hold; pass NULL to query the size
+int pathed_host_read_exr_rgba(const char *path, int *width, int *height, float *rgba, size_t capacity)
+{
+    std::vector<float> data;
+    std::string error;
+    if (!pathed::readExrRGBA(path, width, height, &data, &error)) {
+        g_hostError = error;
+        return 1;
+    }
+    if (rgba) {
+        if (capacity < data.size()) { g_hostError = "buffer too small"; return 2; }
+        std::memcpy(rgba, data.data(), data.size() * sizeof(float));
+    }
+    return 0;
+}
+
+}  // extern "C"

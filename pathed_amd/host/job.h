@@ -1,0 +1,62 @@
+// job.json reader, reference include/job.h:13-75 + src/job.cpp:25-97.
+// Same keys as the reference (spp, integrator, scene, startBounce, lastBounce,
+// output_directory, output_name, showUI, force, width, height); job-file numbers are real
+// JSON numbers.  Optional extra keys with defaults, so reference job files run unchanged:
+//   "seed" (1), "spp_per_launch" (64), "gpu" (0), "asset_root" (directory paths resolve in).
+#pragma once
+
+#include "bounce_controller.h"
+#include "json.h"
+
+#include <memory>
+#include <string>
+
+namespace pathed {
+
+class Integrator;
+
+class Job {
+public:
+    explicit Job(const std::string &jobPath);
+    explicit Job(const Json &json);
+
+    // creates <output_directory>/ and writes report.json (src/job.cpp:33-63)
+    void init();
+
+    bool showUI() const { return m_json["showUI"].isBool() && m_json["showUI"].asBool(); }
+    bool force() const { return m_json["force"].isBool() && m_json["force"].asBool(); }
+
+    int width() const { return m_json["width"].asInt(); }
+    int height() const { return m_json["height"].asInt(); }
+
+    int spp() const
+    {
+        const int spp = m_json["spp"].asInt();
+        return spp > 0 ? spp : 9999999;
+    }
+
+    std::string outputDirectory() const { return m_json["output_directory"].asString() + "/"; }
+    std::string outputName() const { return m_json["output_name"].isString() ? m_json["output_name"].asString() : ""; }
+    std::string scene() const { return m_json["scene"].asString(); }
+    std::string integratorName() const { return m_json["integrator"].asString(); }
+
+    int startBounce() const { return m_bounceController.startBounce(); }
+    int lastBounce() const { return m_bounceController.lastBounce(); }
+    BounceController bounceController() const { return m_bounceController; }
+
+    unsigned long long seed() const { return m_json["seed"].isNumber() ? (unsigned long long)m_json["seed"].asNumber() : 1ull; }
+    int sppPerLaunch() const { return m_json["spp_per_launch"].isNumber() ? m_json["spp_per_launch"].asInt() : 64; }
+    int gpu() const { return m_json["gpu"].isNumber() ? m_json["gpu"].asInt() : 0; }
+    std::string assetRoot() const { return m_json["asset_root"].isString() ? m_json["asset_root"].asString() : ""; }
+
+    // string -> class factory, src/job.cpp:65-97; only the hot-path integrators exist here
+    std::shared_ptr<Integrator> integrator() const;
+
+    const Json &json() const { return m_json; }
+
+private:
+    Json m_json;
+    BounceController m_bounceController;
+};
+
+}  // namespace pathed

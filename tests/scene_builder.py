@@ -1,0 +1,105 @@
+"""Builds PathedSceneDesc structures directly in Python for tests (no files involved)."""
+import ctypes as C
+
+import numpy as np
+
+from pathed_amd import _capi
+
+
+class BuiltScene:
+    """Keeps the numpy arrays alive for as long as the descriptor is used."""
+
+    def __init__(self, width, height, origin, target, up=(0, 1, 0), fov_degrees=40.0, flip=False):
+        self.desc = _capi.PathedSceneDesc()
+        self.desc.abi_version = _capi.PATHED_ABI_VERSION
+        camera = self.desc.camera
+        camera.origin[:] = origin
+        camera.target[:] = target
+        camera.up[:] = up
+        camera.vertical_fov = np.float32(np.float32(fov_degrees) / np.float32(180.0) * np.pi)
+        camera.width, camera.height = width, height
+        camera.flip_handedness = 1 if flip else 0
+        self.positions, self.normals, self.uvs = [], [], []
+        self.indices, self.tri_material = [], []
+        self.spheres, self.geoms, self.materials = [], [], []
+        self.env = None
+        self._keep = []
+
+    def material(self, type_=_capi.MAT_LAMBERTIAN, diffuse=(0.5, 0.5, 0.5), emit=(0, 0, 0), sigma=0.0, alpha=0.1,
+                 ior=1.4, checker=None):
+        m = _capi.PathedMaterial()
+        m.type = type_
+        m.diffuse[:] = diffuse
+        m.emit[:] = emit
+        m.sigma, m.alpha, m.ior = sigma, alpha, ior
+        if checker is not None:
+            m.albedo_type = _capi.ALBEDO_CHECKERBOARD
+            m.checker_on[:] = checker[0]
+            m.checker_off[:] = checker[1]
+            m.checker_res[:] = checker[2]
+        self.materials.append(m)
+        return len(self.materials) - 1
+
+    def mesh(self, vertices, faces, material, normals=None, uvs=None):
+        base = len(self.positions)
+        vertices = np.asarray(vertices, dtype=np.float32)
+        self.positions.extend(vertices.tolist())
+        self.normals.extend((np.zeros_like(vertices) if normals is None else np.asarray(normals, dtype=np.float32)).tolist())
+        self.uvs.extend((np.zeros((len(vertices), 2)) if uvs is None else np.asarray(uvs, dtype=np.float32)).tolist())
+        geom = _capi.PathedGeom(_capi.GEOM_MESH, len(self.indices), len(faces))
+        for face in faces:
+            self.indices.append([base + int(i) for i in face])
+            self.tri_material.append(material)
+        self.geoms.append(geom)
+
+    def quad(self, corners, material):
+        self.mesh(corners, [(0, 1, 2), (0, 2, 3)], material, uvs=[(0, 0), (1, 0), (1, 1), (0, 1)])
+
+    def sphere(self, center, radius, material):
+        s = _capi.PathedSphere()
+        s.center_world[:] = center
+        s.center_sample[:] = center
+        s.radius = radius
+        s.material = material
+        self.geoms.append(_capi.PathedGeom(_capi.GEOM_SPHERE, len(self.spheres), 1))
+        self.spheres.append(s)
+
+    def environment(self, rgba, scale=1.0):
+        rgba = np.ascontiguousarray(rgba, dtype=np.float32)
+        env = _capi.PathedEnvLight()
+        env.height, env.width = rgba.shape[:2]
+        env.rgba = rgba.ctypes.data_as(C.POINTER(C.c_float))
+        env.scale = scale
+        identity = np.eye(4, dtype=np.float32).reshape(-1)
+        env.map_to_world[:] = identity.tolist()
+        env.world_to_map[:] = identity.tolist()
+        self.env = env
+        self._keep.append(rgba)
+
+    def finish(self):
+        d = self.desc
+
+        def floats(values, width):
+            array = np.ascontiguousarray(np.asarray(values, dtype=np.float32).reshape(-1, width))
+            self._keep.append(array)
+            return array.ctypes.data_as(C.POINTER(C.c_float))
+
+        d.n_vertices = len(self.positions)
+        d.positions = floats(self.positions if self.positions else np.zeros((0, 3)), 3)
+        d.normals = floats(self.normals if self.normals else np.zeros((0, 3)), 3)
+        d.uvs = floats(self.uvs if self.uvs else np.zeros((0, 2)), 2)
+        indices = np.ascontiguousarray(np.asarray(self.indices, dtype=np.uint32).reshape(-1, 3))
+        materials = np.ascontiguousarray(np.asarray(self.tri_material, dtype=np.int32))
+        self._keep += [indices, materials]
+        d.n_triangles = len(self.indices)
+        d.indices = indices.ctypes.data_as(C.POINTER(C.c_uint32))
+        d.tri_material = materials.ctypes.data_as(C.POINTER(C.c_int32))
+        sphere_array = (_capi.PathedSphere * max(1, len(self.spheres)))(*self.spheres)
+        geom_array = (_capi.PathedGeom * max(1, len(self.geoms)))(*self.geoms)
+        material_array = (_capi.PathedMaterial * max(1, len(self.materials)))(*self.materials)
+        self._keep += [sphere_array, geom_array, material_array]
+        d.n_spheres, d.spheres = len(self.spheres), sphere_array
+        d.n_geoms, d.geoms = len(self.geoms), geom_array
+        d.n_materials, d.materials = len(self.materials), material_array
+        d.env = C.pointer(self.env) if self.env is not None else None
+        return C.pointer(d)

@@ -1,0 +1,73 @@
+"""The C-ABI shared library: loads, exports every symbol include/pathed_hip.h declares, and
+fails loudly (no fallback) when there is no GPU.  No compute calls here."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from pathed_amd import _capi
+
+
+def _declared_symbols():
+    header = open(os.path.join(_capi.REPO_ROOT, "include", "pathed_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    return sorted(set(re.findall(r"\b(pathed_hip_[a-z_]+)\s*\(", header)))
+
+
+def test_header_and_binding_agree():
+    assert _declared_symbols() == sorted(_capi.HIP_SYMBOLS)
+
+
+def test_library_exports_every_declared_symbol():
+    lib = C.CDLL(_capi.hip_library_path())
+    for name in _declared_symbols():
+        assert hasattr(lib, name), "libpathed_hip.so does not export %s" % name
+
+
+def test_struct_sizes_match_the_header():
+    # sizes the C compiler gives the header's structs (checked here so the ctypes mirror cannot drift)
+    import subprocess
+    import tempfile
+    source = (
+        '#include "pathed_hip.h"\n#include <stdio.h>\n'
+        'int main(void){printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(PathedCamera), sizeof(PathedMaterial),'
+        ' sizeof(PathedSphere), sizeof(PathedGeom), sizeof(PathedEnvLight), sizeof(PathedSceneDesc), sizeof(PathedStats));return 0;}\n'
+    )
+    with tempfile.TemporaryDirectory() as tmp:
+        c_file = os.path.join(tmp, "sizes.c")
+        open(c_file, "w").write(source)
+        exe = os.path.join(tmp, "sizes")
+        subprocess.run(["gcc", "-I", os.path.join(_capi.REPO_ROOT, "include"), c_file, "-o", exe], check=True)
+        sizes = [int(x) for x in subprocess.run([exe], check=True, capture_output=True, text=True).stdout.split()]
+    expected = [C.sizeof(t) for t in (_capi.PathedCamera, _capi.PathedMaterial, _capi.PathedSphere, _capi.PathedGeom,
+                                      _capi.PathedEnvLight, _capi.PathedSceneDesc, _capi.PathedStats)]
+    assert sizes == expected
+
+
+def test_version_string():
+    lib = _capi.load_hip()
+    assert b"gfx950" in lib.pathed_hip_version()
+
+
+def test_no_gpu_means_a_loud_error_not_a_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from pathed_amd.integrator import HipScene, PathedError
+    from pathed_amd.scene import LoadedScene
+    scene = LoadedScene("scenes/cornell.json", 8, 8)
+    with pytest.raises(PathedError, match="no HIP device|pathed_hip"):
+        HipScene(scene.desc, device=0)
+
+
+def test_product_never_imports_the_oracle():
+    # the oracle is test infrastructure: nothing under pathed_amd/ may reference it
+    offenders = []
+    for root, _, files in os.walk(os.path.join(_capi.REPO_ROOT, "pathed_amd")):
+        for name in files:
+            if name.endswith((".py", ".h", ".cpp", ".hip")):
+                text = open(os.path.join(root, name), errors="ignore").read()
+                if re.search(r"oracle_lib|liboracle|oracle/|#include\s+\"oracle", text):
+                    offenders.append(os.path.join(root, name))
+    assert offenders == []

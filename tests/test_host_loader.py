@@ -1,0 +1,190 @@
+"""C++ host side (libpathed_host.so): scene / OBJ / MTL / PLY / quad readers, EXR, job files.
+
+Format rules are the reference's (src/scene_parser.cpp, src/obj_parser.cpp, src/mtl_parser.cpp,
+src/ply_parser.cpp, src/quad.cpp, src/image.cpp); see pathed_amd/host/scene_loader.h.
+"""
+import ctypes as C
+import json
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from pathed_amd import _capi
+from pathed_amd.scene import LoadedScene
+
+
+def _arrays(scene):
+    d = scene.desc.contents
+    positions = np.ctypeslib.as_array(d.positions, shape=(d.n_vertices, 3)).copy()
+    normals = np.ctypeslib.as_array(d.normals, shape=(d.n_vertices, 3)).copy()
+    uvs = np.ctypeslib.as_array(d.uvs, shape=(d.n_vertices, 2)).copy()
+    indices = np.ctypeslib.as_array(d.indices, shape=(d.n_triangles, 3)).copy()
+    tri_material = np.ctypeslib.as_array(d.tri_material, shape=(d.n_triangles,)).copy()
+    return d, positions, normals, uvs, indices, tri_material
+
+
+def test_cornell_scene_matches_reference_parse():
+    scene = LoadedScene("scenes/cornell.json", 256, 256)
+    d, positions, normals, uvs, indices, tri_material = _arrays(scene)
+    # 18 quads "f -4 -3 -2 -1" -> 36 triangles split (0,1,2),(0,2,3) (obj_parser.cpp:377-396)
+    assert d.n_triangles == 36 and d.n_vertices == 72
+    assert indices[0].tolist() == [0, 1, 2] and indices[1].tolist() == [0, 2, 3]
+    # no vn / vt in the file: attributes zero-filled (geometry_parser.cpp:68-89)
+    assert not normals.any() and not uvs.any()
+    # floor quad winding: (v1-v0)x(v2-v0) points into the box (+y), SURVEY.md App. C
+    e1, e2 = positions[1] - positions[0], positions[2] - positions[0]
+    assert np.cross(e1, e2)[1] > 0
+    # camera: fov given in degrees as a string
+    assert abs(d.camera.vertical_fov - np.float32(19.5 / 180 * np.pi)) < 1e-7
+    assert tuple(d.camera.origin) == (0.0, 1.0, np.float32(6.8))
+    # exactly the two light triangles are emissive with Ke = 17 12 4
+    emissive = [i for i in range(36) if tuple(d.materials[tri_material[i]].emit) != (0.0, 0.0, 0.0)]
+    assert len(emissive) == 2
+    assert tuple(d.materials[tri_material[emissive[0]]].emit) == (17.0, 12.0, 4.0)
+    light = positions[indices[emissive[0]]]
+    assert np.cross(light[1] - light[0], light[2] - light[0])[1] < 0  # light faces down
+    assert d.n_geoms == 1 and d.geoms[0].count == 36
+    assert d.env is None or not bool(d.env)
+
+
+def test_triplet_faces_normals_and_transform():
+    # cornell-glass: ball.obj uses v/vt/vn triplets with negative indices + translate (0,0,1)
+    scene = LoadedScene("scenes/cornell-glass.json", 64, 64)
+    d, positions, normals, uvs, indices, tri_material = _arrays(scene)
+    assert d.n_geoms == 3
+    ball = d.geoms[2]
+    assert ball.count == 1088
+    ball_material = d.materials[tri_material[ball.first]]
+    assert ball_material.type == _capi.MAT_GLASS and abs(ball_material.ior - 1.4) < 1e-7
+    box_material = d.materials[tri_material[d.geoms[1].first]]
+    assert box_material.type == _capi.MAT_MIRROR
+    used = np.unique(indices[ball.first:ball.first + ball.count])
+    ball_normals = normals[used]
+    lengths = np.linalg.norm(ball_normals, axis=1)
+    assert np.all(np.abs(lengths - 1) < 1e-3)
+    # smooth normals of a sphere point away from its centre; the centre moved by the translate
+    centre = positions[used].mean(axis=0)
+    reference = LoadedScene("scenes/cornell-glossy.json", 64, 64)
+    d2, positions2, _, _, indices2, _ = _arrays(reference)
+    used2 = np.unique(indices2[d2.geoms[2].first:d2.geoms[2].first + d2.geoms[2].count])
+    centre2 = positions2[used2].mean(axis=0)
+    assert np.allclose(centre - centre2, [0, 0, 1], atol=1e-5)
+    outward = positions[used] - centre
+    outward /= np.linalg.norm(outward, axis=1, keepdims=True)
+    assert np.mean(np.sum(outward * ball_normals, axis=1)) > 0.99
+
+
+def test_obj_face_syntaxes_and_cube_normal_split(tmp_path):
+    obj = tmp_path / "mixed.obj"
+    obj.write_text(
+        "v 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nv 0 0 1\n"
+        "vn 0 0 1\nvn 0 1 0\n"
+        "vt 0.25 0.75\n"
+        "g a\n"
+        "f 1 2 3 4\n"            # quad, geometry only
+        "f 1//1 2//1 3//1\n"     # v//vn
+        "f 1//2 2//2 5//2\n"     # same vertices, other normal -> duplicated vertices
+        "f -5/1/1 -4/1/1 -3/1/1\n"  # triplets with negative indices
+        "usemtl hidden\nf 1 2 3\n"  # skipped (obj_parser.cpp:151)
+    )
+    scene_file = tmp_path / "scene.json"
+    scene_file.write_text(json.dumps({
+        "sensor": {"lookAt": {"origin": ["0", "0", "5"], "target": ["0", "0", "0"], "up": ["0", "1", "0"]}, "fov": "40"},
+        "models": [{"type": "obj", "filename": str(obj), "bsdf": {"type": "mirror"}}],
+    }))
+    scene = LoadedScene(str(scene_file), 8, 8, asset_root="")
+    d, positions, normals, uvs, indices, tri_material = _arrays(scene)
+    assert d.n_triangles == 5
+    assert indices[0].tolist() == [0, 1, 2] and indices[1].tolist() == [0, 2, 3]
+    # face 3 re-uses vertices 0,1 with normal index 1 after they were seen with -1/0:
+    # the reference duplicates them at the back of the vertex list (obj_parser.cpp:60-117)
+    assert d.n_vertices > 5
+    assert all(d.materials[m].type == _capi.MAT_MIRROR for m in tri_material)
+    assert uvs[0].tolist() == [0.25, 0.75]
+
+
+def test_material_lookup_precedence_and_reference(tmp_path):
+    scene = LoadedScene("scenes/cornell-oren-nayar.json", 16, 16)
+    d, _, _, _, _, tri_material = _arrays(scene)
+    types = [d.materials[m].type for m in tri_material]
+    # JSON materials keyed by OBJ group beat the MTL entries (obj_parser.cpp:241-252) ...
+    assert types[0] == _capi.MAT_OREN_NAYAR
+    assert _capi.MAT_MICROFACET in types and _capi.MAT_PLASTIC in types
+    # ... and the group key beats the usemtl key: in CornellBox-Original.obj the tall box's faces
+    # are still in group "shortBox" (its `g tallBox` line comes after them), so BOTH boxes
+    # resolve to the JSON material named "shortBox": 12 + 12 = 24 plastic triangles
+    assert types.count(_capi.MAT_PLASTIC) == 24
+    # ... while the light group has no JSON entry and keeps its MTL emission
+    assert sum(1 for m in tri_material if tuple(d.materials[m].emit) == (17.0, 12.0, 4.0)) == 2
+
+
+def test_quad_sphere_ply_and_env(tmp_path):
+    scene = LoadedScene("scenes/mis-pbrt.json", 32, 32)
+    d, positions, normals, uvs, indices, tri_material = _arrays(scene)
+    assert d.n_spheres == 5 and d.n_geoms == 10
+    assert [g.type for g in d.geoms[0:5]] == [_capi.GEOM_SPHERE] * 5
+    assert abs(d.spheres[2].radius - 0.03333) < 1e-7
+    assert d.camera.flip_handedness == 1
+    plate = d.materials[tri_material[d.geoms[5].first]]
+    assert plate.type == _capi.MAT_PLASTIC and abs(plate.alpha - 0.005) < 1e-9
+
+    teapot = LoadedScene("scenes/teapot.json", 32, 32)
+    d, positions, normals, uvs, indices, tri_material = _arrays(teapot)
+    quad = d.geoms[2]
+    assert quad.count == 2
+    checker = d.materials[tri_material[quad.first]]
+    assert checker.albedo_type == _capi.ALBEDO_CHECKERBOARD and tuple(checker.checker_res) == (20.0, 20.0)
+    assert tuple(checker.diffuse) == (0.0, 0.0, 0.0)  # Lambertian(albedo, emit) ctor zeroes m_diffuse
+    quad_vertices = positions[np.unique(indices[quad.first:quad.first + 2])]
+    # legacy transform: scale 113.071, rotate x by -90 deg -> the z-up quad becomes the y = 0 plane
+    assert np.allclose(quad_vertices[:, 1], 0, atol=1e-3)
+    assert abs(np.abs(quad_vertices).max() - 113.071 * np.sqrt(2)) < 1e-2
+    quad_normal = normals[indices[quad.first][0]]
+    assert np.allclose(np.abs(quad_normal), [0, 1, 0], atol=1e-5)
+    assert bool(d.env) and d.env.contents.width == 256 and d.env.contents.height == 128
+
+
+def test_scene_errors_are_loud(tmp_path):
+    bad = tmp_path / "bad.json"
+    bad.write_text(json.dumps({
+        "sensor": {"lookAt": {"origin": ["0", "0", "5"], "target": ["0", "0", "0"], "up": ["0", "1", "0"]}, "fov": "40"},
+        "models": [{"type": "quad", "bsdf": {"type": "velvet"}}],
+    }))
+    with pytest.raises(RuntimeError, match="Unimplemented material: velvet"):
+        LoadedScene(str(bad), 8, 8, asset_root="")
+    with pytest.raises(RuntimeError):
+        LoadedScene("scenes/does-not-exist.json", 8, 8)
+
+
+def test_exr_round_trip(tmp_path):
+    host = _capi.load_host()
+    rng = np.random.default_rng(3)
+    rgba = rng.uniform(0, 4, size=(5, 7, 4)).astype(np.float32)
+    path = str(tmp_path / "x.exr").encode()
+    assert host.pathed_host_write_exr_float_rgba(path, 7, 5, rgba.ctypes.data_as(C.POINTER(C.c_float))) == 0
+    w, h = C.c_int(), C.c_int()
+    out = np.zeros_like(rgba)
+    assert host.pathed_host_read_exr_rgba(path, C.byref(w), C.byref(h), out.ctypes.data_as(C.POINTER(C.c_float)), out.size) == 0
+    assert (w.value, h.value) == (7, 5)
+    assert np.array_equal(out, rgba)
+    # header: magic, version 2, scanline, uncompressed
+    with open(path, "rb") as handle:
+        blob = handle.read()
+    assert blob[:4] == bytes([0x76, 0x2F, 0x31, 0x01]) and blob[4:8] == bytes([2, 0, 0, 0])
+    assert b"compression\x00compression\x00\x01\x00\x00\x00\x00" in blob
+
+
+def test_one_pixel_env_map_matches_reference_decode():
+    # tests/golden "env_image": the reference's tinyexr decode of test_scenes/1_pixel_test.exr
+    host = _capi.load_host()
+    w, h = C.c_int(), C.c_int()
+    path = os.path.join(_capi.REPO_ROOT, "test_scenes", "1_pixel_test.exr").encode()
+    assert host.pathed_host_read_exr_rgba(path, C.byref(w), C.byref(h), None, 0) == 0
+    assert (w.value, h.value) == (1000, 500)
+    data = np.zeros((500, 1000, 4), dtype=np.float32)
+    assert host.pathed_host_read_exr_rgba(path, C.byref(w), C.byref(h), data.ctypes.data_as(C.POINTER(C.c_float)), data.size) == 0
+    nonzero = np.argwhere(data[..., :3].sum(-1) != 0)
+    assert nonzero.tolist() == [[239, 753]]
+    assert data[239, 753, :3].tolist() == [10000.0, 10000.0, 10000.0]
