@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Headline benchmark: Msamples/s of the GPU PathTracer on scenes/cornell.json, 1024x1024.
 
-A "step" renders `--spp-per-step` camera samples (default 64) for every pixel through the C ABI
-(pathed_hip_render_device) into a device-resident radiance-sum buffer; 64 steps are the
+A "step" renders `--spp-per-step` camera samples (default 256) for every pixel through the C ABI
+(pathed_hip_render_device) into a device-resident radiance-sum buffer; 16 steps are the
 4096-spp configuration BASELINE.json quotes.  With N ranks each rank renders its own,
 disjoint range of sample indices (weak scaling: per-GPU work is fixed) and the sums are
 reduced to rank 0 over RCCL once, inside the timed region.
@@ -27,9 +27,9 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICRO
 def parse_args():
     parser = argparse.ArgumentParser()
     parser.add_argument("--gpus", type=int, default=1)
-    parser.add_argument("--steps", type=int, default=64)
+    parser.add_argument("--steps", type=int, default=16)
     parser.add_argument("--warmup", type=int, default=2)
-    parser.add_argument("--spp-per-step", type=int, default=64)
+    parser.add_argument("--spp-per-step", type=int, default=256)
     parser.add_argument("--width", type=int, default=1024)
     parser.add_argument("--height", type=int, default=1024)
     parser.add_argument("--scene", default="scenes/cornell.json")
@@ -202,7 +202,7 @@ def main():
             "dtype": "f32",
             "data": "synthetic camera samples on scenes/cornell.json (the reference's own scene file)",
             "config": {
-                "workload": "%s %dx%d, %d spp per step x %d steps per GPU (4096-spp config = 64 steps), "
+                "workload": "%s %dx%d, %d spp per step x %d steps per GPU (4096-spp config = 16 steps of 256), "
                             "Lambertian, bounces 0..%d, seed %d" % (
                                 args.scene, args.width, args.height, spp, args.steps, args.last_bounce, args.seed),
                 "spp_per_step": spp,

@@ -196,8 +196,8 @@ void pathed_hip_scene_destroy(PathedScene *scene);
  * SampleIntegrator::sampleImage does to radianceLookup, spp_count times
  * (reference src/sample_integrator.cpp:61-63, src/integrator.cpp:42-51).
  * Bounce window as BounceController (reference src/bounce_controller.cpp:14-25);
- * last_bounce = -1 means unbounded in the reference and is rejected here
- * (PATHED_E_UNSUPPORTED) unless the scene is open; see DESIGN.md. */
+ * last_bounce = -1 means unbounded, as in the reference (paths end on a miss or when the
+ * throughput becomes exactly black). */
 int pathed_hip_render(PathedScene *scene, uint64_t seed,
                       uint32_t spp_begin, uint32_t spp_count,
                       int start_bounce, int last_bounce,
@@ -205,14 +205,21 @@ int pathed_hip_render(PathedScene *scene, uint64_t seed,
 
 /* Same, but the sum buffer is DEVICE memory owned by the caller (e.g. a torch
  * tensor) and the work is enqueued on `stream` (a hipStream_t, NULL = default
- * stream).  The per-pixel sum CONTINUES from the buffer's current contents in
- * sample order, so successive calls are bit-identical to one long call.
- * Returns after the work has been enqueued AND completed on the device only if
- * `blocking` != 0. */
+ * stream).  The per-pixel sum CONTINUES from the buffer's current contents, so successive
+ * calls whose lengths are multiples of the samples-per-unit setting are bit-identical to
+ * one long call.  The call returns when the device work has completed (`blocking` is
+ * reserved; the iteration loop polls a device counter). */
 int pathed_hip_render_device(PathedScene *scene, uint64_t seed,
                              uint32_t spp_begin, uint32_t spp_count,
                              int start_bounce, int last_bounce,
                              float *d_accum_rgb_sum, void *stream, int blocking);
+
+/* Summation granularity.  A pixel's samples are summed in sample order in groups of
+ * `samples` (a work unit); the group sums are then added to the pixel in group order.
+ * The result is deterministic for a given value.  samples == 1 reproduces the reference's
+ * order exactly (radianceLookup += one sample per wave, src/integrator.cpp:42-51) at lower
+ * throughput; the default is 4.  Range [1, 128]. */
+int pathed_hip_set_samples_per_unit(PathedScene *scene, int samples);
 
 /* Test hook onto the intersector that stands in for Embree.
  * rays: n * 8 floats (ox,oy,oz,tnear, dx,dy,dz,tfar), host memory.

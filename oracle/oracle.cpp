@@ -1750,8 +1750,19 @@ int oracle_sample_pixel(OracleScene *scene, uint64_t seed, int row, int col_, ui
     return 0;
 }
 
+int oracle_render_chunked(OracleScene *scene, uint64_t seed, uint32_t spp_begin, uint32_t spp_count,
+                          int start_bounce, int last_bounce, float *accum, int threads, uint64_t *stats, int chunk);
+
 int oracle_render(OracleScene *scene, uint64_t seed, uint32_t spp_begin, uint32_t spp_count,
                   int start_bounce, int last_bounce, float *accum, int threads, uint64_t *stats)
+{
+    return oracle_render_chunked(scene, seed, spp_begin, spp_count, start_bounce, last_bounce, accum, threads, stats, 1);
+}
+
+/* chunk > 1 mirrors the product's summation granularity (pathed_hip_set_samples_per_unit):
+ * samples are summed in order inside groups of `chunk`, group sums are added in order. */
+int oracle_render_chunked(OracleScene *scene, uint64_t seed, uint32_t spp_begin, uint32_t spp_count,
+                          int start_bounce, int last_bounce, float *accum, int threads, uint64_t *stats, int chunk)
 {
     if (!scene || !accum) { g_error = "oracle: null argument"; return -1; }
     const OracleSceneImpl &impl = scene->impl;
@@ -1775,12 +1786,28 @@ int oracle_render(OracleScene *scene, uint64_t seed, uint32_t spp_begin, uint32_
         for (int row = 0; row < height; row++) {
             for (int col_ = 0; col_ < width; col_++) {
                 float *pixel = accum + 3 * ((size_t)row * width + col_);
-                for (uint32_t s = 0; s < spp_count; s++) {
-                    const Color c = impl.samplePixel(seed, row, col_, spp_begin + s, start_bounce, last_bounce, &local);
-                    if (!finiteColor(c)) { local.dropped++; continue; }
-                    pixel[0] += c.r;
-                    pixel[1] += c.g;
-                    pixel[2] += c.b;
+                if (chunk <= 1) {
+                    for (uint32_t s = 0; s < spp_count; s++) {
+                        const Color c = impl.samplePixel(seed, row, col_, spp_begin + s, start_bounce, last_bounce, &local);
+                        if (!finiteColor(c)) { local.dropped++; continue; }
+                        pixel[0] += c.r;
+                        pixel[1] += c.g;
+                        pixel[2] += c.b;
+                    }
+                } else {
+                    for (uint32_t first = 0; first < spp_count; first += (uint32_t)chunk) {
+                        float partial[3] = { 0.f, 0.f, 0.f };
+                        for (uint32_t s = first; s < spp_count && s < first + (uint32_t)chunk; s++) {
+                            const Color c = impl.samplePixel(seed, row, col_, spp_begin + s, start_bounce, last_bounce, &local);
+                            if (!finiteColor(c)) { local.dropped++; continue; }
+                            partial[0] += c.r;
+                            partial[1] += c.g;
+                            partial[2] += c.b;
+                        }
+                        pixel[0] += partial[0];
+                        pixel[1] += partial[1];
+                        pixel[2] += partial[2];
+                    }
                 }
             }
         }

@@ -38,6 +38,16 @@ int oracle_render(OracleScene *scene, uint64_t seed,
                   int start_bounce, int last_bounce,
                   float *accum_rgb_sum, int threads, uint64_t *stats);
 
+/* chunk > 1 mirrors pathed_hip_set_samples_per_unit: group sums of `chunk` samples. */
+int oracle_render_chunked(OracleScene *scene, uint64_t seed,
+                          uint32_t spp_begin, uint32_t spp_count,
+                          int start_bounce, int last_bounce,
+                          float *accum_rgb_sum, int threads, uint64_t *stats, int chunk);
+
+/* Environment-light function-level checks (need an image, hence a scene):
+ * fn in {"env_emit", "env_pdf", "env_sample"}, layouts in tests/golden/README.md. */
+int oracle_env_eval(OracleScene *scene, const char *fn, const float *in, int n_in, float *out, int n_out);
+
 /* Radiance of ONE camera sample (for spot checks): rgb out. */
 int oracle_sample_pixel(OracleScene *scene, uint64_t seed,
                         int row, int col, uint32_t sample,

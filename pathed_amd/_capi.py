@@ -118,6 +118,7 @@ HIP_SYMBOLS = [
     "pathed_hip_render",
     "pathed_hip_render_device",
     "pathed_hip_trace",
+    "pathed_hip_set_samples_per_unit",
     "pathed_hip_set_stats_mode",
     "pathed_hip_get_stats",
     "pathed_hip_reset_stats",
@@ -166,6 +167,8 @@ def load_hip():
     lib.pathed_hip_render_device.restype = C.c_int
     lib.pathed_hip_trace.argtypes = [vp, C.POINTER(C.c_float), C.c_size_t, C.c_int, vp]
     lib.pathed_hip_trace.restype = C.c_int
+    lib.pathed_hip_set_samples_per_unit.argtypes = [vp, C.c_int]
+    lib.pathed_hip_set_samples_per_unit.restype = C.c_int
     lib.pathed_hip_set_stats_mode.argtypes = [vp, C.c_int]
     lib.pathed_hip_set_stats_mode.restype = C.c_int
     lib.pathed_hip_get_stats.argtypes = [vp, C.POINTER(PathedStats)]

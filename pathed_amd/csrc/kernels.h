@@ -1,19 +1,25 @@
 // The wavefront path-tracing kernels (gfx950).
 //
-// One path SLOT per pixel; a slot renders its pixel's samples one after another
-// ("path regeneration"), so every lane stays busy until the sample budget is spent and
-// the per-pixel sum is accumulated in sample order exactly like the reference's wave
-// loop (src/integrator.cpp:42-51, src/sample_integrator.cpp:61-63).
+// Work decomposition.  A UNIT is `chunk` consecutive samples of one pixel; unit u covers pixel
+// u % nPixels and samples sppBegin + (u / nPixels) * chunk + [0, chunk).  A pool of path SLOTS
+// pulls units dynamically (block-aggregated grab from one of kUnitQueues cursors), so lanes stay
+// busy whatever the per-pixel path length ("path regeneration").  A unit's samples are summed in
+// sample order into a partial sum; the partial is written to chunkBuf[u], and k_resolve adds a
+// pixel's partials to the radiance sum in chunk order.  The result is deterministic and does
+// not depend on scheduling; with chunk == 1 it is exactly the reference's order
+// (radianceLookup += one sample per wave, src/integrator.cpp:42-51, sample_integrator.cpp:61-63).
 //
 // Per iteration, two launches on one stream:
-//   k_trace  persistent waves pull 64-ray batches from [slot rays | shadow queue]
-//            closest hit  -> hit[slot]               (Scene::testIntersect's rtcIntersect1)
+//   k_trace  persistent waves walk [slot rays | per-block shadow rays] in a static stride
+//            closest hit  -> hit[slot]                  (Scene::testIntersect's rtcIntersect1)
 //            any hit      -> pend[slot] = 0 if occluded (Scene::testOcclusion's rtcOccluded1)
-//   k_shade  one lane per slot: finishes the previous vertex's BSDF-sampling MIS term with
-//            the new hit, updates throughput, samples the BSDF and one light at the new
-//            vertex (PathTracer::L / direct / directSampleLights / directSampleBSDF,
-//            src/path_tracer.cpp:19-216), emits the next ray and a compacted shadow ray,
-//            or terminates the sample, accumulates it and regenerates a camera ray.
+//   k_shade  one lane per slot: finishes the previous vertex's BSDF-sampling MIS term with the
+//            new hit, updates throughput, samples the BSDF and one light at the new vertex
+//            (PathTracer::L / direct / directSampleLights / directSampleBSDF,
+//            src/path_tracer.cpp:19-216), emits the next ray and a shadow ray, or terminates the
+//            sample, adds it to the unit's partial sum and starts the next sample / unit.
+//            Shadow rays and unit requests are compacted with wave ballots + an LDS block scan.
+// No single-address atomics on the hot path: one counter saturates at ~88 ops/us on MI355X.
 // State is SoA-of-float4 in HBM so a wave reads 1 KiB contiguous per stream.
 #pragma once
 
@@ -23,13 +29,14 @@
 namespace pathed {
 
 static const int kBlock = 256;
+static const int kWavesPerBlock = kBlock / 64;
 static const int kMaxLdsMaterials = 96;  // 96 x 80 B = 7.5 KiB of LDS
+static const int kUnitQueues = 32;       // sharded work-unit cursors
 
 // counters[] layout (unsigned int)
-static const int kCtrShadowCount = 0;  // [0],[1] double-buffered shadow-queue tails
-static const int kCtrCursor = 2;       // [2],[3] double-buffered persistent-trace cursors
-static const int kCtrRemaining = 4;    // slots that still have samples to render
-static const int kCtrCount = 8;
+static const int kCtrRemaining = 0;    // slots that still have work
+static const int kCtrUnitCursor = 8;   // [8 .. 8+kUnitQueues): next unit of each queue
+static const int kCtrCount = 8 + kUnitQueues;
 
 // stats[] layout (unsigned long long)
 static const int kStatSamples = 0;
@@ -40,16 +47,25 @@ static const int kStatTris = 4;
 static const int kStatDropped = 5;
 static const int kStatCount = 8;
 
+// state word (rayD.w): bits 0..15 vertex that spawned the ray (0 = camera ray),
+// 16 eligible, 17 delta, 18 continue (device_scene.h), 19..25 sample index inside the unit
+static const int kStSampleShift = 19;
+static const int kStSampleMask = 0x7F;
+static const int kMaxChunk = 128;
+
 struct PathState {
     float4 *rayO;   // origin.xyz, bits(material of a directly visible emitter, or -1)
     float4 *rayD;   // direction.xyz, bits(state word)
     float4 *hit;    // t, u, v, bits(prim)
     float4 *mod;    // modulation.rgb, pdf of the pending BSDF sample
     float4 *thr;    // throughput.rgb of the pending BSDF sample, |n_s . wi|
-    float4 *res;    // result.rgb, bits(sample index)
+    float4 *res;    // result.rgb of the sample in flight, bits(unit)
     float4 *pend;   // light-sampling term of the pending vertex (zeroed if occluded)
-    float4 *shO;    // shadow queue: origin.xyz, tfar
-    float4 *shD;    // shadow queue: direction.xyz, bits(slot)
+    float4 *acc;    // partial radiance sum of the unit in flight
+    float4 *shO;    // shadow rays, compacted per shade block: origin.xyz, tfar
+    float4 *shD;    //                                           direction.xyz, bits(slot)
+    unsigned int *blockShadowCount;  // shadow rays of each shade block (<= kBlock)
+    float4 *chunkBuf;                // nUnits partial sums, index = unit
 };
 
 struct RenderParams {
@@ -58,12 +74,16 @@ struct RenderParams {
     unsigned int *counters;
     unsigned long long *stats;
     float *accum;          // 3*W*H radiance sums, index 3*(row*W+col)+c
-    int nSlots;
-    int nSlotsPadded;      // multiple of 64
+    int nSlots;            // multiple of kBlock
+    int nPixels;
+    unsigned int nUnits;
+    int nQueues;           // min(kUnitQueues, shade blocks): every queue has a consumer
+    unsigned int unitsPerQueue;
+    int chunk;             // samples per unit
+    int chunksPerPixel;
     uint32_t seedLo, seedHi;
     uint32_t sppBegin, sppEnd;
     int startBounce, lastBounce;
-    int parity;            // iteration & 1
 };
 
 // BounceController, reference src/bounce_controller.cpp:14-25
@@ -107,45 +127,41 @@ __global__ __launch_bounds__(kBlock) void k_trace(RenderParams p)
         geometry.tris = ldsTris;
     }
 
-    const int parity = p.parity;
-    if (blockIdx.x == 0 && threadIdx.x == 0) { p.counters[kCtrShadowCount + (parity ^ 1)] = 0; }
-
-    const unsigned int shadowCount = p.counters[kCtrShadowCount + parity];
-    const unsigned int total = (unsigned int)p.nSlotsPadded + shadowCount;
     const int lane = threadIdx.x & 63;
+    const unsigned int waveId = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const unsigned int waveCount = gridDim.x * kWavesPerBlock;
+    const unsigned int slotBatches = (unsigned int)p.nSlots / 64u;
+    const unsigned int totalBatches = 2u * slotBatches;
 
     TraceCounters counters;
     counters.boxes = 0;
     counters.tris = 0;
     unsigned int closestRays = 0, shadowRays = 0;
 
-    // persistent loop: every wave reaches the exit because the cursor only grows
-    while (true) {
-        unsigned int base = 0;
-        if (lane == 0) { base = atomicAdd(&p.counters[kCtrCursor + parity], 64u); }
-        base = __shfl(base, 0);
-        if (base >= total) { break; }
-
-        const unsigned int item = base + lane;
-        if (base < (unsigned int)p.nSlotsPadded) {
-            if (item < (unsigned int)p.nSlots) {
-                const float4 rd = p.state.rayD[item];
-                if (!(floatAsInt(rd.w) & kStDone)) {
-                    const float4 ro = p.state.rayO[item];
-                    RayHit hit;
-                    traverse<false, COUNT, kBlock>(
-                        geometry, stack, STACK,
-                        v3(ro.x, ro.y, ro.z), v3(rd.x, rd.y, rd.z), PATHED_TNEAR, PATHED_TFAR,
-                        &hit, &counters);
-                    p.state.hit[item] = make_float4(hit.t, hit.u, hit.v, intAsFloat(hit.prim));
-                    if (COUNT) { closestRays++; }
-                }
+    // persistent waves, static stride over 64-ray batches: closest batches (one per 64 slots)
+    // interleaved with the shadow batches of the same slots' shade blocks
+    for (unsigned int batch = waveId; batch < totalBatches; batch += waveCount) {
+        const unsigned int pair = batch >> 1;
+        if ((batch & 1u) == 0u) {
+            const unsigned int slot = pair * 64u + lane;
+            const float4 rd = p.state.rayD[slot];
+            if (!(floatAsInt(rd.w) & kStDone)) {
+                const float4 ro = p.state.rayO[slot];
+                RayHit hit;
+                traverse<false, COUNT, kBlock>(
+                    geometry, stack, STACK,
+                    v3(ro.x, ro.y, ro.z), v3(rd.x, rd.y, rd.z), PATHED_TNEAR, PATHED_TFAR,
+                    &hit, &counters);
+                p.state.hit[slot] = make_float4(hit.t, hit.u, hit.v, intAsFloat(hit.prim));
+                if (COUNT) { closestRays++; }
             }
         } else {
-            const unsigned int q = item - (unsigned int)p.nSlotsPadded;
-            if (q < shadowCount) {
-                const float4 so = p.state.shO[q];
-                const float4 sd = p.state.shD[q];
+            const unsigned int block = pair / kWavesPerBlock;
+            const unsigned int index = (pair % kWavesPerBlock) * 64u + lane;
+            if (index < p.state.blockShadowCount[block]) {
+                const unsigned int entry = block * kBlock + index;
+                const float4 so = p.state.shO[entry];
+                const float4 sd = p.state.shD[entry];
                 RayHit hit;
                 const bool occluded = traverse<true, COUNT, kBlock>(
                     geometry, stack, STACK,
@@ -368,44 +384,109 @@ __device__ inline Rgb sampleLightsTerm(
         / pdf;
 }
 
-// Camera::generateRay(int,int), src/camera.cpp:49-55, for (slot = pixel, sample)
-__device__ inline void startSample(const RenderParams &p, int slot, uint32_t sample, float4 *rayO, float4 *rayD)
+// Camera::generateRay(int,int), src/camera.cpp:49-55, for (pixel, sample)
+__device__ inline void startSample(const RenderParams &p, uint32_t pixel, uint32_t sample, int sampleInUnit, float4 *rayO, float4 *rayD)
 {
     const int width = p.scene.camera.resX;
-    const int row = slot / width;
-    const int col = slot - row * width;
+    const int row = (int)pixel / width;
+    const int col = (int)pixel - row * width;
     Rng random;
-    makeKey(((uint64_t)p.seedHi << 32) | p.seedLo, (uint32_t)slot, sample, &random.k0, &random.k1);
+    makeKey(((uint64_t)p.seedHi << 32) | p.seedLo, pixel, sample, &random.k0, &random.k1);
     random.dimension = 0;
     const float jitterX = random.next() - 0.5f;
     const float jitterY = random.next() - 0.5f;
     V3 origin, direction;
     cameraRay(p.scene.camera, row + jitterY, col + jitterX, &origin, &direction);
     *rayO = make_float4(origin.x, origin.y, origin.z, intAsFloat(-1));
-    *rayD = make_float4(direction.x, direction.y, direction.z, intAsFloat(0));
+    *rayD = make_float4(direction.x, direction.y, direction.z, intAsFloat(sampleInUnit << kStSampleShift));
+}
+
+// Block-aggregated grab of work units: returns this lane's unit (or nUnits-or-more = none).
+// One atomic per block on one of kUnitQueues cursors; queue q owns units [q*U_q, (q+1)*U_q).
+__device__ inline unsigned int grabUnits(const RenderParams &p, bool want, unsigned int *ldsScratch)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const unsigned long long mask = __ballot(want);
+    const unsigned int before = (unsigned int)__popcll(mask & ((1ull << lane) - 1ull));
+    if (lane == 0) { ldsScratch[wave] = (unsigned int)__popcll(mask); }
+    __syncthreads();
+    unsigned int offset = 0, total = 0;
+    #pragma unroll
+    for (int w = 0; w < kWavesPerBlock; w++) {
+        const unsigned int count = ldsScratch[w];
+        if (w < wave) { offset += count; }
+        total += count;
+    }
+    const unsigned int queue = blockIdx.x % (unsigned int)p.nQueues;
+    if (threadIdx.x == 0) {
+        ldsScratch[kWavesPerBlock] = total ? atomicAdd(&p.counters[kCtrUnitCursor + queue], total) : 0u;
+    }
+    __syncthreads();
+    const unsigned int base = ldsScratch[kWavesPerBlock];
+    __syncthreads();  // scratch is reused by the caller
+    if (!want) { return 0xFFFFFFFFu; }
+    const unsigned int k = base + offset + before;
+    if (k >= p.unitsPerQueue) { return 0xFFFFFFFFu; }
+    const unsigned int unit = queue * p.unitsPerQueue + k;
+    return unit < p.nUnits ? unit : 0xFFFFFFFFu;
+}
+
+// first sample index of a unit and one-past-last
+__device__ inline void unitSamples(const RenderParams &p, unsigned int unit, uint32_t *pixel, uint32_t *first, uint32_t *end)
+{
+    const unsigned int chunkIndex = unit / (unsigned int)p.nPixels;
+    *pixel = unit - chunkIndex * (unsigned int)p.nPixels;
+    *first = p.sppBegin + chunkIndex * (unsigned int)p.chunk;
+    const uint32_t last = *first + (unsigned int)p.chunk;
+    *end = last < p.sppEnd ? last : p.sppEnd;
 }
 
 __global__ __launch_bounds__(kBlock) void k_init(RenderParams p)
 {
+    __shared__ unsigned int scratch[kWavesPerBlock + 1];
     const int slot = blockIdx.x * kBlock + threadIdx.x;
-    if (slot == 0) {
-        for (int i = 0; i < kCtrCount; i++) { p.counters[i] = 0; }
-        p.counters[kCtrRemaining] = (p.sppEnd > p.sppBegin) ? (unsigned int)p.nSlots : 0u;
-    }
-    if (slot >= p.nSlots) { return; }
-    float4 rayO, rayD;
-    if (p.sppEnd > p.sppBegin) {
-        startSample(p, slot, p.sppBegin, &rayO, &rayD);
-    } else {
-        rayO = make_float4(0.f, 0.f, 0.f, intAsFloat(-1));
-        rayD = make_float4(0.f, 0.f, 0.f, intAsFloat(kStDone));
+    const unsigned int unit = grabUnits(p, true, scratch);
+
+    float4 rayO = make_float4(0.f, 0.f, 0.f, intAsFloat(-1));
+    float4 rayD = make_float4(0.f, 0.f, 0.f, intAsFloat(kStDone));
+    const bool started = unit != 0xFFFFFFFFu;
+    if (started) {
+        uint32_t pixel, first, end;
+        unitSamples(p, unit, &pixel, &first, &end);
+        startSample(p, pixel, first, 0, &rayO, &rayD);
     }
     p.state.rayO[slot] = rayO;
     p.state.rayD[slot] = rayD;
-    p.state.res[slot] = make_float4(0.f, 0.f, 0.f, intAsFloat((int)p.sppBegin));
+    p.state.res[slot] = make_float4(0.f, 0.f, 0.f, intAsFloat((int)unit));
     p.state.mod[slot] = make_float4(1.f, 1.f, 1.f, 1.f);
     p.state.thr[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
     p.state.pend[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
+    p.state.acc[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (threadIdx.x == 0) { p.state.blockShadowCount[blockIdx.x] = 0; }
+
+    const unsigned long long mask = __ballot(started);
+    if ((threadIdx.x & 63) == 0 && mask != 0ull) {
+        atomicAdd(&p.counters[kCtrRemaining], (unsigned int)__popcll(mask));
+    }
+}
+
+// adds a pixel's unit partial sums to the radiance sum, in chunk order
+__global__ __launch_bounds__(kBlock) void k_resolve(RenderParams p)
+{
+    const int pixel = blockIdx.x * kBlock + threadIdx.x;
+    if (pixel >= p.nPixels) { return; }
+    float *out = p.accum + 3 * (size_t)pixel;
+    float r = out[0], g = out[1], b = out[2];
+    for (int chunk = 0; chunk < p.chunksPerPixel; chunk++) {
+        const float4 partial = p.state.chunkBuf[(size_t)chunk * p.nPixels + pixel];
+        r += partial.x;
+        g += partial.y;
+        b += partial.z;
+    }
+    out[0] = r;
+    out[1] = g;
+    out[2] = b;
 }
 
 template <bool LDS_MATERIALS>
@@ -418,6 +499,7 @@ template <bool LDS_MATERIALS>
 __global__ __launch_bounds__(kBlock) void k_shade(RenderParams p)
 {
     __shared__ DMaterial ldsMaterials[LDS_MATERIALS ? kMaxLdsMaterials : 1];
+    __shared__ unsigned int scratch[kWavesPerBlock + 1];
 
     MaterialAccess<LDS_MATERIALS> materials;
     if (LDS_MATERIALS) {
@@ -434,19 +516,12 @@ __global__ __launch_bounds__(kBlock) void k_shade(RenderParams p)
 
     const int slot = blockIdx.x * kBlock + threadIdx.x;
     const int lane = threadIdx.x & 63;
-    const int parity = p.parity;
-    if (slot == 0) { p.counters[kCtrCursor + (parity ^ 1)] = 0; }
-
+    const int wave = threadIdx.x >> 6;
     const DScene &scene = p.scene;
 
-    bool active = slot < p.nSlots;
-    float4 rd = make_float4(0.f, 0.f, 0.f, 0.f);
-    int st = kStDone;
-    if (active) {
-        rd = p.state.rayD[slot];
-        st = floatAsInt(rd.w);
-        active = !(st & kStDone);
-    }
+    float4 rd = p.state.rayD[slot];
+    int st = floatAsInt(rd.w);
+    const bool active = !(st & kStDone);
 
     ShadowRequest shadow;
     shadow.push = false;
@@ -454,27 +529,41 @@ __global__ __launch_bounds__(kBlock) void k_shade(RenderParams p)
     shadow.direction = v3(0.f, 0.f, 0.f);
     shadow.tfar = 0.f;
 
+    // what the convergent tail needs
+    bool finished = false;        // the sample in flight ended this iteration
+    Rgb color = rgb(0.f);
+    unsigned int unit = 0xFFFFFFFFu;
+    int sampleInUnit = 0;
+    float4 outRayO = make_float4(0.f, 0.f, 0.f, 0.f), outRayD = rd;
+    float4 outMod = make_float4(1.f, 1.f, 1.f, 1.f);
+    float4 outThr = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 outPend = make_float4(0.f, 0.f, 0.f, 0.f);
+    Rgb result = rgb(0.f);
+
     if (active) {
         const float4 ro = p.state.rayO[slot];
         const float4 h = p.state.hit[slot];
         const float4 resIn = p.state.res[slot];
+        outRayO = ro;
 
         const V3 o = v3(ro.x, ro.y, ro.z);
         const V3 d = v3(rd.x, rd.y, rd.z);
         const int rayBounce = st & kStBounceMask;  // vertex that spawned this ray, 0 = camera
+        sampleInUnit = (st >> kStSampleShift) & kStSampleMask;
         const bool miss = floatAsInt(h.w) < 0;
-        uint32_t sample = (uint32_t)floatAsInt(resIn.w);
+        unit = (unsigned int)floatAsInt(resIn.w);
         int firstEmitMaterial = floatAsInt(ro.w);
 
-        Rgb result = rgb(resIn.x, resIn.y, resIn.z);
-        Rgb modulation = rgb(1.f);
+        uint32_t pixel, firstSample, endSample;
+        unitSamples(p, unit, &pixel, &firstSample, &endSample);
+        const uint32_t sample = firstSample + (uint32_t)sampleInUnit;
 
-        bool finished = false;
-        Rgb color = rgb(0.f);
+        result = rgb(resIn.x, resIn.y, resIn.z);
+        Rgb modulation = rgb(1.f);
 
         bool haveVertex = false;  // a new surface vertex to process this iteration
         Isect isect;
-        int vertex = rayBounce + 1;
+        const int vertex = rayBounce + 1;
 
         if (rayBounce == 0) {
             // SampleIntegrator::samplePixel, src/sample_integrator.cpp:18-59
@@ -548,17 +637,14 @@ __global__ __launch_bounds__(kBlock) void k_shade(RenderParams p)
             }
         }
 
-        float4 outRayO = ro, outRayD = rd;
-        float4 outMod = make_float4(modulation.r, modulation.g, modulation.b, 1.f);
-        float4 outThr = make_float4(0.f, 0.f, 0.f, 0.f);
-        float4 outPend = make_float4(0.f, 0.f, 0.f, 0.f);
+        outMod = make_float4(modulation.r, modulation.g, modulation.b, 1.f);
 
         if (haveVertex) {
             // PathTracer::L: sample the BSDF, then direct(), src/path_tracer.cpp:30-36, 60-73
             const DMaterial &material = materials[isect.material];
 
             Rng random;
-            makeKey(((uint64_t)p.seedHi << 32) | p.seedLo, (uint32_t)slot, sample, &random.k0, &random.k1);
+            makeKey(((uint64_t)p.seedHi << 32) | p.seedLo, pixel, sample, &random.k0, &random.k1);
             random.dimension = vertexBase(vertex);
             const BSDFSample bsdfSample = materialSample(material, isect, random);
 
@@ -580,7 +666,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(RenderParams p)
                 color = first + result;
                 shadow.push = false;
             } else {
-                int nextState = vertex;
+                int nextState = vertex | (sampleInUnit << kStSampleShift);
                 if (wantDirect) { nextState |= kStEligible; }
                 if (isDelta(material)) { nextState |= kStDelta; }
                 if (wantContinue) { nextState |= kStContinue; }
@@ -593,51 +679,87 @@ __global__ __launch_bounds__(kBlock) void k_shade(RenderParams p)
                 outPend = make_float4(lightTerm.r, lightTerm.g, lightTerm.b, 0.f);
             }
         }
+    }
 
-        float4 outRes = make_float4(result.r, result.g, result.b, intAsFloat((int)sample));
-
-        if (finished) {
-            // radianceLookup += color, src/sample_integrator.cpp:61-63; non-finite samples dropped
-            const bool finite = isfinite(color.r) && isfinite(color.g) && isfinite(color.b);
-            if (finite) {
-                float *pixel = p.accum + 3 * (size_t)slot;
-                pixel[0] += color.r;
-                pixel[1] += color.g;
-                pixel[2] += color.b;
-            } else {
-                atomicAdd(&p.stats[kStatDropped], 1ull);
-            }
-            sample++;
-            if (sample < p.sppEnd) {
-                startSample(p, slot, sample, &outRayO, &outRayD);
-            } else {
-                outRayD.w = intAsFloat(kStDone);
-                atomicSub(&p.counters[kCtrRemaining], 1u);
-            }
-            outRes = make_float4(0.f, 0.f, 0.f, intAsFloat((int)sample));
-            outMod = make_float4(1.f, 1.f, 1.f, 1.f);
+    // ---- sample / unit bookkeeping --------------------------------------------------------
+    bool needUnit = false;
+    if (active && finished) {
+        // radianceLookup += color, src/sample_integrator.cpp:61-63; non-finite samples dropped
+        float4 partial = p.state.acc[slot];
+        const bool finite = isfinite(color.r) && isfinite(color.g) && isfinite(color.b);
+        if (finite) {
+            partial.x += color.r;
+            partial.y += color.g;
+            partial.z += color.b;
+        } else {
+            atomicAdd(&p.stats[kStatDropped], 1ull);
         }
+        uint32_t pixel, firstSample, endSample;
+        unitSamples(p, unit, &pixel, &firstSample, &endSample);
+        sampleInUnit++;
+        result = rgb(0.f);
+        outMod = make_float4(1.f, 1.f, 1.f, 1.f);
+        outThr = make_float4(0.f, 0.f, 0.f, 0.f);
+        outPend = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (firstSample + (uint32_t)sampleInUnit < endSample) {
+            startSample(p, pixel, firstSample + (uint32_t)sampleInUnit, sampleInUnit, &outRayO, &outRayD);
+            p.state.acc[slot] = partial;
+        } else {
+            p.state.chunkBuf[unit] = partial;
+            p.state.acc[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
+            needUnit = true;
+        }
+    }
 
+    // block-aggregated grab of the next units (wave ballot + LDS scan, one atomic per block)
+    const unsigned int newUnit = grabUnits(p, needUnit, scratch);
+    bool retired = false;
+    if (needUnit) {
+        unit = newUnit;
+        if (newUnit != 0xFFFFFFFFu) {
+            uint32_t pixel, firstSample, endSample;
+            unitSamples(p, newUnit, &pixel, &firstSample, &endSample);
+            startSample(p, pixel, firstSample, 0, &outRayO, &outRayD);
+        } else {
+            outRayD.w = intAsFloat(kStDone);
+            retired = true;
+        }
+    }
+
+    if (active) {
         p.state.rayO[slot] = outRayO;
         p.state.rayD[slot] = outRayD;
         p.state.mod[slot] = outMod;
         p.state.thr[slot] = outThr;
-        p.state.res[slot] = outRes;
+        p.state.res[slot] = make_float4(result.r, result.g, result.b, intAsFloat((int)unit));
         p.state.pend[slot] = outPend;
     }
 
-    // shadow-ray stream compaction: wave ballot + prefix popcount, one atomic per wave
-    const unsigned long long mask = __ballot(shadow.push);
-    if (mask != 0ull) {
-        unsigned int base = 0;
-        const int leader = __ffsll((long long)mask) - 1;
-        if (lane == leader) { base = atomicAdd(&p.counters[kCtrShadowCount + (parity ^ 1)], (unsigned int)__popcll(mask)); }
-        base = __shfl(base, leader);
+    // ---- shadow-ray stream compaction: wave ballot + prefix popcount + LDS block scan -------
+    {
+        const unsigned long long mask = __ballot(shadow.push);
+        const unsigned int before = (unsigned int)__popcll(mask & ((1ull << lane) - 1ull));
+        if (lane == 0) { scratch[wave] = (unsigned int)__popcll(mask); }
+        __syncthreads();
+        unsigned int offset = 0, total = 0;
+        #pragma unroll
+        for (int w = 0; w < kWavesPerBlock; w++) {
+            const unsigned int count = scratch[w];
+            if (w < wave) { offset += count; }
+            total += count;
+        }
+        if (threadIdx.x == 0) { p.state.blockShadowCount[blockIdx.x] = total; }
         if (shadow.push) {
-            const unsigned int index = base + (unsigned int)__popcll(mask & ((1ull << lane) - 1ull));
+            const unsigned int index = blockIdx.x * kBlock + offset + before;
             p.state.shO[index] = make_float4(shadow.origin.x, shadow.origin.y, shadow.origin.z, shadow.tfar);
             p.state.shD[index] = make_float4(shadow.direction.x, shadow.direction.y, shadow.direction.z, intAsFloat(slot));
         }
+    }
+
+    // slots that ran out of units (only at the tail of a render call)
+    const unsigned long long retiredMask = __ballot(retired);
+    if (lane == 0 && retiredMask != 0ull) {
+        atomicSub(&p.counters[kCtrRemaining], (unsigned int)__popcll(retiredMask));
     }
 }
 

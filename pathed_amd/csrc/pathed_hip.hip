@@ -142,9 +142,12 @@ struct PathedScene {
     DeviceBuffer<int> phiEmpty;
 
     // render state, allocated on first use
-    int nSlots = 0, nSlotsPadded = 0;
-    DeviceBuffer<float4> rayO, rayD, hit, mod, thr, res, pend, shO, shD;
-    DeviceBuffer<unsigned int> counters;
+    int nSlots = 0;
+    size_t chunkCapacity = 0;     // float4 entries of chunkBuf
+    int samplesPerUnit = 4;       // "chunk": samples a slot sums before it publishes a partial
+    int maxSlots = 1 << 20;
+    DeviceBuffer<float4> rayO, rayD, hit, mod, thr, res, pend, acc, shO, shD, chunkBuf;
+    DeviceBuffer<unsigned int> counters, blockShadowCount;
     DeviceBuffer<unsigned long long> stats;
     unsigned int *hostRemaining = nullptr;  // pinned
 
@@ -166,8 +169,8 @@ struct PathedScene {
         spheres.release(); materials.release(); lights.release();
         thetaCdf.release(); phiCdf.release(); phiEmpty.release();
         rayO.release(); rayD.release(); hit.release(); mod.release(); thr.release();
-        res.release(); pend.release(); shO.release(); shD.release();
-        counters.release(); stats.release();
+        res.release(); pend.release(); acc.release(); shO.release(); shD.release(); chunkBuf.release();
+        counters.release(); blockShadowCount.release(); stats.release();
         if (hostRemaining) { (void)hipHostFree(hostRemaining); }
         traceEvents.destroy();
         shadeEvents.destroy();
@@ -294,23 +297,31 @@ int validate(const PathedSceneDesc *desc)
     return PATHED_OK;
 }
 
-int ensureRenderState(PathedScene *scene)
+// chunks (units per pixel) rendered per internal pass: bounds chunkBuf to 64 float4 per pixel
+const int kMaxChunksPerPass = 64;
+
+int ensureRenderState(PathedScene *scene, int nSlots, size_t chunkEntries)
 {
-    const int nSlots = scene->width * scene->height;
-    if (scene->nSlots == nSlots && scene->rayO.ptr) { return PATHED_OK; }
-    scene->nSlots = nSlots;
-    scene->nSlotsPadded = (nSlots + 63) / 64 * 64;
-    const size_t n = (size_t)scene->nSlotsPadded;
-    HIP_TRY(scene->rayO.allocate(n));
-    HIP_TRY(scene->rayD.allocate(n));
-    HIP_TRY(scene->hit.allocate(n));
-    HIP_TRY(scene->mod.allocate(n));
-    HIP_TRY(scene->thr.allocate(n));
-    HIP_TRY(scene->res.allocate(n));
-    HIP_TRY(scene->pend.allocate(n));
-    HIP_TRY(scene->shO.allocate(n));
-    HIP_TRY(scene->shD.allocate(n));
-    HIP_TRY(scene->counters.allocate(kCtrCount));
+    if (scene->nSlots != nSlots || !scene->rayO.ptr) {
+        scene->nSlots = nSlots;
+        const size_t n = (size_t)nSlots;
+        HIP_TRY(scene->rayO.allocate(n));
+        HIP_TRY(scene->rayD.allocate(n));
+        HIP_TRY(scene->hit.allocate(n));
+        HIP_TRY(scene->mod.allocate(n));
+        HIP_TRY(scene->thr.allocate(n));
+        HIP_TRY(scene->res.allocate(n));
+        HIP_TRY(scene->pend.allocate(n));
+        HIP_TRY(scene->acc.allocate(n));
+        HIP_TRY(scene->shO.allocate(n));
+        HIP_TRY(scene->shD.allocate(n));
+        HIP_TRY(scene->blockShadowCount.allocate(n / kBlock));
+    }
+    if (scene->chunkCapacity < chunkEntries) {
+        HIP_TRY(scene->chunkBuf.allocate(chunkEntries));
+        scene->chunkCapacity = chunkEntries;
+    }
+    if (!scene->counters.ptr) { HIP_TRY(scene->counters.allocate(kCtrCount)); }
     if (!scene->stats.ptr) {
         HIP_TRY(scene->stats.allocate(kStatCount));
         HIP_TRY(hipMemset(scene->stats.ptr, 0, kStatCount * sizeof(unsigned long long)));
@@ -347,7 +358,7 @@ void launchTrace(PathedScene *scene, const RenderParams &params, hipStream_t str
 
 void launchShade(PathedScene *scene, const RenderParams &params, hipStream_t stream)
 {
-    const dim3 grid((unsigned)((scene->nSlots + kBlock - 1) / kBlock)), block(kBlock);
+    const dim3 grid((unsigned)(scene->nSlots / kBlock)), block(kBlock);
     if (scene->device.nMaterials <= kMaxLdsMaterials) {
         hipLaunchKernelGGL((k_shade<true>), grid, block, 0, stream, params);
     } else {
@@ -557,27 +568,24 @@ void pathed_hip_scene_destroy(PathedScene *scene)
     delete scene;
 }
 
-int pathed_hip_render_device(PathedScene *scene, uint64_t seed,
-                             uint32_t spp_begin, uint32_t spp_count,
-                             int start_bounce, int last_bounce,
-                             float *d_accum_rgb_sum, void *stream_handle, int blocking)
+// one internal pass: samples [begin, begin+count), count <= chunk * kMaxChunksPerPass
+static int renderPass(PathedScene *scene, uint64_t seed, uint32_t begin, uint32_t count,
+                      int start_bounce, int last_bounce, float *d_accum, hipStream_t stream)
 {
-    (void)blocking;  // the iteration loop polls a device counter, so the call always completes
-    if (!scene || !d_accum_rgb_sum) { return fail(PATHED_E_INVALID, "null scene or accumulation buffer"); }
-    if (start_bounce < 0 || (last_bounce != -1 && start_bounce > last_bounce)) {
-        return fail(PATHED_E_INVALID, "bounce window: need 0 <= startBounce <= lastBounce (or lastBounce == -1)");
-    }
-    if (spp_count == 0) { return PATHED_OK; }
-    if ((uint64_t)spp_begin + spp_count > 0x7fffffffull) { return fail(PATHED_E_INVALID, "sample index overflow"); }
+    const int nPixels = scene->width * scene->height;
+    const int chunk = scene->samplesPerUnit;
+    const int chunksPerPixel = (int)((count + (uint32_t)chunk - 1) / (uint32_t)chunk);
+    const unsigned long long nUnits64 = (unsigned long long)nPixels * (unsigned long long)chunksPerPixel;
+    if (nUnits64 >= 0xFFFFFFF0ull) { return fail(PATHED_E_INVALID, "too many work units in one pass"); }
+    const unsigned int nUnits = (unsigned int)nUnits64;
 
-    int code = ensureRenderState(scene);
+    unsigned long long wanted = nUnits64 < (unsigned long long)scene->maxSlots ? nUnits64 : (unsigned long long)scene->maxSlots;
+    const int nSlots = (int)((wanted + kBlock - 1) / kBlock * kBlock);
+    int code = ensureRenderState(scene, nSlots, (size_t)nUnits);
     if (code != PATHED_OK) { return code; }
-    if (scene->timeKernels) {
-        HIP_TRY(scene->traceEvents.create());
-        HIP_TRY(scene->shadeEvents.create());
-    }
 
-    hipStream_t stream = (hipStream_t)stream_handle;
+    const int nBlocks = nSlots / kBlock;
+    const int nQueues = nBlocks < kUnitQueues ? nBlocks : kUnitQueues;
 
     RenderParams params;
     params.scene = scene->device;
@@ -588,27 +596,35 @@ int pathed_hip_render_device(PathedScene *scene, uint64_t seed,
     params.state.thr = scene->thr.ptr;
     params.state.res = scene->res.ptr;
     params.state.pend = scene->pend.ptr;
+    params.state.acc = scene->acc.ptr;
     params.state.shO = scene->shO.ptr;
     params.state.shD = scene->shD.ptr;
+    params.state.blockShadowCount = scene->blockShadowCount.ptr;
+    params.state.chunkBuf = scene->chunkBuf.ptr;
     params.counters = scene->counters.ptr;
     params.stats = scene->stats.ptr;
-    params.accum = d_accum_rgb_sum;
-    params.nSlots = scene->nSlots;
-    params.nSlotsPadded = scene->nSlotsPadded;
+    params.accum = d_accum;
+    params.nSlots = nSlots;
+    params.nPixels = nPixels;
+    params.nUnits = nUnits;
+    params.nQueues = nQueues;
+    params.unitsPerQueue = (nUnits + (unsigned int)nQueues - 1) / (unsigned int)nQueues;
+    params.chunk = chunk;
+    params.chunksPerPixel = chunksPerPixel;
     params.seedLo = (uint32_t)seed;
     params.seedHi = (uint32_t)(seed >> 32);
-    params.sppBegin = spp_begin;
-    params.sppEnd = spp_begin + spp_count;
+    params.sppBegin = begin;
+    params.sppEnd = begin + count;
     params.startBounce = start_bounce;
     params.lastBounce = last_bounce;
-    params.parity = 0;
 
-    const dim3 slotGrid((unsigned)((scene->nSlots + kBlock - 1) / kBlock)), block(kBlock);
+    const dim3 slotGrid((unsigned)nBlocks), block(kBlock);
+    HIP_TRY(hipMemsetAsync(scene->counters.ptr, 0, kCtrCount * sizeof(unsigned int), stream));
     hipLaunchKernelGGL(k_init, slotGrid, block, 0, stream, params);
 
-    // Iterate until every slot has rendered its samples.  `remaining` is polled with a
-    // lag of one chunk so the GPU never waits for the host.
-    const int chunk = 8;
+    // Iterate until every slot has run out of units.  `remaining` is polled with a lag of one
+    // chunk of launches so the GPU never waits for the host.
+    const int launchChunk = 8;
     const int ringSize = 64;
     hipEvent_t pollEvents[2];
     HIP_TRY(hipEventCreateWithFlags(&pollEvents[0], hipEventDisableTiming));
@@ -618,8 +634,7 @@ int pathed_hip_render_device(PathedScene *scene, uint64_t seed,
     bool havePending = false;
     bool done = false;
     while (!done) {
-        for (int k = 0; k < chunk; k++) {
-            params.parity = (int)(iteration & 1);
+        for (int k = 0; k < launchChunk; k++) {
             if (scene->timeKernels) {
                 const int e = scene->traceEvents.acquire();
                 (void)hipEventRecord(scene->traceEvents.start[e], stream);
@@ -647,17 +662,58 @@ int pathed_hip_render_device(PathedScene *scene, uint64_t seed,
         havePending = true;
         pollIndex++;
     }
+    const dim3 pixelGrid((unsigned)((nPixels + kBlock - 1) / kBlock));
+    hipLaunchKernelGGL(k_resolve, pixelGrid, block, 0, stream, params);
     HIP_TRY(hipStreamSynchronize(stream));
     (void)hipEventDestroy(pollEvents[0]);
     (void)hipEventDestroy(pollEvents[1]);
     HIP_TRY(hipGetLastError());
 
     scene->iterations += iteration;
-    scene->cameraSamples += (unsigned long long)spp_count * (unsigned long long)scene->nSlots;
+    scene->cameraSamples += (unsigned long long)count * (unsigned long long)nPixels;
+    return PATHED_OK;
+}
+
+int pathed_hip_render_device(PathedScene *scene, uint64_t seed,
+                             uint32_t spp_begin, uint32_t spp_count,
+                             int start_bounce, int last_bounce,
+                             float *d_accum_rgb_sum, void *stream_handle, int blocking)
+{
+    (void)blocking;  // the iteration loop polls a device counter, so the call always completes
+    if (!scene || !d_accum_rgb_sum) { return fail(PATHED_E_INVALID, "null scene or accumulation buffer"); }
+    if (start_bounce < 0 || (last_bounce != -1 && start_bounce > last_bounce)) {
+        return fail(PATHED_E_INVALID, "bounce window: need 0 <= startBounce <= lastBounce (or lastBounce == -1)");
+    }
+    if (spp_count == 0) { return PATHED_OK; }
+    if ((uint64_t)spp_begin + spp_count > 0x7fffffffull) { return fail(PATHED_E_INVALID, "sample index overflow"); }
+
+    if (scene->timeKernels) {
+        HIP_TRY(scene->traceEvents.create());
+        HIP_TRY(scene->shadeEvents.create());
+    }
+    hipStream_t stream = (hipStream_t)stream_handle;
+
+    // passes of at most chunk * kMaxChunksPerPass samples keep the partial-sum buffer bounded
+    const uint32_t perPass = (uint32_t)scene->samplesPerUnit * (uint32_t)kMaxChunksPerPass;
+    uint32_t done = 0;
+    while (done < spp_count) {
+        const uint32_t count = (spp_count - done < perPass) ? (spp_count - done) : perPass;
+        const int code = renderPass(scene, seed, spp_begin + done, count, start_bounce, last_bounce, d_accum_rgb_sum, stream);
+        if (code != PATHED_OK) { return code; }
+        done += count;
+    }
     if (scene->timeKernels) {
         scene->traceEvents.harvestAll();
         scene->shadeEvents.harvestAll();
     }
+    return PATHED_OK;
+}
+
+int pathed_hip_set_samples_per_unit(PathedScene *scene, int samples)
+{
+    if (!scene) { return fail(PATHED_E_INVALID, "null scene"); }
+    if (samples < 1 || samples > kMaxChunk) { return fail(PATHED_E_INVALID, "samples per unit must be in [1, 128]"); }
+    scene->samplesPerUnit = samples;
     return PATHED_OK;
 }
 

@@ -76,6 +76,11 @@ class HipScene:
         _check(self._lib, code, "pathed_hip_trace")
         return out
 
+    def set_samples_per_unit(self, samples):
+        """Summation granularity (see include/pathed_hip.h); 1 = the reference's exact order."""
+        _check(self._lib, self._lib.pathed_hip_set_samples_per_unit(self._handle, int(samples)),
+               "pathed_hip_set_samples_per_unit")
+
     def set_stats_mode(self, count=False, time_kernels=False):
         mode = (1 if count else 0) | (2 if time_kernels else 0)
         _check(self._lib, self._lib.pathed_hip_set_stats_mode(self._handle, mode), "pathed_hip_set_stats_mode")

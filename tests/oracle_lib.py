@@ -30,6 +30,8 @@ def load():
     lib.oracle_last_error.restype = C.c_char_p
     lib.oracle_render.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, C.c_int, fp, C.c_int, C.POINTER(C.c_uint64)]
     lib.oracle_render.restype = C.c_int
+    lib.oracle_render_chunked.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, C.c_int, fp, C.c_int, C.POINTER(C.c_uint64), C.c_int]
+    lib.oracle_render_chunked.restype = C.c_int
     lib.oracle_sample_pixel.argtypes = [vp, C.c_uint64, C.c_int, C.c_int, C.c_uint32, C.c_int, C.c_int, fp]
     lib.oracle_sample_pixel.restype = C.c_int
     lib.oracle_trace.argtypes = [vp, fp, C.c_size_t, C.c_int, vp]
@@ -69,12 +71,13 @@ class OracleScene:
     def __del__(self):
         self.close()
 
-    def render(self, width, height, seed, spp_begin, spp_count, start_bounce, last_bounce, threads=1, accum=None):
+    def render(self, width, height, seed, spp_begin, spp_count, start_bounce, last_bounce, threads=1, accum=None,
+               chunk=1):
         if accum is None:
             accum = np.zeros((height, width, 3), dtype=np.float32)
         stats = (C.c_uint64 * 8)()
-        code = self.lib.oracle_render(self.handle, seed, spp_begin, spp_count, start_bounce, last_bounce,
-                                      _fptr(accum), threads, stats)
+        code = self.lib.oracle_render_chunked(self.handle, seed, spp_begin, spp_count, start_bounce, last_bounce,
+                                              _fptr(accum), threads, stats, chunk)
         if code != 0:
             raise RuntimeError("oracle_render failed")
         names = ["camera_samples", "closest_rays", "shadow_rays", "box_tests", "tri_tests", "dropped", "vertices"]

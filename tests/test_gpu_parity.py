@@ -79,7 +79,7 @@ def test_empty_and_ragged_inputs(libs):
     image = gpu.render(3, 0, 0, 0, 10)  # zero samples: nothing is added
     assert not image.any()
     image = gpu.render(3, 5, 3, 0, 10)
-    expected, _ = cpu.render(17, 5, 3, 5, 3, 0, 10)
+    expected, _ = cpu.render(17, 5, 3, 5, 3, 0, 10, chunk=4)
     rel, bad = _image_metrics(image, expected)
     assert rel < 2e-3 and bad <= 0.012  # 1 of 85 pixels
 
@@ -147,15 +147,49 @@ def test_batches_continue_the_sum_bit_exactly(libs):
     _, HipScene, LoadedScene = libs
     scene = LoadedScene("scenes/cornell.json", 64, 64)
     gpu = HipScene(scene.desc, device=0)
+    # samples-per-unit 1: the reference's exact per-sample order, any split is bit-identical
+    gpu.set_samples_per_unit(1)
     once = torch.zeros((64, 64, 3), dtype=torch.float32, device="cuda")
     gpu.render_device(4, 0, 12, 0, 10, once.data_ptr())
     split = torch.zeros_like(once)
     for begin, count in ((0, 5), (5, 1), (6, 6)):
         gpu.render_device(4, begin, count, 0, 10, split.data_ptr())
     assert torch.equal(once, split)
+    # default granularity (4): splits on unit boundaries are bit-identical, and the result is
+    # deterministic although slots pull work dynamically (no float atomics anywhere)
+    gpu.set_samples_per_unit(4)
+    once = torch.zeros_like(once)
+    gpu.render_device(4, 0, 24, 0, 10, once.data_ptr())
+    split = torch.zeros_like(once)
+    for begin, count in ((0, 8), (8, 4), (12, 12)):
+        gpu.render_device(4, begin, count, 0, 10, split.data_ptr())
+    assert torch.equal(once, split)
     again = torch.zeros_like(once)
-    gpu.render_device(4, 0, 12, 0, 10, again.data_ptr())
-    assert torch.equal(once, again)  # deterministic: no float atomics on the accumulation path
+    gpu.render_device(4, 0, 24, 0, 10, again.data_ptr())
+    assert torch.equal(once, again)
+
+
+def test_summation_order_matches_the_oracle_bit_for_bit_on_transcendental_free_paths(libs):
+    """Mirror scene, bounce window [0,0]+[1,1] through a mirror: no sinf/cosf/logf on the path, so
+    GPU and oracle must agree to the last bit, including the unit-wise summation order."""
+    oracle_lib, HipScene, _ = libs
+    from scene_builder import BuiltScene
+    from pathed_amd import _capi
+    built = BuiltScene(40, 40, (0, 1, 4), (0, 1, 0), fov_degrees=40)
+    mirror = built.material(type_=_capi.MAT_MIRROR)
+    glass = built.material(type_=_capi.MAT_GLASS, ior=1.5)
+    light = built.material(diffuse=(0, 0, 0), emit=(5, 4, 3))
+    built.quad([(-2, 0, 2), (2, 0, 2), (2, 0, -2), (-2, 0, -2)], mirror)
+    built.quad([(-1, 0.5, -1), (1, 0.5, -1), (1, 2.5, -1), (-1, 2.5, -1)], glass)
+    built.quad([(-3, 3, -3), (3, 3, -3), (3, 3, 3), (-3, 3, 3)], light)  # faces down
+    desc = built.finish()
+    gpu, cpu = HipScene(desc, device=0), oracle_lib.OracleScene(desc)
+    for chunk in (1, 4):
+        gpu.set_samples_per_unit(chunk)
+        image = gpu.render(5, 0, 8, 0, 6)
+        expected, _ = cpu.render(40, 40, 5, 0, 8, 0, 6, chunk=chunk)
+        assert image.any()
+        assert np.array_equal(image.view(np.int32), expected.view(np.int32)), chunk
 
 
 def test_stats_mode_counts_match_the_oracle(libs):
