@@ -107,6 +107,7 @@ class PathedStats(C.Structure):
         ("bvh_bytes", C.c_uint64),
         ("bvh_max_depth", C.c_uint32),
         ("scene_in_lds", C.c_uint32),
+        ("max_boxes_per_ray", C.c_uint64),
     ]
 
 
@@ -136,7 +137,8 @@ class PathedLibraryMissing(RuntimeError):
 
 
 def hip_library_path():
-    return os.path.join(LIB_DIR, "libpathed_hip.so")
+    # PATHED_HIP_LIB selects an experimental build of the same ABI (kernel tuning sweeps)
+    return os.environ.get("PATHED_HIP_LIB") or os.path.join(LIB_DIR, "libpathed_hip.so")
 
 
 def host_library_path():

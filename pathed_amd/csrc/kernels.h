@@ -32,11 +32,19 @@ static const int kBlock = 256;
 static const int kWavesPerBlock = kBlock / 64;
 static const int kMaxLdsMaterials = 96;  // 96 x 80 B = 7.5 KiB of LDS
 static const int kUnitQueues = 32;       // sharded work-unit cursors
+#ifndef PATHED_REFILL
+#define PATHED_REFILL 44
+#endif
+static const int kRefillThreshold = PATHED_REFILL;  // refill a wave's idle lanes once fewer than this many are busy
 
 // counters[] layout (unsigned int)
 static const int kCtrRemaining = 0;    // slots that still have work
 static const int kCtrUnitCursor = 8;   // [8 .. 8+kUnitQueues): next unit of each queue
 static const int kCtrCount = 8 + kUnitQueues;
+#ifndef PATHED_DEAL
+#define PATHED_DEAL 16
+#endif
+static const unsigned int kDeal = PATHED_DEAL;  // ray-pool items per card dealt to the trace waves
 
 // stats[] layout (unsigned long long)
 static const int kStatSamples = 0;
@@ -45,6 +53,7 @@ static const int kStatShadow = 2;
 static const int kStatBoxes = 3;
 static const int kStatTris = 4;
 static const int kStatDropped = 5;
+static const int kStatMaxBoxes = 6;   // most child boxes tested by a single ray (stats mode)
 static const int kStatCount = 8;
 
 // state word (rayD.w): bits 0..15 vertex that spawned the ray (0 = camera ray),
@@ -128,48 +137,94 @@ __global__ __launch_bounds__(kBlock) void k_trace(RenderParams p)
     }
 
     const int lane = threadIdx.x & 63;
+    const unsigned long long lanesBelow = (1ull << lane) - 1ull;
     const unsigned int waveId = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+
+    // Ray pool of this launch: item i < nSlots is the closest-hit ray of slot i; item
+    // nSlots + j is entry j % kBlock of shade block j / kBlock's compacted shadow rays.
+    // The pool is dealt to the persistent waves in kDeal-item cards, round robin: wave w owns
+    // cards w, w + W, w + 2W, ...  Every wave therefore samples the whole image (ray cost is
+    // strongly correlated in image space) and no atomics are needed.  Lanes whose ray has
+    // finished are refilled from the wave's own cards (ballot + prefix popcount).
     const unsigned int waveCount = gridDim.x * kWavesPerBlock;
-    const unsigned int slotBatches = (unsigned int)p.nSlots / 64u;
-    const unsigned int totalBatches = 2u * slotBatches;
+    const unsigned int totalItems = 2u * (unsigned int)p.nSlots;
+    const unsigned int totalCards = totalItems / kDeal;          // nSlots is a multiple of kBlock
+    const unsigned int myCards = (totalCards > waveId) ? (totalCards - waveId + waveCount - 1u) / waveCount : 0u;
+    const unsigned int localEnd = myCards * kDeal;               // wave-local item count
+    unsigned int cursor = 0;                                      // wave-uniform, in local items
 
     TraceCounters counters;
     counters.boxes = 0;
     counters.tris = 0;
     unsigned int closestRays = 0, shadowRays = 0;
+    unsigned int maxBoxes = 0, rayBoxesStart = 0;
 
-    // persistent waves, static stride over 64-ray batches: closest batches (one per 64 slots)
-    // interleaved with the shadow batches of the same slots' shade blocks
-    for (unsigned int batch = waveId; batch < totalBatches; batch += waveCount) {
-        const unsigned int pair = batch >> 1;
-        if ((batch & 1u) == 0u) {
-            const unsigned int slot = pair * 64u + lane;
-            const float4 rd = p.state.rayD[slot];
-            if (!(floatAsInt(rd.w) & kStDone)) {
-                const float4 ro = p.state.rayO[slot];
-                RayHit hit;
-                traverse<false, COUNT, kBlock>(
-                    geometry, stack, STACK,
-                    v3(ro.x, ro.y, ro.z), v3(rd.x, rd.y, rd.z), PATHED_TNEAR, PATHED_TFAR,
-                    &hit, &counters);
-                p.state.hit[slot] = make_float4(hit.t, hit.u, hit.v, intAsFloat(hit.prim));
-                if (COUNT) { closestRays++; }
+    LaneRay ray;
+    bool active = false;
+    unsigned int target = 0;  // slot of the ray in flight on this lane
+
+    while (true) {
+        if (cursor < localEnd) {
+            const unsigned long long idleMask = __ballot(!active);
+            if (idleMask != 0ull) {
+                const unsigned int local = cursor + (unsigned int)__popcll(idleMask & lanesBelow);
+                cursor += (unsigned int)__popcll(idleMask);
+                if (!active && local < localEnd) {
+                    const unsigned int item = ((local / kDeal) * waveCount + waveId) * kDeal + (local % kDeal);
+                    if (item < (unsigned int)p.nSlots) {
+                        const unsigned int slot = item;
+                        const float4 rd = p.state.rayD[slot];
+                        if (!(floatAsInt(rd.w) & kStDone)) {
+                            const float4 ro = p.state.rayO[slot];
+                            laneRayInit(ray, v3(ro.x, ro.y, ro.z), v3(rd.x, rd.y, rd.z), PATHED_TNEAR, PATHED_TFAR, false);
+                            target = slot;
+                            active = true;
+                            if (COUNT) { closestRays++; rayBoxesStart = counters.boxes; }
+                        }
+                    } else {
+                        const unsigned int entry = item - (unsigned int)p.nSlots;
+                        if ((entry % kBlock) < p.state.blockShadowCount[entry / kBlock]) {
+                            const float4 so = p.state.shO[entry];
+                            const float4 sd = p.state.shD[entry];
+                            laneRayInit(ray, v3(so.x, so.y, so.z), v3(sd.x, sd.y, sd.z), PATHED_TNEAR, so.w, true);
+                            target = (unsigned int)floatAsInt(sd.w);
+                            active = true;
+                            if (COUNT) { shadowRays++; rayBoxesStart = counters.boxes; }
+                        }
+                    }
+                }
             }
-        } else {
-            const unsigned int block = pair / kWavesPerBlock;
-            const unsigned int index = (pair % kWavesPerBlock) * 64u + lane;
-            if (index < p.state.blockShadowCount[block]) {
-                const unsigned int entry = block * kBlock + index;
-                const float4 so = p.state.shO[entry];
-                const float4 sd = p.state.shD[entry];
-                RayHit hit;
-                const bool occluded = traverse<true, COUNT, kBlock>(
-                    geometry, stack, STACK,
-                    v3(so.x, so.y, so.z), v3(sd.x, sd.y, sd.z), PATHED_TNEAR, so.w,
-                    &hit, &counters);
-                if (occluded) { p.state.pend[floatAsInt(sd.w)] = make_float4(0.f, 0.f, 0.f, 0.f); }
-                if (COUNT) { shadowRays++; }
+            if (cursor > localEnd) { cursor = localEnd; }
+        }
+
+        if (__ballot(active) == 0ull) {
+            if (cursor >= localEnd) { break; }
+            continue;
+        }
+
+        // traversal burst: one inner node per active lane per step, until the wave has thinned
+        // out enough to be worth refilling
+        while (true) {
+            if (active) {
+                const bool done = (geometry.nNodes == 0)
+                    || traversalStep<COUNT, kBlock>(geometry, stack, STACK, ray, &counters);
+                if (done) {
+                    finishRay(geometry, ray);
+                    if (ray.anyHit) {
+                        if (ray.occluded) { p.state.pend[target] = make_float4(0.f, 0.f, 0.f, 0.f); }
+                    } else {
+                        p.state.hit[target] = make_float4(ray.best, ray.bestU, ray.bestV, intAsFloat(ray.bestPrim));
+                    }
+                    if (COUNT) {
+                        const unsigned int delta = counters.boxes - rayBoxesStart;
+                        maxBoxes = delta > maxBoxes ? delta : maxBoxes;
+                    }
+                    active = false;
+                }
             }
+            const unsigned long long activeMask = __ballot(active);
+            if (activeMask == 0ull) { break; }
+            if (cursor < localEnd && __popcll(activeMask) < kRefillThreshold) { break; }
         }
     }
 
@@ -178,6 +233,7 @@ __global__ __launch_bounds__(kBlock) void k_trace(RenderParams p)
         atomicAdd(&p.stats[kStatTris], (unsigned long long)counters.tris);
         atomicAdd(&p.stats[kStatClosest], (unsigned long long)closestRays);
         atomicAdd(&p.stats[kStatShadow], (unsigned long long)shadowRays);
+        atomicMax(&p.stats[kStatMaxBoxes], (unsigned long long)maxBoxes);
     }
 }
 
@@ -205,12 +261,12 @@ __global__ __launch_bounds__(kBlock) void k_trace_rays(
     hit.t = 0.f; hit.u = 0.f; hit.v = 0.f; hit.prim = -1;
     TraceCounters counters;
     if (anyHit) {
-        const bool occluded = traverse<true, false, kBlock>(
-            geometry, stack, STACK, v3(ro.x, ro.y, ro.z), v3(rd.x, rd.y, rd.z), ro.w, rd.w, &hit, &counters);
+        const bool occluded = traverse<false, kBlock>(
+            geometry, stack, STACK, v3(ro.x, ro.y, ro.z), v3(rd.x, rd.y, rd.z), ro.w, rd.w, true, &hit, &counters);
         occludedOut[i] = occluded ? 1 : 0;
     } else {
-        const bool found = traverse<false, false, kBlock>(
-            geometry, stack, STACK, v3(ro.x, ro.y, ro.z), v3(rd.x, rd.y, rd.z), ro.w, rd.w, &hit, &counters);
+        const bool found = traverse<false, kBlock>(
+            geometry, stack, STACK, v3(ro.x, ro.y, ro.z), v3(rd.x, rd.y, rd.z), ro.w, rd.w, false, &hit, &counters);
         if (!found) { hit.t = 0.f; hit.u = 0.f; hit.v = 0.f; hit.prim = -1; }
         hitsOut[i] = make_float4(hit.t, hit.u, hit.v, intAsFloat(hit.prim));
     }

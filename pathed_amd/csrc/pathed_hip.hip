@@ -559,6 +559,10 @@ int pathed_hip_scene_create(const PathedSceneDesc *desc, PathedScene **out)
     d.env.phiEmpty = scene->phiEmpty.ptr;
 
     configureTrace(scene);
+    if (const char *slots = getenv("PATHED_MAX_SLOTS")) {
+        const long value = atol(slots);
+        if (value >= kBlock) { scene->maxSlots = (int)value; }
+    }
     *out = scene;
     return PATHED_OK;
 }
@@ -821,6 +825,7 @@ int pathed_hip_get_stats(PathedScene *scene, PathedStats *out)
     out->bvh_bytes = (uint64_t)scene->bvh.nodeCount * 64 + (uint64_t)scene->device.nTris * 48;
     out->bvh_max_depth = (uint32_t)scene->bvh.maxDepth;
     out->scene_in_lds = scene->sceneInLds ? 1u : 0u;
+    out->max_boxes_per_ray = device[kStatMaxBoxes];
     return PATHED_OK;
 }
 

@@ -9,6 +9,11 @@
 // Per-lane traversal stack lives in LDS, laid out [depth][thread] so a wave's 64 lanes
 // hit 64 consecutive dwords (bank-conflict-free ds_read_b32 / ds_write_b32).
 //
+// The traversal is written as a per-lane STATE MACHINE (LaneRay + traversalStep): one call
+// visits one inner node.  The persistent kernel interleaves steps of 64 independent rays and
+// refills lanes whose ray has finished from the ray pool, so a wave is not held hostage by its
+// slowest ray (ray costs are heavy-tailed: mean ~10 node visits, worst several hundred).
+//
 // Intersector specification (shared with the CPU checker so hits agree bit for bit):
 //   Moeller-Trumbore with xcross/xdot (explicit fmaf), u,v in Embree's convention,
 //   hit accepted iff t > tnear and (t < best, or t == best and prim < bestPrim);
@@ -89,109 +94,185 @@ struct TraceGeometry {
     int nSpheres;
 };
 
-// One ray.  ANY_HIT: stop at the first accepted hit in (tnear, tfar].
-// `stack` points at this lane's column: entry k is stack[k * STRIDE].
-template <bool ANY_HIT, bool COUNT, int STRIDE>
-__device__ inline bool traverse(
-    const TraceGeometry &g, int *stack, int stackDepth,
-    V3 o, V3 d, float tnear, float tfar,
-    RayHit *hit, TraceCounters *counters
-) {
-    float best = tfar;
-    int bestPrim = -1;
-    float bestU = 0.f, bestV = 0.f;
+// One ray in flight on one lane.
+struct LaneRay {
+    V3 o, d, invD, oInvD;
+    float tnear;
+    float tfar;      // the query's far bound (any-hit accepts t <= tfar)
+    float best;      // closest accepted t so far (starts at tfar)
+    float bestU, bestV;
+    int bestPrim;
+    int current;     // inner node to visit next
+    int sp;          // entries on this lane's LDS stack
+    bool anyHit;
+    bool occluded;
+};
 
+__device__ inline void laneRayInit(LaneRay &ray, V3 o, V3 d, float tnear, float tfar, bool anyHit)
+{
+    ray.o = o;
+    ray.d = d;
     // 1/d clamped to a large FINITE value: with +-inf the one-fma slab form computes
     // inf - inf = NaN for axis-parallel rays.  3e30 x coordinate stays below FLT_MAX for
     // |coordinate| < 1e8 and still orders every slab plane correctly.
     const float kHuge = 3e30f;
-    const V3 invD = v3(
+    ray.invD = v3(
         fminf(fmaxf(1.f / d.x, -kHuge), kHuge),
         fminf(fmaxf(1.f / d.y, -kHuge), kHuge),
         fminf(fmaxf(1.f / d.z, -kHuge), kHuge));
-    const V3 oInvD = v3(o.x * invD.x, o.y * invD.y, o.z * invD.z);
+    ray.oInvD = v3(o.x * ray.invD.x, o.y * ray.invD.y, o.z * ray.invD.z);
+    ray.tnear = tnear;
+    ray.tfar = tfar;
+    ray.best = tfar;
+    ray.bestU = 0.f;
+    ray.bestV = 0.f;
+    ray.bestPrim = -1;
+    ray.current = 0;
+    ray.sp = 0;
+    ray.anyHit = anyHit;
+    ray.occluded = false;
+}
 
-    if (g.nNodes > 0) {
-        int sp = 0;
-        int current = 0;
-        while (true) {
-            const float4 n0 = g.nodes[4 * current + 0];
-            const float4 n1 = g.nodes[4 * current + 1];
-            const float4 n2 = g.nodes[4 * current + 2];
-            const float4 n3 = g.nodes[4 * current + 3];
-            const int leftIndex = floatAsInt(n0.w), leftCount = floatAsInt(n1.w);
-            const int rightIndex = floatAsInt(n2.w), rightCount = floatAsInt(n3.w);
+// Keeps the compiler from sinking a 16-byte load below a branch that may skip its use: the four
+// components must be in VGPRs here, so the load is issued (and waited for) before this point.
+// Without it hipcc splits node / triangle loads into "index first, box later" pairs and every
+// node visit pays two dependent memory latencies instead of one.
+__device__ inline void pinLoaded(const float4 &a)
+{
+    asm volatile("" :: "v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w));
+}
 
-            float tLeft, tRight;
-            const bool hitLeft = (leftCount >= 0) && slabTest(n0, n1, invD, oInvD, tnear, best, &tLeft);
-            const bool hitRight = (rightCount >= 0) && slabTest(n2, n3, invD, oInvD, tnear, best, &tRight);
-            if (COUNT) { counters->boxes += (leftCount >= 0) + (rightCount >= 0); }
+__device__ inline void testLeafTriangle(
+    LaneRay &ray, float4 t0, float4 t1, float4 t2, bool *terminate
+) {
+    float t, u, v;
+    if (!intersectTriangle(ray.o, ray.d, v3(t0.x, t0.y, t0.z), v3(t1.x, t1.y, t1.z), v3(t2.x, t2.y, t2.z), &t, &u, &v)) { return; }
+    if (!(t > ray.tnear)) { return; }
+    const int prim = floatAsInt(t0.w);
+    if (ray.anyHit) {
+        if (t <= ray.tfar) { ray.occluded = true; *terminate = true; }
+    } else {
+        const bool closer = (ray.bestPrim < 0)
+            ? (t <= ray.best)
+            : (t < ray.best || (t == ray.best && prim < ray.bestPrim));
+        if (closer) { ray.best = t; ray.bestU = u; ray.bestV = v; ray.bestPrim = prim; }
+    }
+}
 
-            // leaves of this node first: they can only shrink `best`
-            #pragma unroll
-            for (int side = 0; side < 2; side++) {
-                const bool isLeaf = side == 0 ? (hitLeft && leftCount > 0) : (hitRight && rightCount > 0);
-                if (!isLeaf) { continue; }
-                const int first = side == 0 ? leftIndex : rightIndex;
-                const int count = side == 0 ? leftCount : rightCount;
-                for (int k = 0; k < count; k++) {
-                    const float4 t0 = g.tris[3 * (first + k) + 0];
-                    const float4 t1 = g.tris[3 * (first + k) + 1];
-                    const float4 t2 = g.tris[3 * (first + k) + 2];
-                    if (COUNT) { counters->tris++; }
-                    float t, u, v;
-                    if (!intersectTriangle(o, d, v3(t0.x, t0.y, t0.z), v3(t1.x, t1.y, t1.z), v3(t2.x, t2.y, t2.z), &t, &u, &v)) { continue; }
-                    if (!(t > tnear)) { continue; }
-                    const int prim = floatAsInt(t0.w);
-                    if (ANY_HIT) {
-                        if (t <= tfar) { hit->t = t; hit->prim = prim; return true; }
-                    } else {
-                        const bool closer = (bestPrim < 0) ? (t <= best) : (t < best || (t == best && prim < bestPrim));
-                        if (closer) { best = t; bestU = u; bestV = v; bestPrim = prim; }
-                    }
-                }
+// Visit ONE inner node.  Returns true when the BVH part of the query is complete
+// (stack exhausted, or an any-hit query found its occluder).
+// `stack` points at this lane's column: entry k is stack[k * STRIDE].
+template <bool COUNT, int STRIDE>
+__device__ inline bool traversalStep(
+    const TraceGeometry &g, int *stack, int stackDepth, LaneRay &ray, TraceCounters *counters
+) {
+    // all 64 bytes of the node in one round trip
+    const float4 n0 = g.nodes[4 * ray.current + 0];
+    const float4 n1 = g.nodes[4 * ray.current + 1];
+    const float4 n2 = g.nodes[4 * ray.current + 2];
+    const float4 n3 = g.nodes[4 * ray.current + 3];
+    pinLoaded(n0);
+    pinLoaded(n1);
+    pinLoaded(n2);
+    pinLoaded(n3);
+    const int leftIndex = floatAsInt(n0.w), leftCount = floatAsInt(n1.w);
+    const int rightIndex = floatAsInt(n2.w), rightCount = floatAsInt(n3.w);
+
+    float tLeft, tRight;
+    const bool boxLeft = slabTest(n0, n1, ray.invD, ray.oInvD, ray.tnear, ray.best, &tLeft);
+    const bool boxRight = slabTest(n2, n3, ray.invD, ray.oInvD, ray.tnear, ray.best, &tRight);
+    const bool hitLeft = (leftCount >= 0) && boxLeft;
+    const bool hitRight = (rightCount >= 0) && boxRight;
+    if (COUNT) { counters->boxes += (leftCount >= 0) + (rightCount >= 0); }
+
+    // leaves of this node first (they can only shrink `best`): one loop over the triangles of
+    // both leaf children, the next triangle's 48 bytes in flight while the current one is tested
+    const int leafLeft = (hitLeft && leftCount > 0) ? leftCount : 0;
+    const int leafRight = (hitRight && rightCount > 0) ? rightCount : 0;
+    const int leafTotal = leafLeft + leafRight;
+    if (leafTotal > 0) {
+        int index = leafLeft > 0 ? leftIndex : rightIndex;
+        float4 t0 = g.tris[3 * index + 0];
+        float4 t1 = g.tris[3 * index + 1];
+        float4 t2 = g.tris[3 * index + 2];
+        bool terminate = false;
+        for (int k = 0; k < leafTotal; k++) {
+            pinLoaded(t0);
+            pinLoaded(t1);
+            pinLoaded(t2);
+            const float4 c0 = t0, c1 = t1, c2 = t2;
+            if (k + 1 < leafTotal) {
+                index = (k + 1 < leafLeft) ? leftIndex + k + 1 : rightIndex + (k + 1 - leafLeft);
+                t0 = g.tris[3 * index + 0];
+                t1 = g.tris[3 * index + 1];
+                t2 = g.tris[3 * index + 2];
             }
-
-            const bool goLeft = hitLeft && leftCount == 0;
-            const bool goRight = hitRight && rightCount == 0;
-            if (goLeft && goRight) {
-                const bool leftFirst = tLeft <= tRight;
-                const int nearNode = leftFirst ? leftIndex : rightIndex;
-                const int farNode = leftFirst ? rightIndex : leftIndex;
-                if (sp < stackDepth) { stack[sp * STRIDE] = farNode; sp++; }
-                current = nearNode;
-            } else if (goLeft) {
-                current = leftIndex;
-            } else if (goRight) {
-                current = rightIndex;
-            } else {
-                if (sp == 0) { break; }
-                sp--;
-                current = stack[sp * STRIDE];
-            }
+            if (COUNT) { counters->tris++; }
+            testLeafTriangle(ray, c0, c1, c2, &terminate);
+            if (terminate) { return true; }
         }
     }
 
+    const bool goLeft = hitLeft && leftCount == 0;
+    const bool goRight = hitRight && rightCount == 0;
+    if (goLeft && goRight) {
+        const bool leftFirst = tLeft <= tRight;
+        const int nearNode = leftFirst ? leftIndex : rightIndex;
+        const int farNode = leftFirst ? rightIndex : leftIndex;
+        if (ray.sp < stackDepth) { stack[ray.sp * STRIDE] = farNode; ray.sp++; }
+        ray.current = nearNode;
+    } else if (goLeft) {
+        ray.current = leftIndex;
+    } else if (goRight) {
+        ray.current = rightIndex;
+    } else {
+        if (ray.sp == 0) { return true; }
+        ray.sp--;
+        ray.current = stack[ray.sp * STRIDE];
+    }
+    return false;
+}
+
+// After the BVH: the (few) spheres are tested brute force, then the result is final.
+__device__ inline void finishRay(const TraceGeometry &g, LaneRay &ray)
+{
+    if (ray.anyHit && ray.occluded) { return; }
     for (int i = 0; i < g.nSpheres; i++) {
         const DSphere s = g.spheres[i];
         float t;
-        if (!intersectSphere(o, d, v3(s.centerWorld[0], s.centerWorld[1], s.centerWorld[2]), s.radius, tnear, &t)) { continue; }
-        if (!(t > tnear)) { continue; }
+        if (!intersectSphere(ray.o, ray.d, v3(s.centerWorld[0], s.centerWorld[1], s.centerWorld[2]), s.radius, ray.tnear, &t)) { continue; }
+        if (!(t > ray.tnear)) { continue; }
         const int prim = g.nTris + i;
-        if (ANY_HIT) {
-            if (t <= tfar) { hit->t = t; hit->prim = prim; return true; }
+        if (ray.anyHit) {
+            if (t <= ray.tfar) { ray.occluded = true; return; }
         } else {
-            const bool closer = (bestPrim < 0) ? (t <= best) : (t < best || (t == best && prim < bestPrim));
-            if (closer) { best = t; bestU = 0.f; bestV = 0.f; bestPrim = prim; }
+            const bool closer = (ray.bestPrim < 0)
+                ? (t <= ray.best)
+                : (t < ray.best || (t == ray.best && prim < ray.bestPrim));
+            if (closer) { ray.best = t; ray.bestU = 0.f; ray.bestV = 0.f; ray.bestPrim = prim; }
         }
     }
+}
 
-    if (ANY_HIT) { return false; }
-    hit->t = best;
-    hit->u = bestU;
-    hit->v = bestV;
-    hit->prim = bestPrim;
-    return bestPrim >= 0;
+// One whole ray on one lane (test hook / simple callers).
+template <bool COUNT, int STRIDE>
+__device__ inline bool traverse(
+    const TraceGeometry &g, int *stack, int stackDepth,
+    V3 o, V3 d, float tnear, float tfar, bool anyHit,
+    RayHit *hit, TraceCounters *counters
+) {
+    LaneRay ray;
+    laneRayInit(ray, o, d, tnear, tfar, anyHit);
+    if (g.nNodes > 0) {
+        while (!traversalStep<COUNT, STRIDE>(g, stack, stackDepth, ray, counters)) {}
+    }
+    finishRay(g, ray);
+    if (anyHit) { return ray.occluded; }
+    hit->t = ray.best;
+    hit->u = ray.bestU;
+    hit->v = ray.bestV;
+    hit->prim = ray.bestPrim;
+    return ray.bestPrim >= 0;
 }
 
 }  // namespace pathed
