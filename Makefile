@@ -23,9 +23,9 @@ HOST_HDR  = $(wildcard pathed_amd/host/*.h) include/pathed_hip.h
 HIP_SRC   = $(wildcard pathed_amd/csrc/*.hip)
 HIP_HDR   = $(wildcard pathed_amd/csrc/*.h) include/pathed_hip.h
 
-.PHONY: all host hip oracle ref clean
+.PHONY: all host hip oracle ref assets clean
 
-all: hip host oracle ref
+all: hip host oracle ref assets
 
 hip: $(LIBDIR)/libpathed_hip.so
 host: $(LIBDIR)/libpathed_host.so $(BINDIR)/pathed
@@ -51,6 +51,10 @@ oracle/liboracle.so: oracle/oracle.cpp oracle/oracle.h include/pathed_hip.h
 # exists in the build container only; the output stays out of git (oracle/_ref/).
 ref:
 	@if [ -d /root/reference/src ]; then $(MAKE) -C oracle -f Makefile.ref; else echo "reference sources absent: skipping oracle/_ref"; fi
+
+# synthetic stand-ins for the assets the reference's scene files point at but does not ship
+assets: host
+	python3 tools/make_assets.py
 
 clean:
 	rm -rf $(LIBDIR) $(BINDIR) oracle/liboracle.so oracle/_ref
