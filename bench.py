@@ -178,7 +178,7 @@ def main():
                 "launches": launches,
                 "rays_per_sample": (per_step_stats["closest_rays"] + per_step_stats["shadow_rays"])
                 / (args.width * args.height * spp),
-                "bvh_resident": "LDS" if per_step_stats["scene_in_lds"] else "HBM",
+                "bvh_resident": ["HBM", "LDS", "none (<= 64 triangles: every ray tests all, scalar loads)"][per_step_stats["scene_in_lds"]],
                 "trace_ms_total": trace_ms,
                 "shade_ms_total": timed_stats["shade_ms"],
             }

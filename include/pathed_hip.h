@@ -172,7 +172,7 @@ typedef struct PathedStats {
     uint64_t bvh_nodes;            /* inner nodes (64 B each)                    */
     uint64_t bvh_bytes;            /* nodes + leaf triangles resident in HBM     */
     uint32_t bvh_max_depth;
-    uint32_t scene_in_lds;         /* 1 if the trace kernel stages the BVH in LDS */
+    uint32_t scene_in_lds;         /* 0 BVH in HBM, 1 BVH staged in LDS, 2 tiny scene: all triangles tested (scalar loads) */
     uint64_t max_boxes_per_ray;    /* most child boxes a single closest-hit ray tested — stats mode */
 } PathedStats;
 

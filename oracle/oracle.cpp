@@ -1088,22 +1088,27 @@ struct HitRecord {
 };
 
 /* Moeller-Trumbore on (v0, e1 = v1 - v0, e2 = v2 - v0); u,v follow Embree's
- * convention P = (1-u-v) v0 + u v1 + v v2 */
+ * convention P = (1-u-v) v0 + u v1 + v v2.  The inside test is done in
+ * "det units" (no division for the triangles a ray misses); one division for a hit. */
 inline bool intersectTriangle(Vec3 o, Vec3 d, Vec3 v0, Vec3 e1, Vec3 e2, float *t, float *u, float *v)
 {
     const Vec3 pvec = xcross(d, e2);
     const float det = xdot(e1, pvec);
-    if (det == 0.f) { return false; }
-    const float inv = 1.f / det;
     const Vec3 tvec = o - v0;
-    const float uu = xdot(tvec, pvec) * inv;
-    if (!(uu >= 0.f && uu <= 1.f)) { return false; }
+    const float uScaled = xdot(tvec, pvec);
     const Vec3 qvec = xcross(tvec, e1);
-    const float vv = xdot(d, qvec) * inv;
-    if (!(vv >= 0.f && uu + vv <= 1.f)) { return false; }
+    const float vScaled = xdot(d, qvec);
+    if (det > 0.f) {
+        if (!(uScaled >= 0.f && vScaled >= 0.f && uScaled + vScaled <= det)) { return false; }
+    } else if (det < 0.f) {
+        if (!(uScaled <= 0.f && vScaled <= 0.f && uScaled + vScaled >= det)) { return false; }
+    } else {
+        return false; /* parallel, degenerate or NaN */
+    }
+    const float inv = 1.f / det;
     *t = xdot(e2, qvec) * inv;
-    *u = uu;
-    *v = vv;
+    *u = uScaled * inv;
+    *v = vScaled * inv;
     return true;
 }
 

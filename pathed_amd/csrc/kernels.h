@@ -237,6 +237,135 @@ __global__ __launch_bounds__(kBlock) void k_trace(RenderParams p)
     }
 }
 
+// Tiny scenes (<= kBruteForceMaxTris triangles, e.g. the 36-triangle Cornell box): every ray
+// tests every triangle.  Control flow is wave-uniform, the triangle records are fetched with
+// SCALAR loads (uniform address) and broadcast to all 64 lanes, there is no traversal stack, no
+// LDS and no dependent memory access at all, so the kernel runs at VALU issue rate with full
+// lanes — faster than walking a BVH whose every step diverges.  Hits are identical to the BVH
+// path by the intersector specification (equal-t ties resolve by primitive id, not test order).
+static const int kBruteForceMaxTris = 64;
+
+// The triangle records travel as a KERNEL ARGUMENT (3 KB of the 4 KB kernarg segment): kernarg
+// reads are s_load from the constant address space, so a uniform index gives true scalar loads.
+// (Uniform global_load_dwordx4 still return 1 KiB per wave through the 64 B/clk vector path.)
+struct SmallTris {
+    float4 data[3 * kBruteForceMaxTris];
+};
+
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) void k_trace_small(RenderParams p, SmallTris smallTris)
+{
+    TraceGeometry geometry;
+    geometry.nodes = nullptr;
+    geometry.tris = p.scene.leafTris;
+    geometry.nNodes = 0;
+    geometry.nTris = p.scene.nTris;
+    geometry.spheres = p.scene.spheres;
+    geometry.nSpheres = p.scene.nSpheres;
+
+    const int lane = threadIdx.x & 63;
+    const unsigned int waveId = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const unsigned int waveCount = gridDim.x * kWavesPerBlock;
+    const unsigned int slotBatches = (unsigned int)p.nSlots / 64u;
+    const unsigned int totalBatches = 2u * slotBatches;
+    const int nTris = p.scene.nTris;
+
+    unsigned int closestRays = 0, shadowRays = 0, trisTested = 0;
+
+    for (unsigned int batch = waveId; batch < totalBatches; batch += waveCount) {
+        LaneRay ray;
+        bool valid = false;
+        unsigned int target = 0;
+        if (batch < slotBatches) {
+            const unsigned int slot = batch * 64u + lane;
+            const float4 rd = p.state.rayD[slot];
+            if (!(floatAsInt(rd.w) & kStDone)) {
+                const float4 ro = p.state.rayO[slot];
+                laneRayInit(ray, v3(ro.x, ro.y, ro.z), v3(rd.x, rd.y, rd.z), PATHED_TNEAR, PATHED_TFAR, false);
+                target = slot;
+                valid = true;
+            }
+        } else {
+            const unsigned int entry = (batch - slotBatches) * 64u + lane;
+            if ((entry % kBlock) < p.state.blockShadowCount[entry / kBlock]) {
+                const float4 so = p.state.shO[entry];
+                const float4 sd = p.state.shD[entry];
+                laneRayInit(ray, v3(so.x, so.y, so.z), v3(sd.x, sd.y, sd.z), PATHED_TNEAR, so.w, true);
+                target = (unsigned int)floatAsInt(sd.w);
+                valid = true;
+            }
+        }
+        if (__ballot(valid) == 0ull) { continue; }
+
+        if (valid) {
+            // batches are homogeneous (all closest or all shadow rays), so the query kind is
+            // wave-uniform; the per-triangle inside test is straight-line code (no exec-mask
+            // juggling), and the division + acceptance run only when some lane is inside
+            const bool shadowBatch = batch >= slotBatches;
+            for (int k = 0; k < nTris; k++) {
+                // uniform index into the kernarg segment -> scalar loads, broadcast to the wave
+                const float4 t0 = smallTris.data[3 * k + 0];
+                const float4 t1 = smallTris.data[3 * k + 1];
+                const float4 t2 = smallTris.data[3 * k + 2];
+                const V3 e1 = v3(t1.x, t1.y, t1.z), e2 = v3(t2.x, t2.y, t2.z);
+                const V3 pvec = xcross(ray.d, e2);
+                const float det = xdot(e1, pvec);
+                const V3 tvec = ray.o - v3(t0.x, t0.y, t0.z);
+                const float uScaled = xdot(tvec, pvec);
+                const V3 qvec = xcross(tvec, e1);
+                const float vScaled = xdot(ray.d, qvec);
+                const float sum = uScaled + vScaled;
+                // same predicate as intersectTriangle(), evaluated without short-circuits
+                const bool insidePositive = (det > 0.f) & (uScaled >= 0.f) & (vScaled >= 0.f) & (sum <= det);
+                const bool insideNegative = (det < 0.f) & (uScaled <= 0.f) & (vScaled <= 0.f) & (sum >= det);
+                const bool inside = (insidePositive | insideNegative) & !ray.occluded;
+                if (COUNT) { trisTested += ray.occluded ? 0u : 1u; }
+                if (__ballot(inside) != 0ull) {
+                    if (inside) {
+                        const float inv = 1.f / det;
+                        const float t = xdot(e2, qvec) * inv;
+                        if (t > ray.tnear) {
+                            const int prim = floatAsInt(t0.w);
+                            if (shadowBatch) {
+                                if (t <= ray.tfar) { ray.occluded = true; }
+                            } else {
+                                const bool closer = (ray.bestPrim < 0)
+                                    ? (t <= ray.best)
+                                    : (t < ray.best || (t == ray.best && prim < ray.bestPrim));
+                                if (closer) {
+                                    ray.best = t;
+                                    ray.bestU = uScaled * inv;
+                                    ray.bestV = vScaled * inv;
+                                    ray.bestPrim = prim;
+                                }
+                            }
+                        }
+                    }
+                    // every shadow ray of the wave is occluded: nothing left to find
+                    if (shadowBatch && __ballot(!ray.occluded) == 0ull) { break; }
+                }
+            }
+        }
+
+        if (valid) {
+            finishRay(geometry, ray);
+            if (ray.anyHit) {
+                if (ray.occluded) { p.state.pend[target] = make_float4(0.f, 0.f, 0.f, 0.f); }
+                if (COUNT) { shadowRays++; }
+            } else {
+                p.state.hit[target] = make_float4(ray.best, ray.bestU, ray.bestV, intAsFloat(ray.bestPrim));
+                if (COUNT) { closestRays++; }
+            }
+        }
+    }
+
+    if (COUNT) {
+        atomicAdd(&p.stats[kStatTris], (unsigned long long)trisTested);
+        atomicAdd(&p.stats[kStatClosest], (unsigned long long)closestRays);
+        atomicAdd(&p.stats[kStatShadow], (unsigned long long)shadowRays);
+    }
+}
+
 // test hook kernel behind pathed_hip_trace: plain grid, arbitrary ray intervals
 template <int STACK>
 __global__ __launch_bounds__(kBlock) void k_trace_rays(

@@ -153,6 +153,8 @@ struct PathedScene {
 
     int stackDepth = 8;
     bool sceneInLds = false;
+    bool bruteForce = false;      // <= kBruteForceMaxTris triangles: test them all, no BVH walk
+    SmallTris smallTris;          // their records, passed to k_trace_small as a kernel argument
     size_t traceLdsBytes = 0;
     int traceGrid = 0;
     int computeUnits = 256;
@@ -348,6 +350,12 @@ void launchTraceStack(PathedScene *scene, const RenderParams &params, hipStream_
 
 void launchTrace(PathedScene *scene, const RenderParams &params, hipStream_t stream)
 {
+    if (scene->bruteForce) {
+        const dim3 grid((unsigned)(scene->computeUnits * 8)), block(kBlock);
+        if (scene->countMode) { hipLaunchKernelGGL((k_trace_small<true>), grid, block, 0, stream, params, scene->smallTris); }
+        else { hipLaunchKernelGGL((k_trace_small<false>), grid, block, 0, stream, params, scene->smallTris); }
+        return;
+    }
     switch (scene->stackDepth) {
     case 8: launchTraceStack<8>(scene, params, stream); break;
     case 16: launchTraceStack<16>(scene, params, stream); break;
@@ -559,6 +567,11 @@ int pathed_hip_scene_create(const PathedSceneDesc *desc, PathedScene **out)
     d.env.phiEmpty = scene->phiEmpty.ptr;
 
     configureTrace(scene);
+    scene->bruteForce = scene->device.nTris <= kBruteForceMaxTris && !getenv("PATHED_NO_BRUTE_FORCE");
+    std::memset(&scene->smallTris, 0, sizeof scene->smallTris);
+    if (scene->bruteForce) {
+        std::memcpy(scene->smallTris.data, scene->bvh.leafTris.data(), scene->bvh.leafTris.size() * sizeof(float));
+    }
     if (const char *slots = getenv("PATHED_MAX_SLOTS")) {
         const long value = atol(slots);
         if (value >= kBlock) { scene->maxSlots = (int)value; }
@@ -824,7 +837,7 @@ int pathed_hip_get_stats(PathedScene *scene, PathedStats *out)
     out->bvh_nodes = (uint64_t)scene->bvh.nodeCount;
     out->bvh_bytes = (uint64_t)scene->bvh.nodeCount * 64 + (uint64_t)scene->device.nTris * 48;
     out->bvh_max_depth = (uint32_t)scene->bvh.maxDepth;
-    out->scene_in_lds = scene->sceneInLds ? 1u : 0u;
+    out->scene_in_lds = scene->bruteForce ? 2u : (scene->sceneInLds ? 1u : 0u);
     out->max_boxes_per_ray = device[kStatMaxBoxes];
     return PATHED_OK;
 }
