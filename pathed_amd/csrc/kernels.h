@@ -85,7 +85,8 @@ struct RenderParams {
     float *accum;          // 3*W*H radiance sums, index 3*(row*W+col)+c
     int nSlots;            // multiple of kBlock
     int nPixels;
-    unsigned int nUnits;
+    unsigned int nUnits;   // units of THIS pool
+    unsigned int unitBase; // global id of the pool's first unit (pixel / chunk derive from the global id)
     int nQueues;           // min(kUnitQueues, shade blocks): every queue has a consumer
     unsigned int unitsPerQueue;
     int chunk;             // samples per unit
@@ -620,8 +621,9 @@ __device__ inline unsigned int grabUnits(const RenderParams &p, bool want, unsig
 // first sample index of a unit and one-past-last
 __device__ inline void unitSamples(const RenderParams &p, unsigned int unit, uint32_t *pixel, uint32_t *first, uint32_t *end)
 {
-    const unsigned int chunkIndex = unit / (unsigned int)p.nPixels;
-    *pixel = unit - chunkIndex * (unsigned int)p.nPixels;
+    const unsigned int globalUnit = p.unitBase + unit;
+    const unsigned int chunkIndex = globalUnit / (unsigned int)p.nPixels;
+    *pixel = globalUnit - chunkIndex * (unsigned int)p.nPixels;
     *first = p.sppBegin + chunkIndex * (unsigned int)p.chunk;
     const uint32_t last = *first + (unsigned int)p.chunk;
     *end = last < p.sppEnd ? last : p.sppEnd;

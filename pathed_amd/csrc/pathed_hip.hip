@@ -146,6 +146,10 @@ struct PathedScene {
     size_t chunkCapacity = 0;     // float4 entries of chunkBuf
     int samplesPerUnit = 4;       // "chunk": samples a slot sums before it publishes a partial
     int maxSlots = 1 << 20;
+    int pools = 2;                // independent slot pools on separate streams (trace || shade)
+    hipStream_t poolStreams[2] = { nullptr, nullptr };
+    hipEvent_t poolDone[2] = { nullptr, nullptr };
+    hipEvent_t callerReady = nullptr;
     DeviceBuffer<float4> rayO, rayD, hit, mod, thr, res, pend, acc, shO, shD, chunkBuf;
     DeviceBuffer<unsigned int> counters, blockShadowCount;
     DeviceBuffer<unsigned long long> stats;
@@ -174,6 +178,11 @@ struct PathedScene {
         res.release(); pend.release(); acc.release(); shO.release(); shD.release(); chunkBuf.release();
         counters.release(); blockShadowCount.release(); stats.release();
         if (hostRemaining) { (void)hipHostFree(hostRemaining); }
+        for (int h = 0; h < 2; h++) {
+            if (poolStreams[h]) { (void)hipStreamDestroy(poolStreams[h]); }
+            if (poolDone[h]) { (void)hipEventDestroy(poolDone[h]); }
+        }
+        if (callerReady) { (void)hipEventDestroy(callerReady); }
         traceEvents.destroy();
         shadeEvents.destroy();
     }
@@ -323,7 +332,7 @@ int ensureRenderState(PathedScene *scene, int nSlots, size_t chunkEntries)
         HIP_TRY(scene->chunkBuf.allocate(chunkEntries));
         scene->chunkCapacity = chunkEntries;
     }
-    if (!scene->counters.ptr) { HIP_TRY(scene->counters.allocate(kCtrCount)); }
+    if (!scene->counters.ptr) { HIP_TRY(scene->counters.allocate(2 * kCtrCount)); }
     if (!scene->stats.ptr) {
         HIP_TRY(scene->stats.allocate(kStatCount));
         HIP_TRY(hipMemset(scene->stats.ptr, 0, kStatCount * sizeof(unsigned long long)));
@@ -351,7 +360,9 @@ void launchTraceStack(PathedScene *scene, const RenderParams &params, hipStream_
 void launchTrace(PathedScene *scene, const RenderParams &params, hipStream_t stream)
 {
     if (scene->bruteForce) {
-        const dim3 grid((unsigned)(scene->computeUnits * 8)), block(kBlock);
+        // uniform cost per batch and no per-block setup: one 64-ray batch per wave, the hardware
+        // dispatcher balances (a persistent grid quantises 3.3 batches per wave to 4 rounds)
+        const dim3 grid((unsigned)(2 * params.nSlots / kBlock)), block(kBlock);
         if (scene->countMode) { hipLaunchKernelGGL((k_trace_small<true>), grid, block, 0, stream, params, scene->smallTris); }
         else { hipLaunchKernelGGL((k_trace_small<false>), grid, block, 0, stream, params, scene->smallTris); }
         return;
@@ -366,7 +377,7 @@ void launchTrace(PathedScene *scene, const RenderParams &params, hipStream_t str
 
 void launchShade(PathedScene *scene, const RenderParams &params, hipStream_t stream)
 {
-    const dim3 grid((unsigned)(scene->nSlots / kBlock)), block(kBlock);
+    const dim3 grid((unsigned)(params.nSlots / kBlock)), block(kBlock);
     if (scene->device.nMaterials <= kMaxLdsMaterials) {
         hipLaunchKernelGGL((k_shade<true>), grid, block, 0, stream, params);
     } else {
@@ -572,6 +583,7 @@ int pathed_hip_scene_create(const PathedSceneDesc *desc, PathedScene **out)
     if (scene->bruteForce) {
         std::memcpy(scene->smallTris.data, scene->bvh.leafTris.data(), scene->bvh.leafTris.size() * sizeof(float));
     }
+    if (const char *poolCount = getenv("PATHED_POOLS")) { scene->pools = atoi(poolCount) >= 2 ? 2 : 1; }
     if (const char *slots = getenv("PATHED_MAX_SLOTS")) {
         const long value = atol(slots);
         if (value >= kBlock) { scene->maxSlots = (int)value; }
@@ -585,7 +597,10 @@ void pathed_hip_scene_destroy(PathedScene *scene)
     delete scene;
 }
 
-// one internal pass: samples [begin, begin+count), count <= chunk * kMaxChunksPerPass
+// One internal pass: samples [begin, begin+count), count <= chunk * kMaxChunksPerPass.
+// The slot pool is split into `pools` independent halves, each with its own unit range,
+// counters and HIP stream: while one half runs its (ALU-bound) trace kernel the other runs its
+// (memory-bound) shade kernel, so the two overlap instead of alternating.
 static int renderPass(PathedScene *scene, uint64_t seed, uint32_t begin, uint32_t count,
                       int start_bounce, int last_bounce, float *d_accum, hipStream_t stream)
 {
@@ -596,94 +611,143 @@ static int renderPass(PathedScene *scene, uint64_t seed, uint32_t begin, uint32_
     if (nUnits64 >= 0xFFFFFFF0ull) { return fail(PATHED_E_INVALID, "too many work units in one pass"); }
     const unsigned int nUnits = (unsigned int)nUnits64;
 
+    // small jobs use one pool; otherwise split slots and units evenly
+    int pools = scene->pools;
+    if (nUnits64 < 4ull * kBlock * (unsigned long long)pools) { pools = 1; }
+
     unsigned long long wanted = nUnits64 < (unsigned long long)scene->maxSlots ? nUnits64 : (unsigned long long)scene->maxSlots;
-    const int nSlots = (int)((wanted + kBlock - 1) / kBlock * kBlock);
+    const int slotsPerPool = (int)((wanted / pools + kBlock - 1) / kBlock * kBlock);
+    const int nSlots = slotsPerPool * pools;
     int code = ensureRenderState(scene, nSlots, (size_t)nUnits);
     if (code != PATHED_OK) { return code; }
+    if (pools > 1 && !scene->poolStreams[0]) {
+        for (int h = 0; h < 2; h++) {
+            HIP_TRY(hipStreamCreateWithFlags(&scene->poolStreams[h], hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&scene->poolDone[h], hipEventDisableTiming));
+        }
+        HIP_TRY(hipEventCreateWithFlags(&scene->callerReady, hipEventDisableTiming));
+    }
 
-    const int nBlocks = nSlots / kBlock;
-    const int nQueues = nBlocks < kUnitQueues ? nBlocks : kUnitQueues;
+    const int blocksPerPool = slotsPerPool / kBlock;
+    const int nQueues = blocksPerPool < kUnitQueues ? blocksPerPool : kUnitQueues;
 
-    RenderParams params;
-    params.scene = scene->device;
-    params.state.rayO = scene->rayO.ptr;
-    params.state.rayD = scene->rayD.ptr;
-    params.state.hit = scene->hit.ptr;
-    params.state.mod = scene->mod.ptr;
-    params.state.thr = scene->thr.ptr;
-    params.state.res = scene->res.ptr;
-    params.state.pend = scene->pend.ptr;
-    params.state.acc = scene->acc.ptr;
-    params.state.shO = scene->shO.ptr;
-    params.state.shD = scene->shD.ptr;
-    params.state.blockShadowCount = scene->blockShadowCount.ptr;
-    params.state.chunkBuf = scene->chunkBuf.ptr;
-    params.counters = scene->counters.ptr;
-    params.stats = scene->stats.ptr;
-    params.accum = d_accum;
-    params.nSlots = nSlots;
-    params.nPixels = nPixels;
-    params.nUnits = nUnits;
-    params.nQueues = nQueues;
-    params.unitsPerQueue = (nUnits + (unsigned int)nQueues - 1) / (unsigned int)nQueues;
-    params.chunk = chunk;
-    params.chunksPerPixel = chunksPerPixel;
-    params.seedLo = (uint32_t)seed;
-    params.seedHi = (uint32_t)(seed >> 32);
-    params.sppBegin = begin;
-    params.sppEnd = begin + count;
-    params.startBounce = start_bounce;
-    params.lastBounce = last_bounce;
+    RenderParams params[2];
+    hipStream_t streams[2] = { stream, stream };
+    for (int h = 0; h < pools; h++) {
+        RenderParams &q = params[h];
+        const size_t slotBase = (size_t)h * slotsPerPool;
+        const unsigned int unitBase = (unsigned int)((unsigned long long)nUnits * h / pools);
+        const unsigned int unitEnd = (unsigned int)((unsigned long long)nUnits * (h + 1) / pools);
+        q.scene = scene->device;
+        q.state.rayO = scene->rayO.ptr + slotBase;
+        q.state.rayD = scene->rayD.ptr + slotBase;
+        q.state.hit = scene->hit.ptr + slotBase;
+        q.state.mod = scene->mod.ptr + slotBase;
+        q.state.thr = scene->thr.ptr + slotBase;
+        q.state.res = scene->res.ptr + slotBase;
+        q.state.pend = scene->pend.ptr + slotBase;
+        q.state.acc = scene->acc.ptr + slotBase;
+        q.state.shO = scene->shO.ptr + slotBase;
+        q.state.shD = scene->shD.ptr + slotBase;
+        q.state.blockShadowCount = scene->blockShadowCount.ptr + slotBase / kBlock;
+        q.state.chunkBuf = scene->chunkBuf.ptr + unitBase;
+        q.counters = scene->counters.ptr + (size_t)h * kCtrCount;
+        q.stats = scene->stats.ptr;
+        q.accum = d_accum;
+        q.nSlots = slotsPerPool;
+        q.nPixels = nPixels;
+        q.nUnits = unitEnd - unitBase;
+        q.unitBase = unitBase;
+        q.nQueues = nQueues;
+        q.unitsPerQueue = (q.nUnits + (unsigned int)nQueues - 1) / (unsigned int)nQueues;
+        q.chunk = chunk;
+        q.chunksPerPixel = chunksPerPixel;
+        q.seedLo = (uint32_t)seed;
+        q.seedHi = (uint32_t)(seed >> 32);
+        q.sppBegin = begin;
+        q.sppEnd = begin + count;
+        q.startBounce = start_bounce;
+        q.lastBounce = last_bounce;
+        if (pools > 1) { streams[h] = scene->poolStreams[h]; }
+    }
 
-    const dim3 slotGrid((unsigned)nBlocks), block(kBlock);
-    HIP_TRY(hipMemsetAsync(scene->counters.ptr, 0, kCtrCount * sizeof(unsigned int), stream));
-    hipLaunchKernelGGL(k_init, slotGrid, block, 0, stream, params);
+    if (pools > 1) {
+        // the pool streams start after whatever the caller queued on its stream
+        HIP_TRY(hipEventRecord(scene->callerReady, stream));
+        for (int h = 0; h < pools; h++) { HIP_TRY(hipStreamWaitEvent(streams[h], scene->callerReady, 0)); }
+    }
 
-    // Iterate until every slot has run out of units.  `remaining` is polled with a lag of one
-    // chunk of launches so the GPU never waits for the host.
+    const dim3 slotGrid((unsigned)blocksPerPool), block(kBlock);
+    for (int h = 0; h < pools; h++) {
+        HIP_TRY(hipMemsetAsync(params[h].counters, 0, kCtrCount * sizeof(unsigned int), streams[h]));
+        hipLaunchKernelGGL(k_init, slotGrid, block, 0, streams[h], params[h]);
+    }
+
+    // Iterate until every slot of every pool has run out of units.  `remaining` is polled with
+    // a lag of one chunk of launches so the GPU never waits for the host.
     const int launchChunk = 8;
-    const int ringSize = 64;
-    hipEvent_t pollEvents[2];
-    HIP_TRY(hipEventCreateWithFlags(&pollEvents[0], hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&pollEvents[1], hipEventDisableTiming));
+    const int ringSize = 32;
+    hipEvent_t pollEvents[2][2];
+    for (int h = 0; h < pools; h++) {
+        HIP_TRY(hipEventCreateWithFlags(&pollEvents[h][0], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&pollEvents[h][1], hipEventDisableTiming));
+    }
     unsigned long long iteration = 0;
     int pollIndex = 0;
     bool havePending = false;
-    bool done = false;
-    while (!done) {
+    bool poolDone[2] = { false, pools < 2 };
+    while (!(poolDone[0] && poolDone[1])) {
         for (int k = 0; k < launchChunk; k++) {
-            if (scene->timeKernels) {
-                const int e = scene->traceEvents.acquire();
-                (void)hipEventRecord(scene->traceEvents.start[e], stream);
-                launchTrace(scene, params, stream);
-                (void)hipEventRecord(scene->traceEvents.stop[e], stream);
-                const int s = scene->shadeEvents.acquire();
-                (void)hipEventRecord(scene->shadeEvents.start[s], stream);
-                launchShade(scene, params, stream);
-                (void)hipEventRecord(scene->shadeEvents.stop[s], stream);
-            } else {
-                launchTrace(scene, params, stream);
-                launchShade(scene, params, stream);
+            for (int h = 0; h < pools; h++) {
+                if (poolDone[h]) { continue; }
+                if (scene->timeKernels) {
+                    const int e = scene->traceEvents.acquire();
+                    (void)hipEventRecord(scene->traceEvents.start[e], streams[h]);
+                    launchTrace(scene, params[h], streams[h]);
+                    (void)hipEventRecord(scene->traceEvents.stop[e], streams[h]);
+                    const int s = scene->shadeEvents.acquire();
+                    (void)hipEventRecord(scene->shadeEvents.start[s], streams[h]);
+                    launchShade(scene, params[h], streams[h]);
+                    (void)hipEventRecord(scene->shadeEvents.stop[s], streams[h]);
+                } else {
+                    launchTrace(scene, params[h], streams[h]);
+                    launchShade(scene, params[h], streams[h]);
+                }
             }
             iteration++;
         }
         const int slotIndex = pollIndex % ringSize;
-        HIP_TRY(hipMemcpyAsync(scene->hostRemaining + slotIndex, scene->counters.ptr + kCtrRemaining,
-                               sizeof(unsigned int), hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipEventRecord(pollEvents[pollIndex & 1], stream));
+        for (int h = 0; h < pools; h++) {
+            if (poolDone[h]) { continue; }
+            HIP_TRY(hipMemcpyAsync(scene->hostRemaining + h * ringSize + slotIndex, params[h].counters + kCtrRemaining,
+                                   sizeof(unsigned int), hipMemcpyDeviceToHost, streams[h]));
+            HIP_TRY(hipEventRecord(pollEvents[h][pollIndex & 1], streams[h]));
+        }
         if (havePending) {
             const int previous = pollIndex - 1;
-            HIP_TRY(hipEventSynchronize(pollEvents[previous & 1]));
-            if (scene->hostRemaining[previous % ringSize] == 0) { done = true; }
+            for (int h = 0; h < pools; h++) {
+                if (poolDone[h]) { continue; }
+                HIP_TRY(hipEventSynchronize(pollEvents[h][previous & 1]));
+                if (scene->hostRemaining[h * ringSize + previous % ringSize] == 0) { poolDone[h] = true; }
+            }
         }
         havePending = true;
         pollIndex++;
     }
+    if (pools > 1) {
+        for (int h = 0; h < pools; h++) {
+            HIP_TRY(hipEventRecord(scene->poolDone[h], streams[h]));
+            HIP_TRY(hipStreamWaitEvent(stream, scene->poolDone[h], 0));
+        }
+    }
     const dim3 pixelGrid((unsigned)((nPixels + kBlock - 1) / kBlock));
-    hipLaunchKernelGGL(k_resolve, pixelGrid, block, 0, stream, params);
+    hipLaunchKernelGGL(k_resolve, pixelGrid, block, 0, stream, params[0]);
+    for (int h = 0; h < pools; h++) { HIP_TRY(hipStreamSynchronize(streams[h])); }
     HIP_TRY(hipStreamSynchronize(stream));
-    (void)hipEventDestroy(pollEvents[0]);
-    (void)hipEventDestroy(pollEvents[1]);
+    for (int h = 0; h < pools; h++) {
+        (void)hipEventDestroy(pollEvents[h][0]);
+        (void)hipEventDestroy(pollEvents[h][1]);
+    }
     HIP_TRY(hipGetLastError());
 
     scene->iterations += iteration;
