@@ -399,6 +399,10 @@ void configureTrace(PathedScene *scene)
     int blocksPerCu = (int)((160 * 1024) / (scene->traceLdsBytes ? scene->traceLdsBytes : 1));
     if (blocksPerCu > 8) { blocksPerCu = 8; }
     if (blocksPerCu < 1) { blocksPerCu = 1; }
+    if (const char *override = getenv("PATHED_TRACE_BLOCKS_PER_CU")) {
+        const int value = atoi(override);
+        if (value >= 1 && value <= 16) { blocksPerCu = value; }
+    }
     scene->traceGrid = scene->computeUnits * blocksPerCu;
 }
 

@@ -1,0 +1,104 @@
+#!/usr/bin/env python3
+"""Runs the five BASELINE.json configurations (stand-in assets where the reference ships none) on
+one GPU at the target resolution with reduced spp, plus a small-size parity check against the CPU
+oracle and the oracle's own rate on the host cores.  Output: one table row per config."""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import torch
+
+from pathed_amd.integrator import HipScene
+from pathed_amd.scene import LoadedScene
+import oracle_lib
+
+CONFIGS = [
+    # name, scene, width, height, gpu spp, cpu spp (timing), note
+    ("C1", "scenes/cornell.json", 256, 256, 16, 16, "real scene"),
+    ("C2", "scenes/cornell.json", 1024, 1024, 1024, 8, "real scene; Lambertian"),
+    ("C3", "scenes/mis-pbrt.json", 1024, 1024, 256, 8, "plates/floor synthetic; plastic+Beckmann, sphere lights"),
+    ("C4", "scenes/teapot.json", 1024, 1024, 256, 4, "mesh + env synthetic; glass, checkerboard, env light"),
+    ("C5", "scenes/dragon-standin.json", 1920, 1080, 64, 2, "procedural mesh + env synthetic; plastic, env light"),
+]
+
+
+def relative_l2(a, b):
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+def main():
+    parser = argparse.ArgumentParser()
+    parser.add_argument("--dragon", type=int, default=9)
+    parser.add_argument("--only", default="")
+    args = parser.parse_args()
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_assets.py"), "--dragon", str(args.dragon)], check=True,
+                   stdout=subprocess.DEVNULL)
+    cores = os.cpu_count()
+    rows = []
+    for name, path, w, h, spp, cpu_spp, note in CONFIGS:
+        if args.only and name not in args.only.split(","):
+            continue
+        scene = LoadedScene(path, w, h)
+        t0 = time.perf_counter()
+        gpu = HipScene(scene.desc, device=0)
+        setup = time.perf_counter() - t0
+        accum = torch.zeros((h, w, 3), dtype=torch.float32, device="cuda")
+        gpu.render_device(1, 0, min(spp, 16), 0, 10, accum.data_ptr())  # warm-up
+        accum.zero_()
+        gpu.set_stats_mode(count=False, time_kernels=True)
+        gpu.reset_stats()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        gpu.render_device(1, 0, spp, 0, 10, accum.data_ptr())
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        timed = gpu.stats()
+        gpu.set_stats_mode(count=True)
+        gpu.reset_stats()
+        scratch = torch.zeros_like(accum)
+        count_spp = min(spp, 16)
+        gpu.render_device(1, 0, count_spp, 0, 10, scratch.data_ptr())
+        counted = gpu.stats()
+        gpu.set_stats_mode(count=False)
+        rays = counted["closest_rays"] + counted["shadow_rays"]
+        alg = 48 * counted["closest_rays"] + 36 * counted["shadow_rays"] + 32 * counted["nodes_visited"] + 48 * counted["tris_tested"]
+        alg_total = alg * spp / count_spp
+        gbs = alg_total / (timed["trace_ms"] * 1e-3) / 1e9 if timed["trace_ms"] else 0.0
+
+        # CPU oracle rate at the same resolution
+        oracle = oracle_lib.OracleScene(scene.desc)
+        t0 = time.perf_counter()
+        oracle.render(w, h, 1, 0, cpu_spp, 0, 10, threads=cores)
+        cpu_elapsed = time.perf_counter() - t0
+
+        # parity at a size the oracle finishes quickly
+        pw, ph = (96, 96) if w == h else (128, 72)
+        small = LoadedScene(path, pw, ph)
+        g2, o2 = HipScene(small.desc, device=0), oracle_lib.OracleScene(small.desc)
+        image = g2.render(1, 0, 16, 0, 10)
+        expected, _ = o2.render(pw, ph, 1, 0, 16, 0, 10, threads=cores, chunk=4)
+        rows.append({
+            "config": name, "scene": path, "res": "%dx%d" % (w, h), "spp": spp, "note": note,
+            "triangles": scene.n_triangles, "scene_create_s": round(setup, 2),
+            "gpu_Msamples_s": round(w * h * spp / elapsed / 1e6, 1),
+            "rays_per_sample": round(rays / (w * h * count_spp), 2),
+            "trace_Grays_s": round(rays * spp / count_spp / timed["trace_ms"] / 1e6, 2) if timed["trace_ms"] else None,
+            "trace_algorithmic_GBs": round(gbs, 0), "frac_of_8TBs": round(gbs / 8000.0, 3),
+            "intersector": ["BVH in HBM", "BVH in LDS", "all triangles (scalar loads)"][counted["scene_in_lds"]],
+            "cpu_oracle_Msamples_s": round(w * h * cpu_spp / cpu_elapsed / 1e6, 2), "cpu_cores": cores,
+            "relL2_vs_oracle_%dx%d_16spp" % (pw, ph): "%.2e" % relative_l2(image, expected),
+            "mean_rgb": [round(float(v), 4) for v in (accum / spp).mean(dim=(0, 1)).tolist()],
+        })
+        print(json.dumps(rows[-1]), flush=True)
+    return rows
+
+
+if __name__ == "__main__":
+    main()
