@@ -33,9 +33,13 @@ static const int kWavesPerBlock = kBlock / 64;
 static const int kMaxLdsMaterials = 96;  // 96 x 80 B = 7.5 KiB of LDS
 static const int kUnitQueues = 32;       // sharded work-unit cursors
 #ifndef PATHED_REFILL
-#define PATHED_REFILL 44
+#define PATHED_REFILL 56
 #endif
-static const int kRefillThreshold = PATHED_REFILL;  // refill a wave's idle lanes once fewer than this many are busy
+static const int kRefillThreshold = PATHED_REFILL;
+#ifndef PATHED_LEAF_THRESHOLD
+#define PATHED_LEAF_THRESHOLD 24
+#endif
+static const int kLeafThreshold = PATHED_LEAF_THRESHOLD;  // lanes with a leaf pending that trigger a triangle phase  // refill a wave's idle lanes once fewer than this many are busy
 
 // counters[] layout (unsigned int)
 static const int kCtrRemaining = 0;    // slots that still have work
@@ -54,7 +58,10 @@ static const int kStatBoxes = 3;
 static const int kStatTris = 4;
 static const int kStatDropped = 5;
 static const int kStatMaxBoxes = 6;   // most child boxes tested by a single ray (stats mode)
-static const int kStatCount = 8;
+static const int kStatWaveSteps = 7;  // traversal steps executed by waves (stats mode)
+static const int kStatLaneSteps = 8;  // ... and by lanes: lane utilisation = lane / (64 * wave)
+static const int kStatRefills = 9;
+static const int kStatCount = 12;
 
 // state word (rayD.w): bits 0..15 vertex that spawned the ray (0 = camera ray),
 // 16 eligible, 17 delta, 18 continue (device_scene.h), 19..25 sample index inside the unit
@@ -159,6 +166,7 @@ __global__ __launch_bounds__(kBlock) void k_trace(RenderParams p)
     counters.tris = 0;
     unsigned int closestRays = 0, shadowRays = 0;
     unsigned int maxBoxes = 0, rayBoxesStart = 0;
+    unsigned int waveSteps = 0, laneSteps = 0, refills = 0;
 
     LaneRay ray;
     bool active = false;
@@ -203,25 +211,36 @@ __global__ __launch_bounds__(kBlock) void k_trace(RenderParams p)
             continue;
         }
 
-        // traversal burst: one inner node per active lane per step, until the wave has thinned
-        // out enough to be worth refilling
+        // traversal burst.  Each step the wave runs ONE phase: the triangle phase when enough lanes
+        // have a leaf pending (or nothing else can run), else the inner-node phase; lanes in the
+        // other mode sit the step out.  The burst ends when the wave has thinned out enough to be
+        // worth refilling.
+        if (COUNT && lane == 0) { refills++; }
         while (true) {
-            if (active) {
-                const bool done = (geometry.nNodes == 0)
-                    || traversalStep<COUNT, kBlock>(geometry, stack, STACK, ray, &counters);
-                if (done) {
-                    finishRay(geometry, ray);
-                    if (ray.anyHit) {
-                        if (ray.occluded) { p.state.pend[target] = make_float4(0.f, 0.f, 0.f, 0.f); }
-                    } else {
-                        p.state.hit[target] = make_float4(ray.best, ray.bestU, ray.bestV, intAsFloat(ray.bestPrim));
-                    }
-                    if (COUNT) {
-                        const unsigned int delta = counters.boxes - rayBoxesStart;
-                        maxBoxes = delta > maxBoxes ? delta : maxBoxes;
-                    }
-                    active = false;
+            const unsigned long long leafMask = __ballot(active && ray.pendingLeaf != 0);
+            const unsigned long long innerMask = __ballot(active && ray.pendingLeaf == 0);
+            const bool trianglePhase = __popcll(leafMask) >= kLeafThreshold || innerMask == 0ull;
+            if (COUNT) { waveSteps++; laneSteps += (unsigned int)__popcll(trianglePhase ? leafMask : innerMask); }
+            bool done = false;
+            if (trianglePhase) {
+                if (active && ray.pendingLeaf != 0) { done = leafStep<COUNT, kBlock>(geometry, stack, ray, &counters); }
+            } else {
+                if (active && ray.pendingLeaf == 0) {
+                    done = (geometry.nNodes == 0) || innerStep<COUNT, kBlock>(geometry, stack, STACK, ray, &counters);
                 }
+            }
+            if (done) {
+                finishRay(geometry, ray);
+                if (ray.anyHit) {
+                    if (ray.occluded) { p.state.pend[target] = make_float4(0.f, 0.f, 0.f, 0.f); }
+                } else {
+                    p.state.hit[target] = make_float4(ray.best, ray.bestU, ray.bestV, intAsFloat(ray.bestPrim));
+                }
+                if (COUNT) {
+                    const unsigned int delta = counters.boxes - rayBoxesStart;
+                    maxBoxes = delta > maxBoxes ? delta : maxBoxes;
+                }
+                active = false;
             }
             const unsigned long long activeMask = __ballot(active);
             if (activeMask == 0ull) { break; }
@@ -235,6 +254,11 @@ __global__ __launch_bounds__(kBlock) void k_trace(RenderParams p)
         atomicAdd(&p.stats[kStatClosest], (unsigned long long)closestRays);
         atomicAdd(&p.stats[kStatShadow], (unsigned long long)shadowRays);
         atomicMax(&p.stats[kStatMaxBoxes], (unsigned long long)maxBoxes);
+        if (lane == 0) {
+            atomicAdd(&p.stats[kStatWaveSteps], (unsigned long long)waveSteps);
+            atomicAdd(&p.stats[kStatLaneSteps], (unsigned long long)laneSteps);
+            atomicAdd(&p.stats[kStatRefills], (unsigned long long)refills);
+        }
     }
 }
 

@@ -398,6 +398,9 @@ void configureTrace(PathedScene *scene)
 
     int blocksPerCu = (int)((160 * 1024) / (scene->traceLdsBytes ? scene->traceLdsBytes : 1));
     if (blocksPerCu > 8) { blocksPerCu = 8; }
+    // measured on MI355X: the issue-bound HBM/L2 traversal is fastest at 4 blocks (16 waves) per
+    // CU; a 5th block adds cache pressure without adding issue slots
+    if (!scene->sceneInLds && blocksPerCu > 4) { blocksPerCu = 4; }
     if (blocksPerCu < 1) { blocksPerCu = 1; }
     if (const char *override = getenv("PATHED_TRACE_BLOCKS_PER_CU")) {
         const int value = atoi(override);
@@ -583,6 +586,10 @@ int pathed_hip_scene_create(const PathedSceneDesc *desc, PathedScene **out)
 
     configureTrace(scene);
     scene->bruteForce = scene->device.nTris <= kBruteForceMaxTris && !getenv("PATHED_NO_BRUTE_FORCE");
+    // BVH scenes: more slots = more rays per persistent wave to refill finished lanes from
+    // (ray cost is heavy-tailed); the all-triangles kernel has uniform cost and prefers the
+    // smaller, Infinity-Cache-resident state
+    scene->maxSlots = scene->bruteForce ? (1 << 20) : (1 << 22);
     std::memset(&scene->smallTris, 0, sizeof scene->smallTris);
     if (scene->bruteForce) {
         std::memcpy(scene->smallTris.data, scene->bvh.leafTris.data(), scene->bvh.leafTris.size() * sizeof(float));
@@ -907,6 +914,12 @@ int pathed_hip_get_stats(PathedScene *scene, PathedStats *out)
     out->bvh_max_depth = (uint32_t)scene->bvh.maxDepth;
     out->scene_in_lds = scene->bruteForce ? 2u : (scene->sceneInLds ? 1u : 0u);
     out->max_boxes_per_ray = device[kStatMaxBoxes];
+    if (getenv("PATHED_DEBUG_STATS")) {
+        fprintf(stderr, "[pathed] wave steps %llu lane steps %llu (lane utilisation %.3f) refill rounds %llu\n",
+                device[kStatWaveSteps], device[kStatLaneSteps],
+                device[kStatWaveSteps] ? (double)device[kStatLaneSteps] / (64.0 * (double)device[kStatWaveSteps]) : 0.0,
+                device[kStatRefills]);
+    }
     return PATHED_OK;
 }
 
