@@ -322,11 +322,13 @@ __global__ __launch_bounds__(kBlock) void k_trace_small(RenderParams p, SmallTri
         }
         if (__ballot(valid) == 0ull) { continue; }
 
+        // Phase 1 (wave-uniform, straight-line): every lane runs the inside test of every
+        // triangle on scalar-loaded records and only RECORDS the candidates in a per-lane
+        // bitmask.  A line through the box pierces 4-6 triangles, so with 64 lanes "some lane is
+        // inside" is true for almost every triangle: doing the division and the acceptance logic
+        // there made them two thirds of the instructions.
+        unsigned int candidatesLow = 0, candidatesHigh = 0;
         if (valid) {
-            // batches are homogeneous (all closest or all shadow rays), so the query kind is
-            // wave-uniform; the per-triangle inside test is straight-line code (no exec-mask
-            // juggling), and the division + acceptance run only when some lane is inside
-            const bool shadowBatch = batch >= slotBatches;
             for (int k = 0; k < nTris; k++) {
                 // uniform index into the kernarg segment -> scalar loads, broadcast to the wave
                 const float4 t0 = smallTris.data[3 * k + 0];
@@ -339,36 +341,31 @@ __global__ __launch_bounds__(kBlock) void k_trace_small(RenderParams p, SmallTri
                 const float uScaled = xdot(tvec, pvec);
                 const V3 qvec = xcross(tvec, e1);
                 const float vScaled = xdot(ray.d, qvec);
+                const float tScaled = xdot(e2, qvec);
                 const float sum = uScaled + vScaled;
-                // same predicate as intersectTriangle(), evaluated without short-circuits
-                const bool insidePositive = (det > 0.f) & (uScaled >= 0.f) & (vScaled >= 0.f) & (sum <= det);
-                const bool insideNegative = (det < 0.f) & (uScaled <= 0.f) & (vScaled <= 0.f) & (sum >= det);
-                const bool inside = (insidePositive | insideNegative) & !ray.occluded;
-                if (COUNT) { trisTested += ray.occluded ? 0u : 1u; }
-                if (__ballot(inside) != 0ull) {
-                    if (inside) {
-                        const float inv = 1.f / det;
-                        const float t = xdot(e2, qvec) * inv;
-                        if (t > ray.tnear) {
-                            const int prim = floatAsInt(t0.w);
-                            if (shadowBatch) {
-                                if (t <= ray.tfar) { ray.occluded = true; }
-                            } else {
-                                const bool closer = (ray.bestPrim < 0)
-                                    ? (t <= ray.best)
-                                    : (t < ray.best || (t == ray.best && prim < ray.bestPrim));
-                                if (closer) {
-                                    ray.best = t;
-                                    ray.bestU = uScaled * inv;
-                                    ray.bestV = vScaled * inv;
-                                    ray.bestPrim = prim;
-                                }
-                            }
-                        }
-                    }
-                    // every shadow ray of the wave is occluded: nothing left to find
-                    if (shadowBatch && __ballot(!ray.occluded) == 0ull) { break; }
-                }
+                // the predicate of intersectTriangle(), evaluated without short-circuits, plus the
+                // exact sign of t = tScaled / det (t must exceed tnear > 0)
+                const bool insidePositive = (det > 0.f) & (uScaled >= 0.f) & (vScaled >= 0.f) & (sum <= det) & (tScaled > 0.f);
+                const bool insideNegative = (det < 0.f) & (uScaled <= 0.f) & (vScaled <= 0.f) & (sum >= det) & (tScaled < 0.f);
+                const unsigned int bit = (insidePositive | insideNegative) ? (1u << (k & 31)) : 0u;
+                if (k < 32) { candidatesLow |= bit; } else { candidatesHigh |= bit; }
+                if (COUNT) { trisTested++; }
+            }
+        }
+
+        // Phase 2: the few candidates of each lane (typically 1-3) go through the ordinary
+        // intersector + acceptance rule, so hits are those of the BVH path bit for bit.
+        while (__ballot((candidatesLow | candidatesHigh) != 0u) != 0ull) {
+            if ((candidatesLow | candidatesHigh) != 0u) {
+                int k;
+                if (candidatesLow != 0u) { k = __ffs((int)candidatesLow) - 1; candidatesLow &= candidatesLow - 1u; }
+                else { k = 32 + __ffs((int)candidatesHigh) - 1; candidatesHigh &= candidatesHigh - 1u; }
+                const float4 t0 = geometry.tris[3 * k + 0];
+                const float4 t1 = geometry.tris[3 * k + 1];
+                const float4 t2 = geometry.tris[3 * k + 2];
+                bool terminate = false;
+                testLeafTriangle(ray, t0, t1, t2, &terminate);
+                if (terminate) { candidatesLow = 0u; candidatesHigh = 0u; }  // shadow ray occluded
             }
         }
 
