@@ -59,6 +59,7 @@ extern "C" {
 
 /* microfacet distribution (reference src/scene_parser.cpp:669-683) */
 #define PATHED_DIST_BECKMANN 0
+#define PATHED_DIST_GGX      1   /* reference src/ggx.cpp */
 
 /* geometry kinds in model order (reference src/scene_parser.cpp:251-291) */
 #define PATHED_GEOM_MESH   0

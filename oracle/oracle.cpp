@@ -410,6 +410,7 @@ struct Material {
     float orenA, orenB;
     float alpha;
     float ior;
+    int distribution; /* PATHED_DIST_* */
 };
 
 Material materialFromDesc(const PathedMaterial &m)
@@ -428,6 +429,7 @@ Material materialFromDesc(const PathedMaterial &m)
     out.orenA = 1.f - (sigma2 / (2.f * (sigma2 + 0.33f)));
     out.orenB = (0.45f * sigma2) / (sigma2 + 0.09f);
     out.alpha = m.alpha;
+    out.distribution = m.distribution;
     out.ior = m.ior;
     /* only Lambertian carries emission in the reference's parser
      * (src/scene_parser.cpp:574-667: every other ctor passes Color(0)) */
@@ -574,6 +576,56 @@ Vec3 beckmannSampleWh(float alpha, Rng &random)
     return sphericalToCartesian(phi, cosTheta, sinTheta);
 }
 
+/* src/ggx.cpp:27-46 */
+float ggxD(float alpha, Vec3 wh)
+{
+    const float alpha2 = alpha * alpha;
+    const float cos2Theta = tfCos2Theta(wh);
+    const float cos4Theta = cos2Theta * cos2Theta;
+    const float tan2Theta = tfTan2Theta(wh);
+    if (std::isinf(tan2Theta)) { return 0.f; }
+    const float sum = alpha2 + tan2Theta;
+    const float denominator = kPi * cos4Theta * sum * sum;
+    return alpha2 / denominator;
+}
+
+/* src/ggx.cpp:48-58 */
+float ggxG1(float alpha, Vec3 v)
+{
+    const float tan2Theta = tfTan2Theta(v);
+    if (std::isinf(tan2Theta)) { return 0.f; }
+    const float alpha2 = alpha * alpha;
+    const float sqrtTerm = (1 + alpha2 * tan2Theta);
+    return 2.f / (1 + sqrtf(sqrtTerm));
+}
+
+/* src/ggx.cpp:13-25: theta variate first, then phi (the opposite of Beckmann) */
+Vec3 ggxSampleWh(float alpha, Rng &random)
+{
+    const float xi1 = random.next();
+    const float xi2 = random.next();
+    const float numerator = alpha * sqrtf(xi1);
+    const float denominator = sqrtf(1.f - xi1);
+    const float theta = atanf(numerator / denominator);
+    const float phi = kTwoPi * xi2;
+    return sphericalToCartesian(phi, cosf(theta), sinf(theta));
+}
+
+/* MicrofacetDistribution dispatch (include/microfacet_distribution.h) */
+inline float distributionD(const Material &m, Vec3 wh)
+{
+    return m.distribution == PATHED_DIST_GGX ? ggxD(m.alpha, wh) : beckmannD(m.alpha, wh);
+}
+inline float distributionPdf(const Material &m, Vec3 wh) { return distributionD(m, wh) * fabsf(wh.y); }
+inline float distributionG(const Material &m, Vec3 wo, Vec3 wi)
+{
+    return m.distribution == PATHED_DIST_GGX ? ggxG1(m.alpha, wo) * ggxG1(m.alpha, wi) : beckmannG(m.alpha, wo, wi);
+}
+inline Vec3 distributionSampleWh(const Material &m, Rng &random)
+{
+    return m.distribution == PATHED_DIST_GGX ? ggxSampleWh(m.alpha, random) : beckmannSampleWh(m.alpha, random);
+}
+
 /* src/microfacet.cpp:12-57 */
 Color microfacetF(const Material &m, const Intersection &isect, Vec3 wiWorld, float *pdf)
 {
@@ -587,15 +639,15 @@ Color microfacetF(const Material &m, const Intersection &isect, Vec3 wiWorld, fl
     const float cosThetaI = fabsf(wi.y);
     const Vec3 wh = normalized(wo + wi);
 
-    *pdf = beckmannPdf(m.alpha, wh) / (4.f * dot(wo, wh));
+    *pdf = distributionPdf(m, wh) / (4.f * dot(wo, wh));
 
     if (cosThetaO == 0.f || cosThetaI == 0.f) { return col(0.f); }
     if (wh.x == 0.f && wh.y == 0.f && wh.z == 0.f) { return col(0.f); }
 
     const float cosThetaIncident = clampf(dot(wi, wh), 0.f, 1.f);
     const float fresnel = dielectricReflectance(cosThetaIncident, 1.f, 1.5f);
-    const float distribution = beckmannD(m.alpha, wh);
-    const float masking = beckmannG(m.alpha, wo, wi);
+    const float distribution = distributionD(m, wh);
+    const float masking = distributionG(m, wo, wi);
     const Color albedo = col(1.f);
 
     return albedo * distribution * masking * fresnel / (4 * cosThetaI * cosThetaO);
@@ -605,13 +657,13 @@ Color microfacetF(const Material &m, const Intersection &isect, Vec3 wiWorld, fl
 BSDFSample microfacetSample(const Material &m, const Intersection &isect, Rng &random)
 {
     const Vec3 wo = toLocal(isect.frame, isect.wo);
-    const Vec3 wh = beckmannSampleWh(m.alpha, random);
+    const Vec3 wh = distributionSampleWh(m, random);
     const Vec3 wi = reflect(wo, wh);
     const Vec3 wiWorld = toWorld(isect.frame, wi);
 
     BSDFSample sample;
     sample.wiWorld = wiWorld;
-    sample.pdf = beckmannPdf(m.alpha, wh) / (4.f * dot(wo, wh));
+    sample.pdf = distributionPdf(m, wh) / (4.f * dot(wo, wh));
     float ignored;
     sample.throughput = microfacetF(m, isect, wiWorld, &ignored);
     return sample;
@@ -1992,6 +2044,7 @@ static Material materialFromFloats(const float *p)
     m.sigma = p[16];
     m.alpha = p[17];
     m.ior = p[18];
+    m.distribution = (int)p[19];
     return materialFromDesc(m);
 }
 
@@ -2080,21 +2133,21 @@ int oracle_eval(const char *fn, const float *in, int n_in, float *out, int n_out
         return 4;
     }
     if (name == "material_f") {
-        /* material(19) isect(11) wi(3) -> f(3) pdf */
-        if (!need(33, 4)) { return -2; }
+        /* material(20) isect(11) wi(3) -> f(3) pdf */
+        if (!need(34, 4)) { return -2; }
         const Material m = materialFromFloats(in);
-        const Intersection isect = intersectionFromFloats(in + 19);
+        const Intersection isect = intersectionFromFloats(in + 20);
         float pdf = 0.f;
-        const Color f = materialF(m, isect, v3(in[30], in[31], in[32]), &pdf);
+        const Color f = materialF(m, isect, v3(in[31], in[32], in[33]), &pdf);
         out[0] = f.r; out[1] = f.g; out[2] = f.b; out[3] = pdf;
         return 4;
     }
     if (name == "material_sample") {
-        /* material(19) isect(11) u(3) -> wi(3) pdf thr(3) */
-        if (!need(33, 7)) { return -2; }
+        /* material(20) isect(11) u(3) -> wi(3) pdf thr(3) */
+        if (!need(34, 7)) { return -2; }
         const Material m = materialFromFloats(in);
-        const Intersection isect = intersectionFromFloats(in + 19);
-        Rng random = scriptedRng(in + 30, 3);
+        const Intersection isect = intersectionFromFloats(in + 20);
+        Rng random = scriptedRng(in + 31, 3);
         const BSDFSample s = materialSample(m, isect, random);
         out[0] = s.wiWorld.x; out[1] = s.wiWorld.y; out[2] = s.wiWorld.z; out[3] = s.pdf;
         out[4] = s.throughput.r; out[5] = s.throughput.g; out[6] = s.throughput.b;
@@ -2106,6 +2159,21 @@ int oracle_eval(const char *fn, const float *in, int n_in, float *out, int n_out
         out[0] = beckmannD(in[0], v3(in[1], in[2], in[3]));
         out[1] = beckmannPdf(in[0], v3(in[1], in[2], in[3]));
         out[2] = beckmannG(in[0], v3(in[4], in[5], in[6]), v3(in[7], in[8], in[9]));
+        return 3;
+    }
+    if (name == "ggx") {
+        /* alpha wh(3) wo(3) wi(3) -> D pdf G */
+        if (!need(10, 3)) { return -2; }
+        out[0] = ggxD(in[0], v3(in[1], in[2], in[3]));
+        out[1] = ggxD(in[0], v3(in[1], in[2], in[3])) * fabsf(in[2]);
+        out[2] = ggxG1(in[0], v3(in[4], in[5], in[6])) * ggxG1(in[0], v3(in[7], in[8], in[9]));
+        return 3;
+    }
+    if (name == "ggx_sample") {
+        if (!need(3, 3)) { return -2; }
+        Rng random = scriptedRng(in + 1, 2);
+        const Vec3 wh = ggxSampleWh(in[0], random);
+        out[0] = wh.x; out[1] = wh.y; out[2] = wh.z;
         return 3;
     }
     if (name == "beckmann_sample") {

@@ -54,6 +54,7 @@
 #include "coordinate.h"
 #include "distribution.h"
 #include "fresnel.h"
+#include "ggx.h"
 #include "glass.h"
 #include "intersection.h"
 #include "lambertian.h"
@@ -128,7 +129,7 @@ static void push3(std::vector<float> &v, const Vector3 &a) { v.push_back(a.x());
 static void push3(std::vector<float> &v, const Point3 &a) { v.push_back(a.x()); v.push_back(a.y()); v.push_back(a.z()); }
 static void push3(std::vector<float> &v, const Color &a) { v.push_back(a.r()); v.push_back(a.g()); v.push_back(a.b()); }
 
-/* material parameter block of oracle_eval: 19 floats */
+/* material parameter block of oracle_eval: 20 floats */
 struct MaterialSpec {
     int type = 0;       /* PATHED_MAT_* numbering */
     int albedoType = 0;
@@ -137,6 +138,13 @@ struct MaterialSpec {
     Color on = Color(0.f), off = Color(0.f);
     float resU = 0.f, resV = 0.f;
     float sigma = 0.f, alpha = 0.f, ior = 1.4f;
+    int distribution = 0; /* 0 Beckmann, 1 GGX */
+
+    std::unique_ptr<MicrofacetDistribution> makeDistribution() const
+    {
+        if (distribution == 1) { return std::make_unique<GGX>(alpha); }
+        return std::make_unique<Beckmann>(alpha);
+    }
 
     void push(std::vector<float> &v) const
     {
@@ -144,6 +152,7 @@ struct MaterialSpec {
         push3(v, diffuse); push3(v, emit); push3(v, on); push3(v, off);
         v.push_back(resU); v.push_back(resV);
         v.push_back(sigma); v.push_back(alpha); v.push_back(ior);
+        v.push_back((float)distribution);
     }
 
     std::shared_ptr<Material> build() const
@@ -156,8 +165,8 @@ struct MaterialSpec {
             }
             return std::make_shared<Lambertian>(diffuse, emit);
         case 1: return std::make_shared<OrenNayar>(diffuse, sigma);
-        case 2: return std::make_shared<Microfacet>(std::make_unique<Beckmann>(alpha));
-        case 3: return std::make_shared<Plastic>(diffuse, std::make_unique<Beckmann>(alpha));
+        case 2: return std::make_shared<Microfacet>(makeDistribution());
+        case 3: return std::make_shared<Plastic>(diffuse, makeDistribution());
         case 4: return std::make_shared<Glass>(ior);
         default: return std::make_shared<Mirror>();
         }
@@ -377,6 +386,35 @@ int main(int argc, char **argv)
         }
     }
 
+    /* ---- GGX pieces (reference src/ggx.cpp) -------------------------------------------- */
+    {
+        const float alphas[] = { 0.02f, 0.1f, 0.4f };
+        for (float alpha : alphas) {
+            GGX ggx(alpha);
+            for (int i = 0; i < 16; i++) {
+                const float spread = (i < 8) ? alpha * 3.f : 0.9f;
+                const float theta = uniform01() * spread;
+                const float phi = uniform01() * 6.2831853f;
+                const Vector3 wh(sinf(theta) * cosf(phi), cosf(theta), sinf(theta) * sinf(phi));
+                const Vector3 up(0.f, 1.f, 0.f);
+                const Vector3 wo = randomAbout(up, 0.02f);
+                const Vector3 wi = randomAbout(up, 0.02f);
+                std::vector<float> in;
+                in.push_back(alpha); push3(in, wh); push3(in, wo); push3(in, wi);
+                emit("ggx", in, { ggx.D(wh), ggx.pdf(wh), ggx.G(wo, wi) });
+            }
+            for (int i = 0; i < 8; i++) {
+                RandomGenerator random;
+                random.m_generator.seed(2500u + (unsigned)i);
+                const std::vector<float> u = peek(random, 2);
+                const Vector3 wh = ggx.sampleWh(Vector3(0.f, 1.f, 0.f), random);
+                std::vector<float> in = { alpha, u[0], u[1] }, out;
+                push3(out, wh);
+                emit("ggx_sample", in, out);
+            }
+        }
+    }
+
     /* ---- materials: f / pdf / sample ------------------------------------------------ */
     {
         MaterialSpec lambert;
@@ -409,6 +447,17 @@ int main(int argc, char **argv)
             MaterialSpec plastic;
             plastic.type = 3; plastic.alpha = alpha; plastic.diffuse = Color(0.07f, 0.09f, 0.13f);
             dumpMaterial(plastic, 24, true, 3700u + (unsigned)(alpha * 1000));
+        }
+
+        const float ggxAlphas[] = { 0.05f, 0.3f };
+        for (float alpha : ggxAlphas) {
+            MaterialSpec micro;
+            micro.type = 2; micro.alpha = alpha; micro.distribution = 1;
+            dumpMaterial(micro, 16, true, 3800u + (unsigned)(alpha * 1000));
+
+            MaterialSpec plastic;
+            plastic.type = 3; plastic.alpha = alpha; plastic.distribution = 1; plastic.diffuse = Color(0.1f, 0.1f, 0.4f);
+            dumpMaterial(plastic, 16, true, 3850u + (unsigned)(alpha * 1000));
         }
 
         const float iors[] = { 1.4f, 1.5f, 1.1f };

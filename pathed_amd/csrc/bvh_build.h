@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <vector>
@@ -57,7 +58,19 @@ struct TempNode {
 };
 
 static const int kBins = 16;
-static const uint32_t kMaxLeaf = 4;
+// leaf size: <= 7 (3-bit count in the traversal's leaf references); PATHED_MAX_LEAF overrides for tuning
+inline uint32_t maxLeafSize()
+{
+    static uint32_t value = 0;
+    if (value == 0) {
+        value = 4;
+        if (const char *text = getenv("PATHED_MAX_LEAF")) {
+            const int parsed = atoi(text);
+            if (parsed >= 1 && parsed <= 7) { value = (uint32_t)parsed; }
+        }
+    }
+    return value;
+}
 
 class Builder {
 public:
@@ -79,7 +92,7 @@ public:
         nodes.push_back(node);
 
         const uint32_t count = end - begin;
-        if (count <= kMaxLeaf) {
+        if (count <= maxLeafSize()) {
             nodes[(size_t)index].first = begin;
             nodes[(size_t)index].count = count;
             *maxDepth = std::max(*maxDepth, depth);

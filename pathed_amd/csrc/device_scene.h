@@ -7,7 +7,7 @@
 
 namespace pathed {
 
-// material table entry (80 B), staged in LDS by the shade kernel
+// material table entry (96 B), staged in LDS by the shade kernel
 struct DMaterial {
     int type;
     int albedoType;
@@ -20,6 +20,8 @@ struct DMaterial {
     float checkerResU;
     float checkerOff[3];
     float checkerResV;
+    int distribution;        // PATHED_DIST_*: Beckmann or GGX (Microfacet / Plastic)
+    int pad[3];
 };
 
 // per-triangle shading record, indexed by ORIGINAL primitive id (128 B = 8 x float4):

@@ -30,7 +30,7 @@ namespace pathed {
 
 static const int kBlock = 256;
 static const int kWavesPerBlock = kBlock / 64;
-static const int kMaxLdsMaterials = 96;  // 96 x 80 B = 7.5 KiB of LDS
+static const int kMaxLdsMaterials = 96;  // 96 x 96 B = 9 KiB of LDS
 static const int kUnitQueues = 32;       // sharded work-unit cursors
 #ifndef PATHED_REFILL
 #define PATHED_REFILL 56

@@ -237,6 +237,7 @@ DMaterial buildMaterial(const PathedMaterial &m)
     }
     out.alpha = m.alpha;
     out.ior = m.ior;
+    out.distribution = m.distribution;
     out.checkerResU = m.checker_res[0];
     out.checkerResV = m.checker_res[1];
     return out;
@@ -286,8 +287,10 @@ int validate(const PathedSceneDesc *desc)
     for (uint32_t i = 0; i < desc->n_materials; i++) {
         const int type = desc->materials[i].type;
         if (type < PATHED_MAT_LAMBERTIAN || type > PATHED_MAT_MIRROR) { return fail(PATHED_E_UNSUPPORTED, "unknown material type"); }
-        if ((type == PATHED_MAT_MICROFACET || type == PATHED_MAT_PLASTIC) && desc->materials[i].distribution != PATHED_DIST_BECKMANN) {
-            return fail(PATHED_E_UNSUPPORTED, "only the Beckmann distribution is in scope");
+        const int distribution = desc->materials[i].distribution;
+        if ((type == PATHED_MAT_MICROFACET || type == PATHED_MAT_PLASTIC)
+            && distribution != PATHED_DIST_BECKMANN && distribution != PATHED_DIST_GGX) {
+            return fail(PATHED_E_UNSUPPORTED, "unknown microfacet distribution");
         }
     }
     for (uint32_t i = 0; i < desc->n_geoms; i++) {

@@ -390,6 +390,56 @@ __device__ inline V3 beckmannSampleWh(float alpha, Rng &random)
     return sphericalToCartesian(phi, cosTheta, sinTheta);
 }
 
+// src/ggx.cpp:27-46
+__device__ inline float ggxD(float alpha, V3 wh)
+{
+    const float alpha2 = alpha * alpha;
+    const float cos2Theta = tfCos2Theta(wh);
+    const float cos4Theta = cos2Theta * cos2Theta;
+    const float tan2Theta = tfTan2Theta(wh);
+    if (isinf(tan2Theta)) { return 0.f; }
+    const float sum = alpha2 + tan2Theta;
+    const float denominator = PATHED_PI * cos4Theta * sum * sum;
+    return alpha2 / denominator;
+}
+
+// src/ggx.cpp:48-58
+__device__ inline float ggxG1(float alpha, V3 v)
+{
+    const float tan2Theta = tfTan2Theta(v);
+    if (isinf(tan2Theta)) { return 0.f; }
+    const float alpha2 = alpha * alpha;
+    const float sqrtTerm = (1 + alpha2 * tan2Theta);
+    return 2.f / (1 + sqrtf(sqrtTerm));
+}
+
+// src/ggx.cpp:13-25: theta variate first, then phi (the opposite of Beckmann)
+__device__ inline V3 ggxSampleWh(float alpha, Rng &random)
+{
+    const float xi1 = random.next();
+    const float xi2 = random.next();
+    const float numerator = alpha * sqrtf(xi1);
+    const float denominator = sqrtf(1.f - xi1);
+    const float theta = atanf(numerator / denominator);
+    const float phi = PATHED_TWO_PI * xi2;
+    return sphericalToCartesian(phi, cosf(theta), sinf(theta));
+}
+
+// MicrofacetDistribution dispatch (include/microfacet_distribution.h)
+__device__ inline float distributionD(const DMaterial &m, V3 wh)
+{
+    return m.distribution == PATHED_DIST_GGX ? ggxD(m.alpha, wh) : beckmannD(m.alpha, wh);
+}
+__device__ inline float distributionPdf(const DMaterial &m, V3 wh) { return distributionD(m, wh) * fabsf(wh.y); }
+__device__ inline float distributionG(const DMaterial &m, V3 wo, V3 wi)
+{
+    return m.distribution == PATHED_DIST_GGX ? ggxG1(m.alpha, wo) * ggxG1(m.alpha, wi) : beckmannG(m.alpha, wo, wi);
+}
+__device__ inline V3 distributionSampleWh(const DMaterial &m, Rng &random)
+{
+    return m.distribution == PATHED_DIST_GGX ? ggxSampleWh(m.alpha, random) : beckmannSampleWh(m.alpha, random);
+}
+
 // src/microfacet.cpp:12-57 (Fresnel eta hard-coded to 1.5 at :41)
 __device__ inline Rgb microfacetF(const DMaterial &m, const Isect &isect, V3 wiWorld, float *pdf)
 {
@@ -403,15 +453,15 @@ __device__ inline Rgb microfacetF(const DMaterial &m, const Isect &isect, V3 wiW
     const float cosThetaI = fabsf(wi.y);
     const V3 wh = normalized(wo + wi);
 
-    *pdf = beckmannPdf(m.alpha, wh) / (4.f * dot(wo, wh));
+    *pdf = distributionPdf(m, wh) / (4.f * dot(wo, wh));
 
     if (cosThetaO == 0.f || cosThetaI == 0.f) { return rgb(0.f); }
     if (wh.x == 0.f && wh.y == 0.f && wh.z == 0.f) { return rgb(0.f); }
 
     const float cosThetaIncident = clampf(dot(wi, wh), 0.f, 1.f);
     const float fresnel = dielectricReflectance(cosThetaIncident, 1.f, 1.5f);
-    const float distribution = beckmannD(m.alpha, wh);
-    const float masking = beckmannG(m.alpha, wo, wi);
+    const float distribution = distributionD(m, wh);
+    const float masking = distributionG(m, wo, wi);
     const Rgb albedo = rgb(1.f);
 
     return albedo * distribution * masking * fresnel / (4 * cosThetaI * cosThetaO);
@@ -421,13 +471,13 @@ __device__ inline Rgb microfacetF(const DMaterial &m, const Isect &isect, V3 wiW
 __device__ inline BSDFSample microfacetSample(const DMaterial &m, const Isect &isect, Rng &random)
 {
     const V3 wo = toLocal(isect.frame, isect.wo);
-    const V3 wh = beckmannSampleWh(m.alpha, random);
+    const V3 wh = distributionSampleWh(m, random);
     const V3 wi = reflect(wo, wh);
     const V3 wiWorld = toWorld(isect.frame, wi);
 
     BSDFSample sample;
     sample.wiWorld = wiWorld;
-    sample.pdf = beckmannPdf(m.alpha, wh) / (4.f * dot(wo, wh));
+    sample.pdf = distributionPdf(m, wh) / (4.f * dot(wo, wh));
     float ignored;
     sample.throughput = microfacetF(m, isect, wiWorld, &ignored);
     return sample;

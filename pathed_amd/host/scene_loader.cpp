@@ -182,7 +182,7 @@ void parseDistribution(const Json &json, PathedMaterial *material)
     if (type == "beckmann") {
         material->distribution = PATHED_DIST_BECKMANN;
     } else if (type == "ggx") {
-        throw SceneLoadError("Unsupported distribution (outside hot-path scope, SURVEY.md §8 f4): ggx");
+        material->distribution = PATHED_DIST_GGX;
     } else {
         throw SceneLoadError("Unimplemented distribution: " + type);
     }

@@ -26,6 +26,7 @@ CASES = {
     "cornell_glass_24": ("scenes/cornell-glass.json", 24, 24, 2, 0, 4, 0, 6),
     "cornell_glossy_24": ("scenes/cornell-glossy.json", 24, 24, 2, 0, 4, 0, 6),
     "oren_nayar_24": ("scenes/cornell-oren-nayar.json", 24, 24, 3, 0, 4, 0, 5),
+    "ggx_24": ("scenes/cornell-ggx.json", 24, 24, 8, 0, 4, 0, 5),
     "mis_32x24": ("scenes/mis-pbrt.json", 32, 24, 4, 0, 4, 0, 4),
     "teapot_32x24": ("scenes/teapot.json", 32, 24, 6, 0, 3, 0, 8),
     "env_sampling_24": ("test_scenes/environment_map_sampling.json", 24, 24, 7, 0, 8, 0, 3),

@@ -104,6 +104,7 @@ CASES = {
     "cornell_glass_24": ("scenes/cornell-glass.json", 24, 24, 2, 0, 4, 0, 6, 1e-2),
     "cornell_glossy_24": ("scenes/cornell-glossy.json", 24, 24, 2, 0, 4, 0, 6, 1e-2),
     "oren_nayar_24": ("scenes/cornell-oren-nayar.json", 24, 24, 3, 0, 4, 0, 5, 2e-3),
+    "ggx_24": ("scenes/cornell-ggx.json", 24, 24, 8, 0, 4, 0, 5, 2e-3),
     "mis_32x24": ("scenes/mis-pbrt.json", 32, 24, 4, 0, 4, 0, 4, 2e-3),
     "teapot_32x24": ("scenes/teapot.json", 32, 24, 6, 0, 3, 0, 8, 1e-2),
     "env_sampling_24": ("test_scenes/environment_map_sampling.json", 24, 24, 7, 0, 8, 0, 3, 2e-3),
@@ -319,4 +320,4 @@ def test_unbounded_last_bounce_terminates_and_matches(libs):
     assert rel < 2e-3 and bad <= 2e-3
     assert stats["vertices"] > 0.5 * stats["camera_samples"]  # most camera rays hit and bounce
     shallow, _ = oracle_lib.OracleScene(desc).render(48, 48, 2, 0, 8, 0, 1, chunk=4)
-    assert expected.sum() > shallow.sum() * 1.05  # the unbounded render carries indirect light
+    assert expected.sum() > shallow.sum() * 1.01  # the unbounded render carries indirect light

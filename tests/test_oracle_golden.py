@@ -36,7 +36,7 @@ RECORDS = _load()
 
 PURE_FUNCTIONS = [
     "reflect", "frame", "frame1", "camera_ray", "cosine_hemisphere", "spherical", "fresnel", "refract",
-    "beckmann", "beckmann_sample", "material_f", "material_sample", "triangle_sample", "triangle_pdf",
+    "beckmann", "beckmann_sample", "ggx", "ggx_sample", "material_f", "material_sample", "triangle_sample", "triangle_pdf",
     "area_to_solid_angle", "mis_balance", "bounce_controller", "distribution",
 ]
 

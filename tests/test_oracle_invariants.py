@@ -89,7 +89,7 @@ def test_lambertian_and_beckmann_pdfs_integrate_to_one():
     r = np.sqrt(1 - z * z)
     dirs = np.stack([r * np.cos(phi), z, r * np.sin(phi)], axis=1).astype(np.float32)
     isect = [0, 1, 0, 0, 1, 0, 0.3, 0.9, 0.3162278, 0.5, 0.5]
-    lambert = [0, 0, .5, .5, .5, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0.1, 1.4]
+    lambert = [0, 0, .5, .5, .5, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0.1, 1.4, 0]
     total = 0.0
     for d in dirs[:4000]:
         total += oracle_lib.evaluate("material_f", lambert + isect + d.tolist())[3]
@@ -102,7 +102,7 @@ def test_lambertian_and_beckmann_pdfs_integrate_to_one():
 
 
 def test_glass_sample_conserves_energy_and_fresnel_split():
-    glass = [4, 0] + [0] * 16 + [1.4]
+    glass = [4, 0] + [0] * 16 + [1.4, 0]
     isect = [0, 1, 0, 0, 1, 0, 0.0, 0.8, 0.6, 0, 0]
     fresnel = oracle_lib.evaluate("fresnel", [0.8, 1.0, 1.4])[0]
     reflect = oracle_lib.evaluate("material_sample", glass + isect + [fresnel * 0.5, 0, 0])
