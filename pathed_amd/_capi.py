@@ -215,6 +215,9 @@ def load_host():
     if hasattr(lib, "pathed_host_write_exr_float_rgba"):
         lib.pathed_host_write_exr_float_rgba.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_float)]
         lib.pathed_host_write_exr_float_rgba.restype = C.c_int
+    if hasattr(lib, "pathed_host_write_exr_half_bgr"):
+        lib.pathed_host_write_exr_half_bgr.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_float)]
+        lib.pathed_host_write_exr_half_bgr.restype = C.c_int
     if hasattr(lib, "pathed_host_read_exr_rgba"):
         lib.pathed_host_read_exr_rgba.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_float), C.c_size_t]
         lib.pathed_host_read_exr_rgba.restype = C.c_int

@@ -129,3 +129,28 @@ int pathed_host_read_exr_rgba(const char *path, int *width, int *height, float *
 }
 
 }  // extern "C"
+
+// planar-free helper for the Python multi-GPU job runner: mean image, interleaved RGB, row 0 =
+// BOTTOM scanline (the integrator's layout); written like Image::set + Image::save would
+// (vertical flip, B/G/R HALF, reference src/image.cpp:21-35, 80-154)
+extern "C" int pathed_host_write_exr_half_bgr(const char *path, int width, int height, const float *rgbBottomUp)
+{
+    const size_t pixels = (size_t)width * height;
+    std::vector<float> planes[3];
+    for (int c = 0; c < 3; c++) { planes[c].resize(pixels); }
+    for (int row = 0; row < height; row++) {
+        for (int col = 0; col < width; col++) {
+            const size_t source = (size_t)3 * ((size_t)row * width + col);
+            const size_t target = (size_t)(height - row - 1) * width + col;
+            planes[0][target] = rgbBottomUp[source + 0];
+            planes[1][target] = rgbBottomUp[source + 1];
+            planes[2][target] = rgbBottomUp[source + 2];
+        }
+    }
+    std::string error;
+    if (!pathed::writeExrHalfBGR(path, width, height, planes[0].data(), planes[1].data(), planes[2].data(), &error)) {
+        g_hostError = error;
+        return 1;
+    }
+    return 0;
+}

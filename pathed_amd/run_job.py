@@ -1,0 +1,105 @@
+#!/usr/bin/env python3
+"""Multi-GPU job runner: `pathed <job.json>` with the samples of every pixel sharded over the GPUs
+of one node (one process per GPU, RCCL reduce of the radiance sums to rank 0).
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \\
+        -m pathed_amd.run_job job.json
+    python -m pathed_amd.run_job job.json            # single GPU
+
+Same job.json keys, output files and log lines as the reference (src/job.cpp:33-63,
+src/integrator.cpp:69-102): <output_directory>/report.json, auto.exr, auto-%05dspp.exr at every
+power-of-two sample count, "[<outdir>/] sample: i/N (Xs elapsed)".  Between two checkpoints rank r
+renders a contiguous share of the sample indices (pathed_amd/parallel.py), so the final sums equal
+the single-GPU sums up to fp32 summation order.
+"""
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    job_path = argv[0] if argv else "job.json"
+    asset_root = argv[1] if len(argv) > 1 else None
+
+    import torch
+    import torch.distributed as dist
+
+    from . import _capi, parallel
+    from .integrator import BounceController, HipScene
+    from .scene import LoadedScene
+
+    world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("pathed_amd.run_job needs a GPU: there is no CPU path")
+    torch.cuda.set_device(local_rank)
+    if world_size > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    with open(job_path) as handle:
+        job = json.load(handle)
+    width, height = job["width"], job["height"]
+    spp = job["spp"] if job["spp"] > 0 else 9999999
+    seed = int(job.get("seed", 1))
+    bounces = BounceController(job["startBounce"], job["lastBounce"])
+    if job["integrator"] not in ("PathTracer", "DataParallelIntegrator"):
+        raise SystemExit("Unimplemented")  # the reference throws "Unimplemented" (src/job.cpp:96)
+    out_dir = job["output_directory"] + "/"
+
+    if rank == 0:
+        if os.path.isdir(out_dir):
+            print("Output directory already exists: %s" % out_dir)
+            if not job.get("force", False):
+                raise SystemExit(1)
+        os.makedirs(out_dir, exist_ok=True)
+        with open(os.path.join(out_dir, "report.json"), "w") as handle:
+            json.dump(job, handle, indent=4)
+
+    scene = LoadedScene(job["scene"], width, height, asset_root if asset_root is not None else job.get("asset_root"))
+    gpu = HipScene(scene.desc, device=local_rank)
+    host = _capi.load_host()
+    stream = torch.cuda.current_stream().cuda_stream
+
+    accum = torch.zeros((height, width, 3), dtype=torch.float32, device="cuda")   # this rank's sums
+    total = torch.zeros_like(accum) if rank == 0 else None                         # reduced sums so far
+    done = 0
+    while done < spp:
+        next_power = 1
+        while next_power <= done:
+            next_power *= 2
+        count = min(next_power, spp) - done          # up to the next checkpoint
+        begin, mine = parallel.strong_range(rank, world_size, done, count)
+        t0 = time.perf_counter()
+        accum.zero_()
+        if mine > 0:
+            gpu.render_device(seed, begin, mine, bounces.start_bounce, bounces.last_bounce, accum.data_ptr(), stream)
+        parallel.reduce_to_root(accum, root=0)
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        done += count
+        if rank == 0:
+            total += accum
+            mean = (total / float(done)).cpu().numpy()
+            pointer = mean.ctypes.data_as(C.POINTER(C.c_float))
+            for name in ("auto.exr", "auto-%05dspp.exr" % done):
+                path = os.path.join(out_dir, name)
+                if host.pathed_host_write_exr_half_bgr(path.encode(), width, height, pointer) != 0:
+                    raise RuntimeError(host.pathed_host_last_error().decode())
+                print("Saved exr file. [ %s ] " % path)
+            print("[%s] sample: %d/%d (%.1fs elapsed)" % (out_dir, done, spp, elapsed), flush=True)
+
+    if world_size > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
