@@ -44,11 +44,11 @@ static const int kLeafThreshold = PATHED_LEAF_THRESHOLD;  // lanes with a leaf p
 // counters[] layout (unsigned int)
 static const int kCtrRemaining = 0;    // slots that still have work
 static const int kCtrUnitCursor = 8;   // [8 .. 8+kUnitQueues): next unit of each queue
-static const int kCtrCount = 8 + kUnitQueues;
-#ifndef PATHED_DEAL
-#define PATHED_DEAL 16
-#endif
-static const unsigned int kDeal = PATHED_DEAL;  // ray-pool items per card dealt to the trace waves
+static const int kTraceShards = 32;
+static const int kTraceShardStride = 32;             // words: one 128-B line per shard cursor
+static const int kCtrTraceCursor = 8 + kUnitQueues + 24;  // 256-B aligned; next card of each trace shard (zeroed by k_shade)
+static const int kCtrCount = kCtrTraceCursor + kTraceShards * kTraceShardStride;
+static const int kCard = 64;           // rays per trace card
 
 // stats[] layout (unsigned long long)
 static const int kStatSamples = 0;
@@ -61,7 +61,12 @@ static const int kStatMaxBoxes = 6;   // most child boxes tested by a single ray
 static const int kStatWaveSteps = 7;  // traversal steps executed by waves (stats mode)
 static const int kStatLaneSteps = 8;  // ... and by lanes: lane utilisation = lane / (64 * wave)
 static const int kStatRefills = 9;
-static const int kStatCount = 12;
+static const int kStatWaveCycles = 10;     // sum of trace-wave lifetimes, shader clocks (stats mode)
+static const int kStatWaveCyclesMax = 11;  // longest single trace wave
+static const int kStatTailSteps = 12;      // wave steps run after the card pool ran dry
+static const int kStatTailLaneSteps = 13;
+static const int kStatTailCycles = 14;
+static const int kStatCount = 16;
 
 // state word (rayD.w): bits 0..15 vertex that spawned the ray (0 = camera ray),
 // 16 eligible, 17 delta, 18 continue (device_scene.h), 19..25 sample index inside the unit
@@ -150,16 +155,33 @@ __global__ __launch_bounds__(kBlock) void k_trace(RenderParams p)
 
     // Ray pool of this launch: item i < nSlots is the closest-hit ray of slot i; item
     // nSlots + j is entry j % kBlock of shade block j / kBlock's compacted shadow rays.
-    // The pool is dealt to the persistent waves in kDeal-item cards, round robin: wave w owns
-    // cards w, w + W, w + 2W, ...  Every wave therefore samples the whole image (ray cost is
-    // strongly correlated in image space) and no atomics are needed.  Lanes whose ray has
-    // finished are refilled from the wave's own cards (ballot + prefix popcount).
-    const unsigned int waveCount = gridDim.x * kWavesPerBlock;
+    // The pool is cut into 64-item cards.  Persistent waves draw cards from kTraceShards
+    // sharded cursors (one wave-level atomic per 64 rays; a wave whose home shard has run dry
+    // moves on to the next one), so every wave keeps drawing until the whole pool is dealt and
+    // no wave is left holding a long private queue.  Lanes whose ray has finished are refilled
+    // from the wave's current card (ballot + prefix popcount).
     const unsigned int totalItems = 2u * (unsigned int)p.nSlots;
-    const unsigned int totalCards = totalItems / kDeal;          // nSlots is a multiple of kBlock
-    const unsigned int myCards = (totalCards > waveId) ? (totalCards - waveId + waveCount - 1u) / waveCount : 0u;
-    const unsigned int localEnd = myCards * kDeal;               // wave-local item count
-    unsigned int cursor = 0;                                      // wave-uniform, in local items
+    const unsigned int totalCards = totalItems / kCard;          // nSlots is a multiple of kBlock
+    unsigned int shard = waveId % kTraceShards, shardsTried = 0;
+    unsigned int cardPos = 0, cardLeft = 0;                       // wave-uniform
+    bool exhausted = false;
+    auto drawCard = [&]() {
+        while (shardsTried < kTraceShards) {
+            unsigned int ticket = 0;
+            if (lane == 0) { ticket = atomicAdd(&p.counters[kCtrTraceCursor + shard * kTraceShardStride], 1u); }
+            ticket = (unsigned int)__builtin_amdgcn_readfirstlane((int)ticket);
+            const unsigned int card = ticket * kTraceShards + shard;
+            if (card < totalCards) {
+                cardPos = card * kCard;
+                cardLeft = kCard;
+                return;
+            }
+            shard = (shard + 1u) % kTraceShards;
+            shardsTried++;
+        }
+        exhausted = true;
+    };
+    drawCard();
 
     TraceCounters counters;
     counters.boxes = 0;
@@ -167,49 +189,51 @@ __global__ __launch_bounds__(kBlock) void k_trace(RenderParams p)
     unsigned int closestRays = 0, shadowRays = 0;
     unsigned int maxBoxes = 0, rayBoxesStart = 0;
     unsigned int waveSteps = 0, laneSteps = 0, refills = 0;
+    unsigned long long waveStart = 0, tailStart = 0;
+    unsigned int tailSteps = 0, tailLaneSteps = 0;
+    if (COUNT) { waveStart = __builtin_amdgcn_s_memtime(); }
 
     LaneRay ray;
     bool active = false;
     unsigned int target = 0;  // slot of the ray in flight on this lane
 
     while (true) {
-        if (cursor < localEnd) {
+        while (!exhausted) {
             const unsigned long long idleMask = __ballot(!active);
-            if (idleMask != 0ull) {
-                const unsigned int local = cursor + (unsigned int)__popcll(idleMask & lanesBelow);
-                cursor += (unsigned int)__popcll(idleMask);
-                if (!active && local < localEnd) {
-                    const unsigned int item = ((local / kDeal) * waveCount + waveId) * kDeal + (local % kDeal);
-                    if (item < (unsigned int)p.nSlots) {
-                        const unsigned int slot = item;
-                        const float4 rd = p.state.rayD[slot];
-                        if (!(floatAsInt(rd.w) & kStDone)) {
-                            const float4 ro = p.state.rayO[slot];
-                            laneRayInit(ray, v3(ro.x, ro.y, ro.z), v3(rd.x, rd.y, rd.z), PATHED_TNEAR, PATHED_TFAR, false);
-                            target = slot;
-                            active = true;
-                            if (COUNT) { closestRays++; rayBoxesStart = counters.boxes; }
-                        }
-                    } else {
-                        const unsigned int entry = item - (unsigned int)p.nSlots;
-                        if ((entry % kBlock) < p.state.blockShadowCount[entry / kBlock]) {
-                            const float4 so = p.state.shO[entry];
-                            const float4 sd = p.state.shD[entry];
-                            laneRayInit(ray, v3(so.x, so.y, so.z), v3(sd.x, sd.y, sd.z), PATHED_TNEAR, so.w, true);
-                            target = (unsigned int)floatAsInt(sd.w);
-                            active = true;
-                            if (COUNT) { shadowRays++; rayBoxesStart = counters.boxes; }
-                        }
+            if (idleMask == 0ull) { break; }
+            const unsigned int rank = (unsigned int)__popcll(idleMask & lanesBelow);
+            const unsigned int wanted = (unsigned int)__popcll(idleMask);
+            if (!active && rank < cardLeft) {
+                const unsigned int item = cardPos + rank;
+                if (item < (unsigned int)p.nSlots) {
+                    const unsigned int slot = item;
+                    const float4 rd = p.state.rayD[slot];
+                    if (!(floatAsInt(rd.w) & kStDone)) {
+                        const float4 ro = p.state.rayO[slot];
+                        laneRayInit(ray, v3(ro.x, ro.y, ro.z), v3(rd.x, rd.y, rd.z), PATHED_TNEAR, PATHED_TFAR, false);
+                        target = slot;
+                        active = true;
+                        if (COUNT) { closestRays++; rayBoxesStart = counters.boxes; }
+                    }
+                } else {
+                    const unsigned int entry = item - (unsigned int)p.nSlots;
+                    if ((entry % kBlock) < p.state.blockShadowCount[entry / kBlock]) {
+                        const float4 so = p.state.shO[entry];
+                        const float4 sd = p.state.shD[entry];
+                        laneRayInit(ray, v3(so.x, so.y, so.z), v3(sd.x, sd.y, sd.z), PATHED_TNEAR, so.w, true);
+                        target = (unsigned int)floatAsInt(sd.w);
+                        active = true;
+                        if (COUNT) { shadowRays++; rayBoxesStart = counters.boxes; }
                     }
                 }
             }
-            if (cursor > localEnd) { cursor = localEnd; }
+            const unsigned int taken = wanted < cardLeft ? wanted : cardLeft;
+            cardPos += taken;
+            cardLeft -= taken;
+            if (cardLeft == 0u) { drawCard(); }
         }
 
-        if (__ballot(active) == 0ull) {
-            if (cursor >= localEnd) { break; }
-            continue;
-        }
+        if (__ballot(active) == 0ull) { break; }  // only reached with the pool exhausted
 
         // traversal burst.  Each step the wave runs ONE phase: the triangle phase when enough lanes
         // have a leaf pending (or nothing else can run), else the inner-node phase; lanes in the
@@ -220,7 +244,15 @@ __global__ __launch_bounds__(kBlock) void k_trace(RenderParams p)
             const unsigned long long leafMask = __ballot(active && ray.pendingLeaf != 0);
             const unsigned long long innerMask = __ballot(active && ray.pendingLeaf == 0);
             const bool trianglePhase = __popcll(leafMask) >= kLeafThreshold || innerMask == 0ull;
-            if (COUNT) { waveSteps++; laneSteps += (unsigned int)__popcll(trianglePhase ? leafMask : innerMask); }
+            if (COUNT) {
+                waveSteps++;
+                laneSteps += (unsigned int)__popcll(trianglePhase ? leafMask : innerMask);
+                if (exhausted) {
+                    if (tailSteps == 0) { tailStart = __builtin_amdgcn_s_memtime(); }
+                    tailSteps++;
+                    tailLaneSteps += (unsigned int)__popcll(trianglePhase ? leafMask : innerMask);
+                }
+            }
             bool done = false;
             if (trianglePhase) {
                 if (active && ray.pendingLeaf != 0) { done = leafStep<COUNT, kBlock>(geometry, stack, ray, &counters); }
@@ -244,7 +276,7 @@ __global__ __launch_bounds__(kBlock) void k_trace(RenderParams p)
             }
             const unsigned long long activeMask = __ballot(active);
             if (activeMask == 0ull) { break; }
-            if (cursor < localEnd && __popcll(activeMask) < kRefillThreshold) { break; }
+            if (!exhausted && __popcll(activeMask) < kRefillThreshold) { break; }
         }
     }
 
@@ -258,6 +290,11 @@ __global__ __launch_bounds__(kBlock) void k_trace(RenderParams p)
             atomicAdd(&p.stats[kStatWaveSteps], (unsigned long long)waveSteps);
             atomicAdd(&p.stats[kStatLaneSteps], (unsigned long long)laneSteps);
             atomicAdd(&p.stats[kStatRefills], (unsigned long long)refills);
+            atomicAdd(&p.stats[kStatWaveCycles], (unsigned long long)(__builtin_amdgcn_s_memtime() - waveStart));
+            atomicMax(&p.stats[kStatWaveCyclesMax], (unsigned long long)(__builtin_amdgcn_s_memtime() - waveStart));
+            atomicAdd(&p.stats[kStatTailSteps], (unsigned long long)tailSteps);
+            atomicAdd(&p.stats[kStatTailLaneSteps], (unsigned long long)tailLaneSteps);
+            if (tailSteps) { atomicAdd(&p.stats[kStatTailCycles], (unsigned long long)(__builtin_amdgcn_s_memtime() - tailStart)); }
         }
     }
 }
@@ -726,6 +763,9 @@ __global__ __launch_bounds__(kBlock) void k_shade(RenderParams p)
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const DScene &scene = p.scene;
+
+    // rewind the card cursors for the pool's next trace launch (same stream: it starts after us)
+    if (blockIdx.x == 0 && threadIdx.x < kTraceShards) { p.counters[kCtrTraceCursor + threadIdx.x * kTraceShardStride] = 0u; }
 
     float4 rd = p.state.rayD[slot];
     int st = floatAsInt(rd.w);

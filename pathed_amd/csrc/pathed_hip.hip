@@ -922,6 +922,10 @@ int pathed_hip_get_stats(PathedScene *scene, PathedStats *out)
                 device[kStatWaveSteps], device[kStatLaneSteps],
                 device[kStatWaveSteps] ? (double)device[kStatLaneSteps] / (64.0 * (double)device[kStatWaveSteps]) : 0.0,
                 device[kStatRefills]);
+        fprintf(stderr, "[pathed] sum of wave lifetimes %.3e cycles, longest single wave %.3e cycles\n",
+                (double)device[kStatWaveCycles], (double)device[kStatWaveCyclesMax]);
+        fprintf(stderr, "[pathed] tail (no cards left): %llu wave steps, %llu lane steps, %.3e cycles\n",
+                device[kStatTailSteps], device[kStatTailLaneSteps], (double)device[kStatTailCycles]);
     }
     return PATHED_OK;
 }
