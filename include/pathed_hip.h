@@ -175,6 +175,7 @@ typedef struct PathedStats {
     uint32_t bvh_max_depth;
     uint32_t scene_in_lds;         /* 0 BVH in HBM, 1 BVH staged in LDS, 2 tiny scene: all triangles tested (scalar loads) */
     uint64_t max_boxes_per_ray;    /* most child boxes a single closest-hit ray tested — stats mode */
+    uint64_t parked_rays;          /* rays a trace launch handed on to the next one unfinished — stats mode */
 } PathedStats;
 
 /* ---- life cycle ---------------------------------------------------------- */

@@ -108,6 +108,7 @@ class PathedStats(C.Structure):
         ("bvh_max_depth", C.c_uint32),
         ("scene_in_lds", C.c_uint32),
         ("max_boxes_per_ray", C.c_uint64),
+        ("parked_rays", C.c_uint64),
     ]
 
 

@@ -35,20 +35,36 @@ static const int kUnitQueues = 32;       // sharded work-unit cursors
 #ifndef PATHED_REFILL
 #define PATHED_REFILL 56
 #endif
-static const int kRefillThreshold = PATHED_REFILL;
+static const int kRefillThreshold = PATHED_REFILL;  // refill a wave's idle lanes once fewer than this many are busy
 #ifndef PATHED_LEAF_THRESHOLD
 #define PATHED_LEAF_THRESHOLD 24
 #endif
-static const int kLeafThreshold = PATHED_LEAF_THRESHOLD;  // lanes with a leaf pending that trigger a triangle phase  // refill a wave's idle lanes once fewer than this many are busy
+static const int kLeafThreshold = PATHED_LEAF_THRESHOLD;  // lanes with a leaf pending that trigger a triangle phase
 
 // counters[] layout (unsigned int)
 static const int kCtrRemaining = 0;    // slots that still have work
-static const int kCtrUnitCursor = 8;   // [8 .. 8+kUnitQueues): next unit of each queue
+// Every cursor sits on its own 128-byte line: atomics to one line serialise in L2 (about 88 per
+// microsecond on MI355X), whatever word of the line they address.
+static const int kCursorStride = 32;   // words
+static const int kCtrUnitCursor = kCursorStride;                                  // + queue * kCursorStride: next unit of the queue
 static const int kTraceShards = 32;
-static const int kTraceShardStride = 32;             // words: one 128-B line per shard cursor
-static const int kCtrTraceCursor = 8 + kUnitQueues + 24;  // 256-B aligned; next card of each trace shard (zeroed by k_shade)
-static const int kCtrCount = kCtrTraceCursor + kTraceShards * kTraceShardStride;
+static const int kCtrTraceCursor = kCtrUnitCursor + kUnitQueues * kCursorStride;  // + shard * kCursorStride: next card (rewound by k_shade)
+static const int kCtrCount = kCtrTraceCursor + kTraceShards * kCursorStride;
 static const int kCard = 64;           // rays per trace card
+
+// Tail suspension.  Once the pool is dealt a wave only thins out: the last few long rays would
+// keep it (and the launch) alive at 5-6 busy lanes for a third of its lifetime.  Instead, a wave
+// that has been out of cards for kSuspendPatience steps and is down to fewer than kSuspendLanes
+// rays parks them -- ray, best hit so far and traversal stack -- in its private save area and
+// exits; the same wave of the pool's next trace launch picks them up again, first thing, beside
+// a full load of fresh rays.  The slot of a parked ray is marked (hit.w / pend.w) so k_shade
+// leaves it alone until the ray's result is in.  Results do not depend on any of this: the hit
+// acceptance rule is order-independent and every slot is shaded from its own finished rays.
+static const int kSuspendLanes = 32;                     // default; RenderParams::suspendLanes = 0 disables (PATHED_SUSPEND_LANES)
+static const int kSuspendPatience = 32;                   // default steps a wave rides out its tail before parking it (PATHED_SUSPEND_PATIENCE)
+static const int kSaveWords = 18;                        // per-lane record ahead of the stack entries
+static const int kPrimSuspended = (int)0x80000001u;      // hit.w of a slot whose closest-hit ray is parked
+static const int kShadowSuspended = 0x7fc0dead;          // pend.w of a slot whose shadow ray is parked (a NaN pattern)
 
 // stats[] layout (unsigned long long)
 static const int kStatSamples = 0;
@@ -66,6 +82,7 @@ static const int kStatWaveCyclesMax = 11;  // longest single trace wave
 static const int kStatTailSteps = 12;      // wave steps run after the card pool ran dry
 static const int kStatTailLaneSteps = 13;
 static const int kStatTailCycles = 14;
+static const int kStatParked = 15;         // rays parked by tail suspension
 static const int kStatCount = 16;
 
 // state word (rayD.w): bits 0..15 vertex that spawned the ray (0 = camera ray),
@@ -94,6 +111,10 @@ struct RenderParams {
     PathState state;
     unsigned int *counters;
     unsigned long long *stats;
+    unsigned long long *suspendMask;  // per trace wave: lanes with a parked ray
+    int *suspendData;                 // per trace wave: (kSaveWords + STACK) x 64 words, word-major
+    int suspendLanes;                 // park the tail once fewer rays than this are left (0 = never)
+    int suspendPatience;              // ... and the wave has run this many steps since its last card
     float *accum;          // 3*W*H radiance sums, index 3*(row*W+col)+c
     int nSlots;            // multiple of kBlock
     int nPixels;
@@ -123,8 +144,12 @@ __device__ inline bool checkCounts(int startBounce, int lastBounce, int bounce)
 
 // ------------------------------------------------------------------------- trace
 
+// amdgpu_waves_per_eu(5, 5) caps the kernel at 96 VGPRs: the trace waves resident on a SIMD
+// (3 or 4) must leave registers for a wave of the other pool's k_shade (104), or the two pools
+// stop overlapping.
+
 template <int STACK, bool LDS_SCENE, bool COUNT>
-__global__ __launch_bounds__(kBlock) void k_trace(RenderParams p)
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_trace(RenderParams p)
 {
     extern __shared__ float4 ldsRaw[];
     int *stackBase = reinterpret_cast<int *>(ldsRaw);
@@ -150,7 +175,6 @@ __global__ __launch_bounds__(kBlock) void k_trace(RenderParams p)
     }
 
     const int lane = threadIdx.x & 63;
-    const unsigned long long lanesBelow = (1ull << lane) - 1ull;
     const unsigned int waveId = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
 
     // Ray pool of this launch: item i < nSlots is the closest-hit ray of slot i; item
@@ -168,7 +192,7 @@ __global__ __launch_bounds__(kBlock) void k_trace(RenderParams p)
     auto drawCard = [&]() {
         while (shardsTried < kTraceShards) {
             unsigned int ticket = 0;
-            if (lane == 0) { ticket = atomicAdd(&p.counters[kCtrTraceCursor + shard * kTraceShardStride], 1u); }
+            if (lane == 0) { ticket = atomicAdd(&p.counters[kCtrTraceCursor + shard * kCursorStride], 1u); }
             ticket = (unsigned int)__builtin_amdgcn_readfirstlane((int)ticket);
             const unsigned int card = ticket * kTraceShards + shard;
             if (card < totalCards) {
@@ -197,22 +221,52 @@ __global__ __launch_bounds__(kBlock) void k_trace(RenderParams p)
     bool active = false;
     unsigned int target = 0;  // slot of the ray in flight on this lane
 
+    // rays this wave parked at the end of the pool's previous launch
+    unsigned long long parkedMask = 0ull;
+    bool restored = false;
+    unsigned int stepsSinceLastCard = 0;
+    if (p.suspendLanes > 0) {
+        parkedMask = p.suspendMask[waveId];
+        if ((parkedMask >> lane) & 1ull) {
+            const int *save = p.suspendData + (size_t)waveId * (size_t)((kSaveWords + STACK) * 64) + lane;
+            const V3 o = v3(intAsFloat(save[0 * 64]), intAsFloat(save[1 * 64]), intAsFloat(save[2 * 64]));
+            const V3 d = v3(intAsFloat(save[3 * 64]), intAsFloat(save[4 * 64]), intAsFloat(save[5 * 64]));
+            const int flags = save[14 * 64];
+            laneRayInit(ray, o, d, intAsFloat(save[6 * 64]), intAsFloat(save[7 * 64]), (flags & 1) != 0);
+            ray.best = intAsFloat(save[8 * 64]);
+            ray.bestU = intAsFloat(save[9 * 64]);
+            ray.bestV = intAsFloat(save[10 * 64]);
+            ray.bestPrim = save[11 * 64];
+            ray.current = save[12 * 64];
+            ray.pendingLeaf = save[13 * 64];
+            ray.sp = save[15 * 64];
+            target = (unsigned int)save[16 * 64];
+            if (COUNT) { rayBoxesStart = counters.boxes - (unsigned int)save[17 * 64]; }
+            for (int k = 0; k < ray.sp; k++) { stack[k * kBlock] = save[(kSaveWords + k) * 64]; }
+            active = true;
+            restored = true;
+        }
+        parkedMask = 0ull;
+    }
+
     while (true) {
         while (!exhausted) {
             const unsigned long long idleMask = __ballot(!active);
             if (idleMask == 0ull) { break; }
-            const unsigned int rank = (unsigned int)__popcll(idleMask & lanesBelow);
+            const unsigned int rank = __builtin_amdgcn_mbcnt_hi(
+                (unsigned int)(idleMask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)idleMask, 0u));  // idle lanes below this one
             const unsigned int wanted = (unsigned int)__popcll(idleMask);
             if (!active && rank < cardLeft) {
                 const unsigned int item = cardPos + rank;
                 if (item < (unsigned int)p.nSlots) {
                     const unsigned int slot = item;
                     const float4 rd = p.state.rayD[slot];
-                    if (!(floatAsInt(rd.w) & kStDone)) {
+                    if (!(floatAsInt(rd.w) & (kStDone | kStHold))) {
                         const float4 ro = p.state.rayO[slot];
                         laneRayInit(ray, v3(ro.x, ro.y, ro.z), v3(rd.x, rd.y, rd.z), PATHED_TNEAR, PATHED_TFAR, false);
                         target = slot;
                         active = true;
+                        restored = false;
                         if (COUNT) { closestRays++; rayBoxesStart = counters.boxes; }
                     }
                 } else {
@@ -223,6 +277,7 @@ __global__ __launch_bounds__(kBlock) void k_trace(RenderParams p)
                         laneRayInit(ray, v3(so.x, so.y, so.z), v3(sd.x, sd.y, sd.z), PATHED_TNEAR, so.w, true);
                         target = (unsigned int)floatAsInt(sd.w);
                         active = true;
+                        restored = false;
                         if (COUNT) { shadowRays++; rayBoxesStart = counters.boxes; }
                     }
                 }
@@ -265,6 +320,7 @@ __global__ __launch_bounds__(kBlock) void k_trace(RenderParams p)
                 finishRay(geometry, ray);
                 if (ray.anyHit) {
                     if (ray.occluded) { p.state.pend[target] = make_float4(0.f, 0.f, 0.f, 0.f); }
+                    else if (restored) { reinterpret_cast<int *>(p.state.pend + target)[3] = 0; }
                 } else {
                     p.state.hit[target] = make_float4(ray.best, ray.bestU, ray.bestV, intAsFloat(ray.bestPrim));
                 }
@@ -277,8 +333,36 @@ __global__ __launch_bounds__(kBlock) void k_trace(RenderParams p)
             const unsigned long long activeMask = __ballot(active);
             if (activeMask == 0ull) { break; }
             if (!exhausted && __popcll(activeMask) < kRefillThreshold) { break; }
+            if (exhausted) { stepsSinceLastCard++; }
+            if (exhausted && __popcll(activeMask) < p.suspendLanes && stepsSinceLastCard >= (unsigned int)p.suspendPatience) {
+                if (active) {
+                    int *save = p.suspendData + (size_t)waveId * (size_t)((kSaveWords + STACK) * 64) + lane;
+                    save[0 * 64] = floatAsInt(ray.o.x); save[1 * 64] = floatAsInt(ray.o.y); save[2 * 64] = floatAsInt(ray.o.z);
+                    save[3 * 64] = floatAsInt(ray.d.x); save[4 * 64] = floatAsInt(ray.d.y); save[5 * 64] = floatAsInt(ray.d.z);
+                    save[6 * 64] = floatAsInt(ray.tnear);
+                    save[7 * 64] = floatAsInt(ray.tfar);
+                    save[8 * 64] = floatAsInt(ray.best);
+                    save[9 * 64] = floatAsInt(ray.bestU);
+                    save[10 * 64] = floatAsInt(ray.bestV);
+                    save[11 * 64] = ray.bestPrim;
+                    save[12 * 64] = ray.current;
+                    save[13 * 64] = ray.pendingLeaf;
+                    save[14 * 64] = ray.anyHit ? 1 : 0;
+                    save[15 * 64] = ray.sp;
+                    save[16 * 64] = (int)target;
+                    save[17 * 64] = COUNT ? (int)(counters.boxes - rayBoxesStart) : 0;
+                    for (int k = 0; k < ray.sp; k++) { save[(kSaveWords + k) * 64] = stack[k * kBlock]; }
+                    if (ray.anyHit) { reinterpret_cast<int *>(p.state.pend + target)[3] = kShadowSuspended; }
+                    else { reinterpret_cast<int *>(p.state.hit + target)[3] = kPrimSuspended; }
+                    active = false;
+                }
+                parkedMask = activeMask;
+                if (COUNT && lane == 0) { atomicAdd(&p.stats[kStatParked], (unsigned long long)__popcll(activeMask)); }
+                break;
+            }
         }
     }
+    if (p.suspendLanes > 0 && lane == 0) { p.suspendMask[waveId] = parkedMask; }
 
     if (COUNT) {
         atomicAdd(&p.stats[kStatBoxes], (unsigned long long)counters.boxes);
@@ -664,7 +748,7 @@ __device__ inline unsigned int grabUnits(const RenderParams &p, bool want, unsig
     }
     const unsigned int queue = blockIdx.x % (unsigned int)p.nQueues;
     if (threadIdx.x == 0) {
-        ldsScratch[kWavesPerBlock] = total ? atomicAdd(&p.counters[kCtrUnitCursor + queue], total) : 0u;
+        ldsScratch[kWavesPerBlock] = total ? atomicAdd(&p.counters[kCtrUnitCursor + queue * kCursorStride], total) : 0u;
     }
     __syncthreads();
     const unsigned int base = ldsScratch[kWavesPerBlock];
@@ -765,11 +849,27 @@ __global__ __launch_bounds__(kBlock) void k_shade(RenderParams p)
     const DScene &scene = p.scene;
 
     // rewind the card cursors for the pool's next trace launch (same stream: it starts after us)
-    if (blockIdx.x == 0 && threadIdx.x < kTraceShards) { p.counters[kCtrTraceCursor + threadIdx.x * kTraceShardStride] = 0u; }
+    if (blockIdx.x == 0 && threadIdx.x < kTraceShards) { p.counters[kCtrTraceCursor + threadIdx.x * kCursorStride] = 0u; }
 
     float4 rd = p.state.rayD[slot];
     int st = floatAsInt(rd.w);
-    const bool active = !(st & kStDone);
+    bool active = !(st & kStDone);
+    float4 h = make_float4(0.f, 0.f, 0.f, 0.f), pendIn = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (active) {
+        // a slot with a parked ray (see kSuspendLanes) sits this iteration out, untouched
+        h = p.state.hit[slot];
+        if (st & kStEligible) { pendIn = p.state.pend[slot]; }
+        if (p.suspendLanes > 0) {
+            const bool parked = floatAsInt(h.w) == kPrimSuspended
+                || ((st & kStEligible) && floatAsInt(pendIn.w) == kShadowSuspended);
+            if (parked) {
+                if (!(st & kStHold)) { reinterpret_cast<int *>(p.state.rayD + slot)[3] = st | kStHold; }
+                active = false;
+            }
+            st &= ~kStHold;
+            rd.w = intAsFloat(st);
+        }
+    }
 
     ShadowRequest shadow;
     shadow.push = false;
@@ -790,7 +890,6 @@ __global__ __launch_bounds__(kBlock) void k_shade(RenderParams p)
 
     if (active) {
         const float4 ro = p.state.rayO[slot];
-        const float4 h = p.state.hit[slot];
         const float4 resIn = p.state.res[slot];
         outRayO = ro;
 
@@ -842,7 +941,6 @@ __global__ __launch_bounds__(kBlock) void k_shade(RenderParams p)
 
             if (st & kStEligible) {
                 // PathTracer::directSampleBSDF, src/path_tracer.cpp:167-216
-                const float4 pendIn = p.state.pend[slot];
                 Rgb bsdfTerm = rgb(0.f);
                 if (!miss) {
                     const Rgb emit = matEmit(materials[isect.material]);

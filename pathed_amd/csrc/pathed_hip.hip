@@ -152,6 +152,8 @@ struct PathedScene {
     hipEvent_t callerReady = nullptr;
     DeviceBuffer<float4> rayO, rayD, hit, mod, thr, res, pend, acc, shO, shD, chunkBuf;
     DeviceBuffer<unsigned int> counters, blockShadowCount;
+    DeviceBuffer<unsigned long long> suspendMask;  // per pool, per trace wave (kernels.h: tail suspension)
+    DeviceBuffer<int> suspendData;
     DeviceBuffer<unsigned long long> stats;
     unsigned int *hostRemaining = nullptr;  // pinned
 
@@ -161,6 +163,8 @@ struct PathedScene {
     SmallTris smallTris;          // their records, passed to k_trace_small as a kernel argument
     size_t traceLdsBytes = 0;
     int traceGrid = 0;
+    int suspendLanes = kSuspendLanes;  // PATHED_SUSPEND_LANES overrides (0 = off)
+    int suspendPatience = kSuspendPatience;  // PATHED_SUSPEND_PATIENCE
     int computeUnits = 256;
 
     bool countMode = false;
@@ -177,6 +181,7 @@ struct PathedScene {
         rayO.release(); rayD.release(); hit.release(); mod.release(); thr.release();
         res.release(); pend.release(); acc.release(); shO.release(); shD.release(); chunkBuf.release();
         counters.release(); blockShadowCount.release(); stats.release();
+        suspendMask.release(); suspendData.release();
         if (hostRemaining) { (void)hipHostFree(hostRemaining); }
         for (int h = 0; h < 2; h++) {
             if (poolStreams[h]) { (void)hipStreamDestroy(poolStreams[h]); }
@@ -336,6 +341,11 @@ int ensureRenderState(PathedScene *scene, int nSlots, size_t chunkEntries)
         scene->chunkCapacity = chunkEntries;
     }
     if (!scene->counters.ptr) { HIP_TRY(scene->counters.allocate(2 * kCtrCount)); }
+    if (!scene->suspendMask.ptr && !scene->bruteForce) {
+        const size_t waves = (size_t)scene->traceGrid * kWavesPerBlock;
+        HIP_TRY(scene->suspendMask.allocate(2 * waves));
+        HIP_TRY(scene->suspendData.allocate(2 * waves * (size_t)(kSaveWords + scene->stackDepth) * 64));
+    }
     if (!scene->stats.ptr) {
         HIP_TRY(scene->stats.allocate(kStatCount));
         HIP_TRY(hipMemset(scene->stats.ptr, 0, kStatCount * sizeof(unsigned long long)));
@@ -401,15 +411,24 @@ void configureTrace(PathedScene *scene)
 
     int blocksPerCu = (int)((160 * 1024) / (scene->traceLdsBytes ? scene->traceLdsBytes : 1));
     if (blocksPerCu > 8) { blocksPerCu = 8; }
-    // measured on MI355X: the issue-bound HBM/L2 traversal is fastest at 4 blocks (16 waves) per
-    // CU; a 5th block adds cache pressure without adding issue slots
-    if (!scene->sceneInLds && blocksPerCu > 4) { blocksPerCu = 4; }
+    // measured on MI355X: the issue-bound HBM/L2 traversal alone is fastest at 4 blocks (16
+    // waves) per CU, but with the other pool's memory-bound k_shade sharing the CUs 3 blocks give
+    // the best whole-render rate (teapot 1102 -> 1165, 5.2M-triangle mesh 1021 -> 1064 Msamples/s)
+    if (!scene->sceneInLds && blocksPerCu > 3) { blocksPerCu = scene->pools > 1 ? 3 : 4; }
     if (blocksPerCu < 1) { blocksPerCu = 1; }
     if (const char *override = getenv("PATHED_TRACE_BLOCKS_PER_CU")) {
         const int value = atoi(override);
         if (value >= 1 && value <= 16) { blocksPerCu = value; }
     }
     scene->traceGrid = scene->computeUnits * blocksPerCu;
+    if (const char *override = getenv("PATHED_SUSPEND_PATIENCE")) {
+        const int value = atoi(override);
+        if (value >= 0 && value <= 4096) { scene->suspendPatience = value; }
+    }
+    if (const char *override = getenv("PATHED_SUSPEND_LANES")) {
+        const int value = atoi(override);
+        if (value >= 0 && value <= 64) { scene->suspendLanes = value; }
+    }
 }
 
 }  // namespace
@@ -587,6 +606,7 @@ int pathed_hip_scene_create(const PathedSceneDesc *desc, PathedScene **out)
     d.env.phiCdf = scene->phiCdf.ptr;
     d.env.phiEmpty = scene->phiEmpty.ptr;
 
+    if (const char *poolCount = getenv("PATHED_POOLS")) { scene->pools = atoi(poolCount) >= 2 ? 2 : 1; }
     configureTrace(scene);
     scene->bruteForce = scene->device.nTris <= kBruteForceMaxTris && !getenv("PATHED_NO_BRUTE_FORCE");
     // BVH scenes: more slots = more rays per persistent wave to refill finished lanes from
@@ -597,7 +617,6 @@ int pathed_hip_scene_create(const PathedSceneDesc *desc, PathedScene **out)
     if (scene->bruteForce) {
         std::memcpy(scene->smallTris.data, scene->bvh.leafTris.data(), scene->bvh.leafTris.size() * sizeof(float));
     }
-    if (const char *poolCount = getenv("PATHED_POOLS")) { scene->pools = atoi(poolCount) >= 2 ? 2 : 1; }
     if (const char *slots = getenv("PATHED_MAX_SLOTS")) {
         const long value = atol(slots);
         if (value >= kBlock) { scene->maxSlots = (int)value; }
@@ -666,6 +685,12 @@ static int renderPass(PathedScene *scene, uint64_t seed, uint32_t begin, uint32_
         q.state.blockShadowCount = scene->blockShadowCount.ptr + slotBase / kBlock;
         q.state.chunkBuf = scene->chunkBuf.ptr + unitBase;
         q.counters = scene->counters.ptr + (size_t)h * kCtrCount;
+        const size_t traceWaves = (size_t)scene->traceGrid * kWavesPerBlock;
+        q.suspendLanes = scene->bruteForce ? 0 : scene->suspendLanes;
+        q.suspendPatience = scene->suspendPatience;
+        q.suspendMask = scene->bruteForce ? nullptr : scene->suspendMask.ptr + (size_t)h * traceWaves;
+        q.suspendData = scene->bruteForce ? nullptr
+            : scene->suspendData.ptr + (size_t)h * traceWaves * (size_t)(kSaveWords + scene->stackDepth) * 64;
         q.stats = scene->stats.ptr;
         q.accum = d_accum;
         q.nSlots = slotsPerPool;
@@ -694,6 +719,9 @@ static int renderPass(PathedScene *scene, uint64_t seed, uint32_t begin, uint32_
     const dim3 slotGrid((unsigned)blocksPerPool), block(kBlock);
     for (int h = 0; h < pools; h++) {
         HIP_TRY(hipMemsetAsync(params[h].counters, 0, kCtrCount * sizeof(unsigned int), streams[h]));
+        if (params[h].suspendMask) {
+            HIP_TRY(hipMemsetAsync(params[h].suspendMask, 0, (size_t)scene->traceGrid * kWavesPerBlock * sizeof(unsigned long long), streams[h]));
+        }
         hipLaunchKernelGGL(k_init, slotGrid, block, 0, streams[h], params[h]);
     }
 
@@ -917,6 +945,7 @@ int pathed_hip_get_stats(PathedScene *scene, PathedStats *out)
     out->bvh_max_depth = (uint32_t)scene->bvh.maxDepth;
     out->scene_in_lds = scene->bruteForce ? 2u : (scene->sceneInLds ? 1u : 0u);
     out->max_boxes_per_ray = device[kStatMaxBoxes];
+    out->parked_rays = device[kStatParked];
     if (getenv("PATHED_DEBUG_STATS")) {
         fprintf(stderr, "[pathed] wave steps %llu lane steps %llu (lane utilisation %.3f) refill rounds %llu\n",
                 device[kStatWaveSteps], device[kStatLaneSteps],
@@ -924,8 +953,8 @@ int pathed_hip_get_stats(PathedScene *scene, PathedStats *out)
                 device[kStatRefills]);
         fprintf(stderr, "[pathed] sum of wave lifetimes %.3e cycles, longest single wave %.3e cycles\n",
                 (double)device[kStatWaveCycles], (double)device[kStatWaveCyclesMax]);
-        fprintf(stderr, "[pathed] tail (no cards left): %llu wave steps, %llu lane steps, %.3e cycles\n",
-                device[kStatTailSteps], device[kStatTailLaneSteps], (double)device[kStatTailCycles]);
+        fprintf(stderr, "[pathed] tail (no cards left): %llu wave steps, %llu lane steps, %.3e cycles; %llu rays parked\n",
+                device[kStatTailSteps], device[kStatTailLaneSteps], (double)device[kStatTailCycles], device[kStatParked]);
     }
     return PATHED_OK;
 }

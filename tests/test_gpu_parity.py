@@ -302,6 +302,43 @@ def test_result_does_not_depend_on_scheduling_or_intersector_variant(libs):
     assert np.array_equal(glass_one, glass_two)
 
 
+def _render_counted(libs, env, scene_path, size, seed, spp):
+    _, HipScene, LoadedScene = libs
+    saved = {key: os.environ.get(key) for key in env}
+    os.environ.update(env)
+    try:
+        scene = LoadedScene(scene_path, size, size)
+        gpu = HipScene(scene.desc, device=0)
+        gpu.set_stats_mode(count=True)
+        gpu.reset_stats()
+        return gpu.render(seed, 0, spp, 0, 10), gpu.stats()
+    finally:
+        for key, value in saved.items():
+            if value is None:
+                os.environ.pop(key, None)
+            else:
+                os.environ[key] = value
+
+
+def test_rays_carried_over_between_trace_launches_change_nothing(libs):
+    """A trace wave that is out of work hands its last unfinished rays (ray, best hit so far,
+    traversal stack) to the next launch instead of idling on them.  With that switched off, on, or
+    set so eagerly that most waves hand rays on every launch, the image is the same bit for bit."""
+    # one block per CU: each wave draws enough cards to run well past the minimum step count
+    few_waves = {"PATHED_TRACE_BLOCKS_PER_CU": "1"}
+    off, off_stats = _render_counted(libs, dict(few_waves, PATHED_SUSPEND_LANES="0"), "scenes/cornell-glass.json", 384, 5, 8)
+    assert off_stats["scene_in_lds"] == 0 and off_stats["parked_rays"] == 0
+    default, default_stats = _render_counted(libs, few_waves, "scenes/cornell-glass.json", 384, 5, 8)
+    assert default_stats["parked_rays"] > 0
+    assert np.array_equal(off, default)
+    eager, eager_stats = _render_counted(libs, dict(few_waves, PATHED_SUSPEND_LANES="64"), "scenes/cornell-glass.json", 384, 5, 8)
+    assert eager_stats["parked_rays"] > default_stats["parked_rays"]
+    assert np.array_equal(off, eager)
+    assert eager_stats["closest_rays"] == off_stats["closest_rays"]
+    assert eager_stats["shadow_rays"] == off_stats["shadow_rays"]
+    assert eager_stats["nodes_visited"] == off_stats["nodes_visited"]  # nothing is re-traversed
+
+
 def test_unbounded_last_bounce_terminates_and_matches(libs):
     """lastBounce = -1 (reference: unbounded, src/bounce_controller.cpp:20-25): paths end on a miss or
     when the throughput underflows to exactly black.  Open scene so every path escapes."""
