@@ -391,12 +391,20 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
 // path by the intersector specification (equal-t ties resolve by primitive id, not test order).
 static const int kBruteForceMaxTris = 64;
 
-// The triangle records travel as a KERNEL ARGUMENT (3 KB of the 4 KB kernarg segment): kernarg
+// The triangle records travel as a KERNEL ARGUMENT (2.3 KB of the 4 KB kernarg segment): kernarg
 // reads are s_load from the constant address space, so a uniform index gives true scalar loads.
 // (Uniform global_load_dwordx4 still return 1 KiB per wave through the 64 B/clk vector path.)
+// Triangles are stored two by two, component-interleaved -- (a.v0x, b.v0x), (a.v0y, b.v0y), ... --
+// so that one packed-fp32 instruction (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32, full rate on
+// CDNA3/4) works on triangle a in its low half and triangle b in its high half.
+typedef float f2 __attribute__((ext_vector_type(2)));
+static const int kSmallPairWords = 9;  // f2 per pair: v0.xyz, e1.xyz, e2.xyz
 struct SmallTris {
-    float4 data[3 * kBruteForceMaxTris];
+    f2 data[kSmallPairWords * (kBruteForceMaxTris / 2)];
 };
+
+__device__ inline f2 splat2(float v) { f2 r = { v, v }; return r; }
+__device__ inline f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 
 template <bool COUNT>
 __global__ __launch_bounds__(kBlock) void k_trace_small(RenderParams p, SmallTris smallTris)
@@ -415,6 +423,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_small(RenderParams p, SmallTri
     const unsigned int slotBatches = (unsigned int)p.nSlots / 64u;
     const unsigned int totalBatches = 2u * slotBatches;
     const int nTris = p.scene.nTris;
+    const int nPairs = (nTris + 1) / 2;
 
     unsigned int closestRays = 0, shadowRays = 0, trisTested = 0;
 
@@ -443,34 +452,61 @@ __global__ __launch_bounds__(kBlock) void k_trace_small(RenderParams p, SmallTri
         }
         if (__ballot(valid) == 0ull) { continue; }
 
-        // Phase 1 (wave-uniform, straight-line): every lane runs the inside test of every
-        // triangle on scalar-loaded records and only RECORDS the candidates in a per-lane
-        // bitmask.  A line through the box pierces 4-6 triangles, so with 64 lanes "some lane is
-        // inside" is true for almost every triangle: doing the division and the acceptance logic
-        // there made them two thirds of the instructions.
+        // Phase 1 (wave-uniform, straight-line): every lane runs a CONSERVATIVE inside test of every
+        // triangle on scalar-loaded records, two triangles per packed instruction, and only
+        // RECORDS the candidates in a per-lane bitmask.  A line through the box pierces 4-6
+        // triangles, so with 64 lanes "some lane is inside" is true for almost every triangle:
+        // doing the division and the acceptance logic there made them two thirds of the
+        // instructions.  The test is intersectTriangle()'s predicate with both det signs folded
+        // by multiplying through with det:  u det >= 0, v det >= 0, (det - u - v) det >= 0,
+        // t det >= 0, taken as "not (min < 0)" so that -0, underflow and NaN all err on the side of
+        // keeping the candidate; phase 2 decides.  Bits are shifted in (cand = 2 cand + bit), so
+        // triangle k of a 32-triangle word ends up at bit 31 - (k & 31).
         unsigned int candidatesLow = 0, candidatesHigh = 0;
         if (valid) {
-            for (int k = 0; k < nTris; k++) {
+            const f2 dx = splat2(ray.d.x), dy = splat2(ray.d.y), dz = splat2(ray.d.z);
+            const f2 ox = splat2(ray.o.x), oy = splat2(ray.o.y), oz = splat2(ray.o.z);
+            // one pair of triangles: returns (bit of a) * 2 + bit of b
+            auto testPair = [&](int pair) -> unsigned int {
                 // uniform index into the kernarg segment -> scalar loads, broadcast to the wave
-                const float4 t0 = smallTris.data[3 * k + 0];
-                const float4 t1 = smallTris.data[3 * k + 1];
-                const float4 t2 = smallTris.data[3 * k + 2];
-                const V3 e1 = v3(t1.x, t1.y, t1.z), e2 = v3(t2.x, t2.y, t2.z);
-                const V3 pvec = xcross(ray.d, e2);
-                const float det = xdot(e1, pvec);
-                const V3 tvec = ray.o - v3(t0.x, t0.y, t0.z);
-                const float uScaled = xdot(tvec, pvec);
-                const V3 qvec = xcross(tvec, e1);
-                const float vScaled = xdot(ray.d, qvec);
-                const float tScaled = xdot(e2, qvec);
-                const float sum = uScaled + vScaled;
-                // the predicate of intersectTriangle(), evaluated without short-circuits, plus the
-                // exact sign of t = tScaled / det (t must exceed tnear > 0)
-                const bool insidePositive = (det > 0.f) & (uScaled >= 0.f) & (vScaled >= 0.f) & (sum <= det) & (tScaled > 0.f);
-                const bool insideNegative = (det < 0.f) & (uScaled <= 0.f) & (vScaled <= 0.f) & (sum >= det) & (tScaled < 0.f);
-                const unsigned int bit = (insidePositive | insideNegative) ? (1u << (k & 31)) : 0u;
-                if (k < 32) { candidatesLow |= bit; } else { candidatesHigh |= bit; }
-                if (COUNT) { trisTested++; }
+                const f2 *record = smallTris.data + kSmallPairWords * pair;
+                const f2 v0x = record[0], v0y = record[1], v0z = record[2];
+                const f2 e1x = record[3], e1y = record[4], e1z = record[5];
+                const f2 e2x = record[6], e2y = record[7], e2z = record[8];
+                // pvec = d x e2, det = e1 . pvec
+                const f2 px = fma2(dy, e2z, -(dz * e2y));
+                const f2 py = fma2(dz, e2x, -(dx * e2z));
+                const f2 pz = fma2(dx, e2y, -(dy * e2x));
+                const f2 det = fma2(e1x, px, fma2(e1y, py, e1z * pz));
+                const f2 tx = ox - v0x, ty = oy - v0y, tz = oz - v0z;
+                const f2 uScaled = fma2(tx, px, fma2(ty, py, tz * pz));
+                // qvec = tvec x e1
+                const f2 qx = fma2(ty, e1z, -(tz * e1y));
+                const f2 qy = fma2(tz, e1x, -(tx * e1z));
+                const f2 qz = fma2(tx, e1y, -(ty * e1x));
+                const f2 vScaled = fma2(dx, qx, fma2(dy, qy, dz * qz));
+                const f2 tScaled = fma2(e2x, qx, fma2(e2y, qy, e2z * qz));
+                const f2 a = uScaled * det, b = vScaled * det, c = (det - (uScaled + vScaled)) * det, e = tScaled * det;
+                const float worstA = fminf(fminf(a.x, b.x), fminf(c.x, e.x));
+                const float worstB = fminf(fminf(a.y, b.y), fminf(c.y, e.y));
+                return ((worstA < 0.f) ? 0u : 2u) | ((worstB < 0.f) ? 0u : 1u);
+            };
+            const int lowPairs = nPairs < 16 ? nPairs : 16;
+            for (int pair = 0; pair < lowPairs; pair++) { candidatesLow = (candidatesLow << 2) | testPair(pair); }
+            for (int pair = 16; pair < nPairs; pair++) { candidatesHigh = (candidatesHigh << 2) | testPair(pair); }
+            if (COUNT) { trisTested += (unsigned int)nTris; }
+            // left-align: the last pair shifted in sits at bit 0; pad pairs and a padding triangle drop out
+            const int lowTris = nTris < 32 ? nTris : 32;
+            const int lowShifted = 2 * (nPairs < 16 ? nPairs : 16);
+            if (lowShifted > 0 && lowShifted < 32) { candidatesLow <<= 32 - lowShifted; }
+            candidatesLow &= lowTris > 0 ? 0xFFFFFFFFu << (32 - lowTris) : 0u;
+            const int highTris = nTris - 32;
+            if (highTris > 0) {
+                const int highShifted = 2 * (nPairs - 16);
+                if (highShifted < 32) { candidatesHigh <<= 32 - highShifted; }
+                candidatesHigh &= 0xFFFFFFFFu << (32 - highTris);
+            } else {
+                candidatesHigh = 0u;
             }
         }
 
@@ -478,9 +514,9 @@ __global__ __launch_bounds__(kBlock) void k_trace_small(RenderParams p, SmallTri
         // intersector + acceptance rule, so hits are those of the BVH path bit for bit.
         while (__ballot((candidatesLow | candidatesHigh) != 0u) != 0ull) {
             if ((candidatesLow | candidatesHigh) != 0u) {
-                int k;
-                if (candidatesLow != 0u) { k = __ffs((int)candidatesLow) - 1; candidatesLow &= candidatesLow - 1u; }
-                else { k = 32 + __ffs((int)candidatesHigh) - 1; candidatesHigh &= candidatesHigh - 1u; }
+                int k;  // triangle k of a word is bit 31 - (k & 31): take the highest set bit first
+                if (candidatesLow != 0u) { k = __clz((int)candidatesLow); candidatesLow &= ~(0x80000000u >> k); }
+                else { k = __clz((int)candidatesHigh); candidatesHigh &= ~(0x80000000u >> k); k += 32; }
                 const float4 t0 = geometry.tris[3 * k + 0];
                 const float4 t1 = geometry.tris[3 * k + 1];
                 const float4 t2 = geometry.tris[3 * k + 2];

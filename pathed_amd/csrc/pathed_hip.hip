@@ -615,7 +615,16 @@ int pathed_hip_scene_create(const PathedSceneDesc *desc, PathedScene **out)
     scene->maxSlots = scene->bruteForce ? (1 << 20) : (1 << 22);
     std::memset(&scene->smallTris, 0, sizeof scene->smallTris);
     if (scene->bruteForce) {
-        std::memcpy(scene->smallTris.data, scene->bvh.leafTris.data(), scene->bvh.leafTris.size() * sizeof(float));
+        // pairs of leaf-ordered triangles, component-interleaved (kernels.h: SmallTris); the odd
+        // one out is paired with an all-zero triangle, masked off in the kernel
+        const float *tris = scene->bvh.leafTris.data();
+        for (int k = 0; k < scene->device.nTris; k++) {
+            const float *tri = tris + (size_t)12 * k;  // (v0, prim) (e1, -) (e2, -)
+            f2 *record = scene->smallTris.data + (size_t)kSmallPairWords * (k / 2);
+            for (int row = 0; row < 3; row++) {
+                for (int axis = 0; axis < 3; axis++) { record[3 * row + axis][k & 1] = tri[4 * row + axis]; }
+            }
+        }
     }
     if (const char *slots = getenv("PATHED_MAX_SLOTS")) {
         const long value = atol(slots);
