@@ -49,7 +49,8 @@ static const int kCursorStride = 32;   // words
 static const int kCtrUnitCursor = kCursorStride;                                  // + queue * kCursorStride: next unit of the queue
 static const int kTraceShards = 32;
 static const int kCtrTraceCursor = kCtrUnitCursor + kUnitQueues * kCursorStride;  // + shard * kCursorStride: next card (rewound by k_shade)
-static const int kCtrCount = kCtrTraceCursor + kTraceShards * kCursorStride;
+static const int kCtrShadowCount = kCtrTraceCursor + kTraceShards * kCursorStride;  // + parity * kCursorStride: length of the shadow-ray list
+static const int kCtrCount = kCtrShadowCount + 2 * kCursorStride;
 static const int kCard = 64;           // rays per trace card
 
 // Tail suspension.  Once the pool is dealt a wave only thins out: the last few long rays would
@@ -83,7 +84,11 @@ static const int kStatTailSteps = 12;      // wave steps run after the card pool
 static const int kStatTailLaneSteps = 13;
 static const int kStatTailCycles = 14;
 static const int kStatParked = 15;         // rays parked by tail suspension
-static const int kStatCount = 16;
+static const int kStatRefillCycles = 16;   // shader clocks spent refilling lanes / in inner phases / in triangle phases (stats mode)
+static const int kStatInnerCycles = 17;
+static const int kStatLeafCycles = 18;
+static const int kStatInnerSteps = 19;
+static const int kStatCount = 24;
 
 // state word (rayD.w): bits 0..15 vertex that spawned the ray (0 = camera ray),
 // 16 eligible, 17 delta, 18 continue (device_scene.h), 19..25 sample index inside the unit
@@ -100,9 +105,8 @@ struct PathState {
     float4 *res;    // result.rgb of the sample in flight, bits(unit)
     float4 *pend;   // light-sampling term of the pending vertex (zeroed if occluded)
     float4 *acc;    // partial radiance sum of the unit in flight
-    float4 *shO;    // shadow rays, compacted per shade block: origin.xyz, tfar
-    float4 *shD;    //                                           direction.xyz, bits(slot)
-    unsigned int *blockShadowCount;  // shadow rays of each shade block (<= kBlock)
+    float4 *shO;    // shadow rays, one dense list per iteration: origin.xyz, tfar
+    float4 *shD;    //                                             direction.xyz, bits(slot)
     float4 *chunkBuf;                // nUnits partial sums, index = unit
 };
 
@@ -115,6 +119,7 @@ struct RenderParams {
     int *suspendData;                 // per trace wave: (kSaveWords + STACK) x 64 words, word-major
     int suspendLanes;                 // park the tail once fewer rays than this are left (0 = never)
     int suspendPatience;              // ... and the wave has run this many steps since its last card
+    int parity;                       // iteration & 1: k_shade(n) fills shadow list n & 1, k_trace(n) consumes list (n - 1) & 1
     float *accum;          // 3*W*H radiance sums, index 3*(row*W+col)+c
     int nSlots;            // multiple of kBlock
     int nPixels;
@@ -147,9 +152,12 @@ __device__ inline bool checkCounts(int startBounce, int lastBounce, int bounce)
 // amdgpu_waves_per_eu(5, 5) caps the kernel at 96 VGPRs: the trace waves resident on a SIMD
 // (3 or 4) must leave registers for a wave of the other pool's k_shade (104), or the two pools
 // stop overlapping.
+#ifndef PATHED_TRACE_WAVES
+#define PATHED_TRACE_WAVES 5
+#endif
 
 template <int STACK, bool LDS_SCENE, bool COUNT>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_trace(RenderParams p)
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_TRACE_WAVES, PATHED_TRACE_WAVES))) void k_trace(RenderParams p)
 {
     extern __shared__ float4 ldsRaw[];
     int *stackBase = reinterpret_cast<int *>(ldsRaw);
@@ -163,9 +171,13 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
     geometry.spheres = p.scene.spheres;
     geometry.nSpheres = p.scene.nSpheres;
 
+    // LDS: [STACK][kBlock] traversal stacks, then 2 x kBlock float4 of ray staging (below)
+    float4 *stageO = ldsRaw + (STACK * kBlock) / 4 + (threadIdx.x & ~63);  // this wave's 64 entries
+    float4 *stageD = stageO + kBlock;
+
     if (LDS_SCENE) {
         // small scenes: the whole BVH + leaf triangles are staged in LDS once per block
-        float4 *ldsNodes = ldsRaw + (STACK * kBlock) / 4;
+        float4 *ldsNodes = ldsRaw + (STACK * kBlock) / 4 + 2 * kBlock;
         float4 *ldsTris = ldsNodes + 4 * p.scene.nNodes;
         for (int i = threadIdx.x; i < 4 * p.scene.nNodes; i += kBlock) { ldsNodes[i] = p.scene.nodes[i]; }
         for (int i = threadIdx.x; i < 3 * p.scene.nTris; i += kBlock) { ldsTris[i] = p.scene.leafTris[i]; }
@@ -178,34 +190,64 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
     const unsigned int waveId = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
 
     // Ray pool of this launch: item i < nSlots is the closest-hit ray of slot i; item
-    // nSlots + j is entry j % kBlock of shade block j / kBlock's compacted shadow rays.
+    // nSlots + j is entry j of the shadow-ray list the previous k_shade compacted.
     // The pool is cut into 64-item cards.  Persistent waves draw cards from kTraceShards
     // sharded cursors (one wave-level atomic per 64 rays; a wave whose home shard has run dry
     // moves on to the next one), so every wave keeps drawing until the whole pool is dealt and
-    // no wave is left holding a long private queue.  Lanes whose ray has finished are refilled
-    // from the wave's current card (ballot + prefix popcount).
-    const unsigned int totalItems = 2u * (unsigned int)p.nSlots;
-    const unsigned int totalCards = totalItems / kCard;          // nSlots is a multiple of kBlock
+    // no wave is left holding a long private queue.
+    // A card is fetched by the whole wave at once -- 64 coalesced ray loads, one HBM round trip --
+    // and its live rays are compacted into the wave's LDS staging rows; lanes whose ray has
+    // finished are then refilled from LDS (ballot + prefix popcount), never from HBM.  Refilling
+    // lane by lane from the state streams cost two dependent HBM latencies per refill round and
+    // was a third of the kernel's time.
+    const unsigned int shadowCount = p.counters[kCtrShadowCount + (p.parity ^ 1) * kCursorStride];
+    const unsigned int totalItems = (unsigned int)p.nSlots + shadowCount;
+    const unsigned int totalCards = (totalItems + kCard - 1u) / kCard;   // nSlots is a multiple of kBlock
     unsigned int shard = waveId % kTraceShards, shardsTried = 0;
-    unsigned int cardPos = 0, cardLeft = 0;                       // wave-uniform
-    bool exhausted = false;
-    auto drawCard = [&]() {
+    unsigned int stagedCount = 0, stagedPos = 0;                  // wave-uniform
+    bool stagedShadow = false;                                    // the staged card holds shadow rays
+    bool exhausted = false;                                       // no card left to draw
+
+    auto stageCard = [&]() {
+        unsigned int card = 0;
+        bool have = false;
         while (shardsTried < kTraceShards) {
             unsigned int ticket = 0;
             if (lane == 0) { ticket = atomicAdd(&p.counters[kCtrTraceCursor + shard * kCursorStride], 1u); }
             ticket = (unsigned int)__builtin_amdgcn_readfirstlane((int)ticket);
-            const unsigned int card = ticket * kTraceShards + shard;
-            if (card < totalCards) {
-                cardPos = card * kCard;
-                cardLeft = kCard;
-                return;
-            }
-            shard = (shard + 1u) % kTraceShards;
+            card = ticket * kTraceShards + shard;
+            if (card < totalCards) { have = true; break; }
+            shard = (shard + 1u) % kTraceShards;   // this shard is dealt out: try the next one
             shardsTried++;
         }
-        exhausted = true;
+        if (!have) { exhausted = true; return; }
+        const unsigned int item = card * kCard + (unsigned int)lane;
+        stagedShadow = card * kCard >= (unsigned int)p.nSlots;    // nSlots is a multiple of kCard
+        bool valid = false;
+        float4 first = make_float4(0.f, 0.f, 0.f, 0.f), second = first;
+        if (!stagedShadow) {
+            const float4 rd = p.state.rayD[item];
+            const float4 ro = p.state.rayO[item];
+            valid = !(floatAsInt(rd.w) & (kStDone | kStHold));
+            first = ro;
+            second = make_float4(rd.x, rd.y, rd.z, intAsFloat((int)item));  // .w = the slot
+        } else {
+            const unsigned int entry = item - (unsigned int)p.nSlots;
+            valid = entry < shadowCount;
+            if (valid) {
+                first = p.state.shO[entry];    // .w = tfar
+                second = p.state.shD[entry];   // .w = the slot
+            }
+        }
+        const unsigned long long validMask = __ballot(valid);
+        const unsigned int rank = __builtin_amdgcn_mbcnt_hi(
+            (unsigned int)(validMask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)validMask, 0u));
+        __builtin_amdgcn_wave_barrier();
+        if (valid) { stageO[rank] = first; stageD[rank] = second; }
+        __builtin_amdgcn_wave_barrier();
+        stagedCount = (unsigned int)__popcll(validMask);
+        stagedPos = 0;
     };
-    drawCard();
 
     TraceCounters counters;
     counters.boxes = 0;
@@ -249,46 +291,42 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
         parkedMask = 0ull;
     }
 
+    unsigned long long refillCycles = 0, innerCycles = 0, leafCycles = 0;
+    unsigned int innerSteps = 0;
     while (true) {
-        while (!exhausted) {
+        unsigned long long stamp = 0;
+        if (COUNT) { stamp = __builtin_amdgcn_s_memtime(); }
+        while (true) {
             const unsigned long long idleMask = __ballot(!active);
             if (idleMask == 0ull) { break; }
+            if (stagedPos == stagedCount) {
+                if (exhausted) { break; }
+                stageCard();
+                continue;
+            }
             const unsigned int rank = __builtin_amdgcn_mbcnt_hi(
                 (unsigned int)(idleMask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)idleMask, 0u));  // idle lanes below this one
-            const unsigned int wanted = (unsigned int)__popcll(idleMask);
-            if (!active && rank < cardLeft) {
-                const unsigned int item = cardPos + rank;
-                if (item < (unsigned int)p.nSlots) {
-                    const unsigned int slot = item;
-                    const float4 rd = p.state.rayD[slot];
-                    if (!(floatAsInt(rd.w) & (kStDone | kStHold))) {
-                        const float4 ro = p.state.rayO[slot];
-                        laneRayInit(ray, v3(ro.x, ro.y, ro.z), v3(rd.x, rd.y, rd.z), PATHED_TNEAR, PATHED_TFAR, false);
-                        target = slot;
-                        active = true;
-                        restored = false;
-                        if (COUNT) { closestRays++; rayBoxesStart = counters.boxes; }
-                    }
-                } else {
-                    const unsigned int entry = item - (unsigned int)p.nSlots;
-                    if ((entry % kBlock) < p.state.blockShadowCount[entry / kBlock]) {
-                        const float4 so = p.state.shO[entry];
-                        const float4 sd = p.state.shD[entry];
-                        laneRayInit(ray, v3(so.x, so.y, so.z), v3(sd.x, sd.y, sd.z), PATHED_TNEAR, so.w, true);
-                        target = (unsigned int)floatAsInt(sd.w);
-                        active = true;
-                        restored = false;
-                        if (COUNT) { shadowRays++; rayBoxesStart = counters.boxes; }
-                    }
+            const unsigned int available = stagedCount - stagedPos;
+            if (!active && rank < available) {
+                const float4 first = stageO[stagedPos + rank];
+                const float4 second = stageD[stagedPos + rank];
+                laneRayInit(ray, v3(first.x, first.y, first.z), v3(second.x, second.y, second.z), PATHED_TNEAR,
+                            stagedShadow ? first.w : PATHED_TFAR, stagedShadow);
+                target = (unsigned int)floatAsInt(second.w);
+                active = true;
+                restored = false;
+                if (COUNT) {
+                    if (stagedShadow) { shadowRays++; } else { closestRays++; }
+                    rayBoxesStart = counters.boxes;
                 }
             }
-            const unsigned int taken = wanted < cardLeft ? wanted : cardLeft;
-            cardPos += taken;
-            cardLeft -= taken;
-            if (cardLeft == 0u) { drawCard(); }
+            const unsigned int wanted = (unsigned int)__popcll(idleMask);
+            stagedPos += wanted < available ? wanted : available;
         }
+        const bool dry = exhausted && stagedPos == stagedCount;   // nothing left to hand out
 
-        if (__ballot(active) == 0ull) { break; }  // only reached with the pool exhausted
+        if (COUNT) { refillCycles += __builtin_amdgcn_s_memtime() - stamp; }
+        if (__ballot(active) == 0ull) { break; }  // only reached with the pool dealt out
 
         // traversal burst.  Each step the wave runs ONE phase: the triangle phase when enough lanes
         // have a leaf pending (or nothing else can run), else the inner-node phase; lanes in the
@@ -302,19 +340,24 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
             if (COUNT) {
                 waveSteps++;
                 laneSteps += (unsigned int)__popcll(trianglePhase ? leafMask : innerMask);
-                if (exhausted) {
+                if (dry) {
                     if (tailSteps == 0) { tailStart = __builtin_amdgcn_s_memtime(); }
                     tailSteps++;
                     tailLaneSteps += (unsigned int)__popcll(trianglePhase ? leafMask : innerMask);
                 }
             }
             bool done = false;
+            if (COUNT) { stamp = __builtin_amdgcn_s_memtime(); }
             if (trianglePhase) {
                 if (active && ray.pendingLeaf != 0) { done = leafStep<COUNT, kBlock>(geometry, stack, ray, &counters); }
             } else {
                 if (active && ray.pendingLeaf == 0) {
                     done = (geometry.nNodes == 0) || innerStep<COUNT, kBlock>(geometry, stack, STACK, ray, &counters);
                 }
+            }
+            if (COUNT) {
+                const unsigned long long elapsed = __builtin_amdgcn_s_memtime() - stamp;
+                if (trianglePhase) { leafCycles += elapsed; } else { innerCycles += elapsed; innerSteps++; }
             }
             if (done) {
                 finishRay(geometry, ray);
@@ -332,9 +375,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
             }
             const unsigned long long activeMask = __ballot(active);
             if (activeMask == 0ull) { break; }
-            if (!exhausted && __popcll(activeMask) < kRefillThreshold) { break; }
-            if (exhausted) { stepsSinceLastCard++; }
-            if (exhausted && __popcll(activeMask) < p.suspendLanes && stepsSinceLastCard >= (unsigned int)p.suspendPatience) {
+            if (!dry && __popcll(activeMask) < kRefillThreshold) { break; }
+            if (dry) { stepsSinceLastCard++; }
+            if (dry && __popcll(activeMask) < p.suspendLanes && stepsSinceLastCard >= (unsigned int)p.suspendPatience) {
                 if (active) {
                     int *save = p.suspendData + (size_t)waveId * (size_t)((kSaveWords + STACK) * 64) + lane;
                     save[0 * 64] = floatAsInt(ray.o.x); save[1 * 64] = floatAsInt(ray.o.y); save[2 * 64] = floatAsInt(ray.o.z);
@@ -376,6 +419,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
             atomicAdd(&p.stats[kStatRefills], (unsigned long long)refills);
             atomicAdd(&p.stats[kStatWaveCycles], (unsigned long long)(__builtin_amdgcn_s_memtime() - waveStart));
             atomicMax(&p.stats[kStatWaveCyclesMax], (unsigned long long)(__builtin_amdgcn_s_memtime() - waveStart));
+            atomicAdd(&p.stats[kStatRefillCycles], refillCycles);
+            atomicAdd(&p.stats[kStatInnerCycles], innerCycles);
+            atomicAdd(&p.stats[kStatLeafCycles], leafCycles);
+            atomicAdd(&p.stats[kStatInnerSteps], (unsigned long long)innerSteps);
             atomicAdd(&p.stats[kStatTailSteps], (unsigned long long)tailSteps);
             atomicAdd(&p.stats[kStatTailLaneSteps], (unsigned long long)tailLaneSteps);
             if (tailSteps) { atomicAdd(&p.stats[kStatTailCycles], (unsigned long long)(__builtin_amdgcn_s_memtime() - tailStart)); }
@@ -421,7 +468,8 @@ __global__ __launch_bounds__(kBlock) void k_trace_small(RenderParams p, SmallTri
     const unsigned int waveId = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     const unsigned int waveCount = gridDim.x * kWavesPerBlock;
     const unsigned int slotBatches = (unsigned int)p.nSlots / 64u;
-    const unsigned int totalBatches = 2u * slotBatches;
+    const unsigned int shadowCount = p.counters[kCtrShadowCount + (p.parity ^ 1) * kCursorStride];
+    const unsigned int totalBatches = slotBatches + (shadowCount + 63u) / 64u;
     const int nTris = p.scene.nTris;
     const int nPairs = (nTris + 1) / 2;
 
@@ -442,7 +490,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_small(RenderParams p, SmallTri
             }
         } else {
             const unsigned int entry = (batch - slotBatches) * 64u + lane;
-            if ((entry % kBlock) < p.state.blockShadowCount[entry / kBlock]) {
+            if (entry < shadowCount) {
                 const float4 so = p.state.shO[entry];
                 const float4 sd = p.state.shD[entry];
                 laneRayInit(ray, v3(so.x, so.y, so.z), v3(sd.x, sd.y, sd.z), PATHED_TNEAR, so.w, true);
@@ -828,7 +876,6 @@ __global__ __launch_bounds__(kBlock) void k_init(RenderParams p)
     p.state.thr[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
     p.state.pend[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
     p.state.acc[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (threadIdx.x == 0) { p.state.blockShadowCount[blockIdx.x] = 0; }
 
     const unsigned long long mask = __ballot(started);
     if ((threadIdx.x & 63) == 0 && mask != 0ull) {
@@ -886,6 +933,8 @@ __global__ __launch_bounds__(kBlock) void k_shade(RenderParams p)
 
     // rewind the card cursors for the pool's next trace launch (same stream: it starts after us)
     if (blockIdx.x == 0 && threadIdx.x < kTraceShards) { p.counters[kCtrTraceCursor + threadIdx.x * kCursorStride] = 0u; }
+    // ... and empty the shadow list the NEXT k_shade will fill (the trace launch that read it is over)
+    if (blockIdx.x == 0 && threadIdx.x == kTraceShards) { p.counters[kCtrShadowCount + (p.parity ^ 1) * kCursorStride] = 0u; }
 
     float4 rd = p.state.rayD[slot];
     int st = floatAsInt(rd.w);
@@ -1117,7 +1166,9 @@ __global__ __launch_bounds__(kBlock) void k_shade(RenderParams p)
         p.state.pend[slot] = outPend;
     }
 
-    // ---- shadow-ray stream compaction: wave ballot + prefix popcount + LDS block scan -------
+    // ---- shadow-ray list: wave ballot + prefix popcount + LDS block scan, then ONE atomic per
+    // block reserves the block's range in the iteration's dense list (its order varies from run
+    // to run; results do not: each shadow ray only ever clears its own slot's pending term)
     {
         const unsigned long long mask = __ballot(shadow.push);
         const unsigned int before = (unsigned int)__popcll(mask & ((1ull << lane) - 1ull));
@@ -1130,9 +1181,13 @@ __global__ __launch_bounds__(kBlock) void k_shade(RenderParams p)
             if (w < wave) { offset += count; }
             total += count;
         }
-        if (threadIdx.x == 0) { p.state.blockShadowCount[blockIdx.x] = total; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            scratch[kWavesPerBlock] = total ? atomicAdd(&p.counters[kCtrShadowCount + p.parity * kCursorStride], total) : 0u;
+        }
+        __syncthreads();
         if (shadow.push) {
-            const unsigned int index = blockIdx.x * kBlock + offset + before;
+            const unsigned int index = scratch[kWavesPerBlock] + offset + before;
             p.state.shO[index] = make_float4(shadow.origin.x, shadow.origin.y, shadow.origin.z, shadow.tfar);
             p.state.shD[index] = make_float4(shadow.direction.x, shadow.direction.y, shadow.direction.z, intAsFloat(slot));
         }

@@ -151,7 +151,7 @@ struct PathedScene {
     hipEvent_t poolDone[2] = { nullptr, nullptr };
     hipEvent_t callerReady = nullptr;
     DeviceBuffer<float4> rayO, rayD, hit, mod, thr, res, pend, acc, shO, shD, chunkBuf;
-    DeviceBuffer<unsigned int> counters, blockShadowCount;
+    DeviceBuffer<unsigned int> counters;
     DeviceBuffer<unsigned long long> suspendMask;  // per pool, per trace wave (kernels.h: tail suspension)
     DeviceBuffer<int> suspendData;
     DeviceBuffer<unsigned long long> stats;
@@ -180,7 +180,7 @@ struct PathedScene {
         thetaCdf.release(); phiCdf.release(); phiEmpty.release();
         rayO.release(); rayD.release(); hit.release(); mod.release(); thr.release();
         res.release(); pend.release(); acc.release(); shO.release(); shD.release(); chunkBuf.release();
-        counters.release(); blockShadowCount.release(); stats.release();
+        counters.release(); stats.release();
         suspendMask.release(); suspendData.release();
         if (hostRemaining) { (void)hipHostFree(hostRemaining); }
         for (int h = 0; h < 2; h++) {
@@ -334,7 +334,6 @@ int ensureRenderState(PathedScene *scene, int nSlots, size_t chunkEntries)
         HIP_TRY(scene->acc.allocate(n));
         HIP_TRY(scene->shO.allocate(n));
         HIP_TRY(scene->shD.allocate(n));
-        HIP_TRY(scene->blockShadowCount.allocate(n / kBlock));
     }
     if (scene->chunkCapacity < chunkEntries) {
         HIP_TRY(scene->chunkBuf.allocate(chunkEntries));
@@ -403,7 +402,8 @@ void configureTrace(PathedScene *scene)
     const int depth = scene->bvh.maxDepth + 1;
     scene->stackDepth = depth <= 8 ? 8 : depth <= 16 ? 16 : depth <= 32 ? 32 : 64;
 
-    const size_t stackBytes = (size_t)scene->stackDepth * kBlock * sizeof(int);
+    // per-thread traversal stacks + the waves' ray staging rows (2 float4 per thread)
+    const size_t stackBytes = (size_t)scene->stackDepth * kBlock * sizeof(int) + (size_t)2 * kBlock * sizeof(float4);
     const size_t sceneBytes = (size_t)scene->device.nNodes * 64 + (size_t)scene->device.nTris * 48;
     // stage the BVH in LDS when it is small enough to leave >= 4 blocks per CU
     scene->sceneInLds = scene->device.nNodes > 0 && (stackBytes + sceneBytes) <= 36 * 1024;
@@ -691,7 +691,6 @@ static int renderPass(PathedScene *scene, uint64_t seed, uint32_t begin, uint32_
         q.state.acc = scene->acc.ptr + slotBase;
         q.state.shO = scene->shO.ptr + slotBase;
         q.state.shD = scene->shD.ptr + slotBase;
-        q.state.blockShadowCount = scene->blockShadowCount.ptr + slotBase / kBlock;
         q.state.chunkBuf = scene->chunkBuf.ptr + unitBase;
         q.counters = scene->counters.ptr + (size_t)h * kCtrCount;
         const size_t traceWaves = (size_t)scene->traceGrid * kWavesPerBlock;
@@ -751,6 +750,7 @@ static int renderPass(PathedScene *scene, uint64_t seed, uint32_t begin, uint32_
         for (int k = 0; k < launchChunk; k++) {
             for (int h = 0; h < pools; h++) {
                 if (poolDone[h]) { continue; }
+                params[h].parity = (int)(iteration & 1ull);
                 if (scene->timeKernels) {
                     const int e = scene->traceEvents.acquire();
                     (void)hipEventRecord(scene->traceEvents.start[e], streams[h]);
@@ -962,6 +962,8 @@ int pathed_hip_get_stats(PathedScene *scene, PathedStats *out)
                 device[kStatRefills]);
         fprintf(stderr, "[pathed] sum of wave lifetimes %.3e cycles, longest single wave %.3e cycles\n",
                 (double)device[kStatWaveCycles], (double)device[kStatWaveCyclesMax]);
+        fprintf(stderr, "[pathed] wave cycles: refill %.3e, inner phases %.3e (%llu steps), triangle phases %.3e\n",
+                (double)device[kStatRefillCycles], (double)device[kStatInnerCycles], device[kStatInnerSteps], (double)device[kStatLeafCycles]);
         fprintf(stderr, "[pathed] tail (no cards left): %llu wave steps, %llu lane steps, %.3e cycles; %llu rays parked\n",
                 device[kStatTailSteps], device[kStatTailLaneSteps], (double)device[kStatTailCycles], device[kStatParked]);
     }

@@ -331,7 +331,8 @@ def test_rays_carried_over_between_trace_launches_change_nothing(libs):
     default, default_stats = _render_counted(libs, few_waves, "scenes/cornell-glass.json", 384, 5, 8)
     assert default_stats["parked_rays"] > 0
     assert np.array_equal(off, default)
-    eager, eager_stats = _render_counted(libs, dict(few_waves, PATHED_SUSPEND_LANES="64"), "scenes/cornell-glass.json", 384, 5, 8)
+    eager, eager_stats = _render_counted(libs, dict(few_waves, PATHED_SUSPEND_LANES="64", PATHED_SUSPEND_PATIENCE="0"),
+                                         "scenes/cornell-glass.json", 384, 5, 8)
     assert eager_stats["parked_rays"] > default_stats["parked_rays"]
     assert np.array_equal(off, eager)
     assert eager_stats["closest_rays"] == off_stats["closest_rays"]
