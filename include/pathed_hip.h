@@ -163,14 +163,14 @@ typedef struct PathedStats {
     uint64_t camera_samples;       /* paths started                              */
     uint64_t closest_rays;         /* closest-hit queries traced                 */
     uint64_t shadow_rays;          /* any-hit queries traced                     */
-    uint64_t nodes_visited;        /* child boxes tested (32 B each) — stats mode */
+    uint64_t nodes_visited;        /* child boxes tested (32 B each: a 128-B node holds four) — stats mode */
     uint64_t tris_tested;          /* triangles tested (48 B each)  — stats mode */
     uint64_t dropped_samples;      /* non-finite samples dropped                 */
     uint64_t iterations;           /* wavefront iterations launched              */
     double   trace_ms;             /* HIP-event time inside the trace kernel     */
     double   shade_ms;             /* HIP-event time inside the shade kernel     */
     uint64_t trace_launches;
-    uint64_t bvh_nodes;            /* inner nodes (64 B each)                    */
+    uint64_t bvh_nodes;            /* 4-wide inner nodes (128 B each)            */
     uint64_t bvh_bytes;            /* nodes + leaf triangles resident in HBM     */
     uint32_t bvh_max_depth;
     uint32_t scene_in_lds;         /* 0 BVH in HBM, 1 BVH staged in LDS, 2 tiny scene: all triangles tested (scalar loads) */
@@ -184,7 +184,7 @@ typedef struct PathedStats {
  * Replaces the reference's rtcNewDevice / rtcNewScene (app/main.cpp:46-52). */
 int pathed_hip_init(int device_id);
 
-/* Flatten + upload once: leaf-ordered 48-B triangles, flattened BVH2 (64-B nodes),
+/* Flatten + upload once: leaf-ordered 48-B triangles, flattened 4-wide BVH (128-B nodes),
  * spheres, material table, light table, env map + CDFs, camera.
  * Replaces rtcCommitScene (reference src/scene.cpp:39) and the light list
  * construction (src/scene_parser.cpp:173-190). */
@@ -240,9 +240,13 @@ int pathed_hip_set_stats_mode(PathedScene *scene, int enabled);
 int pathed_hip_get_stats(PathedScene *scene, PathedStats *out);
 int pathed_hip_reset_stats(PathedScene *scene);
 
-/* Export the flattened BVH so a checker can walk the SAME tree
- * (nodes: 16 floats per node; tris: 12 floats per leaf triangle, 4th/8th/12th
- * lanes carry prim id / padding).  Pass NULL to query sizes. */
+/* Export the flattened BVH so a checker can walk the SAME tree.
+ * nodes: 32 floats per 4-wide node, the four children in the components of
+ *   (lo.x[4]) (lo.y[4]) (lo.z[4]) (hi.x[4]) (hi.y[4]) (hi.z[4]) (ref[4]) (unused);
+ *   ref is an int32: >= 0 inner node index, <= -2 leaf with -ref - 1 =
+ *   (first leaf triangle << 3) | triangle count, INT32_MIN empty slot.
+ * tris: 12 floats per leaf triangle (v0.xyz, prim) (e1.xyz, -) (e2.xyz, -).
+ * Pass NULL to query sizes. */
 int pathed_hip_scene_export_bvh(PathedScene *scene,
                                 float *nodes, size_t *n_nodes,
                                 float *tris, size_t *n_tris);

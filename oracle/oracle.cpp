@@ -1292,6 +1292,23 @@ inline bool slabTest(const float bmin[3], const float bmax[3], Vec3 o, Vec3 invD
     return t0 <= t1 * 1.0000004f;
 }
 
+/* the same test, also returning the entry distance (used to order the children of a wide node) */
+inline bool slabTestEntry(const float bmin[3], const float bmax[3], Vec3 o, Vec3 invD, float tnear, float tfar, float *entry)
+{
+    float t0 = tnear, t1 = tfar;
+    const float oo[3] = { o.x, o.y, o.z };
+    const float ii[3] = { invD.x, invD.y, invD.z };
+    for (int a = 0; a < 3; a++) {
+        float ta = (bmin[a] - oo[a]) * ii[a];
+        float tb = (bmax[a] - oo[a]) * ii[a];
+        if (ta > tb) { std::swap(ta, tb); }
+        if (ta > t0) { t0 = ta; }
+        if (tb < t1) { t1 = tb; }
+    }
+    *entry = t0;
+    return t0 <= t1 * 1.0000004f;
+}
+
 struct OracleSceneImpl {
     Camera camera;
     std::vector<Triangle> triangles;
@@ -1961,9 +1978,12 @@ int oracle_count_exported_bvh(const float *nodes, size_t n_nodes, const float *t
                               const float *rays, size_t n, int any_hit, uint64_t *counts)
 {
     /* Layout exported by pathed_hip_scene_export_bvh (see include/pathed_hip.h):
-     * node = 4 x float4: (lmin.xyz, left) (lmax.xyz, lcount) (rmin.xyz, right) (rmax.xyz, rcount);
-     * a child with count > 0 is a leaf whose index is the first triangle; triangles are
-     * 3 x float4: (v0.xyz, prim) (e1.xyz, -) (e2.xyz, -). */
+     * node = 8 x float4 with the four children in the components:
+     *   (lo.x[4]) (lo.y[4]) (lo.z[4]) (hi.x[4]) (hi.y[4]) (hi.z[4]) (ref[4]) (unused);
+     *   ref >= 0 inner node, ref <= -2 leaf with -ref - 1 = (first triangle << 3) | count,
+     *   ref == INT_MIN empty slot;
+     * triangles are 3 x float4: (v0.xyz, prim) (e1.xyz, -) (e2.xyz, -).
+     * The walk visits the hit children leaves first, then near to far, like the kernel. */
     if (!nodes || !tris || !counts) { return -1; }
     uint64_t boxes = 0, triangles = 0;
     for (size_t i = 0; i < n; i++) {
@@ -1999,24 +2019,46 @@ int oracle_count_exported_bvh(const float *nodes, size_t n_nodes, const float *t
             testLeaf(0, (int)n_tris);
             continue;
         }
-        int stack[128];
+        int stack[256];
         int sp = 0;
         stack[sp++] = 0;
         while (sp > 0 && !done) {
-            const int nodeIndex = stack[--sp];
-            if (nodeIndex < 0 || (size_t)nodeIndex >= n_nodes) { return -2; }
-            const float *node = nodes + 16 * (size_t)nodeIndex;
-            for (int child = 0; child < 2 && !done; child++) {
-                const float *lo = node + 8 * child;
-                const float *hi = node + 8 * child + 4;
-                int index, count;
-                std::memcpy(&index, lo + 3, 4);
-                std::memcpy(&count, hi + 3, 4);
-                if (count < 0) { continue; } /* empty child slot */
+            const int entry = stack[--sp];
+            if (entry < 0) {
+                const int leaf = -entry - 1;
+                testLeaf(leaf >> 3, leaf & 7);
+                continue;
+            }
+            if ((size_t)entry >= n_nodes) { return -2; }
+            const float *node = nodes + 32 * (size_t)entry;
+            uint32_t keys[4];
+            int refs[4];
+            int hits = 0;
+            for (int child = 0; child < 4; child++) {
+                int ref;
+                std::memcpy(&ref, node + 24 + child, 4);
+                if (ref == INT32_MIN) { continue; } /* empty child slot */
                 boxes++;
-                if (!slabTest(lo, hi, o, invD, tnear, best)) { continue; }
-                if (count > 0) { testLeaf(index, count); }
-                else if (sp < 127) { stack[sp++] = index; }
+                const float lo[3] = { node[child], node[4 + child], node[8 + child] };
+                const float hi[3] = { node[12 + child], node[16 + child], node[20 + child] };
+                float tEntry;
+                if (!slabTestEntry(lo, hi, o, invD, tnear, best, &tEntry)) { continue; }
+                uint32_t bits;
+                std::memcpy(&bits, &tEntry, 4);
+                keys[hits] = (ref >= 0 ? 0x80000000u : 0u) | ((bits >> 1) & 0x7FFFFFFCu) | (uint32_t)child;
+                refs[hits] = ref;
+                hits++;
+            }
+            for (int a = 1; a < hits; a++) { /* insertion sort, ascending keys */
+                const uint32_t key = keys[a];
+                const int ref = refs[a];
+                int b = a - 1;
+                while (b >= 0 && keys[b] > key) { keys[b + 1] = keys[b]; refs[b + 1] = refs[b]; b--; }
+                keys[b + 1] = key;
+                refs[b + 1] = ref;
+            }
+            for (int k = hits - 1; k >= 0; k--) { /* far first: the nearest is popped next */
+                if (sp < 255) { stack[sp++] = refs[k]; }
             }
         }
     }

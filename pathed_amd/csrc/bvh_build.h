@@ -1,4 +1,4 @@
-// Host-side BVH2 builder (binned SAH) + flattening to the 64-B two-child node layout.
+// Host-side BVH builder: binary binned-SAH tree, collapsed to 4-wide nodes (128 B, trace.h).
 // Stands in for rtcCommitScene (reference src/scene.cpp:39).  Runs once per scene on the
 // host; an on-GPU LBVH builder is the "next" row f3 of SURVEY.md §8.
 #pragma once
@@ -14,11 +14,13 @@
 namespace pathed {
 
 struct FlatBvh {
-    std::vector<float> nodes;     // 16 floats per inner node
+    std::vector<float> nodes;     // 32 floats per 4-wide node
     std::vector<float> leafTris;  // 12 floats per triangle, leaf order
-    int maxDepth = 0;             // inner-node levels on the longest root-to-leaf chain
+    int maxDepth = 0;             // 4-wide node levels on the longest root-to-leaf chain
     int nodeCount = 0;
 };
+static const int kNodeFloats = 32;
+static const int kEmptyChildRef = (int)0x80000000u;
 
 namespace bvh_detail {
 
@@ -236,62 +238,83 @@ inline FlatBvh buildBvh(const float *positions, const uint32_t *indices, uint32_
         tri[11] = 0.f;
     }
 
-    // flatten: inner temp nodes get consecutive ids in DFS order
+    // Collapse to 4-wide nodes: a node adopts its binary children, then repeatedly replaces the
+    // inner child with the largest box by that child's two children until it has four (or only
+    // leaves are left).  Wide nodes get consecutive ids in DFS order.
     const std::vector<TempNode> &temp = builder.nodes;
-    std::vector<int> innerId(temp.size(), -1);
-    int innerCount = 0;
-    {
-        std::vector<int> work;
-        work.push_back(root);
+    struct WideNode {
+        int child[4];   // temp node indices
+        int id[4];      // wide node id of an inner child
+        int count;
+    };
+    std::vector<WideNode> wide;
+    wide.reserve(temp.size() / 3 + 1);
+    int wideDepth = 0;
+    if (temp[(size_t)root].left < 0) {
+        WideNode only;
+        only.child[0] = root;
+        only.id[0] = -1;
+        only.count = 1;
+        wide.push_back(only);
+        wideDepth = 1;
+    } else {
+        struct Pending { int tempNode, parent, slot, depth; };
+        std::vector<Pending> work;
+        work.push_back({ root, -1, 0, 1 });
         while (!work.empty()) {
-            const int t = work.back();
+            const Pending item = work.back();
             work.pop_back();
-            if (temp[(size_t)t].left < 0) { continue; }
-            innerId[(size_t)t] = innerCount++;
-            work.push_back(temp[(size_t)t].right);
-            work.push_back(temp[(size_t)t].left);
+            WideNode node;
+            node.count = 0;
+            node.child[node.count++] = temp[(size_t)item.tempNode].left;
+            node.child[node.count++] = temp[(size_t)item.tempNode].right;
+            while (node.count < 4) {
+                int pick = -1;
+                float pickArea = -1.f;
+                for (int k = 0; k < node.count; k++) {
+                    const TempNode &candidate = temp[(size_t)node.child[k]];
+                    if (candidate.left < 0) { continue; }
+                    const float area = candidate.box.halfArea();
+                    if (area > pickArea) { pickArea = area; pick = k; }
+                }
+                if (pick < 0) { break; }
+                const int opened = node.child[pick];
+                node.child[pick] = temp[(size_t)opened].left;
+                node.child[node.count++] = temp[(size_t)opened].right;
+            }
+            for (int k = 0; k < 4; k++) { node.id[k] = -1; }
+            const int id = (int)wide.size();
+            wide.push_back(node);
+            if (item.parent >= 0) { wide[(size_t)item.parent].id[item.slot] = id; }
+            wideDepth = std::max(wideDepth, item.depth);
+            // push in reverse so that child 0's subtree follows its parent in memory
+            for (int k = node.count - 1; k >= 0; k--) {
+                if (temp[(size_t)node.child[k]].left >= 0) { work.push_back({ node.child[k], id, k, item.depth + 1 }); }
+            }
         }
     }
 
-    auto writeChild = [&](float *slot, int t) {
-        const TempNode &child = temp[(size_t)t];
-        padBox(child.box, slot, slot + 4);
-        if (child.left < 0) {
-            putInt(slot + 3, (int)child.first);
-            putInt(slot + 7, (int)child.count);
-        } else {
-            putInt(slot + 3, innerId[(size_t)t]);
-            putInt(slot + 7, 0);
+    out.nodes.assign((size_t)kNodeFloats * wide.size(), 0.f);
+    for (size_t n = 0; n < wide.size(); n++) {
+        float *node = out.nodes.data() + (size_t)kNodeFloats * n;
+        for (int k = 0; k < 4; k++) {
+            float lo[3] = { 0.f, 0.f, 0.f }, hi[3] = { 0.f, 0.f, 0.f };
+            int ref = kEmptyChildRef;
+            if (k < wide[n].count) {
+                const TempNode &child = temp[(size_t)wide[n].child[k]];
+                padBox(child.box, lo, hi);
+                // leaf: -((first << 3) | count) - 1 (trace.h encodeLeaf); inner: the wide node id
+                ref = child.left < 0 ? -(int)((child.first << 3) | child.count) - 1 : wide[n].id[k];
+            }
+            for (int a = 0; a < 3; a++) {
+                node[4 * a + k] = lo[a];
+                node[12 + 4 * a + k] = hi[a];
+            }
+            putInt(node + 24 + k, ref);
         }
-    };
-    auto writeEmpty = [&](float *slot) {
-        for (int a = 0; a < 3; a++) {
-            slot[a] = std::numeric_limits<float>::infinity();
-            slot[4 + a] = -std::numeric_limits<float>::infinity();
-        }
-        putInt(slot + 3, 0);
-        putInt(slot + 7, -1);
-    };
-
-    if (innerCount == 0) {
-        // the whole scene is one leaf: a root with one real child
-        out.nodes.assign(16, 0.f);
-        writeChild(out.nodes.data(), root);
-        writeEmpty(out.nodes.data() + 8);
-        out.nodeCount = 1;
-        out.maxDepth = 1;
-        return out;
     }
-
-    out.nodes.assign((size_t)16 * innerCount, 0.f);
-    for (size_t t = 0; t < temp.size(); t++) {
-        if (innerId[t] < 0) { continue; }
-        float *node = out.nodes.data() + (size_t)16 * innerId[t];
-        writeChild(node, temp[t].left);
-        writeChild(node + 8, temp[t].right);
-    }
-    out.nodeCount = innerCount;
-    out.maxDepth = maxDepth;
+    out.nodeCount = (int)wide.size();
+    out.maxDepth = wideDepth;
     return out;
 }
 

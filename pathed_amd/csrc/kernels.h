@@ -116,7 +116,9 @@ struct RenderParams {
     unsigned int *counters;
     unsigned long long *stats;
     unsigned long long *suspendMask;  // per trace wave: lanes with a parked ray
-    int *suspendData;                 // per trace wave: (kSaveWords + STACK) x 64 words, word-major
+    int *suspendData;                 // per trace wave: (kSaveWords + maxStack) x 64 words, word-major
+    int *stackOverflow;               // per trace thread: stack entries beyond the LDS rows, [row][thread]
+    int maxStack;                     // the tree's bound on stack entries (3 per level)
     int suspendLanes;                 // park the tail once fewer rays than this are left (0 = never)
     int suspendPatience;              // ... and the wave has run this many steps since its last card
     int parity;                       // iteration & 1: k_shade(n) fills shadow list n & 1, k_trace(n) consumes list (n - 1) & 1
@@ -160,8 +162,12 @@ template <int STACK, bool LDS_SCENE, bool COUNT>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_TRACE_WAVES, PATHED_TRACE_WAVES))) void k_trace(RenderParams p)
 {
     extern __shared__ float4 ldsRaw[];
-    int *stackBase = reinterpret_cast<int *>(ldsRaw);
-    int *stack = stackBase + threadIdx.x;
+    // LDS: [STACK + 1][kBlock] traversal stack rows (the last one is scratch), then 2 x kBlock
+    // float4 of ray staging, then (LDS_SCENE) the tree
+    LaneStack stack;
+    stack.lds = reinterpret_cast<int *>(ldsRaw) + threadIdx.x;
+    stack.overflowStride = (size_t)gridDim.x * kBlock;
+    stack.overflow = p.stackOverflow + ((size_t)blockIdx.x * kBlock + threadIdx.x);
 
     TraceGeometry geometry;
     geometry.nodes = p.scene.nodes;
@@ -171,15 +177,14 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_T
     geometry.spheres = p.scene.spheres;
     geometry.nSpheres = p.scene.nSpheres;
 
-    // LDS: [STACK][kBlock] traversal stacks, then 2 x kBlock float4 of ray staging (below)
-    float4 *stageO = ldsRaw + (STACK * kBlock) / 4 + (threadIdx.x & ~63);  // this wave's 64 entries
+    float4 *stageO = ldsRaw + ((STACK + 1) * kBlock) / 4 + (threadIdx.x & ~63);  // this wave's 64 entries
     float4 *stageD = stageO + kBlock;
 
     if (LDS_SCENE) {
         // small scenes: the whole BVH + leaf triangles are staged in LDS once per block
-        float4 *ldsNodes = ldsRaw + (STACK * kBlock) / 4 + 2 * kBlock;
-        float4 *ldsTris = ldsNodes + 4 * p.scene.nNodes;
-        for (int i = threadIdx.x; i < 4 * p.scene.nNodes; i += kBlock) { ldsNodes[i] = p.scene.nodes[i]; }
+        float4 *ldsNodes = ldsRaw + ((STACK + 1) * kBlock) / 4 + 2 * kBlock;
+        float4 *ldsTris = ldsNodes + 8 * p.scene.nNodes;
+        for (int i = threadIdx.x; i < 8 * p.scene.nNodes; i += kBlock) { ldsNodes[i] = p.scene.nodes[i]; }
         for (int i = threadIdx.x; i < 3 * p.scene.nTris; i += kBlock) { ldsTris[i] = p.scene.leafTris[i]; }
         __syncthreads();
         geometry.nodes = ldsNodes;
@@ -270,7 +275,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_T
     if (p.suspendLanes > 0) {
         parkedMask = p.suspendMask[waveId];
         if ((parkedMask >> lane) & 1ull) {
-            const int *save = p.suspendData + (size_t)waveId * (size_t)((kSaveWords + STACK) * 64) + lane;
+            const int *save = p.suspendData + (size_t)waveId * (size_t)((kSaveWords + p.maxStack) * 64) + lane;
             const V3 o = v3(intAsFloat(save[0 * 64]), intAsFloat(save[1 * 64]), intAsFloat(save[2 * 64]));
             const V3 d = v3(intAsFloat(save[3 * 64]), intAsFloat(save[4 * 64]), intAsFloat(save[5 * 64]));
             const int flags = save[14 * 64];
@@ -284,7 +289,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_T
             ray.sp = save[15 * 64];
             target = (unsigned int)save[16 * 64];
             if (COUNT) { rayBoxesStart = counters.boxes - (unsigned int)save[17 * 64]; }
-            for (int k = 0; k < ray.sp; k++) { stack[k * kBlock] = save[(kSaveWords + k) * 64]; }
+            for (int k = 0; k < ray.sp; k++) { stackWrite<STACK, kBlock>(stack, k, save[(kSaveWords + k) * 64]); }
             active = true;
             restored = true;
         }
@@ -349,10 +354,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_T
             bool done = false;
             if (COUNT) { stamp = __builtin_amdgcn_s_memtime(); }
             if (trianglePhase) {
-                if (active && ray.pendingLeaf != 0) { done = leafStep<COUNT, kBlock>(geometry, stack, ray, &counters); }
+                if (active && ray.pendingLeaf != 0) { done = leafStep<COUNT, STACK, kBlock>(geometry, stack, ray, &counters); }
             } else {
                 if (active && ray.pendingLeaf == 0) {
-                    done = (geometry.nNodes == 0) || innerStep<COUNT, kBlock>(geometry, stack, STACK, ray, &counters);
+                    done = (geometry.nNodes == 0) || innerStep<COUNT, STACK, kBlock>(geometry, stack, p.maxStack, ray, &counters);
                 }
             }
             if (COUNT) {
@@ -379,7 +384,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_T
             if (dry) { stepsSinceLastCard++; }
             if (dry && __popcll(activeMask) < p.suspendLanes && stepsSinceLastCard >= (unsigned int)p.suspendPatience) {
                 if (active) {
-                    int *save = p.suspendData + (size_t)waveId * (size_t)((kSaveWords + STACK) * 64) + lane;
+                    int *save = p.suspendData + (size_t)waveId * (size_t)((kSaveWords + p.maxStack) * 64) + lane;
                     save[0 * 64] = floatAsInt(ray.o.x); save[1 * 64] = floatAsInt(ray.o.y); save[2 * 64] = floatAsInt(ray.o.z);
                     save[3 * 64] = floatAsInt(ray.d.x); save[4 * 64] = floatAsInt(ray.d.y); save[5 * 64] = floatAsInt(ray.d.z);
                     save[6 * 64] = floatAsInt(ray.tnear);
@@ -394,7 +399,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_T
                     save[15 * 64] = ray.sp;
                     save[16 * 64] = (int)target;
                     save[17 * 64] = COUNT ? (int)(counters.boxes - rayBoxesStart) : 0;
-                    for (int k = 0; k < ray.sp; k++) { save[(kSaveWords + k) * 64] = stack[k * kBlock]; }
+                    for (int k = 0; k < ray.sp; k++) { save[(kSaveWords + k) * 64] = stackRead<STACK, kBlock>(stack, k); }
                     if (ray.anyHit) { reinterpret_cast<int *>(p.state.pend + target)[3] = kShadowSuspended; }
                     else { reinterpret_cast<int *>(p.state.hit + target)[3] = kPrimSuspended; }
                     active = false;
@@ -596,10 +601,14 @@ __global__ __launch_bounds__(kBlock) void k_trace_small(RenderParams p, SmallTri
 // test hook kernel behind pathed_hip_trace: plain grid, arbitrary ray intervals
 template <int STACK>
 __global__ __launch_bounds__(kBlock) void k_trace_rays(
-    DScene scene, const float4 *rays, int n, int anyHit, float4 *hitsOut, int *occludedOut
+    DScene scene, const float4 *rays, int n, int anyHit, float4 *hitsOut, int *occludedOut,
+    int *stackOverflow, int maxStack
 ) {
     extern __shared__ float4 ldsRaw[];
-    int *stack = reinterpret_cast<int *>(ldsRaw) + threadIdx.x;
+    LaneStack stack;
+    stack.lds = reinterpret_cast<int *>(ldsRaw) + threadIdx.x;
+    stack.overflowStride = (size_t)gridDim.x * kBlock;
+    stack.overflow = stackOverflow + ((size_t)blockIdx.x * kBlock + threadIdx.x);
 
     TraceGeometry geometry;
     geometry.nodes = scene.nodes;
@@ -617,12 +626,12 @@ __global__ __launch_bounds__(kBlock) void k_trace_rays(
     hit.t = 0.f; hit.u = 0.f; hit.v = 0.f; hit.prim = -1;
     TraceCounters counters;
     if (anyHit) {
-        const bool occluded = traverse<false, kBlock>(
-            geometry, stack, STACK, v3(ro.x, ro.y, ro.z), v3(rd.x, rd.y, rd.z), ro.w, rd.w, true, &hit, &counters);
+        const bool occluded = traverse<false, STACK, kBlock>(
+            geometry, stack, maxStack, v3(ro.x, ro.y, ro.z), v3(rd.x, rd.y, rd.z), ro.w, rd.w, true, &hit, &counters);
         occludedOut[i] = occluded ? 1 : 0;
     } else {
-        const bool found = traverse<false, kBlock>(
-            geometry, stack, STACK, v3(ro.x, ro.y, ro.z), v3(rd.x, rd.y, rd.z), ro.w, rd.w, false, &hit, &counters);
+        const bool found = traverse<false, STACK, kBlock>(
+            geometry, stack, maxStack, v3(ro.x, ro.y, ro.z), v3(rd.x, rd.y, rd.z), ro.w, rd.w, false, &hit, &counters);
         if (!found) { hit.t = 0.f; hit.u = 0.f; hit.v = 0.f; hit.prim = -1; }
         hitsOut[i] = make_float4(hit.t, hit.u, hit.v, intAsFloat(hit.prim));
     }

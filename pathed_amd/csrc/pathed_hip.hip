@@ -154,10 +154,12 @@ struct PathedScene {
     DeviceBuffer<unsigned int> counters;
     DeviceBuffer<unsigned long long> suspendMask;  // per pool, per trace wave (kernels.h: tail suspension)
     DeviceBuffer<int> suspendData;
+    DeviceBuffer<int> stackOverflow;  // per pool, per trace thread, (maxStack - stackRows) rows
     DeviceBuffer<unsigned long long> stats;
     unsigned int *hostRemaining = nullptr;  // pinned
 
-    int stackDepth = 8;
+    int stackRows = 8;    // LDS rows of the per-lane traversal stack (8 / 16 / 22)
+    int maxStack = 0;     // the tree's bound on stack entries; entries beyond stackRows spill to stackOverflow
     bool sceneInLds = false;
     bool bruteForce = false;      // <= kBruteForceMaxTris triangles: test them all, no BVH walk
     SmallTris smallTris;          // their records, passed to k_trace_small as a kernel argument
@@ -181,7 +183,7 @@ struct PathedScene {
         rayO.release(); rayD.release(); hit.release(); mod.release(); thr.release();
         res.release(); pend.release(); acc.release(); shO.release(); shD.release(); chunkBuf.release();
         counters.release(); stats.release();
-        suspendMask.release(); suspendData.release();
+        suspendMask.release(); suspendData.release(); stackOverflow.release();
         if (hostRemaining) { (void)hipHostFree(hostRemaining); }
         for (int h = 0; h < 2; h++) {
             if (poolStreams[h]) { (void)hipStreamDestroy(poolStreams[h]); }
@@ -343,7 +345,9 @@ int ensureRenderState(PathedScene *scene, int nSlots, size_t chunkEntries)
     if (!scene->suspendMask.ptr && !scene->bruteForce) {
         const size_t waves = (size_t)scene->traceGrid * kWavesPerBlock;
         HIP_TRY(scene->suspendMask.allocate(2 * waves));
-        HIP_TRY(scene->suspendData.allocate(2 * waves * (size_t)(kSaveWords + scene->stackDepth) * 64));
+        HIP_TRY(scene->suspendData.allocate(2 * waves * (size_t)(kSaveWords + scene->maxStack) * 64));
+        const size_t overflowRows = (size_t)(scene->maxStack > scene->stackRows ? scene->maxStack - scene->stackRows : 0);
+        HIP_TRY(scene->stackOverflow.allocate(2 * (size_t)scene->traceGrid * kBlock * (overflowRows ? overflowRows : 1)));
     }
     if (!scene->stats.ptr) {
         HIP_TRY(scene->stats.allocate(kStatCount));
@@ -379,11 +383,10 @@ void launchTrace(PathedScene *scene, const RenderParams &params, hipStream_t str
         else { hipLaunchKernelGGL((k_trace_small<false>), grid, block, 0, stream, params, scene->smallTris); }
         return;
     }
-    switch (scene->stackDepth) {
+    switch (scene->stackRows) {
     case 8: launchTraceStack<8>(scene, params, stream); break;
     case 16: launchTraceStack<16>(scene, params, stream); break;
-    case 32: launchTraceStack<32>(scene, params, stream); break;
-    default: launchTraceStack<64>(scene, params, stream); break;
+    default: launchTraceStack<22>(scene, params, stream); break;
     }
 }
 
@@ -399,22 +402,25 @@ void launchShade(PathedScene *scene, const RenderParams &params, hipStream_t str
 
 void configureTrace(PathedScene *scene)
 {
-    const int depth = scene->bvh.maxDepth + 1;
-    scene->stackDepth = depth <= 8 ? 8 : depth <= 16 ? 16 : depth <= 32 ? 32 : 64;
+    // a 4-wide node stacks up to three children: 3 entries per level bound the stack.  22 rows
+    // (+1 scratch, +8 KB staging = 31 KB per block) keep five blocks per CU possible; the rare
+    // deeper entries spill to HBM.
+    scene->maxStack = 3 * scene->bvh.maxDepth + 1;
+    scene->stackRows = scene->maxStack <= 8 ? 8 : scene->maxStack <= 16 ? 16 : 22;
 
     // per-thread traversal stacks + the waves' ray staging rows (2 float4 per thread)
-    const size_t stackBytes = (size_t)scene->stackDepth * kBlock * sizeof(int) + (size_t)2 * kBlock * sizeof(float4);
-    const size_t sceneBytes = (size_t)scene->device.nNodes * 64 + (size_t)scene->device.nTris * 48;
+    const size_t stackBytes = (size_t)(scene->stackRows + 1) * kBlock * sizeof(int) + (size_t)2 * kBlock * sizeof(float4);
+    const size_t sceneBytes = (size_t)scene->device.nNodes * 128 + (size_t)scene->device.nTris * 48;
     // stage the BVH in LDS when it is small enough to leave >= 4 blocks per CU
     scene->sceneInLds = scene->device.nNodes > 0 && (stackBytes + sceneBytes) <= 36 * 1024;
     scene->traceLdsBytes = stackBytes + (scene->sceneInLds ? sceneBytes : 0);
 
     int blocksPerCu = (int)((160 * 1024) / (scene->traceLdsBytes ? scene->traceLdsBytes : 1));
     if (blocksPerCu > 8) { blocksPerCu = 8; }
-    // measured on MI355X: the issue-bound HBM/L2 traversal alone is fastest at 4 blocks (16
-    // waves) per CU, but with the other pool's memory-bound k_shade sharing the CUs 3 blocks give
-    // the best whole-render rate (teapot 1102 -> 1165, 5.2M-triangle mesh 1021 -> 1064 Msamples/s)
-    if (!scene->sceneInLds && blocksPerCu > 3) { blocksPerCu = scene->pools > 1 ? 3 : 4; }
+    // measured on MI355X (4-wide tree, 5.2M-triangle mesh / teapot, Msamples/s): with the other
+    // pool's k_shade sharing the CUs 3 blocks per CU are best (1325 / 1452; 4: 1219 / 1298;
+    // 5: 1192 / 1292); a single pool wants all five the LDS allows (1266 / 1316).
+    if (!scene->sceneInLds) { blocksPerCu = scene->pools > 1 ? (blocksPerCu < 3 ? blocksPerCu : 3) : (blocksPerCu < 5 ? blocksPerCu : 5); }
     if (blocksPerCu < 1) { blocksPerCu = 1; }
     if (const char *override = getenv("PATHED_TRACE_BLOCKS_PER_CU")) {
         const int value = atoi(override);
@@ -698,7 +704,13 @@ static int renderPass(PathedScene *scene, uint64_t seed, uint32_t begin, uint32_
         q.suspendPatience = scene->suspendPatience;
         q.suspendMask = scene->bruteForce ? nullptr : scene->suspendMask.ptr + (size_t)h * traceWaves;
         q.suspendData = scene->bruteForce ? nullptr
-            : scene->suspendData.ptr + (size_t)h * traceWaves * (size_t)(kSaveWords + scene->stackDepth) * 64;
+            : scene->suspendData.ptr + (size_t)h * traceWaves * (size_t)(kSaveWords + scene->maxStack) * 64;
+        {
+            const size_t overflowRows = (size_t)(scene->maxStack > scene->stackRows ? scene->maxStack - scene->stackRows : 0);
+            q.stackOverflow = scene->bruteForce ? nullptr
+                : scene->stackOverflow.ptr + (size_t)h * (size_t)scene->traceGrid * kBlock * (overflowRows ? overflowRows : 1);
+            q.maxStack = scene->maxStack;
+        }
         q.stats = scene->stats.ptr;
         q.accum = d_accum;
         q.nSlots = slotsPerPool;
@@ -882,6 +894,7 @@ int pathed_hip_trace(PathedScene *scene, const float *rays, size_t n, int any_hi
     float4 *deviceRays = nullptr;
     float4 *deviceHits = nullptr;
     int *deviceOccluded = nullptr;
+    int *deviceOverflow = nullptr;
     HIP_TRY(hipMalloc((void **)&deviceRays, n * 2 * sizeof(float4)));
     hipError_t status = hipMemcpy(deviceRays, rays, n * 8 * sizeof(float), hipMemcpyHostToDevice);
     if (status == hipSuccess) {
@@ -889,12 +902,15 @@ int pathed_hip_trace(PathedScene *scene, const float *rays, size_t n, int any_hi
     }
     if (status == hipSuccess) {
         const dim3 grid((unsigned)((n + kBlock - 1) / kBlock)), block(kBlock);
-        const size_t lds = (size_t)scene->stackDepth * kBlock * sizeof(int);
-        switch (scene->stackDepth) {
-        case 8: hipLaunchKernelGGL((k_trace_rays<8>), grid, block, lds, 0, scene->device, deviceRays, (int)n, any_hit, deviceHits, deviceOccluded); break;
-        case 16: hipLaunchKernelGGL((k_trace_rays<16>), grid, block, lds, 0, scene->device, deviceRays, (int)n, any_hit, deviceHits, deviceOccluded); break;
-        case 32: hipLaunchKernelGGL((k_trace_rays<32>), grid, block, lds, 0, scene->device, deviceRays, (int)n, any_hit, deviceHits, deviceOccluded); break;
-        default: hipLaunchKernelGGL((k_trace_rays<64>), grid, block, lds, 0, scene->device, deviceRays, (int)n, any_hit, deviceHits, deviceOccluded); break;
+        const size_t lds = (size_t)(scene->stackRows + 1) * kBlock * sizeof(int);
+        const size_t overflowRows = (size_t)(scene->maxStack > scene->stackRows ? scene->maxStack - scene->stackRows : 0);
+        status = hipMalloc((void **)&deviceOverflow, (size_t)grid.x * kBlock * (overflowRows ? overflowRows : 1) * sizeof(int));
+        if (status == hipSuccess) {
+            switch (scene->stackRows) {
+            case 8: hipLaunchKernelGGL((k_trace_rays<8>), grid, block, lds, 0, scene->device, deviceRays, (int)n, any_hit, deviceHits, deviceOccluded, deviceOverflow, scene->maxStack); break;
+            case 16: hipLaunchKernelGGL((k_trace_rays<16>), grid, block, lds, 0, scene->device, deviceRays, (int)n, any_hit, deviceHits, deviceOccluded, deviceOverflow, scene->maxStack); break;
+            default: hipLaunchKernelGGL((k_trace_rays<22>), grid, block, lds, 0, scene->device, deviceRays, (int)n, any_hit, deviceHits, deviceOccluded, deviceOverflow, scene->maxStack); break;
+            }
         }
         status = hipDeviceSynchronize();
     }
@@ -906,6 +922,7 @@ int pathed_hip_trace(PathedScene *scene, const float *rays, size_t n, int any_hi
     (void)hipFree(deviceRays);
     if (deviceHits) { (void)hipFree(deviceHits); }
     if (deviceOccluded) { (void)hipFree(deviceOccluded); }
+    if (deviceOverflow) { (void)hipFree(deviceOverflow); }
     if (status != hipSuccess) { return fail(PATHED_E_DEVICE, hipGetErrorString(status)); }
     return PATHED_OK;
 }
@@ -950,7 +967,7 @@ int pathed_hip_get_stats(PathedScene *scene, PathedStats *out)
     out->shade_ms = scene->shadeEvents.totalMs;
     out->trace_launches = scene->traceEvents.launches;
     out->bvh_nodes = (uint64_t)scene->bvh.nodeCount;
-    out->bvh_bytes = (uint64_t)scene->bvh.nodeCount * 64 + (uint64_t)scene->device.nTris * 48;
+    out->bvh_bytes = (uint64_t)scene->bvh.nodeCount * 128 + (uint64_t)scene->device.nTris * 48;
     out->bvh_max_depth = (uint32_t)scene->bvh.maxDepth;
     out->scene_in_lds = scene->bruteForce ? 2u : (scene->sceneInLds ? 1u : 0u);
     out->max_boxes_per_ray = device[kStatMaxBoxes];
@@ -977,7 +994,7 @@ int pathed_hip_scene_export_bvh(PathedScene *scene, float *nodes, size_t *n_node
     const size_t triCount = scene->bvh.leafTris.size() / 12;
     if (nodes) {
         if (*n_nodes < nodeCount) { return fail(PATHED_E_INVALID, "node buffer too small"); }
-        std::memcpy(nodes, scene->bvh.nodes.data(), nodeCount * 16 * sizeof(float));
+        std::memcpy(nodes, scene->bvh.nodes.data(), nodeCount * kNodeFloats * sizeof(float));
     }
     if (tris) {
         if (*n_tris < triCount) { return fail(PATHED_E_INVALID, "triangle buffer too small"); }

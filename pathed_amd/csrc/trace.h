@@ -1,13 +1,15 @@
-// BVH2 traversal + primitive intersection for CDNA4 (the stand-in for Embree's
+// BVH4 traversal + primitive intersection for CDNA4 (the stand-in for Embree's
 // rtcIntersect1 / rtcOccluded1, reference src/scene.cpp:113, :374).
 //
 // Layout (DESIGN.md "Data layout"):
-//   node   4 x float4 = 64 B: (lmin.xyz, left) (lmax.xyz, lcount) (rmin.xyz, right) (rmax.xyz, rcount)
-//          count > 0: leaf, index = first leaf triangle; count == 0: inner node index;
-//          count < 0: empty slot
+//   node   8 x float4 = 128 B, children in the four components:
+//          (lo.x[4]) (lo.y[4]) (lo.z[4]) (hi.x[4]) (hi.y[4]) (hi.z[4]) (ref[4]) (-)
+//          ref >= 0: inner node index; ref <= -2: leaf, -ref - 1 = (first triangle << 3) | count;
+//          ref == kEmptyChild: empty slot
 //   tri    3 x float4 = 48 B: (v0.xyz, prim) (e1.xyz, -) (e2.xyz, -), leaf order
-// Per-lane traversal stack lives in LDS, laid out [depth][thread] so a wave's 64 lanes
-// hit 64 consecutive dwords (bank-conflict-free ds_read_b32 / ds_write_b32).
+// Per-lane traversal stack: the first ROWS entries live in LDS, laid out [row][thread] so a
+// wave's 64 lanes hit 64 consecutive dwords (bank-conflict-free ds_read_b32 / ds_write_b32);
+// deeper entries (rare: a 4-wide tree of depth d can stack 3d) spill to a per-thread column in HBM.
 //
 // The traversal is written as a per-lane STATE MACHINE (LaneRay + innerStep / leafStep): one call
 // visits one inner node or tests one leaf.  The persistent kernel interleaves steps of 64 independent rays and
@@ -172,73 +174,123 @@ __device__ inline void testLeafTriangle(
 // wave once enough lanes have a leaf pending.  Testing leaves inline left ~1 lane in 6 busy in
 // the triangle code and made it two thirds of the instructions issued; hits are unaffected by
 // the order (the acceptance rule is order-independent), only the culling bound shrinks later.
-__device__ inline int encodeLeaf(int first, int count) { return (first << 3) | count; }
+__host__ __device__ inline int encodeLeaf(int first, int count) { return (first << 3) | count; }
+static const int kEmptyChild = (int)0x80000000u;
+
+// One lane's traversal stack: ROWS entries in LDS (+ one scratch row that absorbs the writes of
+// children that are not pushed), the rest in a global column.
+struct LaneStack {
+    int *lds;             // entry k at lds[k * STRIDE]
+    int *overflow;        // entry ROWS + k at overflow[k * overflowStride]
+    size_t overflowStride;
+};
+
+template <int ROWS, int STRIDE>
+__device__ inline int stackRead(const LaneStack &s, int index)
+{
+    if (index < ROWS) { return s.lds[index * STRIDE]; }
+    return s.overflow[(size_t)(index - ROWS) * s.overflowStride];
+}
+
+template <int ROWS, int STRIDE>
+__device__ inline void stackWrite(const LaneStack &s, int index, int value)
+{
+    if (index < ROWS) { s.lds[index * STRIDE] = value; }
+    else { s.overflow[(size_t)(index - ROWS) * s.overflowStride] = value; }
+}
 
 // Pops the lane's next piece of work.  Returns true when the stack is exhausted.
-template <int STRIDE>
-__device__ inline bool popWork(int *stack, LaneRay &ray)
+template <int ROWS, int STRIDE>
+__device__ inline bool popWork(const LaneStack &stack, LaneRay &ray)
 {
     if (ray.sp == 0) { return true; }
     ray.sp--;
-    const int entry = stack[ray.sp * STRIDE];
+    const int entry = stackRead<ROWS, STRIDE>(stack, ray.sp);
     if (entry >= 0) { ray.current = entry; ray.pendingLeaf = 0; }
     else { ray.pendingLeaf = -entry - 1; }
     return false;
 }
 
-// Visit ONE inner node (lane must not have a leaf pending).  Returns true when the BVH part of
-// the query is complete.  `stack` points at this lane's column: entry k is stack[k * STRIDE].
-template <bool COUNT, int STRIDE>
+// Visit ONE inner node (lane must not have a leaf pending): four slab tests, the children that
+// are hit sorted leaves-first then near-to-far, the first becomes the lane's next piece of work,
+// the others are stacked far-to-near.  Returns true when the BVH part of the query is complete.
+// `maxStack` is the tree's bound on stack entries (3 per level).
+template <bool COUNT, int ROWS, int STRIDE>
 __device__ inline bool innerStep(
-    const TraceGeometry &g, int *stack, int stackDepth, LaneRay &ray, TraceCounters *counters
+    const TraceGeometry &g, const LaneStack &stack, int maxStack, LaneRay &ray, TraceCounters *counters
 ) {
-    // all 64 bytes of the node in one round trip
-    const float4 n0 = g.nodes[4 * ray.current + 0];
-    const float4 n1 = g.nodes[4 * ray.current + 1];
-    const float4 n2 = g.nodes[4 * ray.current + 2];
-    const float4 n3 = g.nodes[4 * ray.current + 3];
-    pinLoaded(n0);
-    pinLoaded(n1);
-    pinLoaded(n2);
-    pinLoaded(n3);
-    const int leftIndex = floatAsInt(n0.w), leftCount = floatAsInt(n1.w);
-    const int rightIndex = floatAsInt(n2.w), rightCount = floatAsInt(n3.w);
+    // all 112 used bytes of the node in one round trip
+    const float4 *node = g.nodes + 8 * ray.current;
+    const float4 lox = node[0], loy = node[1], loz = node[2];
+    const float4 hix = node[3], hiy = node[4], hiz = node[5];
+    const float4 refBits = node[6];
+    pinLoaded(lox); pinLoaded(loy); pinLoaded(loz);
+    pinLoaded(hix); pinLoaded(hiy); pinLoaded(hiz);
+    pinLoaded(refBits);
 
-    float tLeft, tRight;
-    const bool boxLeft = slabTest(n0, n1, ray.invD, ray.oInvD, ray.tnear, ray.best, &tLeft);
-    const bool boxRight = slabTest(n2, n3, ray.invD, ray.oInvD, ray.tnear, ray.best, &tRight);
-    const bool hitLeft = (leftCount >= 0) && boxLeft;
-    const bool hitRight = (rightCount >= 0) && boxRight;
-    if (COUNT) { counters->boxes += (leftCount >= 0) + (rightCount >= 0); }
+    const float lx[4] = { lox.x, lox.y, lox.z, lox.w }, ly[4] = { loy.x, loy.y, loy.z, loy.w }, lz[4] = { loz.x, loz.y, loz.z, loz.w };
+    const float hx[4] = { hix.x, hix.y, hix.z, hix.w }, hy[4] = { hiy.x, hiy.y, hiy.z, hiy.w }, hz[4] = { hiz.x, hiz.y, hiz.z, hiz.w };
+    int ref[4] = { floatAsInt(refBits.x), floatAsInt(refBits.y), floatAsInt(refBits.z), floatAsInt(refBits.w) };
 
-    // the two children as work items: >= 0 inner node, < 0 leaf
-    const int workLeft = leftCount > 0 ? -encodeLeaf(leftIndex, leftCount) - 1 : leftIndex;
-    const int workRight = rightCount > 0 ? -encodeLeaf(rightIndex, rightCount) - 1 : rightIndex;
-
-    int next;
-    if (hitLeft && hitRight) {
-        // leaves before inner nodes (they shrink `best`), otherwise the nearer child first
-        bool leftFirst = tLeft <= tRight;
-        if ((workLeft < 0) != (workRight < 0)) { leftFirst = workLeft < 0; }
-        next = leftFirst ? workLeft : workRight;
-        const int later = leftFirst ? workRight : workLeft;
-        if (ray.sp < stackDepth) { stack[ray.sp * STRIDE] = later; ray.sp++; }
-    } else if (hitLeft) {
-        next = workLeft;
-    } else if (hitRight) {
-        next = workRight;
-    } else {
-        return popWork<STRIDE>(stack, ray);
+    // sort key: misses last, leaves before inner nodes (they shrink `best`), then entry distance,
+    // then the child slot (keys are distinct, so the order is total and the same everywhere)
+    unsigned int key[4];
+    int hits = 0;
+    #pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const float tx0 = fmaf(lx[c], ray.invD.x, -ray.oInvD.x);
+        const float tx1 = fmaf(hx[c], ray.invD.x, -ray.oInvD.x);
+        const float ty0 = fmaf(ly[c], ray.invD.y, -ray.oInvD.y);
+        const float ty1 = fmaf(hy[c], ray.invD.y, -ray.oInvD.y);
+        const float tz0 = fmaf(lz[c], ray.invD.z, -ray.oInvD.z);
+        const float tz1 = fmaf(hz[c], ray.invD.z, -ray.oInvD.z);
+        // fminf/fmaxf return the non-NaN operand, which is what a conservative test wants
+        const float tmin = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), ray.tnear));
+        const float tmax = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fminf(fmaxf(tz0, tz1), ray.best));
+        const bool valid = ref[c] != kEmptyChild;
+        const bool hit = valid && (tmin <= tmax * 1.0000004f);
+        if (COUNT) { counters->boxes += valid ? 1u : 0u; }
+        const unsigned int inner = ref[c] >= 0 ? 0x80000000u : 0u;
+        key[c] = hit ? (inner | (((unsigned int)floatAsInt(tmin) >> 1) & 0x7FFFFFFCu) | (unsigned int)c) : 0xFFFFFFFFu;
+        hits += hit ? 1 : 0;
     }
-    if (next >= 0) { ray.current = next; }
-    else { ray.pendingLeaf = -next - 1; }
+
+    // 5-comparator sorting network on (key, ref)
+    #define PATHED_SORT2(a, b) { \
+        const bool swap = key[b] < key[a]; \
+        const unsigned int lowKey = swap ? key[b] : key[a], highKey = swap ? key[a] : key[b]; \
+        const int lowRef = swap ? ref[b] : ref[a], highRef = swap ? ref[a] : ref[b]; \
+        key[a] = lowKey; key[b] = highKey; ref[a] = lowRef; ref[b] = highRef; }
+    PATHED_SORT2(0, 1) PATHED_SORT2(2, 3) PATHED_SORT2(0, 2) PATHED_SORT2(1, 3) PATHED_SORT2(1, 2)
+    #undef PATHED_SORT2
+
+    if (hits == 0) { return popWork<ROWS, STRIDE>(stack, ray); }
+
+    // ref[1 .. hits-1] go on the stack far-to-near, so the nearest of them is popped first
+    const int top = ray.sp + hits - 1;   // stack size after the pushes
+    if (top <= ROWS) {
+        // common case, branch-free: a child that is not pushed writes the scratch row (ROWS)
+        #pragma unroll
+        for (int k = 1; k < 4; k++) {
+            const int row = k < hits ? top - k : ROWS;
+            stack.lds[row * STRIDE] = ref[k];
+        }
+        ray.sp = top;
+    } else {
+        #pragma unroll
+        for (int k = 3; k >= 1; k--) {
+            if (k < hits && ray.sp < maxStack) { stackWrite<ROWS, STRIDE>(stack, ray.sp, ref[k]); ray.sp++; }
+        }
+    }
+    if (ref[0] >= 0) { ray.current = ref[0]; }
+    else { ray.pendingLeaf = -ref[0] - 1; }
     return false;
 }
 
 // Test the lane's pending leaf (<= 7 triangles), then pop the next piece of work.
 // Returns true when the query is complete.
-template <bool COUNT, int STRIDE>
-__device__ inline bool leafStep(const TraceGeometry &g, int *stack, LaneRay &ray, TraceCounters *counters)
+template <bool COUNT, int ROWS, int STRIDE>
+__device__ inline bool leafStep(const TraceGeometry &g, const LaneStack &stack, LaneRay &ray, TraceCounters *counters)
 {
     const int first = ray.pendingLeaf >> 3;
     const int count = ray.pendingLeaf & 7;
@@ -262,7 +314,7 @@ __device__ inline bool leafStep(const TraceGeometry &g, int *stack, LaneRay &ray
         testLeafTriangle(ray, c0, c1, c2, &terminate);
         if (terminate) { return true; }
     }
-    return popWork<STRIDE>(stack, ray);
+    return popWork<ROWS, STRIDE>(stack, ray);
 }
 
 // After the BVH: the (few) spheres are tested brute force, then the result is final.
@@ -287,9 +339,9 @@ __device__ inline void finishRay(const TraceGeometry &g, LaneRay &ray)
 }
 
 // One whole ray on one lane (test hook / simple callers).
-template <bool COUNT, int STRIDE>
+template <bool COUNT, int ROWS, int STRIDE>
 __device__ inline bool traverse(
-    const TraceGeometry &g, int *stack, int stackDepth,
+    const TraceGeometry &g, const LaneStack &stack, int maxStack,
     V3 o, V3 d, float tnear, float tfar, bool anyHit,
     RayHit *hit, TraceCounters *counters
 ) {
@@ -299,8 +351,8 @@ __device__ inline bool traverse(
         bool done = false;
         while (!done) {
             done = ray.pendingLeaf
-                ? leafStep<COUNT, STRIDE>(g, stack, ray, counters)
-                : innerStep<COUNT, STRIDE>(g, stack, stackDepth, ray, counters);
+                ? leafStep<COUNT, ROWS, STRIDE>(g, stack, ray, counters)
+                : innerStep<COUNT, ROWS, STRIDE>(g, stack, maxStack, ray, counters);
         }
     }
     finishRay(g, ray);

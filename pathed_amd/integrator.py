@@ -97,7 +97,7 @@ class HipScene:
         n_nodes, n_tris = C.c_size_t(0), C.c_size_t(0)
         _check(self._lib, self._lib.pathed_hip_scene_export_bvh(self._handle, None, C.byref(n_nodes), None, C.byref(n_tris)),
                "pathed_hip_scene_export_bvh")
-        nodes = np.zeros((n_nodes.value, 16), dtype=np.float32)
+        nodes = np.zeros((n_nodes.value, 32), dtype=np.float32)
         tris = np.zeros((n_tris.value, 12), dtype=np.float32)
         _check(self._lib, self._lib.pathed_hip_scene_export_bvh(
             self._handle, nodes.ctypes.data_as(C.POINTER(C.c_float)), C.byref(n_nodes),
