@@ -51,7 +51,11 @@ static const int kTraceShards = 32;
 static const int kCtrTraceCursor = kCtrUnitCursor + kUnitQueues * kCursorStride;  // + shard * kCursorStride: next card (rewound by k_shade)
 static const int kCtrShadowCount = kCtrTraceCursor + kTraceShards * kCursorStride;  // + parity * kCursorStride: length of the shadow-ray list
 static const int kCtrCount = kCtrShadowCount + 2 * kCursorStride;
-static const int kCard = 64;           // rays per trace card
+#ifndef PATHED_CARD_ROUNDS
+#define PATHED_CARD_ROUNDS 2
+#endif
+static const int kCardRounds = PATHED_CARD_ROUNDS;   // every lane fetches this many rays of a card
+static const int kCard = 64 * kCardRounds;           // rays per trace card
 
 // Tail suspension.  Once the pool is dealt a wave only thins out: the last few long rays would
 // keep it (and the launch) alive at 5-6 busy lanes for a third of its lifetime.  Instead, a wave
@@ -62,7 +66,7 @@ static const int kCard = 64;           // rays per trace card
 // leaves it alone until the ray's result is in.  Results do not depend on any of this: the hit
 // acceptance rule is order-independent and every slot is shaded from its own finished rays.
 static const int kSuspendLanes = 32;                     // default; RenderParams::suspendLanes = 0 disables (PATHED_SUSPEND_LANES)
-static const int kSuspendPatience = 32;                   // default steps a wave rides out its tail before parking it (PATHED_SUSPEND_PATIENCE)
+static const int kSuspendPatience = 48;                   // default steps a wave rides out its tail before parking it (PATHED_SUSPEND_PATIENCE)
 static const int kSaveWords = 18;                        // per-lane record ahead of the stack entries
 static const int kPrimSuspended = (int)0x80000001u;      // hit.w of a slot whose closest-hit ray is parked
 static const int kShadowSuspended = 0x7fc0dead;          // pend.w of a slot whose shadow ray is parked (a NaN pattern)
@@ -177,12 +181,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_T
     geometry.spheres = p.scene.spheres;
     geometry.nSpheres = p.scene.nSpheres;
 
-    float4 *stageO = ldsRaw + ((STACK + 1) * kBlock) / 4 + (threadIdx.x & ~63);  // this wave's 64 entries
-    float4 *stageD = stageO + kBlock;
+    float4 *stageO = ldsRaw + ((STACK + 1) * kBlock) / 4 + (threadIdx.x >> 6) * kCard;  // this wave's kCard entries
+    float4 *stageD = stageO + kBlock * kCardRounds;
 
     if (LDS_SCENE) {
         // small scenes: the whole BVH + leaf triangles are staged in LDS once per block
-        float4 *ldsNodes = ldsRaw + ((STACK + 1) * kBlock) / 4 + 2 * kBlock;
+        float4 *ldsNodes = ldsRaw + ((STACK + 1) * kBlock) / 4 + 2 * kBlock * kCardRounds;
         float4 *ldsTris = ldsNodes + 8 * p.scene.nNodes;
         for (int i = threadIdx.x; i < 8 * p.scene.nNodes; i += kBlock) { ldsNodes[i] = p.scene.nodes[i]; }
         for (int i = threadIdx.x; i < 3 * p.scene.nTris; i += kBlock) { ldsTris[i] = p.scene.leafTris[i]; }
@@ -226,31 +230,42 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_T
             shardsTried++;
         }
         if (!have) { exhausted = true; return; }
-        const unsigned int item = card * kCard + (unsigned int)lane;
         stagedShadow = card * kCard >= (unsigned int)p.nSlots;    // nSlots is a multiple of kCard
-        bool valid = false;
-        float4 first = make_float4(0.f, 0.f, 0.f, 0.f), second = first;
-        if (!stagedShadow) {
-            const float4 rd = p.state.rayD[item];
-            const float4 ro = p.state.rayO[item];
-            valid = !(floatAsInt(rd.w) & (kStDone | kStHold));
-            first = ro;
-            second = make_float4(rd.x, rd.y, rd.z, intAsFloat((int)item));  // .w = the slot
-        } else {
-            const unsigned int entry = item - (unsigned int)p.nSlots;
-            valid = entry < shadowCount;
-            if (valid) {
-                first = p.state.shO[entry];    // .w = tfar
-                second = p.state.shD[entry];   // .w = the slot
+        bool valid[kCardRounds];
+        float4 first[kCardRounds], second[kCardRounds];
+        #pragma unroll
+        for (int r = 0; r < kCardRounds; r++) {
+            const unsigned int item = card * kCard + (unsigned int)(r * 64 + lane);
+            valid[r] = false;
+            first[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+            second[r] = first[r];
+            if (!stagedShadow) {
+                const float4 rd = p.state.rayD[item];
+                const float4 ro = p.state.rayO[item];
+                valid[r] = !(floatAsInt(rd.w) & (kStDone | kStHold));
+                first[r] = ro;
+                second[r] = make_float4(rd.x, rd.y, rd.z, intAsFloat((int)item));  // .w = the slot
+            } else {
+                const unsigned int entry = item - (unsigned int)p.nSlots;
+                valid[r] = entry < shadowCount;
+                if (valid[r]) {
+                    first[r] = p.state.shO[entry];    // .w = tfar
+                    second[r] = p.state.shD[entry];   // .w = the slot
+                }
             }
         }
-        const unsigned long long validMask = __ballot(valid);
-        const unsigned int rank = __builtin_amdgcn_mbcnt_hi(
-            (unsigned int)(validMask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)validMask, 0u));
         __builtin_amdgcn_wave_barrier();
-        if (valid) { stageO[rank] = first; stageD[rank] = second; }
+        unsigned int staged = 0;
+        #pragma unroll
+        for (int r = 0; r < kCardRounds; r++) {
+            const unsigned long long validMask = __ballot(valid[r]);
+            const unsigned int rank = staged + __builtin_amdgcn_mbcnt_hi(
+                (unsigned int)(validMask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)validMask, 0u));
+            if (valid[r]) { stageO[rank] = first[r]; stageD[rank] = second[r]; }
+            staged += (unsigned int)__popcll(validMask);
+        }
         __builtin_amdgcn_wave_barrier();
-        stagedCount = (unsigned int)__popcll(validMask);
+        stagedCount = staged;
         stagedPos = 0;
     };
 

@@ -407,9 +407,13 @@ void configureTrace(PathedScene *scene)
     // deeper entries spill to HBM.
     scene->maxStack = 3 * scene->bvh.maxDepth + 1;
     scene->stackRows = scene->maxStack <= 8 ? 8 : scene->maxStack <= 16 ? 16 : 22;
+    if (const char *override = getenv("PATHED_STACK_ROWS")) {   // tests: force the HBM spill path
+        const int value = atoi(override);
+        if (value == 8 || value == 16 || value == 22) { scene->stackRows = value; }
+    }
 
     // per-thread traversal stacks + the waves' ray staging rows (2 float4 per thread)
-    const size_t stackBytes = (size_t)(scene->stackRows + 1) * kBlock * sizeof(int) + (size_t)2 * kBlock * sizeof(float4);
+    const size_t stackBytes = (size_t)(scene->stackRows + 1) * kBlock * sizeof(int) + (size_t)2 * kBlock * kCardRounds * sizeof(float4);
     const size_t sceneBytes = (size_t)scene->device.nNodes * 128 + (size_t)scene->device.nTris * 48;
     // stage the BVH in LDS when it is small enough to leave >= 4 blocks per CU
     scene->sceneInLds = scene->device.nNodes > 0 && (stackBytes + sceneBytes) <= 36 * 1024;

@@ -340,6 +340,42 @@ def test_rays_carried_over_between_trace_launches_change_nothing(libs):
     assert eager_stats["nodes_visited"] == off_stats["nodes_visited"]  # nothing is re-traversed
 
 
+def test_traversal_stack_spill_to_hbm_changes_nothing(libs):
+    """The per-lane traversal stack keeps its first rows in LDS and spills deeper entries to a
+    per-thread column in HBM.  With only 8 LDS rows the teapot's tree (bound: 3 entries per level)
+    spills for a large share of the rays, in the test hook, in the render kernel and in the
+    records of parked rays: hits and image stay bit-identical."""
+    oracle_lib, HipScene, LoadedScene = libs
+    saved = os.environ.get("PATHED_STACK_ROWS")
+    try:
+        os.environ["PATHED_STACK_ROWS"] = "8"
+        scene = LoadedScene("scenes/teapot.json", 96, 96)
+        spilling = HipScene(scene.desc, device=0)
+        assert spilling.stats()["bvh_max_depth"] * 3 + 1 > 8
+        rays = _rays(100000, 21, (0, 4, 0), 9.0)
+        hits = spilling.trace(rays)
+        occluded = spilling.trace(rays, any_hit=True)
+        few_waves = {"PATHED_TRACE_BLOCKS_PER_CU": "1", "PATHED_SUSPEND_LANES": "64", "PATHED_SUSPEND_PATIENCE": "0"}
+        os.environ.update(few_waves)
+        parked_scene = HipScene(scene.desc, device=0)
+        parked_scene.set_stats_mode(count=True)
+        image = parked_scene.render(3, 0, 8, 0, 8)
+        assert parked_scene.stats()["parked_rays"] > 0
+    finally:
+        for key in ("PATHED_TRACE_BLOCKS_PER_CU", "PATHED_SUSPEND_LANES", "PATHED_SUSPEND_PATIENCE"):
+            os.environ.pop(key, None)
+        if saved is None:
+            os.environ.pop("PATHED_STACK_ROWS", None)
+        else:
+            os.environ["PATHED_STACK_ROWS"] = saved
+    cpu = oracle_lib.OracleScene(scene.desc)
+    assert np.array_equal(hits.view(np.int32), cpu.trace(rays).view(np.int32))
+    assert np.array_equal(occluded, cpu.trace(rays, any_hit=True))
+    default = HipScene(scene.desc, device=0)
+    assert np.array_equal(default.trace(rays).view(np.int32), hits.view(np.int32))
+    assert np.array_equal(default.render(3, 0, 8, 0, 8), image)
+
+
 def test_unbounded_last_bounce_terminates_and_matches(libs):
     """lastBounce = -1 (reference: unbounded, src/bounce_controller.cpp:20-25): paths end on a miss or
     when the throughput underflows to exactly black.  Open scene so every path escapes."""

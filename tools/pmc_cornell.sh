@@ -21,6 +21,6 @@ for d in sorted(glob.glob("$OUT/p*/")):
             k=(r["Kernel_Name"].split("(")[0][-40:], r["Counter_Name"])
             agg[k][0]+=1; agg[k][1]+=float(r["Counter_Value"])
         for k,v in sorted(agg.items()):
-            if ("k_trace" in k[0] or "k_shade" in k[0]) and "true>" not in k[0]:
+            if "k_shade" in k[0] or ("k_trace" in k[0] and "true>" not in k[0]):
                 print(d.split("/")[-2], k[0], k[1], "n=%d avg=%.4g"%(v[0], v[1]/v[0]))
 PY
