@@ -33,7 +33,7 @@ static const int kWavesPerBlock = kBlock / 64;
 static const int kMaxLdsMaterials = 96;  // 96 x 96 B = 9 KiB of LDS
 static const int kUnitQueues = 32;       // sharded work-unit cursors
 #ifndef PATHED_REFILL
-#define PATHED_REFILL 56
+#define PATHED_REFILL 48
 #endif
 static const int kRefillThreshold = PATHED_REFILL;  // refill a wave's idle lanes once fewer than this many are busy
 #ifndef PATHED_LEAF_THRESHOLD
@@ -66,7 +66,7 @@ static const int kCard = 64 * kCardRounds;           // rays per trace card
 // leaves it alone until the ray's result is in.  Results do not depend on any of this: the hit
 // acceptance rule is order-independent and every slot is shaded from its own finished rays.
 static const int kSuspendLanes = 32;                     // default; RenderParams::suspendLanes = 0 disables (PATHED_SUSPEND_LANES)
-static const int kSuspendPatience = 48;                   // default steps a wave rides out its tail before parking it (PATHED_SUSPEND_PATIENCE)
+static const int kSuspendPatience = 24;                   // default steps a wave rides out its tail before parking it (PATHED_SUSPEND_PATIENCE)
 static const int kSaveWords = 18;                        // per-lane record ahead of the stack entries
 static const int kPrimSuspended = (int)0x80000001u;      // hit.w of a slot whose closest-hit ray is parked
 static const int kShadowSuspended = 0x7fc0dead;          // pend.w of a slot whose shadow ray is parked (a NaN pattern)
@@ -125,6 +125,7 @@ struct RenderParams {
     int maxStack;                     // the tree's bound on stack entries (3 per level)
     int suspendLanes;                 // park the tail once fewer rays than this are left (0 = never)
     int suspendPatience;              // ... and the wave has run this many steps since its last card
+    int parkMinCardsPerWave;          // ... and the pool still has this many cards' worth of live slots per wave
     int parity;                       // iteration & 1: k_shade(n) fills shadow list n & 1, k_trace(n) consumes list (n - 1) & 1
     float *accum;          // 3*W*H radiance sums, index 3*(row*W+col)+c
     int nSlots;            // multiple of kBlock
@@ -212,6 +213,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_T
     const unsigned int shadowCount = p.counters[kCtrShadowCount + (p.parity ^ 1) * kCursorStride];
     const unsigned int totalItems = (unsigned int)p.nSlots + shadowCount;
     const unsigned int totalCards = (totalItems + kCard - 1u) / kCard;   // nSlots is a multiple of kBlock
+    // parking pays only in a launch with plenty of rays per wave; at the end of a render, when a
+    // launch carries a few stragglers, they are simply run to completion
+    const bool mayPark = p.counters[kCtrRemaining] >= (unsigned int)p.parkMinCardsPerWave * kCard * gridDim.x * kWavesPerBlock;
     unsigned int shard = waveId % kTraceShards, shardsTried = 0;
     unsigned int stagedCount = 0, stagedPos = 0;                  // wave-uniform
     bool stagedShadow = false;                                    // the staged card holds shadow rays
@@ -397,7 +401,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_T
             if (activeMask == 0ull) { break; }
             if (!dry && __popcll(activeMask) < kRefillThreshold) { break; }
             if (dry) { stepsSinceLastCard++; }
-            if (dry && __popcll(activeMask) < p.suspendLanes && stepsSinceLastCard >= (unsigned int)p.suspendPatience) {
+            if (dry && mayPark && __popcll(activeMask) < p.suspendLanes && stepsSinceLastCard >= (unsigned int)p.suspendPatience) {
                 if (active) {
                     int *save = p.suspendData + (size_t)waveId * (size_t)((kSaveWords + p.maxStack) * 64) + lane;
                     save[0 * 64] = floatAsInt(ray.o.x); save[1 * 64] = floatAsInt(ray.o.y); save[2 * 64] = floatAsInt(ray.o.z);

@@ -167,6 +167,7 @@ struct PathedScene {
     int traceGrid = 0;
     int suspendLanes = kSuspendLanes;  // PATHED_SUSPEND_LANES overrides (0 = off)
     int suspendPatience = kSuspendPatience;  // PATHED_SUSPEND_PATIENCE
+    int parkMinCards = 1;                    // PATHED_PARK_MIN_CARDS
     int computeUnits = 256;
 
     bool countMode = false;
@@ -431,6 +432,10 @@ void configureTrace(PathedScene *scene)
         if (value >= 1 && value <= 16) { blocksPerCu = value; }
     }
     scene->traceGrid = scene->computeUnits * blocksPerCu;
+    if (const char *override = getenv("PATHED_PARK_MIN_CARDS")) {
+        const int value = atoi(override);
+        if (value >= 0 && value <= 1024) { scene->parkMinCards = value; }
+    }
     if (const char *override = getenv("PATHED_SUSPEND_PATIENCE")) {
         const int value = atoi(override);
         if (value >= 0 && value <= 4096) { scene->suspendPatience = value; }
@@ -706,6 +711,7 @@ static int renderPass(PathedScene *scene, uint64_t seed, uint32_t begin, uint32_
         const size_t traceWaves = (size_t)scene->traceGrid * kWavesPerBlock;
         q.suspendLanes = scene->bruteForce ? 0 : scene->suspendLanes;
         q.suspendPatience = scene->suspendPatience;
+        q.parkMinCardsPerWave = scene->parkMinCards;
         q.suspendMask = scene->bruteForce ? nullptr : scene->suspendMask.ptr + (size_t)h * traceWaves;
         q.suspendData = scene->bruteForce ? nullptr
             : scene->suspendData.ptr + (size_t)h * traceWaves * (size_t)(kSaveWords + scene->maxStack) * 64;
