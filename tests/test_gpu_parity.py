@@ -355,14 +355,15 @@ def test_traversal_stack_spill_to_hbm_changes_nothing(libs):
         rays = _rays(100000, 21, (0, 4, 0), 9.0)
         hits = spilling.trace(rays)
         occluded = spilling.trace(rays, any_hit=True)
-        few_waves = {"PATHED_TRACE_BLOCKS_PER_CU": "1", "PATHED_SUSPEND_LANES": "64", "PATHED_SUSPEND_PATIENCE": "0"}
+        few_waves = {"PATHED_TRACE_BLOCKS_PER_CU": "1", "PATHED_SUSPEND_LANES": "64", "PATHED_SUSPEND_PATIENCE": "0",
+                     "PATHED_PARK_MIN_CARDS": "0"}  # park although the pool is small
         os.environ.update(few_waves)
         parked_scene = HipScene(scene.desc, device=0)
         parked_scene.set_stats_mode(count=True)
         image = parked_scene.render(3, 0, 8, 0, 8)
         assert parked_scene.stats()["parked_rays"] > 0
     finally:
-        for key in ("PATHED_TRACE_BLOCKS_PER_CU", "PATHED_SUSPEND_LANES", "PATHED_SUSPEND_PATIENCE"):
+        for key in ("PATHED_TRACE_BLOCKS_PER_CU", "PATHED_SUSPEND_LANES", "PATHED_SUSPEND_PATIENCE", "PATHED_PARK_MIN_CARDS"):
             os.environ.pop(key, None)
         if saved is None:
             os.environ.pop("PATHED_STACK_ROWS", None)
