@@ -4,11 +4,13 @@
 #pragma once
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <thread>
 #include <vector>
 
 namespace pathed {
@@ -80,6 +82,13 @@ public:
 
     std::vector<TempNode> nodes;
 
+    // Subtrees of at most deferThreshold primitives (0 = never) are not built but recorded, so
+    // that the caller can build them on other threads: they work on disjoint ranges of the
+    // primitive array and make the same decisions as a sequential build, so the tree is the same.
+    struct Deferred { int nodeIndex; uint32_t begin, end; int depth; };
+    std::vector<Deferred> deferred;
+    uint32_t deferThreshold = 0;
+
     int build(uint32_t begin, uint32_t end, int depth, int *maxDepth)
     {
         TempNode node;
@@ -98,6 +107,10 @@ public:
             nodes[(size_t)index].first = begin;
             nodes[(size_t)index].count = count;
             *maxDepth = std::max(*maxDepth, depth);
+            return index;
+        }
+        if (deferThreshold != 0 && count <= deferThreshold) {
+            deferred.push_back({ index, begin, end, depth });
             return index;
         }
 
@@ -218,7 +231,44 @@ inline FlatBvh buildBvh(const float *positions, const uint32_t *indices, uint32_
     Builder builder(prims);
     builder.nodes.reserve((size_t)triangleCount);
     int maxDepth = 0;
+    // large meshes: the top of the tree here, its subtrees on the host's other cores
+    unsigned int hostThreads = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+    if (const char *text = getenv("PATHED_BUILD_THREADS")) {
+        const int parsed = atoi(text);
+        if (parsed >= 1 && parsed <= 256) { hostThreads = (unsigned int)parsed; }
+    }
+    if (triangleCount >= 200000 && hostThreads > 1) { builder.deferThreshold = triangleCount / 256; }
     const int root = builder.build(0, triangleCount, 0, &maxDepth);
+    if (!builder.deferred.empty()) {
+        const size_t jobs = builder.deferred.size();
+        std::vector<std::vector<TempNode>> built(jobs);
+        std::atomic<size_t> next(0);
+        auto worker = [&]() {
+            for (size_t job = next.fetch_add(1); job < jobs; job = next.fetch_add(1)) {
+                const Builder::Deferred &item = builder.deferred[job];
+                Builder sub(prims);
+                sub.nodes.reserve((size_t)(item.end - item.begin));
+                int subDepth = 0;
+                sub.build(item.begin, item.end, item.depth, &subDepth);
+                built[job].swap(sub.nodes);
+            }
+        };
+        std::vector<std::thread> pool;
+        for (unsigned int t = 1; t < hostThreads; t++) { pool.emplace_back(worker); }
+        worker();
+        for (std::thread &thread : pool) { thread.join(); }
+        // splice: a subtree's root replaces its placeholder, the rest is appended
+        for (size_t job = 0; job < jobs; job++) {
+            const int offset = (int)builder.nodes.size() - 1;   // sub node k (k >= 1) lands at offset + k
+            const std::vector<TempNode> &sub = built[job];
+            auto moved = [&](TempNode node) {
+                if (node.left >= 0) { node.left += offset; node.right += offset; }
+                return node;
+            };
+            builder.nodes[(size_t)builder.deferred[job].nodeIndex] = moved(sub[0]);
+            for (size_t k = 1; k < sub.size(); k++) { builder.nodes.push_back(moved(sub[k])); }
+        }
+    }
 
     // leaf-ordered triangles: (v0, prim) (e1, 0) (e2, 0)
     out.leafTris.resize((size_t)12 * triangleCount);

@@ -377,6 +377,34 @@ def test_traversal_stack_spill_to_hbm_changes_nothing(libs):
     assert np.array_equal(default.render(3, 0, 8, 0, 8), image)
 
 
+def test_threaded_bvh_build_gives_the_sequential_tree(libs):
+    """Meshes of >= 200 000 triangles are built with the top of the tree on one thread and its
+    subtrees on the others; the exported tree must be the one a single thread builds."""
+    import subprocess
+    import sys
+    _, HipScene, LoadedScene = libs
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run([sys.executable, os.path.join(root, "tools", "make_assets.py"), "--dragon", "7"], check=True,
+                   stdout=subprocess.DEVNULL)
+    scene = LoadedScene("scenes/dragon-standin.json", 64, 36)
+    assert scene.n_triangles >= 200000
+    saved = os.environ.get("PATHED_BUILD_THREADS")
+    try:
+        os.environ["PATHED_BUILD_THREADS"] = "1"
+        nodes_one, tris_one = HipScene(scene.desc, device=0).export_bvh()
+        os.environ["PATHED_BUILD_THREADS"] = "8"
+        threaded = HipScene(scene.desc, device=0)
+        nodes_many, tris_many = threaded.export_bvh()
+    finally:
+        if saved is None:
+            os.environ.pop("PATHED_BUILD_THREADS", None)
+        else:
+            os.environ["PATHED_BUILD_THREADS"] = saved
+    assert np.array_equal(nodes_one.view(np.int32), nodes_many.view(np.int32))
+    assert np.array_equal(tris_one.view(np.int32), tris_many.view(np.int32))
+    assert threaded.render(1, 0, 2, 0, 4).any()
+
+
 def test_unbounded_last_bounce_terminates_and_matches(libs):
     """lastBounce = -1 (reference: unbounded, src/bounce_controller.cpp:20-25): paths end on a miss or
     when the throughput underflows to exactly black.  Open scene so every path escapes."""
