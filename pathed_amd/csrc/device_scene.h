@@ -55,6 +55,10 @@ struct DEnv {
     const float *thetaCdf;     // height
     const float *phiCdf;       // height*width, row-major
     const int *phiEmpty;       // height flags: 1 = the row has zero weight
+    // guide tables (one entry per CDF entry + 1): guide[j] = first i with cdf[i] >= j / size, so a
+    // sample xi is bracketed by two table reads instead of a log2(size)-deep chain of dependent loads
+    const int *thetaGuide;     // height + 1
+    const int *phiGuide;       // height * (width + 1), row-major
     int thetaEmpty;
     float scale;
     float mapToWorld[9];       // 3x3 part, row-major (the reference applies it to directions only)

@@ -139,7 +139,7 @@ struct PathedScene {
     DeviceBuffer<DMaterial> materials;
     DeviceBuffer<DLight> lights;
     DeviceBuffer<float> thetaCdf, phiCdf;
-    DeviceBuffer<int> phiEmpty;
+    DeviceBuffer<int> phiEmpty, thetaGuide, phiGuide;
 
     // render state, allocated on first use
     int nSlots = 0;
@@ -180,7 +180,7 @@ struct PathedScene {
     {
         nodes.release(); leafTris.release(); triShade.release(); envRgba.release();
         spheres.release(); materials.release(); lights.release();
-        thetaCdf.release(); phiCdf.release(); phiEmpty.release();
+        thetaCdf.release(); phiCdf.release(); phiEmpty.release(); thetaGuide.release(); phiGuide.release();
         rayO.release(); rayD.release(); hit.release(); mod.release(); thr.release();
         res.release(); pend.release(); acc.release(); shO.release(); shD.release(); chunkBuf.release();
         counters.release(); stats.release();
@@ -545,7 +545,7 @@ int pathed_hip_scene_create(const PathedSceneDesc *desc, PathedScene **out)
     // environment light: EnvironmentLight ctor, reference src/environment_light.cpp:14-53
     std::vector<float4> envRgba;
     std::vector<float> thetaCdf, phiCdf;
-    std::vector<int> phiEmpty;
+    std::vector<int> phiEmpty, thetaGuide, phiGuide;
     if (desc->env) {
         const PathedEnvLight &env = *desc->env;
         const size_t texels = (size_t)env.width * env.height;
@@ -568,6 +568,21 @@ int pathed_hip_scene_create(const PathedSceneDesc *desc, PathedScene **out)
             thetaData[(size_t)row] = thetaSum;
         }
         d.env.thetaEmpty = buildCdf(thetaData.data(), (size_t)env.height, thetaCdf.data()) ? 1 : 0;
+        // guide[j] = first i with cdf[i] >= j / size (the last entry when there is none)
+        auto buildGuide = [](const float *cdf, size_t size, int *guide) {
+            size_t i = 0;
+            for (size_t j = 0; j <= size; j++) {
+                const float threshold = (float)j / (float)size;
+                while (i + 1 < size && !(cdf[i] >= threshold)) { i++; }
+                guide[j] = (int)i;
+            }
+        };
+        thetaGuide.resize((size_t)env.height + 1);
+        buildGuide(thetaCdf.data(), (size_t)env.height, thetaGuide.data());
+        phiGuide.resize((size_t)env.height * ((size_t)env.width + 1));
+        for (int row = 0; row < env.height; row++) {
+            buildGuide(&phiCdf[(size_t)row * env.width], (size_t)env.width, &phiGuide[(size_t)row * (env.width + 1)]);
+        }
         d.env.width = env.width;
         d.env.height = env.height;
         d.env.scale = env.scale;
@@ -604,6 +619,8 @@ int pathed_hip_scene_create(const PathedSceneDesc *desc, PathedScene **out)
     if ((status = scene->thetaCdf.upload(thetaCdf)) != hipSuccess) { return fail_cleanup(status, "upload env cdf"); }
     if ((status = scene->phiCdf.upload(phiCdf)) != hipSuccess) { return fail_cleanup(status, "upload env cdf"); }
     if ((status = scene->phiEmpty.upload(phiEmpty)) != hipSuccess) { return fail_cleanup(status, "upload env cdf"); }
+    if ((status = scene->thetaGuide.upload(thetaGuide)) != hipSuccess) { return fail_cleanup(status, "upload env cdf"); }
+    if ((status = scene->phiGuide.upload(phiGuide)) != hipSuccess) { return fail_cleanup(status, "upload env cdf"); }
 
     d.nodes = scene->nodes.ptr;
     d.leafTris = scene->leafTris.ptr;
@@ -620,6 +637,8 @@ int pathed_hip_scene_create(const PathedSceneDesc *desc, PathedScene **out)
     d.env.thetaCdf = scene->thetaCdf.ptr;
     d.env.phiCdf = scene->phiCdf.ptr;
     d.env.phiEmpty = scene->phiEmpty.ptr;
+    d.env.thetaGuide = scene->thetaGuide.ptr;
+    d.env.phiGuide = scene->phiGuide.ptr;
 
     if (const char *poolCount = getenv("PATHED_POOLS")) { scene->pools = atoi(poolCount) >= 2 ? 2 : 1; }
     configureTrace(scene);

@@ -719,12 +719,18 @@ __device__ inline V3 apply3x3(const float *m, V3 v)
 }
 
 // Distribution::sample, src/distribution.cpp:35-53: the reference scans linearly for the
-// first i with xi <= cdf[i]; the CDF is non-decreasing, so a lower-bound binary search
-// returns the same i.
-__device__ inline int cdfSample(const float *cdf, int size, int empty, float xi, float *pdf)
+// first i with xi <= cdf[i] (Distribution::sample, src/distribution.cpp:35-53, scans linearly); the
+// CDF is non-decreasing, so a lower-bound binary search returns the same i.  The guide table
+// brackets the answer first: guide[j] = first i with cdf[i] >= j / size, and (j - 1) / size < xi <=
+// (j + 2) / size for j = (int)(xi * size) whatever the rounding of the product, so the answer lies
+// in [guide[j - 1], guide[j + 2]] -- usually one or two entries instead of log2(size) probes.
+__device__ inline int cdfSample(const float *cdf, const int *guide, int size, int empty, float xi, float *pdf)
 {
     if (empty) { *pdf = 0.f; return 0; }
-    int lo = 0, hi = size - 1;
+    const int bucket = (int)(xi * (float)size);
+    const int below = bucket - 1 < 0 ? 0 : (bucket - 1 > size ? size : bucket - 1);
+    const int above = bucket + 2 > size ? size : bucket + 2;
+    int lo = guide[below], hi = guide[above];
     while (lo < hi) {
         const int mid = (lo + hi) >> 1;
         if (xi <= cdf[mid]) { hi = mid; } else { lo = mid + 1; }
@@ -763,9 +769,10 @@ __device__ inline Rgb envEmit(const DEnv &env, V3 lightWo)
 __device__ inline SurfaceSample envSample(const DEnv &env, V3 point, Rng &random)
 {
     float thetaPDF, phiPDF;
-    const int thetaStep = cdfSample(env.thetaCdf, env.height, env.thetaEmpty, random.next(), &thetaPDF);
+    const int thetaStep = cdfSample(env.thetaCdf, env.thetaGuide, env.height, env.thetaEmpty, random.next(), &thetaPDF);
     const int phiStep = cdfSample(
-        env.phiCdf + (size_t)thetaStep * env.width, env.width, env.phiEmpty[thetaStep], random.next(), &phiPDF);
+        env.phiCdf + (size_t)thetaStep * env.width, env.phiGuide + (size_t)thetaStep * (env.width + 1), env.width,
+        env.phiEmpty[thetaStep], random.next(), &phiPDF);
 
     const float phiCanonical = (phiStep + 0.5f) / env.width;
     const float thetaCanonical = (thetaStep + 0.5f) / env.height;
