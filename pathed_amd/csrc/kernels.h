@@ -964,13 +964,17 @@ __global__ __launch_bounds__(kBlock) void k_shade(RenderParams p)
     // ... and empty the shadow list the NEXT k_shade will fill (the trace launch that read it is over)
     if (blockIdx.x == 0 && threadIdx.x == kTraceShards) { p.counters[kCtrShadowCount + (p.parity ^ 1) * kCursorStride] = 0u; }
 
+    // state word and hit record travel together: the shading-record gather that depends on the
+    // hit then starts one HBM round trip earlier
     float4 rd = p.state.rayD[slot];
+    float4 h = p.state.hit[slot];
+    pinLoaded(rd);
+    pinLoaded(h);
     int st = floatAsInt(rd.w);
     bool active = !(st & kStDone);
-    float4 h = make_float4(0.f, 0.f, 0.f, 0.f), pendIn = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 pendIn = make_float4(0.f, 0.f, 0.f, 0.f);
     if (active) {
         // a slot with a parked ray (see kSuspendLanes) sits this iteration out, untouched
-        h = p.state.hit[slot];
         if (st & kStEligible) { pendIn = p.state.pend[slot]; }
         if (p.suspendLanes > 0) {
             const bool parked = floatAsInt(h.w) == kPrimSuspended
