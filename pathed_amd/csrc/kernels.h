@@ -1028,6 +1028,10 @@ __global__ __launch_bounds__(kBlock) void k_shade(RenderParams p)
         bool haveVertex = false;  // a new surface vertex to process this iteration
         Isect isect;
         const int vertex = rayBounce + 1;
+        // ONE inlined copy of the intersection record, ahead of the bounce-0 / later-bounce split:
+        // the lanes of a wave sit at different path depths, and code inlined in both branches is
+        // executed twice by every mixed wave
+        if (!miss) { isect = makeIsect(scene, o, d, h); }
 
         if (rayBounce == 0) {
             // SampleIntegrator::samplePixel, src/sample_integrator.cpp:18-59
@@ -1035,7 +1039,6 @@ __global__ __launch_bounds__(kBlock) void k_shade(RenderParams p)
                 color = rgb(0.f) + environmentL(scene, d);
                 finished = true;
             } else {
-                isect = makeIsect(scene, o, d, h);
                 firstEmitMaterial = -1;
                 if (checkCounts(p.startBounce, p.lastBounce, 0)) {
                     const Rgb emit = matEmit(materials[isect.material]);
@@ -1053,8 +1056,6 @@ __global__ __launch_bounds__(kBlock) void k_shade(RenderParams p)
             const float bsdfPdf = modIn.w;
             const Rgb throughput = rgb(thrIn.x, thrIn.y, thrIn.z);
             const float cosTheta = thrIn.w;
-
-            if (!miss) { isect = makeIsect(scene, o, d, h); }
 
             if (st & kStEligible) {
                 // PathTracer::directSampleBSDF, src/path_tracer.cpp:167-216
@@ -1146,6 +1147,8 @@ __global__ __launch_bounds__(kBlock) void k_shade(RenderParams p)
 
     // ---- sample / unit bookkeeping --------------------------------------------------------
     bool needUnit = false;
+    bool startNext = false;       // the slot starts a camera ray: one inlined copy of startSample below
+    uint32_t nextPixel = 0, nextSample = 0;
     if (active && finished) {
         // radianceLookup += color, src/sample_integrator.cpp:61-63; non-finite samples dropped
         float4 partial = p.state.acc[slot];
@@ -1165,7 +1168,9 @@ __global__ __launch_bounds__(kBlock) void k_shade(RenderParams p)
         outThr = make_float4(0.f, 0.f, 0.f, 0.f);
         outPend = make_float4(0.f, 0.f, 0.f, 0.f);
         if (firstSample + (uint32_t)sampleInUnit < endSample) {
-            startSample(p, pixel, firstSample + (uint32_t)sampleInUnit, sampleInUnit, &outRayO, &outRayD);
+            startNext = true;
+            nextPixel = pixel;
+            nextSample = firstSample + (uint32_t)sampleInUnit;
             p.state.acc[slot] = partial;
         } else {
             p.state.chunkBuf[unit] = partial;
@@ -1180,14 +1185,17 @@ __global__ __launch_bounds__(kBlock) void k_shade(RenderParams p)
     if (needUnit) {
         unit = newUnit;
         if (newUnit != 0xFFFFFFFFu) {
-            uint32_t pixel, firstSample, endSample;
-            unitSamples(p, newUnit, &pixel, &firstSample, &endSample);
-            startSample(p, pixel, firstSample, 0, &outRayO, &outRayD);
+            uint32_t endSample;
+            unitSamples(p, newUnit, &nextPixel, &nextSample, &endSample);
+            sampleInUnit = 0;
+            startNext = true;
         } else {
             outRayD.w = intAsFloat(kStDone);
             retired = true;
         }
     }
+
+    if (startNext) { startSample(p, nextPixel, nextSample, sampleInUnit, &outRayO, &outRayD); }
 
     if (active) {
         p.state.rayO[slot] = outRayO;
