@@ -968,8 +968,12 @@ __global__ __launch_bounds__(kBlock) void k_shade(RenderParams p)
     // hit then starts one HBM round trip earlier
     float4 rd = p.state.rayD[slot];
     float4 h = p.state.hit[slot];
+    const float4 roIn = p.state.rayO[slot];
+    const float4 resIn0 = p.state.res[slot];
     pinLoaded(rd);
     pinLoaded(h);
+    pinLoaded(roIn);
+    pinLoaded(resIn0);
     int st = floatAsInt(rd.w);
     bool active = !(st & kStDone);
     float4 pendIn = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1006,8 +1010,8 @@ __global__ __launch_bounds__(kBlock) void k_shade(RenderParams p)
     Rgb result = rgb(0.f);
 
     if (active) {
-        const float4 ro = p.state.rayO[slot];
-        const float4 resIn = p.state.res[slot];
+        const float4 ro = roIn;
+        const float4 resIn = resIn0;
         outRayO = ro;
 
         const V3 o = v3(ro.x, ro.y, ro.z);
