@@ -377,6 +377,39 @@ def test_traversal_stack_spill_to_hbm_changes_nothing(libs):
     assert np.array_equal(default.render(3, 0, 8, 0, 8), image)
 
 
+def test_large_mesh_intersector_and_render_parity(libs):
+    """The large-BVH configuration in small: the procedural stand-in mesh at 82 K triangles (deep
+    4-wide tree, nodes in L2/HBM, stack spill possible), traced and rendered against the oracle."""
+    import subprocess
+    import sys
+    oracle_lib, HipScene, LoadedScene = libs
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run([sys.executable, os.path.join(root, "tools", "make_assets.py"), "--dragon", "6"], check=True,
+                   stdout=subprocess.DEVNULL)
+    scene = LoadedScene("scenes/dragon-standin.json", 96, 54)
+    assert scene.n_triangles > 80000
+    gpu, cpu = HipScene(scene.desc, device=0), oracle_lib.OracleScene(scene.desc)
+    stats = gpu.stats()
+    assert stats["scene_in_lds"] == 0 and stats["bvh_max_depth"] >= 8
+    rng = np.random.default_rng(4)
+    n = 100000
+    rays = np.zeros((n, 8), dtype=np.float32)
+    rays[:, 0:3] = rng.normal(size=(n, 3)) * 120 + [0, 0, 25]
+    target = rng.normal(size=(n, 3)) * 30 + [0, 0, 25]
+    direction = target - rays[:, 0:3]
+    rays[:, 4:7] = direction / np.linalg.norm(direction, axis=1, keepdims=True)
+    rays[:, 3] = 1e-3
+    rays[:, 7] = 1e5
+    hits_gpu, hits_cpu = gpu.trace(rays), cpu.trace(rays)
+    assert np.array_equal(hits_gpu.view(np.int32), hits_cpu.view(np.int32))
+    assert (hits_cpu[:, 3].view(np.int32) >= 0).mean() > 0.5
+    assert np.array_equal(gpu.trace(rays, any_hit=True), cpu.trace(rays, any_hit=True))
+    image = gpu.render(1, 0, 8, 0, 10)
+    expected, _ = cpu.render(96, 54, 1, 0, 8, 0, 10, threads=os.cpu_count(), chunk=4)
+    rel, bad = _image_metrics(image, expected)
+    assert rel <= 2e-3 and bad <= 2e-3, (rel, bad)
+
+
 def test_threaded_bvh_build_gives_the_sequential_tree(libs):
     """Meshes of >= 200 000 triangles are built with the top of the tree on one thread and its
     subtrees on the others; the exported tree must be the one a single thread builds."""
