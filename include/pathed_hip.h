@@ -176,6 +176,9 @@ typedef struct PathedStats {
     uint32_t scene_in_lds;         /* 0 BVH in HBM, 1 BVH staged in LDS, 2 tiny scene: all triangles tested (scalar loads) */
     uint64_t max_boxes_per_ray;    /* most child boxes a single closest-hit ray tested — stats mode */
     uint64_t parked_rays;          /* rays a trace launch handed on to the next one unfinished — stats mode */
+    double   bvh_build_ms;         /* scene_create's BVH build: host wall time (SAH) or HIP-event time (LBVH) */
+    uint32_t bvh_builder;          /* PATHED_BVH_* the scene was built with                 */
+    uint32_t reserved0;
 } PathedStats;
 
 /* ---- life cycle ---------------------------------------------------------- */
@@ -183,6 +186,16 @@ typedef struct PathedStats {
 /* Select the device this process renders on (one process per GPU).
  * Replaces the reference's rtcNewDevice / rtcNewScene (app/main.cpp:46-52). */
 int pathed_hip_init(int device_id);
+
+/* Which builder stands in for rtcCommitScene (reference src/scene.cpp:39) in the scene_create
+ * calls that follow (process-wide; the environment variable PATHED_BVH_BUILDER=sah|lbvh overrides):
+ *   PATHED_BVH_SAH_HOST     binned-SAH tree built on the host cores (default: cheapest to traverse)
+ *   PATHED_BVH_LBVH_DEVICE  Morton-code linear BVH built on the GPU in milliseconds;
+ *                           same node format, so hits and images are bit-identical, traversal costs more.
+ * Meshes of <= 64 triangles always take the host path (they are not traversed at all). */
+#define PATHED_BVH_SAH_HOST    0
+#define PATHED_BVH_LBVH_DEVICE 1
+int pathed_hip_set_bvh_builder(int builder);
 
 /* Flatten + upload once: leaf-ordered 48-B triangles, flattened 4-wide BVH (128-B nodes),
  * spheres, material table, light table, env map + CDFs, camera.

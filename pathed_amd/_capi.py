@@ -109,12 +109,16 @@ class PathedStats(C.Structure):
         ("scene_in_lds", C.c_uint32),
         ("max_boxes_per_ray", C.c_uint64),
         ("parked_rays", C.c_uint64),
+        ("bvh_build_ms", C.c_double),
+        ("bvh_builder", C.c_uint32),
+        ("reserved0", C.c_uint32),
     ]
 
 
 # every symbol include/pathed_hip.h declares; tests check that the library exports all
 HIP_SYMBOLS = [
     "pathed_hip_init",
+    "pathed_hip_set_bvh_builder",
     "pathed_hip_scene_create",
     "pathed_hip_scene_destroy",
     "pathed_hip_render",
@@ -160,6 +164,8 @@ def load_hip():
     vp = C.c_void_p
     lib.pathed_hip_init.argtypes = [C.c_int]
     lib.pathed_hip_init.restype = C.c_int
+    lib.pathed_hip_set_bvh_builder.argtypes = [C.c_int]
+    lib.pathed_hip_set_bvh_builder.restype = C.c_int
     lib.pathed_hip_scene_create.argtypes = [C.POINTER(PathedSceneDesc), C.POINTER(vp)]
     lib.pathed_hip_scene_create.restype = C.c_int
     lib.pathed_hip_scene_destroy.argtypes = [vp]

@@ -1,0 +1,33 @@
+// On-GPU BVH build: a linear BVH over 63-bit Morton codes (Karras 2012),
+// leaves of up to four triangles, collapsed on the device to the SAME 4-wide 128-byte node
+// format the host builder (bvh_build.h) emits, so k_trace walks either tree unchanged.
+// Stands in for rtcCommitScene (reference src/scene.cpp:39), which is a serial host phase in the
+// reference; here 5 M triangles take milliseconds instead of seconds.
+//
+// Hits do not depend on the tree: the intersector's acceptance rule is order-independent
+// (DESIGN.md "Intersector specification"), so an image rendered over the LBVH is bit-identical to
+// one rendered over the SAH tree (GPU test); only the traversal cost differs.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+
+namespace pathed {
+
+struct DeviceBvh {
+    float4 *nodes = nullptr;      // nodeCapacity x 8 float4 (hipMalloc'ed; the caller owns it)
+    float4 *leafTris = nullptr;   // 3 float4 per triangle, leaf (= Morton) order
+    size_t nodeCapacity = 0;
+    int nodeCount = 0;
+    int maxDepth = 0;             // 4-wide levels
+    float buildMs = 0.f;          // device time, HIP events around the whole build
+};
+
+// positions / indices are DEVICE pointers (3 floats per vertex, 3 indices per triangle).
+// triangleCount must exceed 4 (smaller meshes go through the host builder).
+hipError_t buildLbvhOnDevice(const float *positions, const uint32_t *indices, uint32_t triangleCount,
+                             hipStream_t stream, DeviceBvh *out, std::string *error);
+
+}  // namespace pathed

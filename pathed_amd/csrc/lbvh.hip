@@ -1,0 +1,508 @@
+// On-GPU linear BVH build for gfx950 (see lbvh.h).  Seven steps, all on one stream:
+//   1 k_lbvh_prims      triangle boxes + centroid bounds (wave min/max, one atomic per wave)
+//   2 k_lbvh_morton     63-bit Morton code of the box centre (21 bits per axis)
+//   3 rocprim radix sort of (code, triangle) pairs
+//   4 k_lbvh_hierarchy  Karras' binary radix tree over the sorted codes (ties broken by position)
+//   5 k_lbvh_fit        boxes bottom-up: the second thread to reach a node merges its children
+//   6 k_lbvh_wide_*     breadth-first collapse to 4-wide nodes, one level per launch pair; ids are
+//                       handed out by an exclusive scan, so the tree is the same every run
+//   7 k_lbvh_leaf_tris  (v0, prim) (e1) (e2) records in leaf order
+// Subtrees of at most four triangles become leaves (their triangles are consecutive in sorted order).
+#include <cstring>
+
+#include <hip/hip_runtime.h>
+#include <rocprim/rocprim.hpp>
+
+#include "lbvh.h"
+
+namespace pathed {
+
+namespace {
+
+constexpr int kLbvhBlock = 256;
+constexpr unsigned int kLeafFlag = 0x80000000u;   // child reference: a single sorted triangle
+constexpr unsigned int kNoChild = 0xFFFFFFFFu;
+constexpr int kLbvhMaxLeaf = 4;                   // as the host builder's default leaf size
+constexpr int kEmptyRef = (int)0x80000000u;       // trace.h kEmptyChild
+
+// float <-> unsigned with the same order
+__device__ inline unsigned int orderedBits(float v)
+{
+    const unsigned int u = __float_as_uint(v);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__host__ __device__ inline float fromOrderedBits(unsigned int u)
+{
+    const unsigned int bits = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u;
+    float v;
+    memcpy(&v, &bits, 4);
+    return v;
+}
+
+__global__ __launch_bounds__(kLbvhBlock) void k_lbvh_prims(
+    const float *positions, const uint32_t *indices, uint32_t n,
+    float4 *boxLo, float4 *boxHi, unsigned int *centroidBounds)
+{
+    const uint32_t i = blockIdx.x * kLbvhBlock + threadIdx.x;
+    const float inf = __builtin_huge_valf();
+    float cmin[3] = { inf, inf, inf }, cmax[3] = { -inf, -inf, -inf };
+    if (i < n) {
+        const uint32_t i0 = indices[3 * (size_t)i + 0], i1 = indices[3 * (size_t)i + 1], i2 = indices[3 * (size_t)i + 2];
+        float lo[3], hi[3];
+        #pragma unroll
+        for (int a = 0; a < 3; a++) {
+            const float c0 = positions[3 * (size_t)i0 + a];
+            const float c1 = positions[3 * (size_t)i1 + a];
+            const float c2 = positions[3 * (size_t)i2 + a];
+            lo[a] = fminf(c0, fminf(c1, c2));
+            hi[a] = fmaxf(c0, fmaxf(c1, c2));
+            const float centre = 0.5f * (lo[a] + hi[a]);   // bvh_build.h: the box centre is the "centroid"
+            cmin[a] = centre;
+            cmax[a] = centre;
+        }
+        boxLo[i] = make_float4(lo[0], lo[1], lo[2], 0.f);
+        boxHi[i] = make_float4(hi[0], hi[1], hi[2], 0.f);
+    }
+    #pragma unroll
+    for (int a = 0; a < 3; a++) {
+        float low = cmin[a], high = cmax[a];
+        #pragma unroll
+        for (int offset = 32; offset > 0; offset >>= 1) {
+            low = fminf(low, __shfl_xor(low, offset));
+            high = fmaxf(high, __shfl_xor(high, offset));
+        }
+        if ((threadIdx.x & 63) == 0 && low <= high) {
+            atomicMin(&centroidBounds[a], orderedBits(low));
+            atomicMax(&centroidBounds[3 + a], orderedBits(high));
+        }
+    }
+}
+
+__device__ inline unsigned long long spread21(unsigned long long v)
+{
+    v &= 0x1FFFFFull;
+    v = (v | (v << 32)) & 0x001F00000000FFFFull;
+    v = (v | (v << 16)) & 0x001F0000FF0000FFull;
+    v = (v | (v << 8)) & 0x100F00F00F00F00Full;
+    v = (v | (v << 4)) & 0x10C30C30C30C30C3ull;
+    v = (v | (v << 2)) & 0x1249249249249249ull;
+    return v;
+}
+
+__global__ __launch_bounds__(kLbvhBlock) void k_lbvh_morton(
+    const float4 *boxLo, const float4 *boxHi, uint32_t n, const unsigned int *centroidBounds,
+    unsigned long long *keys, unsigned int *values)
+{
+    const uint32_t i = blockIdx.x * kLbvhBlock + threadIdx.x;
+    if (i >= n) { return; }
+    const float4 lo = boxLo[i], hi = boxHi[i];
+    const float centre[3] = { 0.5f * (lo.x + hi.x), 0.5f * (lo.y + hi.y), 0.5f * (lo.z + hi.z) };
+    unsigned long long code = 0ull;
+    #pragma unroll
+    for (int a = 0; a < 3; a++) {
+        const float low = fromOrderedBits(centroidBounds[a]);
+        const float high = fromOrderedBits(centroidBounds[3 + a]);
+        const float extent = high - low;
+        float q = extent > 0.f ? (centre[a] - low) / extent * 2097152.f : 0.f;
+        q = fminf(fmaxf(q, 0.f), 2097151.f);   // NaN -> 0
+        code |= spread21((unsigned long long)(unsigned int)q) << (2 - a);
+    }
+    keys[i] = code;
+    values[i] = i;
+}
+
+// length of the common prefix of sorted entries i and j; equal codes fall back to the positions
+__device__ inline int commonPrefix(const unsigned long long *keys, int n, unsigned long long ki, int i, int j)
+{
+    if (j < 0 || j >= n) { return -1; }
+    const unsigned long long kj = keys[j];
+    if (ki == kj) { return 64 + __clz((unsigned int)(i ^ j)); }
+    return __clzll((long long)(ki ^ kj));
+}
+
+// Karras 2012, "Maximizing parallelism in the construction of BVHs, octrees, and k-d trees", §3-4
+__global__ __launch_bounds__(kLbvhBlock) void k_lbvh_hierarchy(
+    const unsigned long long *keys, int n,
+    uint2 *children, int2 *range, int *parentOfInternal, int *parentOfLeaf)
+{
+    const int i = blockIdx.x * kLbvhBlock + threadIdx.x;
+    if (i >= n - 1) { return; }
+    const unsigned long long ki = keys[i];
+    const int direction = commonPrefix(keys, n, ki, i, i + 1) - commonPrefix(keys, n, ki, i, i - 1) >= 0 ? 1 : -1;
+    const int floorPrefix = commonPrefix(keys, n, ki, i, i - direction);
+    int reach = 2;
+    while (commonPrefix(keys, n, ki, i, i + reach * direction) > floorPrefix) { reach *= 2; }
+    int length = 0;
+    for (int step = reach / 2; step >= 1; step /= 2) {
+        if (commonPrefix(keys, n, ki, i, i + (length + step) * direction) > floorPrefix) { length += step; }
+    }
+    const int j = i + length * direction;
+    const int nodePrefix = commonPrefix(keys, n, ki, i, j);
+    int split = 0;
+    for (int step = (length + 1) / 2; ; step = (step + 1) / 2) {
+        if (commonPrefix(keys, n, ki, i, i + (split + step) * direction) > nodePrefix) { split += step; }
+        if (step <= 1) { break; }
+    }
+    const int gamma = i + split * direction + (direction < 0 ? -1 : 0);
+    const int first = i < j ? i : j, last = i < j ? j : i;
+
+    unsigned int left, right;
+    if (first == gamma) { left = (unsigned int)gamma | kLeafFlag; parentOfLeaf[gamma] = i; }
+    else { left = (unsigned int)gamma; parentOfInternal[gamma] = i; }
+    if (last == gamma + 1) { right = (unsigned int)(gamma + 1) | kLeafFlag; parentOfLeaf[gamma + 1] = i; }
+    else { right = (unsigned int)(gamma + 1); parentOfInternal[gamma + 1] = i; }
+    children[i] = make_uint2(left, right);
+    range[i] = make_int2(first, last);
+    if (i == 0) { parentOfInternal[0] = -1; }
+}
+
+// a box another thread of this launch may have written: read it past the (non-coherent) vector L1
+__device__ inline float loadCoherent(const float *address)
+{
+    return __hip_atomic_load(address, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ __launch_bounds__(kLbvhBlock) void k_lbvh_fit(
+    int n, const unsigned int *sorted, const float4 *boxLo, const float4 *boxHi,
+    const uint2 *children, const int *parentOfInternal, const int *parentOfLeaf,
+    float4 *nodeLo, float4 *nodeHi, unsigned int *arrivals)
+{
+    const int i = blockIdx.x * kLbvhBlock + threadIdx.x;
+    if (i >= n) { return; }
+    int node = parentOfLeaf[i];
+    // every thread either stops at a node it is first to reach or climbs one level: the loop ends
+    while (node >= 0) {
+        __threadfence();                                   // our box below `node` is visible ...
+        const unsigned int earlier = atomicAdd(&arrivals[node], 1u);
+        if (earlier == 0u) { return; }                     // ... the sibling's thread will merge
+        __threadfence();
+        const uint2 pair = children[node];
+        float lo[3], hi[3];
+        #pragma unroll
+        for (int side = 0; side < 2; side++) {
+            const unsigned int ref = side == 0 ? pair.x : pair.y;
+            float clo[3], chi[3];
+            if (ref & kLeafFlag) {
+                const unsigned int tri = sorted[ref & ~kLeafFlag];
+                const float4 a = boxLo[tri], b = boxHi[tri];
+                clo[0] = a.x; clo[1] = a.y; clo[2] = a.z;
+                chi[0] = b.x; chi[1] = b.y; chi[2] = b.z;
+            } else {
+                const float *a = reinterpret_cast<const float *>(nodeLo + ref);
+                const float *b = reinterpret_cast<const float *>(nodeHi + ref);
+                #pragma unroll
+                for (int k = 0; k < 3; k++) { clo[k] = loadCoherent(a + k); chi[k] = loadCoherent(b + k); }
+            }
+            #pragma unroll
+            for (int k = 0; k < 3; k++) {
+                lo[k] = side == 0 ? clo[k] : fminf(lo[k], clo[k]);
+                hi[k] = side == 0 ? chi[k] : fmaxf(hi[k], chi[k]);
+            }
+        }
+        nodeLo[node] = make_float4(lo[0], lo[1], lo[2], 0.f);
+        nodeHi[node] = make_float4(hi[0], hi[1], hi[2], 0.f);
+        node = parentOfInternal[node];
+    }
+}
+
+// binary nodes that stay inner nodes of the wide tree (more than kLbvhMaxLeaf triangles below)
+__global__ __launch_bounds__(kLbvhBlock) void k_lbvh_count_inner(const int2 *range, int nInternal, unsigned int *count)
+{
+    const int i = blockIdx.x * kLbvhBlock + threadIdx.x;
+    const bool inner = i < nInternal && (range[i].y - range[i].x + 1) > kLbvhMaxLeaf;
+    const unsigned long long mask = __ballot(inner);
+    if ((threadIdx.x & 63) == 0 && mask != 0ull) { atomicAdd(count, (unsigned int)__popcll(mask)); }
+}
+
+struct WideInputs {
+    const uint2 *children;
+    const int2 *range;
+    const float4 *nodeLo, *nodeHi;
+    const float4 *boxLo, *boxHi;
+    const unsigned int *sorted;
+};
+
+__device__ inline bool isInnerRef(const WideInputs &in, unsigned int ref)
+{
+    if (ref == kNoChild || (ref & kLeafFlag)) { return false; }
+    const int2 r = in.range[ref];
+    return r.y - r.x + 1 > kLbvhMaxLeaf;
+}
+
+// A wide node adopts the two children of its binary root, then keeps replacing the inner child
+// with the largest box by that child's two children until it has four (bvh_build.h, same rule).
+__global__ __launch_bounds__(kLbvhBlock) void k_lbvh_wide_children(
+    WideInputs in, const unsigned int *frontier, unsigned int m, uint4 *adopted, unsigned int *innerCount)
+{
+    const unsigned int e = blockIdx.x * kLbvhBlock + threadIdx.x;
+    if (e >= m) { return; }
+    const uint2 pair = in.children[frontier[e]];
+    unsigned int c0 = pair.x, c1 = pair.y, c2 = kNoChild, c3 = kNoChild;
+    #pragma unroll
+    for (int round = 0; round < 2; round++) {
+        // slot to fill this round: 2, then 3
+        int pick = -1;
+        float pickArea = -1.f;
+        #pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const unsigned int ref = k == 0 ? c0 : k == 1 ? c1 : c2;
+            if (k >= 2 + round || !isInnerRef(in, ref)) { continue; }
+            const float4 lo = in.nodeLo[ref], hi = in.nodeHi[ref];
+            const float dx = hi.x - lo.x, dy = hi.y - lo.y, dz = hi.z - lo.z;
+            const float area = dx * dy + dy * dz + dz * dx;
+            if (area > pickArea) { pickArea = area; pick = k; }
+        }
+        if (pick < 0) { break; }
+        const unsigned int opened = pick == 0 ? c0 : pick == 1 ? c1 : c2;
+        const uint2 inside = in.children[opened];
+        if (pick == 0) { c0 = inside.x; } else if (pick == 1) { c1 = inside.x; } else { c2 = inside.x; }
+        if (round == 0) { c2 = inside.y; } else { c3 = inside.y; }
+    }
+    adopted[e] = make_uint4(c0, c1, c2, c3);
+    innerCount[e] = (isInnerRef(in, c0) ? 1u : 0u) + (isInnerRef(in, c1) ? 1u : 0u)
+        + (isInnerRef(in, c2) ? 1u : 0u) + (isInnerRef(in, c3) ? 1u : 0u);
+}
+
+__global__ __launch_bounds__(kLbvhBlock) void k_lbvh_wide_emit(
+    WideInputs in, unsigned int m, unsigned int levelBase,
+    const uint4 *adopted, const unsigned int *innerCount, const unsigned int *childBase,
+    unsigned int *nextFrontier, unsigned int *nextCount, float4 *nodesOut)
+{
+    const unsigned int e = blockIdx.x * kLbvhBlock + threadIdx.x;
+    if (e >= m) { return; }
+    const uint4 four = adopted[e];
+    const unsigned int base = childBase[e];
+    unsigned int rank = 0;
+    float lo[3][4], hi[3][4];
+    int refs[4];
+    #pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const unsigned int ref = k == 0 ? four.x : k == 1 ? four.y : k == 2 ? four.z : four.w;
+        float4 boxLow = make_float4(0.f, 0.f, 0.f, 0.f), boxHigh = boxLow;
+        refs[k] = kEmptyRef;
+        bool present = ref != kNoChild;
+        if (present) {
+            if (ref & kLeafFlag) {
+                const unsigned int position = ref & ~kLeafFlag;
+                const unsigned int tri = in.sorted[position];
+                boxLow = in.boxLo[tri];
+                boxHigh = in.boxHi[tri];
+                refs[k] = -(int)((position << 3) | 1u) - 1;   // trace.h encodeLeaf
+            } else {
+                const int2 r = in.range[ref];
+                const int count = r.y - r.x + 1;
+                boxLow = in.nodeLo[ref];
+                boxHigh = in.nodeHi[ref];
+                if (count <= kLbvhMaxLeaf) {
+                    refs[k] = -(int)(((unsigned int)r.x << 3) | (unsigned int)count) - 1;
+                } else {
+                    refs[k] = (int)(levelBase + m + base + rank);   // next level's ids follow this level's
+                    nextFrontier[base + rank] = ref;
+                    rank++;
+                }
+            }
+        }
+        const float low[3] = { boxLow.x, boxLow.y, boxLow.z }, high[3] = { boxHigh.x, boxHigh.y, boxHigh.z };
+        #pragma unroll
+        for (int a = 0; a < 3; a++) {
+            // bvh_build.h padBox: a hit computed in fp32 on a face lying in a box plane must survive the slab test
+            const float pad = 1e-5f * fmaxf(1.f, fmaxf(fabsf(low[a]), fabsf(high[a])));
+            lo[a][k] = present ? low[a] - pad : 0.f;
+            hi[a][k] = present ? high[a] + pad : 0.f;
+        }
+    }
+    float4 *node = nodesOut + (size_t)8 * (levelBase + e);
+    #pragma unroll
+    for (int a = 0; a < 3; a++) {
+        node[a] = make_float4(lo[a][0], lo[a][1], lo[a][2], lo[a][3]);
+        node[3 + a] = make_float4(hi[a][0], hi[a][1], hi[a][2], hi[a][3]);
+    }
+    node[6] = make_float4(__int_as_float(refs[0]), __int_as_float(refs[1]), __int_as_float(refs[2]), __int_as_float(refs[3]));
+    node[7] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (e == m - 1) { *nextCount = base + innerCount[e]; }
+}
+
+__global__ __launch_bounds__(kLbvhBlock) void k_lbvh_leaf_tris(
+    const float *positions, const uint32_t *indices, const unsigned int *sorted, uint32_t n, float4 *leafTris)
+{
+    const uint32_t i = blockIdx.x * kLbvhBlock + threadIdx.x;
+    if (i >= n) { return; }
+    const unsigned int prim = sorted[i];
+    const float *v0 = positions + 3 * (size_t)indices[3 * (size_t)prim + 0];
+    const float *v1 = positions + 3 * (size_t)indices[3 * (size_t)prim + 1];
+    const float *v2 = positions + 3 * (size_t)indices[3 * (size_t)prim + 2];
+    const float ax = v0[0], ay = v0[1], az = v0[2];
+    leafTris[3 * (size_t)i + 0] = make_float4(ax, ay, az, __int_as_float((int)prim));
+    leafTris[3 * (size_t)i + 1] = make_float4(v1[0] - ax, v1[1] - ay, v1[2] - az, 0.f);
+    leafTris[3 * (size_t)i + 2] = make_float4(v2[0] - ax, v2[1] - ay, v2[2] - az, 0.f);
+}
+
+struct Scratch {
+    void *pointers[24];
+    int used = 0;
+    hipError_t status = hipSuccess;
+
+    template <typename T>
+    T *get(size_t count)
+    {
+        if (status != hipSuccess) { return nullptr; }
+        void *p = nullptr;
+        status = hipMalloc(&p, (count ? count : 1) * sizeof(T));
+        if (status != hipSuccess) { return nullptr; }
+        pointers[used++] = p;
+        return static_cast<T *>(p);
+    }
+
+    ~Scratch()
+    {
+        for (int i = 0; i < used; i++) { (void)hipFree(pointers[i]); }
+    }
+};
+
+inline unsigned int blocksFor(size_t n) { return (unsigned int)((n + kLbvhBlock - 1) / kLbvhBlock); }
+
+}  // namespace
+
+hipError_t buildLbvhOnDevice(const float *positions, const uint32_t *indices, uint32_t triangleCount,
+                             hipStream_t stream, DeviceBvh *out, std::string *error)
+{
+    auto failed = [&](hipError_t status, const char *what) {
+        if (error) { *error = std::string("lbvh: ") + what + ": " + hipGetErrorString(status); }
+        if (out->nodes) { (void)hipFree(out->nodes); out->nodes = nullptr; }
+        if (out->leafTris) { (void)hipFree(out->leafTris); out->leafTris = nullptr; }
+        return status == hipSuccess ? hipErrorInvalidValue : status;
+    };
+    *out = DeviceBvh();
+    const uint32_t n = triangleCount;
+    if (n <= (uint32_t)kLbvhMaxLeaf) { return failed(hipErrorInvalidValue, "fewer than five triangles"); }
+    if (n >= (1u << 28)) { return failed(hipErrorInvalidValue, "more than 2^28 triangles"); }
+
+    hipEvent_t started = nullptr, finished = nullptr;
+    hipError_t status;
+    if ((status = hipEventCreate(&started)) != hipSuccess) { return failed(status, "event"); }
+    if ((status = hipEventCreate(&finished)) != hipSuccess) { (void)hipEventDestroy(started); return failed(status, "event"); }
+    struct EventGuard {
+        hipEvent_t a, b;
+        ~EventGuard() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); }
+    } guard { started, finished };
+    (void)hipEventRecord(started, stream);
+
+    Scratch scratch;
+    float4 *boxLo = scratch.get<float4>(n);
+    float4 *boxHi = scratch.get<float4>(n);
+    unsigned int *words = scratch.get<unsigned int>(16);   // 0..5 centroid bounds, 6 inner count, 7 next frontier size
+    unsigned long long *keysIn = scratch.get<unsigned long long>(n);
+    unsigned long long *keysOut = scratch.get<unsigned long long>(n);
+    unsigned int *valuesIn = scratch.get<unsigned int>(n);
+    unsigned int *sorted = scratch.get<unsigned int>(n);
+    uint2 *children = scratch.get<uint2>(n - 1);
+    int2 *range = scratch.get<int2>(n - 1);
+    int *parentOfInternal = scratch.get<int>(n - 1);
+    int *parentOfLeaf = scratch.get<int>(n);
+    float4 *nodeLo = scratch.get<float4>(n - 1);
+    float4 *nodeHi = scratch.get<float4>(n - 1);
+    unsigned int *arrivals = scratch.get<unsigned int>(n - 1);
+    if (scratch.status != hipSuccess) { return failed(scratch.status, "scratch allocation"); }
+
+    // 1-2: boxes, centroid bounds, Morton codes
+    {
+        const unsigned int init[8] = { 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u, 0u, 0u };
+        if ((status = hipMemcpyAsync(words, init, sizeof init, hipMemcpyHostToDevice, stream)) != hipSuccess) { return failed(status, "init"); }
+        if ((status = hipStreamSynchronize(stream)) != hipSuccess) { return failed(status, "init"); }   // `init` is on this stack frame
+    }
+    hipLaunchKernelGGL(k_lbvh_prims, dim3(blocksFor(n)), dim3(kLbvhBlock), 0, stream, positions, indices, n, boxLo, boxHi, words);
+    hipLaunchKernelGGL(k_lbvh_morton, dim3(blocksFor(n)), dim3(kLbvhBlock), 0, stream, boxLo, boxHi, n, words, keysIn, valuesIn);
+
+    // 3: sort
+    {
+        size_t bytes = 0;
+        if ((status = rocprim::radix_sort_pairs(nullptr, bytes, keysIn, keysOut, valuesIn, sorted, (size_t)n, 0u, 63u, stream)) != hipSuccess) {
+            return failed(status, "radix sort (query)");
+        }
+        void *temporary = scratch.get<unsigned char>(bytes);
+        if (scratch.status != hipSuccess) { return failed(scratch.status, "radix sort scratch"); }
+        if ((status = rocprim::radix_sort_pairs(temporary, bytes, keysIn, keysOut, valuesIn, sorted, (size_t)n, 0u, 63u, stream)) != hipSuccess) {
+            return failed(status, "radix sort");
+        }
+    }
+
+    // 4-5: hierarchy, boxes
+    if ((status = hipMemsetAsync(arrivals, 0, (size_t)(n - 1) * sizeof(unsigned int), stream)) != hipSuccess) { return failed(status, "memset"); }
+    hipLaunchKernelGGL(k_lbvh_hierarchy, dim3(blocksFor(n - 1)), dim3(kLbvhBlock), 0, stream,
+                       keysOut, (int)n, children, range, parentOfInternal, parentOfLeaf);
+    hipLaunchKernelGGL(k_lbvh_fit, dim3(blocksFor(n)), dim3(kLbvhBlock), 0, stream,
+                       (int)n, sorted, boxLo, boxHi, children, parentOfInternal, parentOfLeaf, nodeLo, nodeHi, arrivals);
+
+    // 6: wide nodes.  Every wide node is rooted at a binary node with more than four triangles
+    // below it, so their number bounds the allocation.
+    hipLaunchKernelGGL(k_lbvh_count_inner, dim3(blocksFor(n - 1)), dim3(kLbvhBlock), 0, stream, range, (int)(n - 1), words + 6);
+    unsigned int capacity = 0;
+    if ((status = hipMemcpyAsync(&capacity, words + 6, sizeof capacity, hipMemcpyDeviceToHost, stream)) != hipSuccess) { return failed(status, "count"); }
+    if ((status = hipStreamSynchronize(stream)) != hipSuccess) { return failed(status, "hierarchy kernels"); }
+    if (capacity == 0) { return failed(hipErrorInvalidValue, "empty hierarchy"); }
+
+    if ((status = hipMalloc((void **)&out->nodes, (size_t)capacity * 8 * sizeof(float4))) != hipSuccess) { return failed(status, "node allocation"); }
+    if ((status = hipMalloc((void **)&out->leafTris, (size_t)n * 3 * sizeof(float4))) != hipSuccess) { return failed(status, "triangle allocation"); }
+    out->nodeCapacity = capacity;
+
+    unsigned int *frontierA = scratch.get<unsigned int>(capacity);
+    unsigned int *frontierB = scratch.get<unsigned int>(capacity);
+    uint4 *adopted = scratch.get<uint4>(capacity);
+    unsigned int *innerCount = scratch.get<unsigned int>(capacity);
+    unsigned int *childBase = scratch.get<unsigned int>(capacity);
+    if (scratch.status != hipSuccess) { return failed(scratch.status, "frontier allocation"); }
+    size_t scanBytes = 0;
+    if ((status = rocprim::exclusive_scan(nullptr, scanBytes, innerCount, childBase, 0u, (size_t)capacity, rocprim::plus<unsigned int>(), stream)) != hipSuccess) {
+        return failed(status, "scan (query)");
+    }
+    void *scanTemporary = scratch.get<unsigned char>(scanBytes);
+    if (scratch.status != hipSuccess) { return failed(scratch.status, "scan scratch"); }
+
+    WideInputs inputs;
+    inputs.children = children;
+    inputs.range = range;
+    inputs.nodeLo = nodeLo;
+    inputs.nodeHi = nodeHi;
+    inputs.boxLo = boxLo;
+    inputs.boxHi = boxHi;
+    inputs.sorted = sorted;
+
+    if ((status = hipMemsetAsync(frontierA, 0, sizeof(unsigned int), stream)) != hipSuccess) { return failed(status, "memset"); }   // the root
+    unsigned int levelBase = 0, m = 1;
+    int depth = 0;
+    unsigned int *frontier = frontierA, *nextFrontier = frontierB;
+    while (m > 0) {
+        if ((size_t)levelBase + m > capacity) { return failed(hipErrorInvalidValue, "wide node count exceeds its bound"); }
+        depth++;
+        hipLaunchKernelGGL(k_lbvh_wide_children, dim3(blocksFor(m)), dim3(kLbvhBlock), 0, stream, inputs, frontier, m, adopted, innerCount);
+        size_t bytes = scanBytes;
+        if ((status = rocprim::exclusive_scan(scanTemporary, bytes, innerCount, childBase, 0u, (size_t)m, rocprim::plus<unsigned int>(), stream)) != hipSuccess) {
+            return failed(status, "scan");
+        }
+        hipLaunchKernelGGL(k_lbvh_wide_emit, dim3(blocksFor(m)), dim3(kLbvhBlock), 0, stream,
+                           inputs, m, levelBase, adopted, innerCount, childBase, nextFrontier, words + 7, out->nodes);
+        unsigned int next = 0;
+        if ((status = hipMemcpyAsync(&next, words + 7, sizeof next, hipMemcpyDeviceToHost, stream)) != hipSuccess) { return failed(status, "frontier size"); }
+        if ((status = hipStreamSynchronize(stream)) != hipSuccess) { return failed(status, "collapse kernels"); }
+        levelBase += m;
+        m = next;
+        unsigned int *swap = frontier;
+        frontier = nextFrontier;
+        nextFrontier = swap;
+        if (depth > 4096) { return failed(hipErrorInvalidValue, "runaway hierarchy depth"); }
+    }
+    out->nodeCount = (int)levelBase;
+    out->maxDepth = depth;
+
+    // 7: leaf-ordered triangle records
+    hipLaunchKernelGGL(k_lbvh_leaf_tris, dim3(blocksFor(n)), dim3(kLbvhBlock), 0, stream, positions, indices, sorted, n, out->leafTris);
+
+    (void)hipEventRecord(finished, stream);
+    if ((status = hipStreamSynchronize(stream)) != hipSuccess) { return failed(status, "build"); }
+    if ((status = hipGetLastError()) != hipSuccess) { return failed(status, "kernel launch"); }
+    (void)hipEventElapsedTime(&out->buildMs, started, finished);
+    return hipSuccess;
+}
+
+}  // namespace pathed

@@ -5,9 +5,11 @@
 
 #include "bvh_build.h"
 #include "kernels.h"
+#include "lbvh.h"
 
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -20,6 +22,7 @@ namespace {
 
 thread_local std::string g_error;
 int g_device = -1;
+int g_bvhBuilder = PATHED_BVH_SAH_HOST;   // pathed_hip_set_bvh_builder / PATHED_BVH_BUILDER
 
 int fail(int code, const std::string &message)
 {
@@ -131,8 +134,11 @@ struct PathedScene {
     DScene device;
     int width = 0, height = 0;
 
-    // host copies kept for export / introspection
+    // host copy kept for export / introspection (a device-built tree is downloaded on demand)
     FlatBvh bvh;
+    bool bvhOnHost = true;
+    int bvhBuilder = PATHED_BVH_SAH_HOST;
+    double bvhBuildMs = 0.0;
 
     DeviceBuffer<float4> nodes, leafTris, triShade, envRgba;
     DeviceBuffer<DSphere> spheres;
@@ -467,6 +473,13 @@ int pathed_hip_init(int device_id)
     return PATHED_OK;
 }
 
+int pathed_hip_set_bvh_builder(int builder)
+{
+    if (builder != PATHED_BVH_SAH_HOST && builder != PATHED_BVH_LBVH_DEVICE) { return fail(PATHED_E_INVALID, "unknown BVH builder"); }
+    g_bvhBuilder = builder;
+    return PATHED_OK;
+}
+
 int pathed_hip_scene_create(const PathedSceneDesc *desc, PathedScene **out)
 {
     if (!out) { return fail(PATHED_E_INVALID, "out pointer is null"); }
@@ -596,15 +609,46 @@ int pathed_hip_scene_create(const PathedSceneDesc *desc, PathedScene **out)
         lights.push_back({ 2, 0 });
     }
 
-    scene->bvh = buildBvh(desc->positions, desc->indices, desc->n_triangles);
-
     auto fail_cleanup = [&](hipError_t status, const char *what) {
         delete scene;
         return fail(PATHED_E_DEVICE, std::string(what) + ": " + hipGetErrorString(status));
     };
 
     hipError_t status;
-    {
+    int builder = g_bvhBuilder;
+    if (const char *text = getenv("PATHED_BVH_BUILDER")) {
+        if (!strcmp(text, "lbvh")) { builder = PATHED_BVH_LBVH_DEVICE; }
+        else if (!strcmp(text, "sah")) { builder = PATHED_BVH_SAH_HOST; }
+    }
+    // tiny meshes take the all-triangles kernel, which wants the host copy of the records
+    if (desc->n_triangles <= (uint32_t)kBruteForceMaxTris) { builder = PATHED_BVH_SAH_HOST; }
+    scene->bvhBuilder = builder;
+    if (builder == PATHED_BVH_LBVH_DEVICE) {
+        // rtcCommitScene's stand-in on the device (lbvh.h): upload the soup, build, keep the result in place
+        DeviceBuffer<float> devicePositions;
+        DeviceBuffer<uint32_t> deviceIndices;
+        status = devicePositions.allocate((size_t)3 * desc->n_vertices);
+        if (status == hipSuccess) { status = deviceIndices.allocate((size_t)3 * desc->n_triangles); }
+        if (status == hipSuccess) { status = hipMemcpy(devicePositions.ptr, desc->positions, (size_t)3 * desc->n_vertices * sizeof(float), hipMemcpyHostToDevice); }
+        if (status == hipSuccess) { status = hipMemcpy(deviceIndices.ptr, desc->indices, (size_t)3 * desc->n_triangles * sizeof(uint32_t), hipMemcpyHostToDevice); }
+        DeviceBvh built;
+        std::string message;
+        if (status == hipSuccess) { status = buildLbvhOnDevice(devicePositions.ptr, deviceIndices.ptr, desc->n_triangles, nullptr, &built, &message); }
+        devicePositions.release();
+        deviceIndices.release();
+        if (status != hipSuccess) { return fail_cleanup(status, message.empty() ? "device BVH build" : message.c_str()); }
+        scene->nodes.ptr = built.nodes;
+        scene->nodes.count = built.nodeCapacity * 8;
+        scene->leafTris.ptr = built.leafTris;
+        scene->leafTris.count = (size_t)desc->n_triangles * 3;
+        scene->bvh.nodeCount = built.nodeCount;
+        scene->bvh.maxDepth = built.maxDepth;
+        scene->bvhOnHost = false;
+        scene->bvhBuildMs = built.buildMs;
+    } else {
+        const auto buildStart = std::chrono::steady_clock::now();
+        scene->bvh = buildBvh(desc->positions, desc->indices, desc->n_triangles);
+        scene->bvhBuildMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - buildStart).count();
         std::vector<float4> nodes(scene->bvh.nodes.size() / 4), tris(scene->bvh.leafTris.size() / 4);
         std::memcpy(nodes.data(), scene->bvh.nodes.data(), scene->bvh.nodes.size() * sizeof(float));
         std::memcpy(tris.data(), scene->bvh.leafTris.data(), scene->bvh.leafTris.size() * sizeof(float));
@@ -1001,6 +1045,9 @@ int pathed_hip_get_stats(PathedScene *scene, PathedStats *out)
     out->scene_in_lds = scene->bruteForce ? 2u : (scene->sceneInLds ? 1u : 0u);
     out->max_boxes_per_ray = device[kStatMaxBoxes];
     out->parked_rays = device[kStatParked];
+    out->bvh_build_ms = scene->bvhBuildMs;
+    out->bvh_builder = (uint32_t)scene->bvhBuilder;
+    out->reserved0 = 0;
     if (getenv("PATHED_DEBUG_STATS")) {
         fprintf(stderr, "[pathed] wave steps %llu lane steps %llu (lane utilisation %.3f) refill rounds %llu\n",
                 device[kStatWaveSteps], device[kStatLaneSteps],
@@ -1019,6 +1066,14 @@ int pathed_hip_get_stats(PathedScene *scene, PathedStats *out)
 int pathed_hip_scene_export_bvh(PathedScene *scene, float *nodes, size_t *n_nodes, float *tris, size_t *n_tris)
 {
     if (!scene || !n_nodes || !n_tris) { return fail(PATHED_E_INVALID, "null argument"); }
+    if (!scene->bvhOnHost) {
+        // a device-built tree: fetch it once
+        scene->bvh.nodes.resize((size_t)scene->bvh.nodeCount * kNodeFloats);
+        scene->bvh.leafTris.resize((size_t)scene->device.nTris * 12);
+        HIP_TRY(hipMemcpy(scene->bvh.nodes.data(), scene->nodes.ptr, scene->bvh.nodes.size() * sizeof(float), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(scene->bvh.leafTris.data(), scene->leafTris.ptr, scene->bvh.leafTris.size() * sizeof(float), hipMemcpyDeviceToHost));
+        scene->bvhOnHost = true;
+    }
     const size_t nodeCount = (size_t)scene->bvh.nodeCount;
     const size_t triCount = scene->bvh.leafTris.size() / 12;
     if (nodes) {

@@ -27,12 +27,18 @@ def _check(lib, code, what):
 class HipScene:
     """A scene uploaded to one GPU (PathedScene handle)."""
 
-    def __init__(self, desc_pointer, device=None):
+    BVH_BUILDERS = {"sah": 0, "lbvh": 1}  # PATHED_BVH_SAH_HOST / PATHED_BVH_LBVH_DEVICE
+
+    def __init__(self, desc_pointer, device=None, bvh_builder="sah"):
         self._lib = _capi.load_hip()
         if device is not None:
             _check(self._lib, self._lib.pathed_hip_init(int(device)), "pathed_hip_init")
         handle = C.c_void_p()
-        _check(self._lib, self._lib.pathed_hip_scene_create(desc_pointer, C.byref(handle)), "pathed_hip_scene_create")
+        _check(self._lib, self._lib.pathed_hip_set_bvh_builder(self.BVH_BUILDERS[bvh_builder]), "pathed_hip_set_bvh_builder")
+        try:
+            _check(self._lib, self._lib.pathed_hip_scene_create(desc_pointer, C.byref(handle)), "pathed_hip_scene_create")
+        finally:
+            self._lib.pathed_hip_set_bvh_builder(0)
         self._handle = handle
         self.width = int(desc_pointer.contents.camera.width)
         self.height = int(desc_pointer.contents.camera.height)

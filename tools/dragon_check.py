@@ -10,6 +10,7 @@ parser.add_argument("--width", type=int, default=1920)
 parser.add_argument("--height", type=int, default=1080)
 parser.add_argument("--spp", type=int, default=16)
 parser.add_argument("--no-oracle", action="store_true")
+parser.add_argument("--builder", default="sah", choices=["sah", "lbvh"], help="host binned-SAH build or the on-GPU LBVH build")
 args = parser.parse_args()
 
 t = time.time()
@@ -21,7 +22,7 @@ from pathed_amd.integrator import HipScene
 import oracle_lib
 
 t = time.time(); scene = LoadedScene("scenes/dragon-standin.json", args.width, args.height); print("load %.1fs tris=%d" % (time.time() - t, scene.n_triangles))
-t = time.time(); gpu = HipScene(scene.desc, device=0); print("scene_create (BVH build + upload) %.1fs" % (time.time() - t))
+t = time.time(); gpu = HipScene(scene.desc, device=0, bvh_builder=args.builder); print("scene_create (%s BVH build + upload) %.2fs, of which build %.1f ms" % (args.builder, time.time() - t, gpu.stats()["bvh_build_ms"]))
 print(gpu.stats())
 
 if not args.no_oracle:
