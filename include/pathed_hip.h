@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define PATHED_ABI_VERSION 1
+#define PATHED_ABI_VERSION 2   /* 2: image-texture albedo (PathedTexture, PathedMaterial.texture) */
 
 /* error codes */
 #define PATHED_OK            0
@@ -56,6 +56,7 @@ extern "C" {
 /* Lambertian albedo source (reference include/albedo.h, src/checkerboard.cpp:9-20) */
 #define PATHED_ALBEDO_CONSTANT     0
 #define PATHED_ALBEDO_CHECKERBOARD 1
+#define PATHED_ALBEDO_TEXTURE      2   /* reference src/texture.cpp:33-49 */
 
 /* microfacet distribution (reference src/scene_parser.cpp:669-683) */
 #define PATHED_DIST_BECKMANN 0
@@ -92,7 +93,17 @@ typedef struct PathedMaterial {
     float alpha;             /* Beckmann alpha                                 */
     float ior;               /* Glass ior (reference default 1.4, glass.cpp:16-18) */
     int32_t distribution;    /* PATHED_DIST_*                                  */
+    int32_t texture;         /* PATHED_ALBEDO_TEXTURE: index into PathedSceneDesc.textures */
 } PathedMaterial;
+
+/* Image texture — reference Texture (src/texture.cpp): what stbi_load(path, .., 3) returns,
+ * 8-bit RGB, row 0 = first row of the file.  The lookup wraps uv, flips v, rounds to the
+ * nearest texel and applies powf(x / 255, 2.2) (texture.cpp:33-49). */
+typedef struct PathedTexture {
+    int32_t width;           /* 1 .. 65535                                     */
+    int32_t height;
+    const uint8_t *rgb;      /* 3*width*height                                 */
+} PathedTexture;
 
 /* Sphere — reference Sphere (src/sphere.cpp).  The reference intersects the
  * TRANSFORMED centre (sphere.cpp:30-35) but samples the UNTRANSFORMED m_center
@@ -153,6 +164,9 @@ typedef struct PathedSceneDesc {
     const PathedMaterial *materials;
 
     const PathedEnvLight *env; /* NULL = no environment light                   */
+
+    uint32_t n_textures;
+    const PathedTexture *textures;
 } PathedSceneDesc;
 
 typedef struct PathedScene PathedScene;   /* opaque; owns all device memory     */

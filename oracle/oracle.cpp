@@ -411,6 +411,9 @@ struct Material {
     float alpha;
     float ior;
     int distribution; /* PATHED_DIST_* */
+    /* image texture (PATHED_ALBEDO_TEXTURE): 8-bit RGB as stbi_load returns it; not owned */
+    const unsigned char *texData;
+    int texWidth, texHeight;
 };
 
 Material materialFromDesc(const PathedMaterial &m)
@@ -418,6 +421,9 @@ Material materialFromDesc(const PathedMaterial &m)
     Material out;
     out.type = m.type;
     out.albedoType = m.albedo_type;
+    out.texData = nullptr;
+    out.texWidth = 0;
+    out.texHeight = 0;
     out.diffuse = col(m.diffuse[0], m.diffuse[1], m.diffuse[2]);
     out.emit = col(m.emit[0], m.emit[1], m.emit[2]);
     out.checkerOn = col(m.checker_on[0], m.checker_on[1], m.checker_on[2]);
@@ -451,6 +457,23 @@ Color checkerboardLookup(const Material &m, const Intersection &isect)
     return m.checkerOff;
 }
 
+/* Texture::lookup, src/texture.cpp:33-49.  The clamp only matters for non-finite uv, where
+ * the reference reads out of bounds. */
+Color textureLookup(const Material &m, const Intersection &isect)
+{
+    /* Handle wrapping (:37-39) */
+    const float u = isect.u - (int)floorf(isect.u);
+    const float v = 1.f - (isect.v - (int)floorf(isect.v));
+
+    int x = (int)roundf(u * (m.texWidth - 1));
+    int y = (int)roundf(v * (m.texHeight - 1));
+    x = std::min(std::max(x, 0), m.texWidth - 1);
+    y = std::min(std::max(y, 0), m.texHeight - 1);
+
+    const unsigned char *texel = m.texData + 3 * ((size_t)y * m.texWidth + x);
+    return col(powf(texel[0] / 255.f, 2.2f), powf(texel[1] / 255.f, 2.2f), powf(texel[2] / 255.f, 2.2f));
+}
+
 /* src/lambertian.cpp:16-40 */
 Color lambertianF(const Material &m, const Intersection &isect, Vec3 wiWorld, float *pdf)
 {
@@ -461,6 +484,7 @@ Color lambertianF(const Material &m, const Intersection &isect, Vec3 wiWorld, fl
     *pdf = cosineHemispherePdf(wi);
 
     if (m.albedoType == PATHED_ALBEDO_CHECKERBOARD) { return checkerboardLookup(m, isect) / kPi; }
+    if (m.albedoType == PATHED_ALBEDO_TEXTURE) { return textureLookup(m, isect) / kPi; }
     return m.diffuse / kPi;
 }
 
@@ -1314,6 +1338,7 @@ struct OracleSceneImpl {
     std::vector<Triangle> triangles;
     std::vector<Sphere> spheres;
     std::vector<Material> materials;
+    std::vector<std::vector<unsigned char>> textures; /* copies: the caller owns the description */
     Bvh bvh;
 
     struct Light {
@@ -1742,7 +1767,25 @@ OracleScene *oracle_scene_create(const PathedSceneDesc *desc)
     impl.height = desc->camera.height;
 
     impl.materials.resize(desc->n_materials);
-    for (uint32_t i = 0; i < desc->n_materials; i++) { impl.materials[i] = materialFromDesc(desc->materials[i]); }
+    impl.textures.resize(desc->n_textures);
+    for (uint32_t t = 0; t < desc->n_textures; t++) {
+        const PathedTexture &texture = desc->textures[t];
+        impl.textures[t].assign(texture.rgb, texture.rgb + (size_t)3 * texture.width * texture.height);
+    }
+    for (uint32_t i = 0; i < desc->n_materials; i++) {
+        impl.materials[i] = materialFromDesc(desc->materials[i]);
+        if (desc->materials[i].albedo_type == PATHED_ALBEDO_TEXTURE) {
+            const int t = desc->materials[i].texture;
+            if (t < 0 || (uint32_t)t >= desc->n_textures) {
+                g_error = "oracle: material texture index out of range";
+                delete scene;
+                return nullptr;
+            }
+            impl.materials[i].texData = impl.textures[(size_t)t].data();
+            impl.materials[i].texWidth = desc->textures[t].width;
+            impl.materials[i].texHeight = desc->textures[t].height;
+        }
+    }
 
     auto vertex = [&](uint32_t index) {
         return v3(desc->positions[3 * index + 0], desc->positions[3 * index + 1], desc->positions[3 * index + 2]);
@@ -2116,6 +2159,26 @@ int oracle_eval(const char *fn, const float *in, int n_in, float *out, int n_out
         if (!need(6, 3)) { return -2; }
         const Vec3 r = reflect(v3(in[0], in[1], in[2]), v3(in[3], in[4], in[5]));
         out[0] = r.x; out[1] = r.y; out[2] = r.z;
+        return 3;
+    }
+    if (name == "texture_lookup") {
+        /* in: width height u v, then 3*width*height texel bytes as floats; out: rgb */
+        if (!need(4, 3)) { return -2; }
+        const int width = (int)in[0], height = (int)in[1];
+        if (width < 1 || height < 1 || n_in < 4 + 3 * width * height) { return -2; }
+        std::vector<unsigned char> bytes((size_t)3 * width * height);
+        for (size_t k = 0; k < bytes.size(); k++) { bytes[k] = (unsigned char)in[4 + k]; }
+        Material m = materialFromFloats(std::vector<float>(20, 0.f).data());
+        m.albedoType = PATHED_ALBEDO_TEXTURE;
+        m.texData = bytes.data();
+        m.texWidth = width;
+        m.texHeight = height;
+        Intersection isect;
+        std::memset(&isect, 0, sizeof isect);
+        isect.u = in[2];
+        isect.v = in[3];
+        const Color c = textureLookup(m, isect);
+        out[0] = c.r; out[1] = c.g; out[2] = c.b;
         return 3;
     }
     if (name == "frame") {

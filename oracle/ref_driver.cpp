@@ -38,12 +38,16 @@
 
 #define TINYEXR_IMPLEMENTATION
 #include "tinyexr.h"
+/* the reference defines the stb_image implementation in its executables (app/main.cpp:16) */
+#define STB_IMAGE_IMPLEMENTATION
+#include "stb_image.h"
 
 #define private public
 #define protected public
 #include "random_generator.h"
 #include "transform.h"
 #include "environment_light.h"
+#include "texture.h"
 #undef private
 #undef protected
 
@@ -585,6 +589,41 @@ int main(int argc, char **argv)
                 push3(in, point); in.push_back(u[0]); in.push_back(u[1]);
                 push3(out, sample.point); push3(out, sample.normal); out.push_back(sample.invPDF);
                 emit("env_sample", in, out);
+            }
+        }
+    }
+
+    /* ---- Texture (src/texture.cpp) on the committed fixture files --------------------- */
+    /* texture_image:  in = file index            out = width height, then the 8-bit RGB texels
+     *                                                  stbi_load(path, .., 3) returned
+     * texture_lookup: in = file index, u, v       out = Texture::lookup rgb */
+    {
+        const std::string directory = (argc > 3) ? argv[3] : "tests/golden/textures";
+        const char *files[] = { "rgb8_7x5.png", "rgba16_4x3.png", "greyalpha8_3x4.png", "grey2_5x6.png",
+                                "palette4_5x4.png", "rgb_2x3.ppm", "wood_48x32.png" };
+        for (int f = 0; f < 7; f++) {
+            const std::string path = directory + "/" + files[f];
+            std::ifstream probe(path);
+            if (!probe.good()) { fprintf(stderr, "texture fixture missing: %s\n", path.c_str()); continue; }
+            Texture texture(path);
+            texture.load();
+            std::vector<float> image = { (float)texture.m_width, (float)texture.m_height };
+            for (int i = 0; i < 3 * texture.m_width * texture.m_height; i++) { image.push_back((float)texture.m_data[i]); }
+            emit("texture_image", { (float)f }, image);
+
+            Intersection isect(true, 1.f, Point3(0.f, 0.f, 0.f), Vector3(0.f, 1.f, 0.f), Vector3(0.f, 1.f, 0.f),
+                               Vector3(0.f, 1.f, 0.f), UV({ 0.f, 0.f }), nullptr, nullptr);
+            const int lookups = f == 6 ? 24 : 40;
+            for (int i = 0; i < lookups; i++) {
+                float u = uniform01(), v = uniform01();
+                if (i % 4 == 1) { u = u * 6.f - 3.f; v = v * 6.f - 3.f; }          /* wrapping, negative uv */
+                if (i % 8 == 2) { u = (float)(i % 3); v = (float)(i % 5) - 2.f; }   /* integers: the flipped v lands on 1 */
+                if (i % 8 == 6) { u = (0.5f + (float)(i % texture.m_width)) / (float)(texture.m_width - 1 > 0 ? texture.m_width - 1 : 1); }  /* rounding ties */
+                isect.uv = { u, v };
+                const Color c = texture.lookup(isect);
+                std::vector<float> out;
+                push3(out, c);
+                emit("texture_lookup", { (float)f, u, v }, out);
             }
         }
     }

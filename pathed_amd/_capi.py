@@ -11,10 +11,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 REPO_ROOT = os.path.dirname(_HERE)
 LIB_DIR = os.path.join(_HERE, "lib")
 
-PATHED_ABI_VERSION = 1
+PATHED_ABI_VERSION = 2
 
 MAT_LAMBERTIAN, MAT_OREN_NAYAR, MAT_MICROFACET, MAT_PLASTIC, MAT_GLASS, MAT_MIRROR = range(6)
-ALBEDO_CONSTANT, ALBEDO_CHECKERBOARD = 0, 1
+ALBEDO_CONSTANT, ALBEDO_CHECKERBOARD, ALBEDO_TEXTURE = 0, 1, 2
 GEOM_MESH, GEOM_SPHERE = 0, 1
 
 
@@ -43,6 +43,7 @@ class PathedMaterial(C.Structure):
         ("alpha", C.c_float),
         ("ior", C.c_float),
         ("distribution", C.c_int32),
+        ("texture", C.c_int32),
     ]
 
 
@@ -70,6 +71,14 @@ class PathedEnvLight(C.Structure):
     ]
 
 
+class PathedTexture(C.Structure):
+    _fields_ = [
+        ("width", C.c_int32),
+        ("height", C.c_int32),
+        ("rgb", C.POINTER(C.c_uint8)),
+    ]
+
+
 class PathedSceneDesc(C.Structure):
     _fields_ = [
         ("abi_version", C.c_uint32),
@@ -88,6 +97,8 @@ class PathedSceneDesc(C.Structure):
         ("n_materials", C.c_uint32),
         ("materials", C.POINTER(PathedMaterial)),
         ("env", C.POINTER(PathedEnvLight)),
+        ("n_textures", C.c_uint32),
+        ("textures", C.POINTER(PathedTexture)),
     ]
 
 
@@ -225,6 +236,9 @@ def load_host():
     if hasattr(lib, "pathed_host_write_exr_half_bgr"):
         lib.pathed_host_write_exr_half_bgr.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_float)]
         lib.pathed_host_write_exr_half_bgr.restype = C.c_int
+    if hasattr(lib, "pathed_host_load_image_rgb8"):
+        lib.pathed_host_load_image_rgb8.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_uint8), C.c_size_t]
+        lib.pathed_host_load_image_rgb8.restype = C.c_int
     if hasattr(lib, "pathed_host_read_exr_rgba"):
         lib.pathed_host_read_exr_rgba.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_float), C.c_size_t]
         lib.pathed_host_read_exr_rgba.restype = C.c_int

@@ -21,8 +21,10 @@ struct DMaterial {
     float checkerOff[3];
     float checkerResV;
     int distribution;        // PATHED_DIST_*: Beckmann or GGX (Microfacet / Plastic)
-    int pad[3];
+    int texSize;             // image texture: width | height << 16
+    const float4 *texels;    // ... its texels, already through powf(x / 255, 2.2) (reference src/texture.cpp:44-48)
 };
+static_assert(sizeof(DMaterial) == 96, "DMaterial is staged in LDS as 24 words");
 
 // per-triangle shading record, indexed by ORIGINAL primitive id (128 B = 8 x float4):
 //   q0 = (p0, material)  q1 = (p1, uv0.u)  q2 = (p2, uv0.v)

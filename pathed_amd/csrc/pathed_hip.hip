@@ -140,7 +140,7 @@ struct PathedScene {
     int bvhBuilder = PATHED_BVH_SAH_HOST;
     double bvhBuildMs = 0.0;
 
-    DeviceBuffer<float4> nodes, leafTris, triShade, envRgba;
+    DeviceBuffer<float4> nodes, leafTris, triShade, envRgba, texels;
     DeviceBuffer<DSphere> spheres;
     DeviceBuffer<DMaterial> materials;
     DeviceBuffer<DLight> lights;
@@ -184,7 +184,7 @@ struct PathedScene {
 
     ~PathedScene()
     {
-        nodes.release(); leafTris.release(); triShade.release(); envRgba.release();
+        nodes.release(); leafTris.release(); triShade.release(); envRgba.release(); texels.release();
         spheres.release(); materials.release(); lights.release();
         thetaCdf.release(); phiCdf.release(); phiEmpty.release(); thetaGuide.release(); phiGuide.release();
         rayO.release(); rayD.release(); hit.release(); mod.release(); thr.release();
@@ -301,10 +301,23 @@ int validate(const PathedSceneDesc *desc)
     for (uint32_t i = 0; i < desc->n_materials; i++) {
         const int type = desc->materials[i].type;
         if (type < PATHED_MAT_LAMBERTIAN || type > PATHED_MAT_MIRROR) { return fail(PATHED_E_UNSUPPORTED, "unknown material type"); }
+        const int albedo = desc->materials[i].albedo_type;
+        if (albedo < PATHED_ALBEDO_CONSTANT || albedo > PATHED_ALBEDO_TEXTURE) { return fail(PATHED_E_UNSUPPORTED, "unknown albedo type"); }
+        if (albedo == PATHED_ALBEDO_TEXTURE) {
+            const int texture = desc->materials[i].texture;
+            if (texture < 0 || (uint32_t)texture >= desc->n_textures || !desc->textures) { return fail(PATHED_E_INVALID, "material texture index out of range"); }
+        }
         const int distribution = desc->materials[i].distribution;
         if ((type == PATHED_MAT_MICROFACET || type == PATHED_MAT_PLASTIC)
             && distribution != PATHED_DIST_BECKMANN && distribution != PATHED_DIST_GGX) {
             return fail(PATHED_E_UNSUPPORTED, "unknown microfacet distribution");
+        }
+    }
+    if (desc->n_textures && !desc->textures) { return fail(PATHED_E_INVALID, "texture array missing"); }
+    for (uint32_t i = 0; i < desc->n_textures; i++) {
+        const PathedTexture &texture = desc->textures[i];
+        if (texture.width < 1 || texture.height < 1 || texture.width > 65535 || texture.height > 65535 || !texture.rgb) {
+            return fail(PATHED_E_INVALID, "texture size must be 1..65535 and its texels present");
         }
     }
     for (uint32_t i = 0; i < desc->n_geoms; i++) {
@@ -458,7 +471,7 @@ extern "C" {
 
 const char *pathed_hip_last_error(void) { return g_error.c_str(); }
 
-const char *pathed_hip_version(void) { return "pathed_hip 0.1.0 (gfx950, abi 1)"; }
+const char *pathed_hip_version(void) { return "pathed_hip 0.2.0 (gfx950, abi 2)"; }
 
 int pathed_hip_init(int device_id)
 {
@@ -504,9 +517,38 @@ int pathed_hip_scene_create(const PathedSceneDesc *desc, PathedScene **out)
     DScene &d = scene->device;
     buildCamera(desc->camera, &d.camera);
 
+    // image textures: one float4 array, texels already through Texture::lookup's
+    // powf(x / 255.f, 2.2f) (reference src/texture.cpp:44-48; 256 possible values per channel)
+    std::vector<size_t> textureOffset(desc->n_textures);
+    {
+        float gammaTable[256];
+        for (int value = 0; value < 256; value++) { gammaTable[value] = powf((unsigned char)value / 255.f, 2.2f); }
+        std::vector<float4> texels;
+        for (uint32_t t = 0; t < desc->n_textures; t++) {
+            const PathedTexture &texture = desc->textures[t];
+            textureOffset[t] = texels.size();
+            const size_t count = (size_t)texture.width * texture.height;
+            for (size_t k = 0; k < count; k++) {
+                texels.push_back(make_float4(gammaTable[texture.rgb[3 * k + 0]], gammaTable[texture.rgb[3 * k + 1]], gammaTable[texture.rgb[3 * k + 2]], 0.f));
+            }
+        }
+        const hipError_t uploaded = scene->texels.upload(texels);
+        if (uploaded != hipSuccess) {
+            delete scene;
+            return fail(PATHED_E_DEVICE, std::string("upload textures: ") + hipGetErrorString(uploaded));
+        }
+    }
+
     // materials
     std::vector<DMaterial> materials(desc->n_materials);
-    for (uint32_t i = 0; i < desc->n_materials; i++) { materials[i] = buildMaterial(desc->materials[i]); }
+    for (uint32_t i = 0; i < desc->n_materials; i++) {
+        materials[i] = buildMaterial(desc->materials[i]);
+        if (desc->materials[i].albedo_type == PATHED_ALBEDO_TEXTURE) {
+            const PathedTexture &texture = desc->textures[desc->materials[i].texture];
+            materials[i].texSize = texture.width | (texture.height << 16);
+            materials[i].texels = scene->texels.ptr + textureOffset[(size_t)desc->materials[i].texture];
+        }
+    }
 
     // per-triangle shading records, original primitive order
     std::vector<float4> triShade((size_t)kTriShadeQuads * desc->n_triangles);

@@ -264,6 +264,23 @@ __device__ inline Rgb checkerboardLookup(const DMaterial &m, const Isect &isect)
     return rgb(m.checkerOff[0], m.checkerOff[1], m.checkerOff[2]);
 }
 
+// Texture::lookup, src/texture.cpp:33-49.  The 8-bit texel -> powf(x / 255, 2.2) step has 256
+// possible results per channel; the host applies it once (glibc powf, the function the reference
+// calls), so the device reads finished float texels.  The clamp only matters for non-finite uv,
+// where the reference reads out of bounds.
+__device__ inline Rgb textureLookup(const DMaterial &m, const Isect &isect)
+{
+    const int width = m.texSize & 0xFFFF, height = (m.texSize >> 16) & 0xFFFF;
+    const float u = isect.u - (float)(int)floorf(isect.u);
+    const float v = 1.f - (isect.v - (float)(int)floorf(isect.v));
+    int x = (int)roundf(u * (float)(width - 1));
+    int y = (int)roundf(v * (float)(height - 1));
+    x = imin(imax(x, 0), width - 1);
+    y = imin(imax(y, 0), height - 1);
+    const float4 texel = m.texels[(size_t)y * width + x];
+    return rgb(texel.x, texel.y, texel.z);
+}
+
 // src/lambertian.cpp:16-40
 __device__ inline Rgb lambertianF(const DMaterial &m, const Isect &isect, V3 wiWorld, float *pdf)
 {
@@ -274,6 +291,7 @@ __device__ inline Rgb lambertianF(const DMaterial &m, const Isect &isect, V3 wiW
     *pdf = cosineHemispherePdf(wi);
 
     if (m.albedoType == PATHED_ALBEDO_CHECKERBOARD) { return checkerboardLookup(m, isect) / PATHED_PI; }
+    if (m.albedoType == PATHED_ALBEDO_TEXTURE) { return textureLookup(m, isect) / PATHED_PI; }
     return matDiffuse(m) / PATHED_PI;
 }
 

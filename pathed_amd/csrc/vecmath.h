@@ -70,6 +70,7 @@ __host__ __device__ inline bool isBlack(Rgb c) { return c.r == 0.f && c.g == 0.f
 __host__ __device__ inline float smax(float a, float b) { return (a < b) ? b : a; }
 __host__ __device__ inline float smin(float a, float b) { return (b < a) ? b : a; }
 __host__ __device__ inline int imin(int a, int b) { return (b < a) ? b : a; }
+__host__ __device__ inline int imax(int a, int b) { return (a < b) ? b : a; }
 
 // util::clamp, include/util.h:49-51: std::min(highest, std::max(value, lowest))
 __host__ __device__ inline float clampf(float value, float lowest, float highest)

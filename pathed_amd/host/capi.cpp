@@ -51,6 +51,7 @@ void pathed_host_free_scene(void *handle)
 // ---- job runner (shared by the `pathed` executable and the Python harness) ----------
 
 #include "exr.h"
+#include "image_decode.h"
 #include "integrator.h"
 #include "job.h"
 
@@ -124,6 +125,22 @@ int pathed_host_read_exr_rgba(const char *path, int *width, int *height, float *
     if (rgba) {
         if (capacity < data.size()) { g_hostError = "buffer too small"; return 2; }
         std::memcpy(rgba, data.data(), data.size() * sizeof(float));
+    }
+    return 0;
+}
+
+// 8-bit RGB decode of a texture file (image_decode.h); pass rgb = NULL to query the size
+int pathed_host_load_image_rgb8(const char *path, int *width, int *height, unsigned char *rgb, size_t capacity)
+{
+    std::vector<uint8_t> data;
+    std::string error;
+    if (!pathed::loadImageRgb8(path, width, height, &data, &error)) {
+        g_hostError = error;
+        return 1;
+    }
+    if (rgb) {
+        if (capacity < data.size()) { g_hostError = "buffer too small"; return 2; }
+        std::memcpy(rgb, data.data(), data.size());
     }
     return 0;
 }

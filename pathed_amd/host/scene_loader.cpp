@@ -1,5 +1,7 @@
 #include "scene_loader.h"
 
+#include "image_decode.h"
+
 #include "exr.h"
 #include "json.h"
 #include "transform.h"
@@ -34,6 +36,26 @@ struct LoaderContext {
     {
         scene->materials.push_back(material);
         return (int)scene->materials.size() - 1;
+    }
+
+    // Texture::load, reference src/texture.cpp:12-31 (throws "Error loading texture")
+    int addTexture(const std::string &filename)
+    {
+        const std::string path = resolve(filename);
+        auto found = scene->textureByPath.find(path);
+        if (found != scene->textureByPath.end()) { return found->second; }
+        PathedTexture texture;
+        std::vector<uint8_t> data;
+        std::string error;
+        if (!loadImageRgb8(path, &texture.width, &texture.height, &data, &error)) {
+            throw SceneLoadError("Error loading texture: " + error);
+        }
+        texture.rgb = nullptr;  // set by FlatScene::desc()
+        scene->textures.push_back(texture);
+        scene->textureData.push_back(std::move(data));
+        const int index = (int)scene->textures.size() - 1;
+        scene->textureByPath[path] = index;
+        return index;
     }
 };
 
@@ -223,18 +245,23 @@ int parseMaterial(const Json &json, LoaderContext &context)
         parseColor(json["diffuseReflectance"], kBlack, material.diffuse);
         parseDistribution(json["distribution"], &material);
         if (json["texture"].isString()) {
-            throw SceneLoadError("Unsupported albedo (outside hot-path scope, SURVEY.md §8 f4): image texture");
+            // Plastic(Lambertian(texture, 0), distribution), scene_parser.cpp:624-636
+            material.albedo_type = PATHED_ALBEDO_TEXTURE;
+            material.texture = context.addTexture(json["texture"].asString());
+            for (int i = 0; i < 3; i++) { material.diffuse[i] = 0.f; }
         }
         return context.addMaterial(material);
     } else if (type == "lambertian") {
         PathedMaterial material = blankMaterial(PATHED_MAT_LAMBERTIAN);
         parseColor(json["diffuseReflectance"], kBlack, material.diffuse);
         parseColor(json["emit"], kBlack, material.emit);
-        if (json["texture"].isString()) {
-            throw SceneLoadError("Unsupported albedo (outside hot-path scope, SURVEY.md §8 f4): image texture");
-        }
         const Json &albedo = json["albedo"];
-        if (albedo.isObject() && albedo["type"].isString() && albedo["type"].asString() == "checkerboard") {
+        if (json["texture"].isString()) {
+            // Lambertian(texture, emit), scene_parser.cpp:641-648; takes precedence over "albedo"
+            material.albedo_type = PATHED_ALBEDO_TEXTURE;
+            material.texture = context.addTexture(json["texture"].asString());
+            for (int i = 0; i < 3; i++) { material.diffuse[i] = 0.f; }
+        } else if (albedo.isObject() && albedo["type"].isString() && albedo["type"].asString() == "checkerboard") {
             material.albedo_type = PATHED_ALBEDO_CHECKERBOARD;
             parseColor(albedo["onColor"], kBlack, material.checker_on);
             parseColor(albedo["offColor"], kBlack, material.checker_off);
@@ -826,6 +853,9 @@ PathedSceneDesc FlatScene::desc() const
         const_cast<FlatScene *>(this)->env.rgba = envData.data();
     }
     d.env = hasEnv ? &env : nullptr;
+    for (size_t t = 0; t < textures.size(); t++) { const_cast<FlatScene *>(this)->textures[t].rgb = textureData[t].data(); }
+    d.n_textures = (uint32_t)textures.size();
+    d.textures = textures.data();
     return d;
 }
 

@@ -10,6 +10,7 @@
 //   PLY          reference src/ply_parser.cpp:29-151
 //   quad         reference src/quad.cpp:7-151
 //   sphere       reference src/sphere.cpp:16-48, src/scene_parser.cpp:484-512
+//   textures     reference src/texture.cpp:12-31 (PNG / PNM here, see image_decode.h)
 #pragma once
 
 #include "pathed_hip.h"
@@ -37,6 +38,11 @@ struct FlatScene {
     bool hasEnv = false;
     PathedEnvLight env;
     std::vector<float> envData;
+
+    // image textures (reference src/texture.cpp): 8-bit RGB, one entry per distinct file
+    std::vector<PathedTexture> textures;
+    std::vector<std::vector<uint8_t>> textureData;
+    std::map<std::string, int> textureByPath;
 
     // valid as long as this FlatScene is alive and unmodified
     PathedSceneDesc desc() const;

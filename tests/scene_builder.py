@@ -23,10 +23,21 @@ class BuiltScene:
         self.indices, self.tri_material = [], []
         self.spheres, self.geoms, self.materials = [], [], []
         self.env = None
+        self.textures = []
         self._keep = []
 
+    def texture(self, rgb):
+        """rgb: (H, W, 3) uint8, row 0 = first row of the image file; returns the texture index."""
+        rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+        t = _capi.PathedTexture()
+        t.height, t.width = rgb.shape[:2]
+        t.rgb = rgb.ctypes.data_as(C.POINTER(C.c_uint8))
+        self._keep.append(rgb)
+        self.textures.append(t)
+        return len(self.textures) - 1
+
     def material(self, type_=_capi.MAT_LAMBERTIAN, diffuse=(0.5, 0.5, 0.5), emit=(0, 0, 0), sigma=0.0, alpha=0.1,
-                 ior=1.4, checker=None):
+                 ior=1.4, checker=None, texture=None):
         m = _capi.PathedMaterial()
         m.type = type_
         m.diffuse[:] = diffuse
@@ -37,6 +48,9 @@ class BuiltScene:
             m.checker_on[:] = checker[0]
             m.checker_off[:] = checker[1]
             m.checker_res[:] = checker[2]
+        if texture is not None:
+            m.albedo_type = _capi.ALBEDO_TEXTURE
+            m.texture = texture
         self.materials.append(m)
         return len(self.materials) - 1
 
@@ -102,4 +116,7 @@ class BuiltScene:
         d.n_geoms, d.geoms = len(self.geoms), geom_array
         d.n_materials, d.materials = len(self.materials), material_array
         d.env = C.pointer(self.env) if self.env is not None else None
+        texture_array = (_capi.PathedTexture * max(1, len(self.textures)))(*self.textures)
+        self._keep.append(texture_array)
+        d.n_textures, d.textures = len(self.textures), texture_array
         return C.pointer(d)
