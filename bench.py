@@ -164,6 +164,31 @@ def main():
             if os.path.exists(traffic_path):
                 with open(traffic_path) as handle:
                     traffic = json.load(handle).get("trace_hbm_bytes_per_launch")
+            # what a plain streaming kernel reaches on this box: the second denominator
+            from pathed_amd.integrator import measure_bandwidth
+            measured_read, measured_copy = measure_bandwidth(gib=2.0, repeats=10)
+            # Secondary bound for the all-triangles scenes ("FP32 VALU issue rate"):
+            # wave instructions per launch from the committed PMC pass of this very workload
+            # (profiles/r1s2_pmc_cornell.json, SQ_INSTS_VALU), launches and time measured live.
+            # A wave64 VALU instruction occupies its SIMD for 4 cycles; 4 SIMDs per CU.
+            valu = None
+            pmc_path = os.path.join(REPO_ROOT, "profiles", "r1s2_pmc_cornell.json")
+            if os.path.exists(pmc_path) and per_step_stats["scene_in_lds"] == 2 and args.scene == "scenes/cornell.json" \
+                    and (args.width, args.height, spp) == (1024, 1024, 256):
+                with open(pmc_path) as handle:
+                    pmc = json.load(handle)["kernels"]
+                trace_instructions = pmc["void pathed::k_trace_small<false>"]["SQ_INSTS_VALU"]
+                shade_instructions = pmc["void pathed::k_shade<true>"]["SQ_INSTS_VALU"]
+                simds = 4 * torch.cuda.get_device_properties(local_rank).multi_processor_count
+                clock_hz = 2.4e9  # MI355X peak engine clock, /opt/skills/guides/MI355X_MICROARCH.md
+                issued = launches * (trace_instructions + shade_instructions)
+                valu = {
+                    "bound": "valu issue",
+                    "wave_instructions_per_launch": {"k_trace_small": trace_instructions, "k_shade": shade_instructions},
+                    "achieved": issued / elapsed / 1e9, "peak": simds * clock_hz / 4 / 1e9, "unit": "G wave-instructions/s",
+                    "frac": issued * 4 / (simds * clock_hz * elapsed),
+                    "note": "whole pipeline (both kernels, both pools) over the timed region; counts from profiles/r1s2_pmc_cornell.json",
+                }
             roofline = {
                 "bound": "hbm",
                 "kernel": "k_trace (BVH traversal + triangle/sphere intersect, closest + any-hit)",
@@ -171,6 +196,9 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
+                "peak_measured": {"stream_read": measured_read, "stream_copy": measured_copy, "unit": "GB/s",
+                                  "note": "2 GiB probe, 16 B per lane, HIP events (pathed_hip_measure_bandwidth)"},
+                "frac_of_measured_read": (achieved / measured_read) if achieved else None,
                 "traffic": traffic,
                 "algorithmic_bytes_per_launch": (total_bytes / launches) if launches else None,
                 "algorithmic_bytes_per_sample": bytes_per_step / (args.width * args.height * spp),
@@ -181,6 +209,7 @@ def main():
                 "bvh_resident": ["HBM", "LDS", "none (<= 64 triangles: every ray tests all, scalar loads)"][per_step_stats["scene_in_lds"]],
                 "trace_ms_total": trace_ms,
                 "shade_ms_total": timed_stats["shade_ms"],
+                "valu": valu,
             }
 
         baseline = None

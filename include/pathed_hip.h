@@ -278,6 +278,13 @@ int pathed_hip_scene_export_bvh(PathedScene *scene,
                                 float *nodes, size_t *n_nodes,
                                 float *tris, size_t *n_tris);
 
+/* Measurement aid: what a plain streaming kernel reaches on THIS device, as a
+ * second denominator beside the 8 TB/s HBM3E spec figure.  Allocates two probe buffers of `bytes`
+ * (use >= 1 GiB: beyond the 256 MB Infinity Cache), times `repeats` passes of a 16-byte-per-lane
+ * read kernel and of a copy kernel with HIP events.  read_gbs = bytes read / s; copy_gbs counts
+ * bytes read + bytes written. */
+int pathed_hip_measure_bandwidth(size_t bytes, int repeats, double *read_gbs, double *copy_gbs);
+
 const char *pathed_hip_last_error(void);
 const char *pathed_hip_version(void);
 

@@ -140,6 +140,7 @@ HIP_SYMBOLS = [
     "pathed_hip_get_stats",
     "pathed_hip_reset_stats",
     "pathed_hip_scene_export_bvh",
+    "pathed_hip_measure_bandwidth",
     "pathed_hip_last_error",
     "pathed_hip_version",
 ]
@@ -199,6 +200,8 @@ def load_hip():
         vp, C.POINTER(C.c_float), C.POINTER(C.c_size_t), C.POINTER(C.c_float), C.POINTER(C.c_size_t)
     ]
     lib.pathed_hip_scene_export_bvh.restype = C.c_int
+    lib.pathed_hip_measure_bandwidth.argtypes = [C.c_size_t, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    lib.pathed_hip_measure_bandwidth.restype = C.c_int
     lib.pathed_hip_last_error.argtypes = []
     lib.pathed_hip_last_error.restype = C.c_char_p
     lib.pathed_hip_version.argtypes = []

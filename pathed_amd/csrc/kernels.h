@@ -1244,4 +1244,25 @@ __global__ __launch_bounds__(kBlock) void k_shade(RenderParams p)
     }
 }
 
+// ------------------------------------------------------------------------- bandwidth probe
+// What this box's HBM actually delivers to a plain streaming kernel: the second denominator beside
+// the 8 TB/s spec figure.  16 bytes per lane per access, grid-stride.
+__global__ __launch_bounds__(kBlock) void k_stream_read(const float4 *source, size_t count, float *sink)
+{
+    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < count; i += stride) {
+        const float4 v = source[i];
+        sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+    }
+    // never true for the zero-filled probe buffer, but keeps the loads alive
+    if (sum.x + sum.y + sum.z + sum.w == 12345.678f) { *sink = sum.x; }
+}
+
+__global__ __launch_bounds__(kBlock) void k_stream_copy(const float4 *source, float4 *target, size_t count)
+{
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < count; i += stride) { target[i] = source[i]; }
+}
+
 }  // namespace pathed

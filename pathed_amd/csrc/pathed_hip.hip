@@ -486,6 +486,59 @@ int pathed_hip_init(int device_id)
     return PATHED_OK;
 }
 
+int pathed_hip_measure_bandwidth(size_t bytes, int repeats, double *read_gbs, double *copy_gbs)
+{
+    if (!read_gbs || !copy_gbs || repeats < 1 || repeats > 1000) { return fail(PATHED_E_INVALID, "bad argument"); }
+    if (bytes < (1u << 20) || bytes > ((size_t)64 << 30)) { return fail(PATHED_E_INVALID, "probe size must be 1 MiB .. 64 GiB"); }
+    if (g_device < 0) {
+        const int code = pathed_hip_init(0);
+        if (code != PATHED_OK) { return code; }
+    }
+    const size_t count = bytes / sizeof(float4);
+    DeviceBuffer<float4> source, target;
+    DeviceBuffer<float> sink;
+    hipEvent_t start = nullptr, stop = nullptr;
+    auto cleanup = [&]() {
+        source.release(); target.release(); sink.release();
+        if (start) { (void)hipEventDestroy(start); }
+        if (stop) { (void)hipEventDestroy(stop); }
+    };
+    hipError_t status = source.allocate(count);
+    if (status == hipSuccess) { status = target.allocate(count); }
+    if (status == hipSuccess) { status = sink.allocate(1); }
+    if (status == hipSuccess) { status = hipMemset(source.ptr, 0, count * sizeof(float4)); }
+    if (status == hipSuccess) { status = hipMemset(target.ptr, 0, count * sizeof(float4)); }
+    if (status == hipSuccess) { status = hipEventCreate(&start); }
+    if (status == hipSuccess) { status = hipEventCreate(&stop); }
+    if (status != hipSuccess) { cleanup(); return fail(PATHED_E_DEVICE, std::string("bandwidth probe: ") + hipGetErrorString(status)); }
+
+    hipDeviceProp_t properties;
+    int units = 256;
+    if (hipGetDeviceProperties(&properties, g_device) == hipSuccess && properties.multiProcessorCount > 0) { units = properties.multiProcessorCount; }
+    const dim3 grid((unsigned)(units * 16)), block(kBlock);
+    float readMs = 0.f, copyMs = 0.f;
+    hipLaunchKernelGGL(k_stream_read, grid, block, 0, nullptr, source.ptr, count, sink.ptr);   // warm-up
+    hipLaunchKernelGGL(k_stream_copy, grid, block, 0, nullptr, source.ptr, target.ptr, count);
+    (void)hipEventRecord(start, nullptr);
+    for (int r = 0; r < repeats; r++) { hipLaunchKernelGGL(k_stream_read, grid, block, 0, nullptr, source.ptr, count, sink.ptr); }
+    (void)hipEventRecord(stop, nullptr);
+    status = hipEventSynchronize(stop);
+    if (status == hipSuccess) { status = hipEventElapsedTime(&readMs, start, stop); }
+    (void)hipEventRecord(start, nullptr);
+    for (int r = 0; r < repeats; r++) { hipLaunchKernelGGL(k_stream_copy, grid, block, 0, nullptr, source.ptr, target.ptr, count); }
+    (void)hipEventRecord(stop, nullptr);
+    if (status == hipSuccess) { status = hipEventSynchronize(stop); }
+    if (status == hipSuccess) { status = hipEventElapsedTime(&copyMs, start, stop); }
+    cleanup();
+    if (status != hipSuccess || !(readMs > 0.f) || !(copyMs > 0.f)) {
+        return fail(PATHED_E_DEVICE, std::string("bandwidth probe: ") + hipGetErrorString(status));
+    }
+    const double moved = (double)count * sizeof(float4) * repeats;
+    *read_gbs = moved / (readMs * 1e-3) / 1e9;
+    *copy_gbs = 2.0 * moved / (copyMs * 1e-3) / 1e9;   // bytes read + bytes written
+    return PATHED_OK;
+}
+
 int pathed_hip_set_bvh_builder(int builder)
 {
     if (builder != PATHED_BVH_SAH_HOST && builder != PATHED_BVH_LBVH_DEVICE) { return fail(PATHED_E_INVALID, "unknown BVH builder"); }

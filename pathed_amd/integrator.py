@@ -24,6 +24,15 @@ def _check(lib, code, what):
         raise PathedError("%s failed (%d): %s" % (what, code, lib.pathed_hip_last_error().decode()))
 
 
+def measure_bandwidth(gib=2.0, repeats=10):
+    """(read GB/s, copy GB/s) of a plain streaming kernel on the current device (pathed_hip_measure_bandwidth)."""
+    lib = _capi.load_hip()
+    read, copy = C.c_double(0.0), C.c_double(0.0)
+    _check(lib, lib.pathed_hip_measure_bandwidth(int(gib * (1 << 30)), int(repeats), C.byref(read), C.byref(copy)),
+           "pathed_hip_measure_bandwidth")
+    return read.value, copy.value
+
+
 class HipScene:
     """A scene uploaded to one GPU (PathedScene handle)."""
 

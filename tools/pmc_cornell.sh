@@ -7,7 +7,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 run() {
   name=$1; shift
-  rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/$name -- python3 $ROOT/bench.py --steps 1 --warmup 0 --spp-per-step 32 --no-cpu-baseline --no-kernel-timing > $OUT/$name.log 2>&1
+  rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/$name -- python3 $ROOT/bench.py --steps 1 --warmup 0 --spp-per-step ${SPP:-256} --no-cpu-baseline --no-kernel-timing > $OUT/$name.log 2>&1
 }
 run p1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU
 run p4 SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_THREAD_CYCLES_VALU SQ_INST_CYCLES_SALU SQ_INSTS_VMEM_WR SQ_WAVES_EQ_64
