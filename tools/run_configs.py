@@ -37,7 +37,10 @@ def main():
     parser = argparse.ArgumentParser()
     parser.add_argument("--dragon", type=int, default=9)
     parser.add_argument("--only", default="")
+    parser.add_argument("--full", action="store_true", help="render the spp BASELINE.json names (C2 4096, C3 1024, C4 2048, C5 8192) on this one GPU")
+    parser.add_argument("--builder", default="sah", choices=["sah", "lbvh"])
     args = parser.parse_args()
+    full_spp = {"C1": 16, "C2": 4096, "C3": 1024, "C4": 2048, "C5": 8192}
     subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_assets.py"), "--dragon", str(args.dragon)], check=True,
                    stdout=subprocess.DEVNULL)
     cores = os.cpu_count()
@@ -45,9 +48,11 @@ def main():
     for name, path, w, h, spp, cpu_spp, note in CONFIGS:
         if args.only and name not in args.only.split(","):
             continue
+        if args.full:
+            spp = full_spp[name]
         scene = LoadedScene(path, w, h)
         t0 = time.perf_counter()
-        gpu = HipScene(scene.desc, device=0)
+        gpu = HipScene(scene.desc, device=0, bvh_builder=args.builder)
         setup = time.perf_counter() - t0
         accum = torch.zeros((h, w, 3), dtype=torch.float32, device="cuda")
         gpu.render_device(1, 0, min(spp, 16), 0, 10, accum.data_ptr())  # warm-up
@@ -86,7 +91,8 @@ def main():
         expected, _ = o2.render(pw, ph, 1, 0, 16, 0, 10, threads=cores, chunk=4)
         rows.append({
             "config": name, "scene": path, "res": "%dx%d" % (w, h), "spp": spp, "note": note,
-            "triangles": scene.n_triangles, "scene_create_s": round(setup, 2),
+            "triangles": scene.n_triangles, "scene_create_s": round(setup, 2), "bvh_builder": args.builder,
+            "bvh_build_ms": round(timed["bvh_build_ms"], 1), "render_s": round(elapsed, 3),
             "gpu_Msamples_s": round(w * h * spp / elapsed / 1e6, 1),
             "rays_per_sample": round(rays / (w * h * count_spp), 2),
             "trace_Grays_s": round(rays * spp / count_spp / timed["trace_ms"] / 1e6, 2) if timed["trace_ms"] else None,
