@@ -213,7 +213,8 @@ def main():
             }
 
         baseline = None
-        if not args.no_cpu_baseline:
+        # the CPU oracle is timed on rank 0 of the single-GPU run only
+        if not args.no_cpu_baseline and world_size == 1:
             baseline = cpu_baseline(scene, args)
 
         mean = (accum / float(spp * args.steps * world_size)).mean(dim=(0, 1)).tolist()

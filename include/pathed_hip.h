@@ -202,13 +202,16 @@ typedef struct PathedStats {
 int pathed_hip_init(int device_id);
 
 /* Which builder stands in for rtcCommitScene (reference src/scene.cpp:39) in the scene_create
- * calls that follow (process-wide; the environment variable PATHED_BVH_BUILDER=sah|lbvh overrides):
+ * calls that follow (process-wide; the environment variable PATHED_BVH_BUILDER=sah|lbvh|ploc overrides):
  *   PATHED_BVH_SAH_HOST     binned-SAH tree built on the host cores (default: cheapest to traverse)
  *   PATHED_BVH_LBVH_DEVICE  Morton-code linear BVH built on the GPU in milliseconds;
  *                           same node format, so hits and images are bit-identical, traversal costs more.
+ *   PATHED_BVH_PLOC_DEVICE  bottom-up clustering along the Morton order on the GPU (PLOC): a few times
+ *                           the LBVH's build time, tree quality close to the SAH build's.
  * Meshes of <= 64 triangles always take the host path (they are not traversed at all). */
 #define PATHED_BVH_SAH_HOST    0
 #define PATHED_BVH_LBVH_DEVICE 1
+#define PATHED_BVH_PLOC_DEVICE 2
 int pathed_hip_set_bvh_builder(int builder);
 
 /* Flatten + upload once: leaf-ordered 48-B triangles, flattened 4-wide BVH (128-B nodes),

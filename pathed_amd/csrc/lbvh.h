@@ -1,6 +1,8 @@
-// On-GPU BVH build: a linear BVH over 63-bit Morton codes (Karras 2012),
-// leaves of up to four triangles, collapsed on the device to the SAME 4-wide 128-byte node
-// format the host builder (bvh_build.h) emits, so k_trace walks either tree unchanged.
+// On-GPU BVH build.  Two binary builders over 63-bit Morton codes -- a linear
+// BVH (Karras 2012: fastest) and PLOC (Meister & Bittner 2018: bottom-up clustering along the Morton
+// order, close to SAH quality) -- then leaves of up to four triangles and a collapse on the device to
+// the SAME 4-wide 128-byte node format the host builder (bvh_build.h) emits, so k_trace walks any
+// of the three trees unchanged.
 // Stands in for rtcCommitScene (reference src/scene.cpp:39), which is a serial host phase in the
 // reference; here 5 M triangles take milliseconds instead of seconds.
 //
@@ -23,11 +25,15 @@ struct DeviceBvh {
     int nodeCount = 0;
     int maxDepth = 0;             // 4-wide levels
     float buildMs = 0.f;          // device time, HIP events around the whole build
+    int rounds = 0;               // PLOC: clustering rounds
 };
+
+static const int kDeviceBuilderLbvh = 1;   // PATHED_BVH_LBVH_DEVICE
+static const int kDeviceBuilderPloc = 2;   // PATHED_BVH_PLOC_DEVICE
 
 // positions / indices are DEVICE pointers (3 floats per vertex, 3 indices per triangle).
 // triangleCount must exceed 4 (smaller meshes go through the host builder).
-hipError_t buildLbvhOnDevice(const float *positions, const uint32_t *indices, uint32_t triangleCount,
-                             hipStream_t stream, DeviceBvh *out, std::string *error);
+hipError_t buildBvhOnDevice(int builder, const float *positions, const uint32_t *indices, uint32_t triangleCount,
+                            hipStream_t stream, DeviceBvh *out, std::string *error);
 
 }  // namespace pathed

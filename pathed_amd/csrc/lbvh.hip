@@ -1,13 +1,18 @@
-// On-GPU linear BVH build for gfx950 (see lbvh.h).  Seven steps, all on one stream:
+// On-GPU BVH build for gfx950 (see lbvh.h), all on one stream:
 //   1 k_lbvh_prims      triangle boxes + centroid bounds (wave min/max, one atomic per wave)
 //   2 k_lbvh_morton     63-bit Morton code of the box centre (21 bits per axis)
 //   3 rocprim radix sort of (code, triangle) pairs
-//   4 k_lbvh_hierarchy  Karras' binary radix tree over the sorted codes (ties broken by position)
-//   5 k_lbvh_fit        boxes bottom-up: the second thread to reach a node merges its children
+//   4-5 a binary tree over the sorted triangles, with boxes and triangle counts:
+//       LBVH  k_lbvh_hierarchy  Karras' binary radix tree over the codes (ties broken by position)
+//             k_lbvh_fit        boxes bottom-up: the second thread to reach a node merges its children
+//       PLOC  k_ploc_nearest / _flags / _merge, once per round: mutual nearest neighbours (by the
+//             surface area of their union, within 16 places of the Morton order) merge; compaction
+//             by exclusive scans; ~25 rounds for millions of triangles
 //   6 k_lbvh_wide_*     breadth-first collapse to 4-wide nodes, one level per launch pair; ids are
-//                       handed out by an exclusive scan, so the tree is the same every run
-//   7 k_lbvh_leaf_tris  (v0, prim) (e1) (e2) records in leaf order
-// Subtrees of at most four triangles become leaves (their triangles are consecutive in sorted order).
+//                       handed out by an exclusive scan, so the tree is the same every run.  A
+//                       frontier entry carries its subtree's first position in leaf order; subtrees
+//                       of at most four triangles become leaves and write their (v0, prim) (e1) (e2)
+//                       records there.
 #include <cstring>
 
 #include <hip/hip_runtime.h>
@@ -124,7 +129,7 @@ __device__ inline int commonPrefix(const unsigned long long *keys, int n, unsign
 // Karras 2012, "Maximizing parallelism in the construction of BVHs, octrees, and k-d trees", §3-4
 __global__ __launch_bounds__(kLbvhBlock) void k_lbvh_hierarchy(
     const unsigned long long *keys, int n,
-    uint2 *children, int2 *range, int *parentOfInternal, int *parentOfLeaf)
+    uint2 *children, unsigned int *count, int *parentOfInternal, int *parentOfLeaf)
 {
     const int i = blockIdx.x * kLbvhBlock + threadIdx.x;
     if (i >= n - 1) { return; }
@@ -153,7 +158,7 @@ __global__ __launch_bounds__(kLbvhBlock) void k_lbvh_hierarchy(
     if (last == gamma + 1) { right = (unsigned int)(gamma + 1) | kLeafFlag; parentOfLeaf[gamma + 1] = i; }
     else { right = (unsigned int)(gamma + 1); parentOfInternal[gamma + 1] = i; }
     children[i] = make_uint2(left, right);
-    range[i] = make_int2(first, last);
+    count[i] = (unsigned int)(last - first + 1);   // the subtree's triangles are sorted entries first..last
     if (i == 0) { parentOfInternal[0] = -1; }
 }
 
@@ -206,73 +211,213 @@ __global__ __launch_bounds__(kLbvhBlock) void k_lbvh_fit(
     }
 }
 
+// ------------------------------------------------------------------------- PLOC
+// Parallel locally-ordered clustering (Meister & Bittner 2018): bottom-up agglomeration along the
+// Morton order.  Every round, each cluster looks kPlocRadius places left and right for the
+// neighbour whose union with it has the smallest surface area; mutual nearest neighbours merge
+// into a new binary node; the cluster array is compacted (exclusive scans, so node ids and order
+// are the same every run) and the round repeats until one cluster is left.  Quality is close to a
+// top-down SAH build, at a few tens of launches.
+constexpr int kPlocRadius = 16;
+
+struct PlocClusters {
+    float4 *lo, *hi;
+    unsigned int *node;    // child reference: triangle | kLeafFlag, or binary node id
+    unsigned int *count;   // triangles below
+};
+
+__global__ __launch_bounds__(kLbvhBlock) void k_ploc_init(
+    uint32_t n, const unsigned int *sorted, const float4 *boxLo, const float4 *boxHi, PlocClusters clusters)
+{
+    const uint32_t i = blockIdx.x * kLbvhBlock + threadIdx.x;
+    if (i >= n) { return; }
+    const unsigned int tri = sorted[i];
+    clusters.lo[i] = boxLo[tri];
+    clusters.hi[i] = boxHi[tri];
+    clusters.node[i] = i | kLeafFlag;
+    clusters.count[i] = 1u;
+}
+
+__global__ __launch_bounds__(kLbvhBlock) void k_ploc_nearest(PlocClusters clusters, unsigned int c, unsigned int *nearest)
+{
+    __shared__ float4 tileLo[kLbvhBlock + 2 * kPlocRadius];
+    __shared__ float4 tileHi[kLbvhBlock + 2 * kPlocRadius];
+    const long long blockStart = (long long)blockIdx.x * kLbvhBlock;
+    for (int k = threadIdx.x; k < kLbvhBlock + 2 * kPlocRadius; k += kLbvhBlock) {
+        const long long j = blockStart - kPlocRadius + k;
+        if (j >= 0 && j < (long long)c) {
+            tileLo[k] = clusters.lo[j];
+            tileHi[k] = clusters.hi[j];
+        }
+    }
+    __syncthreads();
+    const long long i = blockStart + threadIdx.x;
+    if (i >= (long long)c) { return; }
+    const float4 lo = tileLo[threadIdx.x + kPlocRadius], hi = tileHi[threadIdx.x + kPlocRadius];
+    float bestArea = __builtin_huge_valf();
+    unsigned int best = (unsigned int)i;
+    for (int d = -kPlocRadius; d <= kPlocRadius; d++) {
+        const long long j = i + d;
+        if (d == 0 || j < 0 || j >= (long long)c) { continue; }
+        const float4 olo = tileLo[threadIdx.x + kPlocRadius + d], ohi = tileHi[threadIdx.x + kPlocRadius + d];
+        const float dx = fmaxf(hi.x, ohi.x) - fminf(lo.x, olo.x);
+        const float dy = fmaxf(hi.y, ohi.y) - fminf(lo.y, olo.y);
+        const float dz = fmaxf(hi.z, ohi.z) - fminf(lo.z, olo.z);
+        const float area = dx * dy + dy * dz + dz * dx;
+        if (area < bestArea) { bestArea = area; best = (unsigned int)j; }   // ascending j: ties go to the lower index
+    }
+    nearest[i] = best;
+}
+
+// flags: x = this cluster survives the round, y = it absorbs its partner into a new node
+__global__ __launch_bounds__(kLbvhBlock) void k_ploc_flags(unsigned int c, const unsigned int *nearest, unsigned int *survives, unsigned int *merges)
+{
+    const unsigned int i = blockIdx.x * kLbvhBlock + threadIdx.x;
+    if (i >= c) { return; }
+    const unsigned int j = nearest[i];
+    const bool mutual = j != i && nearest[j] == i;
+    survives[i] = (mutual && i > j) ? 0u : 1u;
+    merges[i] = (mutual && i < j) ? 1u : 0u;
+}
+
+__global__ __launch_bounds__(kLbvhBlock) void k_ploc_merge(
+    PlocClusters from, PlocClusters to, unsigned int c, const unsigned int *nearest,
+    const unsigned int *survives, const unsigned int *survivorIndex, const unsigned int *merges, const unsigned int *mergeIndex,
+    unsigned int nodeBase, uint2 *children, unsigned int *count, float4 *nodeLo, float4 *nodeHi, unsigned int *totals)
+{
+    const unsigned int i = blockIdx.x * kLbvhBlock + threadIdx.x;
+    if (i >= c) { return; }
+    if (i == c - 1) {
+        totals[0] = survivorIndex[i] + survives[i];
+        totals[1] = mergeIndex[i] + merges[i];
+    }
+    if (!survives[i]) { return; }
+    const unsigned int position = survivorIndex[i];
+    float4 lo = from.lo[i], hi = from.hi[i];
+    unsigned int node = from.node[i], triangles = from.count[i];
+    if (merges[i]) {
+        const unsigned int j = nearest[i];
+        const float4 olo = from.lo[j], ohi = from.hi[j];
+        lo = make_float4(fminf(lo.x, olo.x), fminf(lo.y, olo.y), fminf(lo.z, olo.z), 0.f);
+        hi = make_float4(fmaxf(hi.x, ohi.x), fmaxf(hi.y, ohi.y), fmaxf(hi.z, ohi.z), 0.f);
+        const unsigned int id = nodeBase + mergeIndex[i];
+        children[id] = make_uint2(node, from.node[j]);   // i < j: Morton order is kept left to right
+        triangles += from.count[j];
+        count[id] = triangles;
+        nodeLo[id] = lo;
+        nodeHi[id] = hi;
+        node = id;
+    }
+    to.lo[position] = lo;
+    to.hi[position] = hi;
+    to.node[position] = node;
+    to.count[position] = triangles;
+}
+
+// ------------------------------------------------------------------------- collapse to 4-wide
 // binary nodes that stay inner nodes of the wide tree (more than kLbvhMaxLeaf triangles below)
-__global__ __launch_bounds__(kLbvhBlock) void k_lbvh_count_inner(const int2 *range, int nInternal, unsigned int *count)
+__global__ __launch_bounds__(kLbvhBlock) void k_lbvh_count_inner(const unsigned int *count, int nInternal, unsigned int *total)
 {
     const int i = blockIdx.x * kLbvhBlock + threadIdx.x;
-    const bool inner = i < nInternal && (range[i].y - range[i].x + 1) > kLbvhMaxLeaf;
+    const bool inner = i < nInternal && count[i] > (unsigned int)kLbvhMaxLeaf;
     const unsigned long long mask = __ballot(inner);
-    if ((threadIdx.x & 63) == 0 && mask != 0ull) { atomicAdd(count, (unsigned int)__popcll(mask)); }
+    if ((threadIdx.x & 63) == 0 && mask != 0ull) { atomicAdd(total, (unsigned int)__popcll(mask)); }
 }
 
 struct WideInputs {
     const uint2 *children;
-    const int2 *range;
+    const unsigned int *count;       // triangles below a binary node
     const float4 *nodeLo, *nodeHi;
     const float4 *boxLo, *boxHi;
     const unsigned int *sorted;
+    const float *positions;
+    const uint32_t *indices;
 };
+
+__device__ inline unsigned int trianglesBelow(const WideInputs &in, unsigned int ref)
+{
+    if (ref == kNoChild) { return 0u; }
+    return (ref & kLeafFlag) ? 1u : in.count[ref];
+}
 
 __device__ inline bool isInnerRef(const WideInputs &in, unsigned int ref)
 {
-    if (ref == kNoChild || (ref & kLeafFlag)) { return false; }
-    const int2 r = in.range[ref];
-    return r.y - r.x + 1 > kLbvhMaxLeaf;
+    return ref != kNoChild && !(ref & kLeafFlag) && in.count[ref] > (unsigned int)kLbvhMaxLeaf;
 }
 
 // A wide node adopts the two children of its binary root, then keeps replacing the inner child
 // with the largest box by that child's two children until it has four (bvh_build.h, same rule).
+// The children stay in left-to-right order of the binary tree, so that a subtree's triangles are
+// consecutive in leaf order: child k starts at the node's first triangle + the triangles of 0..k-1.
 __global__ __launch_bounds__(kLbvhBlock) void k_lbvh_wide_children(
-    WideInputs in, const unsigned int *frontier, unsigned int m, uint4 *adopted, unsigned int *innerCount)
+    WideInputs in, const uint2 *frontier, unsigned int m, uint4 *adopted, unsigned int *innerCount)
 {
     const unsigned int e = blockIdx.x * kLbvhBlock + threadIdx.x;
     if (e >= m) { return; }
-    const uint2 pair = in.children[frontier[e]];
-    unsigned int c0 = pair.x, c1 = pair.y, c2 = kNoChild, c3 = kNoChild;
-    #pragma unroll
-    for (int round = 0; round < 2; round++) {
-        // slot to fill this round: 2, then 3
+    const uint2 pair = in.children[frontier[e].x];
+    unsigned int c[4] = { pair.x, pair.y, kNoChild, kNoChild };
+    int held = 2;
+    while (held < 4) {
         int pick = -1;
         float pickArea = -1.f;
-        #pragma unroll
-        for (int k = 0; k < 3; k++) {
-            const unsigned int ref = k == 0 ? c0 : k == 1 ? c1 : c2;
-            if (k >= 2 + round || !isInnerRef(in, ref)) { continue; }
-            const float4 lo = in.nodeLo[ref], hi = in.nodeHi[ref];
+        for (int k = 0; k < held; k++) {
+            if (!isInnerRef(in, c[k])) { continue; }
+            const float4 lo = in.nodeLo[c[k]], hi = in.nodeHi[c[k]];
             const float dx = hi.x - lo.x, dy = hi.y - lo.y, dz = hi.z - lo.z;
             const float area = dx * dy + dy * dz + dz * dx;
             if (area > pickArea) { pickArea = area; pick = k; }
         }
         if (pick < 0) { break; }
-        const unsigned int opened = pick == 0 ? c0 : pick == 1 ? c1 : c2;
-        const uint2 inside = in.children[opened];
-        if (pick == 0) { c0 = inside.x; } else if (pick == 1) { c1 = inside.x; } else { c2 = inside.x; }
-        if (round == 0) { c2 = inside.y; } else { c3 = inside.y; }
+        const uint2 inside = in.children[c[pick]];
+        for (int k = held; k > pick + 1; k--) { c[k] = c[k - 1]; }   // keep the order: both halves take the opened slot's place
+        c[pick] = inside.x;
+        c[pick + 1] = inside.y;
+        held++;
     }
-    adopted[e] = make_uint4(c0, c1, c2, c3);
-    innerCount[e] = (isInnerRef(in, c0) ? 1u : 0u) + (isInnerRef(in, c1) ? 1u : 0u)
-        + (isInnerRef(in, c2) ? 1u : 0u) + (isInnerRef(in, c3) ? 1u : 0u);
+    adopted[e] = make_uint4(c[0], c[1], c[2], c[3]);
+    innerCount[e] = (isInnerRef(in, c[0]) ? 1u : 0u) + (isInnerRef(in, c[1]) ? 1u : 0u)
+        + (isInnerRef(in, c[2]) ? 1u : 0u) + (isInnerRef(in, c[3]) ? 1u : 0u);
+}
+
+// the (v0, prim) (e1) (e2) records of a leaf's triangles, left to right, starting at `first`
+__device__ inline void writeLeafTriangles(const WideInputs &in, unsigned int ref, unsigned int first, float4 *leafTris)
+{
+    unsigned int stack[kLbvhMaxLeaf];
+    int sp = 0;
+    stack[sp++] = ref;
+    unsigned int at = first;
+    while (sp > 0) {
+        const unsigned int r = stack[--sp];
+        if (r & kLeafFlag) {
+            const unsigned int prim = in.sorted[r & ~kLeafFlag];
+            const float *v0 = in.positions + 3 * (size_t)in.indices[3 * (size_t)prim + 0];
+            const float *v1 = in.positions + 3 * (size_t)in.indices[3 * (size_t)prim + 1];
+            const float *v2 = in.positions + 3 * (size_t)in.indices[3 * (size_t)prim + 2];
+            const float ax = v0[0], ay = v0[1], az = v0[2];
+            leafTris[3 * (size_t)at + 0] = make_float4(ax, ay, az, __int_as_float((int)prim));
+            leafTris[3 * (size_t)at + 1] = make_float4(v1[0] - ax, v1[1] - ay, v1[2] - az, 0.f);
+            leafTris[3 * (size_t)at + 2] = make_float4(v2[0] - ax, v2[1] - ay, v2[2] - az, 0.f);
+            at++;
+        } else {
+            const uint2 pair = in.children[r];
+            if (sp + 2 <= kLbvhMaxLeaf) {   // always true below a node of <= kLbvhMaxLeaf triangles
+                stack[sp++] = pair.y;
+                stack[sp++] = pair.x;
+            }
+        }
+    }
 }
 
 __global__ __launch_bounds__(kLbvhBlock) void k_lbvh_wide_emit(
-    WideInputs in, unsigned int m, unsigned int levelBase,
+    WideInputs in, const uint2 *frontier, unsigned int m, unsigned int levelBase,
     const uint4 *adopted, const unsigned int *innerCount, const unsigned int *childBase,
-    unsigned int *nextFrontier, unsigned int *nextCount, float4 *nodesOut)
+    uint2 *nextFrontier, unsigned int *nextCount, float4 *nodesOut, float4 *leafTris)
 {
     const unsigned int e = blockIdx.x * kLbvhBlock + threadIdx.x;
     if (e >= m) { return; }
     const uint4 four = adopted[e];
     const unsigned int base = childBase[e];
+    unsigned int first = frontier[e].y;   // leaf-order position of this subtree's first triangle
     unsigned int rank = 0;
     float lo[3][4], hi[3][4];
     int refs[4];
@@ -281,27 +426,26 @@ __global__ __launch_bounds__(kLbvhBlock) void k_lbvh_wide_emit(
         const unsigned int ref = k == 0 ? four.x : k == 1 ? four.y : k == 2 ? four.z : four.w;
         float4 boxLow = make_float4(0.f, 0.f, 0.f, 0.f), boxHigh = boxLow;
         refs[k] = kEmptyRef;
-        bool present = ref != kNoChild;
+        const bool present = ref != kNoChild;
         if (present) {
+            const unsigned int triangles = trianglesBelow(in, ref);
             if (ref & kLeafFlag) {
-                const unsigned int position = ref & ~kLeafFlag;
-                const unsigned int tri = in.sorted[position];
+                const unsigned int tri = in.sorted[ref & ~kLeafFlag];
                 boxLow = in.boxLo[tri];
                 boxHigh = in.boxHi[tri];
-                refs[k] = -(int)((position << 3) | 1u) - 1;   // trace.h encodeLeaf
             } else {
-                const int2 r = in.range[ref];
-                const int count = r.y - r.x + 1;
                 boxLow = in.nodeLo[ref];
                 boxHigh = in.nodeHi[ref];
-                if (count <= kLbvhMaxLeaf) {
-                    refs[k] = -(int)(((unsigned int)r.x << 3) | (unsigned int)count) - 1;
-                } else {
-                    refs[k] = (int)(levelBase + m + base + rank);   // next level's ids follow this level's
-                    nextFrontier[base + rank] = ref;
-                    rank++;
-                }
             }
+            if (triangles <= (unsigned int)kLbvhMaxLeaf) {
+                refs[k] = -(int)((first << 3) | triangles) - 1;   // trace.h encodeLeaf
+                writeLeafTriangles(in, ref, first, leafTris);
+            } else {
+                refs[k] = (int)(levelBase + m + base + rank);     // next level's ids follow this level's
+                nextFrontier[base + rank] = make_uint2(ref, first);
+                rank++;
+            }
+            first += triangles;
         }
         const float low[3] = { boxLow.x, boxLow.y, boxLow.z }, high[3] = { boxHigh.x, boxHigh.y, boxHigh.z };
         #pragma unroll
@@ -323,23 +467,8 @@ __global__ __launch_bounds__(kLbvhBlock) void k_lbvh_wide_emit(
     if (e == m - 1) { *nextCount = base + innerCount[e]; }
 }
 
-__global__ __launch_bounds__(kLbvhBlock) void k_lbvh_leaf_tris(
-    const float *positions, const uint32_t *indices, const unsigned int *sorted, uint32_t n, float4 *leafTris)
-{
-    const uint32_t i = blockIdx.x * kLbvhBlock + threadIdx.x;
-    if (i >= n) { return; }
-    const unsigned int prim = sorted[i];
-    const float *v0 = positions + 3 * (size_t)indices[3 * (size_t)prim + 0];
-    const float *v1 = positions + 3 * (size_t)indices[3 * (size_t)prim + 1];
-    const float *v2 = positions + 3 * (size_t)indices[3 * (size_t)prim + 2];
-    const float ax = v0[0], ay = v0[1], az = v0[2];
-    leafTris[3 * (size_t)i + 0] = make_float4(ax, ay, az, __int_as_float((int)prim));
-    leafTris[3 * (size_t)i + 1] = make_float4(v1[0] - ax, v1[1] - ay, v1[2] - az, 0.f);
-    leafTris[3 * (size_t)i + 2] = make_float4(v2[0] - ax, v2[1] - ay, v2[2] - az, 0.f);
-}
-
 struct Scratch {
-    void *pointers[24];
+    void *pointers[48];
     int used = 0;
     hipError_t status = hipSuccess;
 
@@ -347,6 +476,7 @@ struct Scratch {
     T *get(size_t count)
     {
         if (status != hipSuccess) { return nullptr; }
+        if (used >= 48) { status = hipErrorOutOfMemory; return nullptr; }
         void *p = nullptr;
         status = hipMalloc(&p, (count ? count : 1) * sizeof(T));
         if (status != hipSuccess) { return nullptr; }
@@ -364,17 +494,18 @@ inline unsigned int blocksFor(size_t n) { return (unsigned int)((n + kLbvhBlock 
 
 }  // namespace
 
-hipError_t buildLbvhOnDevice(const float *positions, const uint32_t *indices, uint32_t triangleCount,
-                             hipStream_t stream, DeviceBvh *out, std::string *error)
+hipError_t buildBvhOnDevice(int builder, const float *positions, const uint32_t *indices, uint32_t triangleCount,
+                            hipStream_t stream, DeviceBvh *out, std::string *error)
 {
     auto failed = [&](hipError_t status, const char *what) {
-        if (error) { *error = std::string("lbvh: ") + what + ": " + hipGetErrorString(status); }
+        if (error) { *error = std::string("device bvh: ") + what + ": " + hipGetErrorString(status); }
         if (out->nodes) { (void)hipFree(out->nodes); out->nodes = nullptr; }
         if (out->leafTris) { (void)hipFree(out->leafTris); out->leafTris = nullptr; }
         return status == hipSuccess ? hipErrorInvalidValue : status;
     };
     *out = DeviceBvh();
     const uint32_t n = triangleCount;
+    if (builder != kDeviceBuilderLbvh && builder != kDeviceBuilderPloc) { return failed(hipErrorInvalidValue, "unknown builder"); }
     if (n <= (uint32_t)kLbvhMaxLeaf) { return failed(hipErrorInvalidValue, "fewer than five triangles"); }
     if (n >= (1u << 28)) { return failed(hipErrorInvalidValue, "more than 2^28 triangles"); }
 
@@ -391,23 +522,20 @@ hipError_t buildLbvhOnDevice(const float *positions, const uint32_t *indices, ui
     Scratch scratch;
     float4 *boxLo = scratch.get<float4>(n);
     float4 *boxHi = scratch.get<float4>(n);
-    unsigned int *words = scratch.get<unsigned int>(16);   // 0..5 centroid bounds, 6 inner count, 7 next frontier size
+    unsigned int *words = scratch.get<unsigned int>(16);   // 0..5 centroid bounds, 6 inner count, 7 next frontier size, 8..9 PLOC totals
     unsigned long long *keysIn = scratch.get<unsigned long long>(n);
     unsigned long long *keysOut = scratch.get<unsigned long long>(n);
     unsigned int *valuesIn = scratch.get<unsigned int>(n);
     unsigned int *sorted = scratch.get<unsigned int>(n);
     uint2 *children = scratch.get<uint2>(n - 1);
-    int2 *range = scratch.get<int2>(n - 1);
-    int *parentOfInternal = scratch.get<int>(n - 1);
-    int *parentOfLeaf = scratch.get<int>(n);
+    unsigned int *count = scratch.get<unsigned int>(n - 1);
     float4 *nodeLo = scratch.get<float4>(n - 1);
     float4 *nodeHi = scratch.get<float4>(n - 1);
-    unsigned int *arrivals = scratch.get<unsigned int>(n - 1);
     if (scratch.status != hipSuccess) { return failed(scratch.status, "scratch allocation"); }
 
     // 1-2: boxes, centroid bounds, Morton codes
     {
-        const unsigned int init[8] = { 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u, 0u, 0u };
+        const unsigned int init[10] = { 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u, 0u, 0u, 0u, 0u };
         if ((status = hipMemcpyAsync(words, init, sizeof init, hipMemcpyHostToDevice, stream)) != hipSuccess) { return failed(status, "init"); }
         if ((status = hipStreamSynchronize(stream)) != hipSuccess) { return failed(status, "init"); }   // `init` is on this stack frame
     }
@@ -427,16 +555,70 @@ hipError_t buildLbvhOnDevice(const float *positions, const uint32_t *indices, ui
         }
     }
 
-    // 4-5: hierarchy, boxes
-    if ((status = hipMemsetAsync(arrivals, 0, (size_t)(n - 1) * sizeof(unsigned int), stream)) != hipSuccess) { return failed(status, "memset"); }
-    hipLaunchKernelGGL(k_lbvh_hierarchy, dim3(blocksFor(n - 1)), dim3(kLbvhBlock), 0, stream,
-                       keysOut, (int)n, children, range, parentOfInternal, parentOfLeaf);
-    hipLaunchKernelGGL(k_lbvh_fit, dim3(blocksFor(n)), dim3(kLbvhBlock), 0, stream,
-                       (int)n, sorted, boxLo, boxHi, children, parentOfInternal, parentOfLeaf, nodeLo, nodeHi, arrivals);
+    unsigned int root = 0;
+    int rounds = 0;
+    if (builder == kDeviceBuilderLbvh) {
+        // 4-5: Karras hierarchy (root = node 0), boxes bottom-up
+        int *parentOfInternal = scratch.get<int>(n - 1);
+        int *parentOfLeaf = scratch.get<int>(n);
+        unsigned int *arrivals = scratch.get<unsigned int>(n - 1);
+        if (scratch.status != hipSuccess) { return failed(scratch.status, "scratch allocation"); }
+        if ((status = hipMemsetAsync(arrivals, 0, (size_t)(n - 1) * sizeof(unsigned int), stream)) != hipSuccess) { return failed(status, "memset"); }
+        hipLaunchKernelGGL(k_lbvh_hierarchy, dim3(blocksFor(n - 1)), dim3(kLbvhBlock), 0, stream,
+                           keysOut, (int)n, children, count, parentOfInternal, parentOfLeaf);
+        hipLaunchKernelGGL(k_lbvh_fit, dim3(blocksFor(n)), dim3(kLbvhBlock), 0, stream,
+                           (int)n, sorted, boxLo, boxHi, children, parentOfInternal, parentOfLeaf, nodeLo, nodeHi, arrivals);
+        root = 0;
+    } else {
+        // 4-5 (PLOC): agglomerate along the Morton order until one cluster is left
+        PlocClusters a, b;
+        a.lo = scratch.get<float4>(n); a.hi = scratch.get<float4>(n); a.node = scratch.get<unsigned int>(n); a.count = scratch.get<unsigned int>(n);
+        b.lo = scratch.get<float4>(n); b.hi = scratch.get<float4>(n); b.node = scratch.get<unsigned int>(n); b.count = scratch.get<unsigned int>(n);
+        unsigned int *nearest = scratch.get<unsigned int>(n);
+        unsigned int *survives = scratch.get<unsigned int>(n);
+        unsigned int *survivorIndex = scratch.get<unsigned int>(n);
+        unsigned int *merges = scratch.get<unsigned int>(n);
+        unsigned int *mergeIndex = scratch.get<unsigned int>(n);
+        if (scratch.status != hipSuccess) { return failed(scratch.status, "scratch allocation"); }
+        size_t scanBytes = 0;
+        if ((status = rocprim::exclusive_scan(nullptr, scanBytes, survives, survivorIndex, 0u, (size_t)n, rocprim::plus<unsigned int>(), stream)) != hipSuccess) {
+            return failed(status, "scan (query)");
+        }
+        void *scanTemporary = scratch.get<unsigned char>(scanBytes);
+        if (scratch.status != hipSuccess) { return failed(scratch.status, "scan scratch"); }
+
+        hipLaunchKernelGGL(k_ploc_init, dim3(blocksFor(n)), dim3(kLbvhBlock), 0, stream, n, sorted, boxLo, boxHi, a);
+        unsigned int c = n, nodeBase = 0;
+        while (c > 1) {
+            if (++rounds > 4096) { return failed(hipErrorInvalidValue, "clustering does not converge"); }
+            hipLaunchKernelGGL(k_ploc_nearest, dim3(blocksFor(c)), dim3(kLbvhBlock), 0, stream, a, c, nearest);
+            hipLaunchKernelGGL(k_ploc_flags, dim3(blocksFor(c)), dim3(kLbvhBlock), 0, stream, c, nearest, survives, merges);
+            size_t bytes = scanBytes;
+            if ((status = rocprim::exclusive_scan(scanTemporary, bytes, survives, survivorIndex, 0u, (size_t)c, rocprim::plus<unsigned int>(), stream)) != hipSuccess) { return failed(status, "scan"); }
+            bytes = scanBytes;
+            if ((status = rocprim::exclusive_scan(scanTemporary, bytes, merges, mergeIndex, 0u, (size_t)c, rocprim::plus<unsigned int>(), stream)) != hipSuccess) { return failed(status, "scan"); }
+            hipLaunchKernelGGL(k_ploc_merge, dim3(blocksFor(c)), dim3(kLbvhBlock), 0, stream,
+                               a, b, c, nearest, survives, survivorIndex, merges, mergeIndex, nodeBase, children, count, nodeLo, nodeHi, words + 8);
+            unsigned int totals[2] = { 0u, 0u };
+            if ((status = hipMemcpyAsync(totals, words + 8, sizeof totals, hipMemcpyDeviceToHost, stream)) != hipSuccess) { return failed(status, "round totals"); }
+            if ((status = hipStreamSynchronize(stream)) != hipSuccess) { return failed(status, "clustering kernels"); }
+            // the closest pair of a round is always mutual, so every round merges at least once
+            if (totals[1] == 0u || totals[0] + totals[1] != c || (size_t)nodeBase + totals[1] > (size_t)n - 1) {
+                return failed(hipErrorInvalidValue, "clustering round made no progress");
+            }
+            nodeBase += totals[1];
+            c = totals[0];
+            const PlocClusters swap = a;
+            a = b;
+            b = swap;
+        }
+        if (nodeBase != n - 1) { return failed(hipErrorInvalidValue, "clustering ended with a wrong node count"); }
+        root = n - 2;   // the last node created
+    }
 
     // 6: wide nodes.  Every wide node is rooted at a binary node with more than four triangles
     // below it, so their number bounds the allocation.
-    hipLaunchKernelGGL(k_lbvh_count_inner, dim3(blocksFor(n - 1)), dim3(kLbvhBlock), 0, stream, range, (int)(n - 1), words + 6);
+    hipLaunchKernelGGL(k_lbvh_count_inner, dim3(blocksFor(n - 1)), dim3(kLbvhBlock), 0, stream, count, (int)(n - 1), words + 6);
     unsigned int capacity = 0;
     if ((status = hipMemcpyAsync(&capacity, words + 6, sizeof capacity, hipMemcpyDeviceToHost, stream)) != hipSuccess) { return failed(status, "count"); }
     if ((status = hipStreamSynchronize(stream)) != hipSuccess) { return failed(status, "hierarchy kernels"); }
@@ -446,8 +628,8 @@ hipError_t buildLbvhOnDevice(const float *positions, const uint32_t *indices, ui
     if ((status = hipMalloc((void **)&out->leafTris, (size_t)n * 3 * sizeof(float4))) != hipSuccess) { return failed(status, "triangle allocation"); }
     out->nodeCapacity = capacity;
 
-    unsigned int *frontierA = scratch.get<unsigned int>(capacity);
-    unsigned int *frontierB = scratch.get<unsigned int>(capacity);
+    uint2 *frontierA = scratch.get<uint2>(capacity);
+    uint2 *frontierB = scratch.get<uint2>(capacity);
     uint4 *adopted = scratch.get<uint4>(capacity);
     unsigned int *innerCount = scratch.get<unsigned int>(capacity);
     unsigned int *childBase = scratch.get<unsigned int>(capacity);
@@ -461,42 +643,45 @@ hipError_t buildLbvhOnDevice(const float *positions, const uint32_t *indices, ui
 
     WideInputs inputs;
     inputs.children = children;
-    inputs.range = range;
+    inputs.count = count;
     inputs.nodeLo = nodeLo;
     inputs.nodeHi = nodeHi;
     inputs.boxLo = boxLo;
     inputs.boxHi = boxHi;
     inputs.sorted = sorted;
+    inputs.positions = positions;
+    inputs.indices = indices;
 
-    if ((status = hipMemsetAsync(frontierA, 0, sizeof(unsigned int), stream)) != hipSuccess) { return failed(status, "memset"); }   // the root
+    {
+        const uint2 rootEntry = make_uint2(root, 0u);   // (binary node, first triangle in leaf order)
+        if ((status = hipMemcpyAsync(frontierA, &rootEntry, sizeof rootEntry, hipMemcpyHostToDevice, stream)) != hipSuccess) { return failed(status, "root"); }
+        if ((status = hipStreamSynchronize(stream)) != hipSuccess) { return failed(status, "root"); }
+    }
     unsigned int levelBase = 0, m = 1;
     int depth = 0;
-    unsigned int *frontier = frontierA, *nextFrontier = frontierB;
+    uint2 *frontier = frontierA, *nextFrontier = frontierB;
     while (m > 0) {
         if ((size_t)levelBase + m > capacity) { return failed(hipErrorInvalidValue, "wide node count exceeds its bound"); }
-        depth++;
+        if (++depth > 4096) { return failed(hipErrorInvalidValue, "runaway hierarchy depth"); }
         hipLaunchKernelGGL(k_lbvh_wide_children, dim3(blocksFor(m)), dim3(kLbvhBlock), 0, stream, inputs, frontier, m, adopted, innerCount);
         size_t bytes = scanBytes;
         if ((status = rocprim::exclusive_scan(scanTemporary, bytes, innerCount, childBase, 0u, (size_t)m, rocprim::plus<unsigned int>(), stream)) != hipSuccess) {
             return failed(status, "scan");
         }
         hipLaunchKernelGGL(k_lbvh_wide_emit, dim3(blocksFor(m)), dim3(kLbvhBlock), 0, stream,
-                           inputs, m, levelBase, adopted, innerCount, childBase, nextFrontier, words + 7, out->nodes);
+                           inputs, frontier, m, levelBase, adopted, innerCount, childBase, nextFrontier, words + 7, out->nodes, out->leafTris);
         unsigned int next = 0;
         if ((status = hipMemcpyAsync(&next, words + 7, sizeof next, hipMemcpyDeviceToHost, stream)) != hipSuccess) { return failed(status, "frontier size"); }
         if ((status = hipStreamSynchronize(stream)) != hipSuccess) { return failed(status, "collapse kernels"); }
         levelBase += m;
         m = next;
-        unsigned int *swap = frontier;
+        uint2 *swap = frontier;
         frontier = nextFrontier;
         nextFrontier = swap;
-        if (depth > 4096) { return failed(hipErrorInvalidValue, "runaway hierarchy depth"); }
     }
     out->nodeCount = (int)levelBase;
     out->maxDepth = depth;
-
-    // 7: leaf-ordered triangle records
-    hipLaunchKernelGGL(k_lbvh_leaf_tris, dim3(blocksFor(n)), dim3(kLbvhBlock), 0, stream, positions, indices, sorted, n, out->leafTris);
+    out->rounds = rounds;
 
     (void)hipEventRecord(finished, stream);
     if ((status = hipStreamSynchronize(stream)) != hipSuccess) { return failed(status, "build"); }

@@ -541,7 +541,9 @@ int pathed_hip_measure_bandwidth(size_t bytes, int repeats, double *read_gbs, do
 
 int pathed_hip_set_bvh_builder(int builder)
 {
-    if (builder != PATHED_BVH_SAH_HOST && builder != PATHED_BVH_LBVH_DEVICE) { return fail(PATHED_E_INVALID, "unknown BVH builder"); }
+    if (builder != PATHED_BVH_SAH_HOST && builder != PATHED_BVH_LBVH_DEVICE && builder != PATHED_BVH_PLOC_DEVICE) {
+        return fail(PATHED_E_INVALID, "unknown BVH builder");
+    }
     g_bvhBuilder = builder;
     return PATHED_OK;
 }
@@ -713,12 +715,13 @@ int pathed_hip_scene_create(const PathedSceneDesc *desc, PathedScene **out)
     int builder = g_bvhBuilder;
     if (const char *text = getenv("PATHED_BVH_BUILDER")) {
         if (!strcmp(text, "lbvh")) { builder = PATHED_BVH_LBVH_DEVICE; }
+        else if (!strcmp(text, "ploc")) { builder = PATHED_BVH_PLOC_DEVICE; }
         else if (!strcmp(text, "sah")) { builder = PATHED_BVH_SAH_HOST; }
     }
     // tiny meshes take the all-triangles kernel, which wants the host copy of the records
     if (desc->n_triangles <= (uint32_t)kBruteForceMaxTris) { builder = PATHED_BVH_SAH_HOST; }
     scene->bvhBuilder = builder;
-    if (builder == PATHED_BVH_LBVH_DEVICE) {
+    if (builder == PATHED_BVH_LBVH_DEVICE || builder == PATHED_BVH_PLOC_DEVICE) {
         // rtcCommitScene's stand-in on the device (lbvh.h): upload the soup, build, keep the result in place
         DeviceBuffer<float> devicePositions;
         DeviceBuffer<uint32_t> deviceIndices;
@@ -728,7 +731,10 @@ int pathed_hip_scene_create(const PathedSceneDesc *desc, PathedScene **out)
         if (status == hipSuccess) { status = hipMemcpy(deviceIndices.ptr, desc->indices, (size_t)3 * desc->n_triangles * sizeof(uint32_t), hipMemcpyHostToDevice); }
         DeviceBvh built;
         std::string message;
-        if (status == hipSuccess) { status = buildLbvhOnDevice(devicePositions.ptr, deviceIndices.ptr, desc->n_triangles, nullptr, &built, &message); }
+        if (status == hipSuccess) {
+            status = buildBvhOnDevice(builder == PATHED_BVH_PLOC_DEVICE ? kDeviceBuilderPloc : kDeviceBuilderLbvh,
+                                      devicePositions.ptr, deviceIndices.ptr, desc->n_triangles, nullptr, &built, &message);
+        }
         devicePositions.release();
         deviceIndices.release();
         if (status != hipSuccess) { return fail_cleanup(status, message.empty() ? "device BVH build" : message.c_str()); }

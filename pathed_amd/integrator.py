@@ -36,7 +36,7 @@ def measure_bandwidth(gib=2.0, repeats=10):
 class HipScene:
     """A scene uploaded to one GPU (PathedScene handle)."""
 
-    BVH_BUILDERS = {"sah": 0, "lbvh": 1}  # PATHED_BVH_SAH_HOST / PATHED_BVH_LBVH_DEVICE
+    BVH_BUILDERS = {"sah": 0, "lbvh": 1, "ploc": 2}  # PATHED_BVH_SAH_HOST / _LBVH_DEVICE / _PLOC_DEVICE
 
     def __init__(self, desc_pointer, device=None, bvh_builder="sah"):
         self._lib = _capi.load_hip()

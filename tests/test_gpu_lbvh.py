@@ -99,23 +99,27 @@ def check_tree(nodes, tris, n_triangles, reported_depth):
             assert (hi[level[inner], :, k] >= subtree_hi[child] - 1e-4 * np.abs(subtree_hi[child])).all()
 
 
+DEVICE_BUILDERS = [("lbvh", 1), ("ploc", 2)]
+
+
+@pytest.mark.parametrize("builder,builder_code", DEVICE_BUILDERS)
 @pytest.mark.parametrize("scene_path,centre,extent", [
     ("scenes/cornell-glossy.json", (0, 1, 0), 1.0),
     ("scenes/teapot.json", (0, 4, 0), 9.0),
 ])
-def test_device_built_tree_is_valid_and_gives_identical_hits_and_images(libs, scene_path, centre, extent):
+def test_device_built_tree_is_valid_and_gives_identical_hits_and_images(libs, scene_path, centre, extent, builder, builder_code):
     oracle_lib, HipScene, LoadedScene = libs
     scene = LoadedScene(scene_path, 48, 48)
     assert scene.n_triangles > 64
     sah = HipScene(scene.desc, device=0)
-    lbvh = HipScene(scene.desc, device=0, bvh_builder="lbvh")
-    assert sah.stats()["bvh_builder"] == 0 and lbvh.stats()["bvh_builder"] == 1
+    lbvh = HipScene(scene.desc, device=0, bvh_builder=builder)
+    assert sah.stats()["bvh_builder"] == 0 and lbvh.stats()["bvh_builder"] == builder_code
     assert lbvh.stats()["bvh_build_ms"] > 0
     check_tree(*sah.export_bvh(), scene.n_triangles, sah.stats()["bvh_max_depth"])   # the checker itself, on the host tree
     nodes, tris = lbvh.export_bvh()
     check_tree(nodes, tris, scene.n_triangles, lbvh.stats()["bvh_max_depth"])
     # the same tree every run (ids come from a scan, not from atomics)
-    nodes_again, tris_again = HipScene(scene.desc, device=0, bvh_builder="lbvh").export_bvh()
+    nodes_again, tris_again = HipScene(scene.desc, device=0, bvh_builder=builder).export_bvh()
     assert np.array_equal(nodes.view(np.int32), nodes_again.view(np.int32))
     assert np.array_equal(tris.view(np.int32), tris_again.view(np.int32))
 
@@ -127,7 +131,8 @@ def test_device_built_tree_is_valid_and_gives_identical_hits_and_images(libs, sc
     assert np.array_equal(lbvh.render(5, 0, 8, 0, 10), sah.render(5, 0, 8, 0, 10))
 
 
-def test_device_build_on_a_large_mesh(libs):
+@pytest.mark.parametrize("builder,builder_code", DEVICE_BUILDERS)
+def test_device_build_on_a_large_mesh(libs, builder, builder_code):
     """The stand-in dragon at ~330 K triangles: valid tree, hits and image identical to the SAH
     tree's, and the counting kernel says what the cheaper build costs in traversal work."""
     _, HipScene, LoadedScene = libs
@@ -136,7 +141,7 @@ def test_device_build_on_a_large_mesh(libs):
     scene = LoadedScene("scenes/dragon-standin.json", 96, 54)
     assert scene.n_triangles >= 200000
     sah = HipScene(scene.desc, device=0)
-    lbvh = HipScene(scene.desc, device=0, bvh_builder="lbvh")
+    lbvh = HipScene(scene.desc, device=0, bvh_builder=builder)
     nodes, tris = lbvh.export_bvh()
     check_tree(nodes, tris, scene.n_triangles, lbvh.stats()["bvh_max_depth"])
     rng = np.random.default_rng(4)
@@ -156,8 +161,8 @@ def test_device_build_on_a_large_mesh(libs):
         work[name] = (gpu.render(1, 0, 4, 0, 10), gpu.stats())
     assert np.array_equal(work["sah"][0], work["lbvh"][0])
     boxes = {name: entry[1]["nodes_visited"] for name, entry in work.items()}
-    print("build ms: sah %.1f (host) lbvh %.2f (device); child boxes tested: sah %d lbvh %d (x%.2f)" % (
-        sah.stats()["bvh_build_ms"], lbvh.stats()["bvh_build_ms"], boxes["sah"], boxes["lbvh"], boxes["lbvh"] / boxes["sah"]))
+    print("build ms: sah %.1f (host) %s %.2f (device); child boxes tested: sah %d %s %d (x%.2f)" % (
+        sah.stats()["bvh_build_ms"], builder, lbvh.stats()["bvh_build_ms"], boxes["sah"], builder, boxes["lbvh"], boxes["lbvh"] / boxes["sah"]))
     assert boxes["lbvh"] < 3 * boxes["sah"]
     assert lbvh.stats()["bvh_build_ms"] < sah.stats()["bvh_build_ms"]
 
@@ -188,16 +193,17 @@ def test_degenerate_inputs(libs):
         built, desc = build(vertices, faces)
         n_triangles = len(faces) + 2
         assert n_triangles > 64
-        sah = HipScene(desc, device=0)
-        lbvh = HipScene(desc, device=0, bvh_builder="lbvh")
-        assert lbvh.stats()["bvh_builder"] == 1, name
-        nodes, tris = lbvh.export_bvh()
-        check_tree(nodes, tris, n_triangles, lbvh.stats()["bvh_max_depth"])
-        rays = _rays(20000, 5, (0, 0, 0), 3.0)
-        hits = lbvh.trace(rays)
-        assert np.array_equal(hits.view(np.int32), sah.trace(rays).view(np.int32)), name
-        assert np.array_equal(hits.view(np.int32), oracle_lib.OracleScene(desc).trace(rays).view(np.int32)), name
-        assert np.array_equal(lbvh.render(3, 0, 4, 0, 6), sah.render(3, 0, 4, 0, 6)), name
+        for builder, builder_code in DEVICE_BUILDERS:
+            sah = HipScene(desc, device=0)
+            lbvh = HipScene(desc, device=0, bvh_builder=builder)
+            assert lbvh.stats()["bvh_builder"] == builder_code, name
+            nodes, tris = lbvh.export_bvh()
+            check_tree(nodes, tris, n_triangles, lbvh.stats()["bvh_max_depth"])
+            rays = _rays(20000, 5, (0, 0, 0), 3.0)
+            hits = lbvh.trace(rays)
+            assert np.array_equal(hits.view(np.int32), sah.trace(rays).view(np.int32)), (name, builder)
+            assert np.array_equal(hits.view(np.int32), oracle_lib.OracleScene(desc).trace(rays).view(np.int32)), (name, builder)
+            assert np.array_equal(lbvh.render(3, 0, 4, 0, 6), sah.render(3, 0, 4, 0, 6)), (name, builder)
 
 
 def test_tiny_meshes_keep_the_host_path(libs):

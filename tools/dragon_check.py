@@ -10,7 +10,7 @@ parser.add_argument("--width", type=int, default=1920)
 parser.add_argument("--height", type=int, default=1080)
 parser.add_argument("--spp", type=int, default=16)
 parser.add_argument("--no-oracle", action="store_true")
-parser.add_argument("--builder", default="sah", choices=["sah", "lbvh"], help="host binned-SAH build or the on-GPU LBVH build")
+parser.add_argument("--builder", default="sah", choices=["sah", "lbvh", "ploc"], help="host binned-SAH build or the on-GPU LBVH build")
 args = parser.parse_args()
 
 t = time.time()

@@ -38,7 +38,7 @@ def main():
     parser.add_argument("--dragon", type=int, default=9)
     parser.add_argument("--only", default="")
     parser.add_argument("--full", action="store_true", help="render the spp BASELINE.json names (C2 4096, C3 1024, C4 2048, C5 8192) on this one GPU")
-    parser.add_argument("--builder", default="sah", choices=["sah", "lbvh"])
+    parser.add_argument("--builder", default="sah", choices=["sah", "lbvh", "ploc"])
     args = parser.parse_args()
     full_spp = {"C1": 16, "C2": 4096, "C3": 1024, "C4": 2048, "C5": 8192}
     subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_assets.py"), "--dragon", str(args.dragon)], check=True,
