@@ -13,6 +13,7 @@
 //                       frontier entry carries its subtree's first position in leaf order; subtrees
 //                       of at most four triangles become leaves and write their (v0, prim) (e1) (e2)
 //                       records there.
+#include <cstdlib>
 #include <cstring>
 
 #include <hip/hip_runtime.h>
@@ -218,7 +219,8 @@ __global__ __launch_bounds__(kLbvhBlock) void k_lbvh_fit(
 // into a new binary node; the cluster array is compacted (exclusive scans, so node ids and order
 // are the same every run) and the round repeats until one cluster is left.  Quality is close to a
 // top-down SAH build, at a few tens of launches.
-constexpr int kPlocRadius = 16;
+constexpr int kPlocRadius = 16;      // default search radius
+constexpr int kPlocMaxRadius = 64;   // PATHED_PLOC_RADIUS may raise it up to here (LDS tile size)
 
 struct PlocClusters {
     float4 *lo, *hi;
@@ -238,13 +240,13 @@ __global__ __launch_bounds__(kLbvhBlock) void k_ploc_init(
     clusters.count[i] = 1u;
 }
 
-__global__ __launch_bounds__(kLbvhBlock) void k_ploc_nearest(PlocClusters clusters, unsigned int c, unsigned int *nearest)
+__global__ __launch_bounds__(kLbvhBlock) void k_ploc_nearest(PlocClusters clusters, unsigned int c, int radius, unsigned int *nearest)
 {
-    __shared__ float4 tileLo[kLbvhBlock + 2 * kPlocRadius];
-    __shared__ float4 tileHi[kLbvhBlock + 2 * kPlocRadius];
+    __shared__ float4 tileLo[kLbvhBlock + 2 * kPlocMaxRadius];
+    __shared__ float4 tileHi[kLbvhBlock + 2 * kPlocMaxRadius];
     const long long blockStart = (long long)blockIdx.x * kLbvhBlock;
-    for (int k = threadIdx.x; k < kLbvhBlock + 2 * kPlocRadius; k += kLbvhBlock) {
-        const long long j = blockStart - kPlocRadius + k;
+    for (int k = threadIdx.x; k < kLbvhBlock + 2 * radius; k += kLbvhBlock) {
+        const long long j = blockStart - radius + k;
         if (j >= 0 && j < (long long)c) {
             tileLo[k] = clusters.lo[j];
             tileHi[k] = clusters.hi[j];
@@ -253,13 +255,13 @@ __global__ __launch_bounds__(kLbvhBlock) void k_ploc_nearest(PlocClusters cluste
     __syncthreads();
     const long long i = blockStart + threadIdx.x;
     if (i >= (long long)c) { return; }
-    const float4 lo = tileLo[threadIdx.x + kPlocRadius], hi = tileHi[threadIdx.x + kPlocRadius];
+    const float4 lo = tileLo[threadIdx.x + radius], hi = tileHi[threadIdx.x + radius];
     float bestArea = __builtin_huge_valf();
     unsigned int best = (unsigned int)i;
-    for (int d = -kPlocRadius; d <= kPlocRadius; d++) {
+    for (int d = -radius; d <= radius; d++) {
         const long long j = i + d;
         if (d == 0 || j < 0 || j >= (long long)c) { continue; }
-        const float4 olo = tileLo[threadIdx.x + kPlocRadius + d], ohi = tileHi[threadIdx.x + kPlocRadius + d];
+        const float4 olo = tileLo[threadIdx.x + radius + d], ohi = tileHi[threadIdx.x + radius + d];
         const float dx = fmaxf(hi.x, ohi.x) - fminf(lo.x, olo.x);
         const float dy = fmaxf(hi.y, ohi.y) - fminf(lo.y, olo.y);
         const float dz = fmaxf(hi.z, ohi.z) - fminf(lo.z, olo.z);
@@ -587,11 +589,16 @@ hipError_t buildBvhOnDevice(int builder, const float *positions, const uint32_t 
         void *scanTemporary = scratch.get<unsigned char>(scanBytes);
         if (scratch.status != hipSuccess) { return failed(scratch.status, "scan scratch"); }
 
+        int radius = kPlocRadius;
+        if (const char *text = getenv("PATHED_PLOC_RADIUS")) {   // tuning
+            const int value = atoi(text);
+            if (value >= 1 && value <= kPlocMaxRadius) { radius = value; }
+        }
         hipLaunchKernelGGL(k_ploc_init, dim3(blocksFor(n)), dim3(kLbvhBlock), 0, stream, n, sorted, boxLo, boxHi, a);
         unsigned int c = n, nodeBase = 0;
         while (c > 1) {
             if (++rounds > 4096) { return failed(hipErrorInvalidValue, "clustering does not converge"); }
-            hipLaunchKernelGGL(k_ploc_nearest, dim3(blocksFor(c)), dim3(kLbvhBlock), 0, stream, a, c, nearest);
+            hipLaunchKernelGGL(k_ploc_nearest, dim3(blocksFor(c)), dim3(kLbvhBlock), 0, stream, a, c, radius, nearest);
             hipLaunchKernelGGL(k_ploc_flags, dim3(blocksFor(c)), dim3(kLbvhBlock), 0, stream, c, nearest, survives, merges);
             size_t bytes = scanBytes;
             if ((status = rocprim::exclusive_scan(scanTemporary, bytes, survives, survivorIndex, 0u, (size_t)c, rocprim::plus<unsigned int>(), stream)) != hipSuccess) { return failed(status, "scan"); }
