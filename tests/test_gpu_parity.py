@@ -457,3 +457,10 @@ def test_unbounded_last_bounce_terminates_and_matches(libs):
     assert stats["vertices"] > 0.5 * stats["camera_samples"]  # most camera rays hit and bounce
     shallow, _ = oracle_lib.OracleScene(desc).render(48, 48, 2, 0, 8, 0, 1, chunk=4)
     assert expected.sum() > shallow.sum() * 1.01  # the unbounded render carries indirect light
+
+
+def test_bandwidth_probe_reports_a_plausible_rate():
+    """pathed_hip_measure_bandwidth: the measured roofline denominator bench.py prints."""
+    from pathed_amd.integrator import measure_bandwidth
+    read, copy = measure_bandwidth(gib=1.0, repeats=5)
+    assert 1000.0 < read < 9000.0 and 1000.0 < copy < 9000.0, (read, copy)   # GB/s on an MI355X (8 TB/s peak)
