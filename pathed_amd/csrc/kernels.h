@@ -1244,6 +1244,31 @@ __global__ __launch_bounds__(kBlock) void k_shade(RenderParams p)
     }
 }
 
+// ------------------------------------------------------------------------- scene set-up
+// The per-triangle shading records (device_scene.h: kTriShadeQuads) gathered on the device from the
+// vertex arrays: pure copies, so the table is the one the host loop used to build, without writing
+// and uploading 128 bytes per triangle from one host thread.
+__global__ __launch_bounds__(kBlock) void k_build_tri_shade(
+    const float *positions, const float *normals, const float *uvs, const uint32_t *indices, const int *triMaterial,
+    uint32_t nTriangles, float4 *triShade)
+{
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= nTriangles) { return; }
+    const size_t i0 = indices[3 * (size_t)i + 0], i1 = indices[3 * (size_t)i + 1], i2 = indices[3 * (size_t)i + 2];
+    const float *p0 = positions + 3 * i0, *p1 = positions + 3 * i1, *p2 = positions + 3 * i2;
+    const float *n0 = normals + 3 * i0, *n1 = normals + 3 * i1, *n2 = normals + 3 * i2;
+    const float *t0 = uvs + 2 * i0, *t1 = uvs + 2 * i1, *t2 = uvs + 2 * i2;
+    float4 *q = triShade + (size_t)kTriShadeQuads * i;
+    q[0] = make_float4(p0[0], p0[1], p0[2], intAsFloat(triMaterial[i]));
+    q[1] = make_float4(p1[0], p1[1], p1[2], t0[0]);
+    q[2] = make_float4(p2[0], p2[1], p2[2], t0[1]);
+    q[3] = make_float4(n0[0], n0[1], n0[2], t1[0]);
+    q[4] = make_float4(n1[0], n1[1], n1[2], t1[1]);
+    q[5] = make_float4(n2[0], n2[1], n2[2], t2[0]);
+    q[6] = make_float4(t2[1], 0.f, 0.f, 0.f);
+    q[7] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
 // ------------------------------------------------------------------------- bandwidth probe
 // What this box's HBM actually delivers to a plain streaming kernel: the second denominator beside
 // the 8 TB/s spec figure.  16 bytes per lane per access, grid-stride.

@@ -605,27 +605,6 @@ int pathed_hip_scene_create(const PathedSceneDesc *desc, PathedScene **out)
         }
     }
 
-    // per-triangle shading records, original primitive order
-    std::vector<float4> triShade((size_t)kTriShadeQuads * desc->n_triangles);
-    for (uint32_t i = 0; i < desc->n_triangles; i++) {
-        const uint32_t i0 = desc->indices[3 * i + 0], i1 = desc->indices[3 * i + 1], i2 = desc->indices[3 * i + 2];
-        const float *p0 = desc->positions + 3 * i0, *p1 = desc->positions + 3 * i1, *p2 = desc->positions + 3 * i2;
-        const float *n0 = desc->normals + 3 * i0, *n1 = desc->normals + 3 * i1, *n2 = desc->normals + 3 * i2;
-        const float *t0 = desc->uvs + 2 * i0, *t1 = desc->uvs + 2 * i1, *t2 = desc->uvs + 2 * i2;
-        float4 *q = triShade.data() + (size_t)kTriShadeQuads * i;
-        int material = desc->tri_material[i];
-        float materialBits;
-        std::memcpy(&materialBits, &material, 4);
-        q[0] = make_float4(p0[0], p0[1], p0[2], materialBits);
-        q[1] = make_float4(p1[0], p1[1], p1[2], t0[0]);
-        q[2] = make_float4(p2[0], p2[1], p2[2], t0[1]);
-        q[3] = make_float4(n0[0], n0[1], n0[2], t1[0]);
-        q[4] = make_float4(n1[0], n1[1], n1[2], t1[1]);
-        q[5] = make_float4(n2[0], n2[1], n2[2], t2[0]);
-        q[6] = make_float4(t2[1], 0.f, 0.f, 0.f);
-        q[7] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-
     std::vector<DSphere> spheres(desc->n_spheres);
     for (uint32_t i = 0; i < desc->n_spheres; i++) {
         const PathedSphere &s = desc->spheres[i];
@@ -721,23 +700,42 @@ int pathed_hip_scene_create(const PathedSceneDesc *desc, PathedScene **out)
     // tiny meshes take the all-triangles kernel, which wants the host copy of the records
     if (desc->n_triangles <= (uint32_t)kBruteForceMaxTris) { builder = PATHED_BVH_SAH_HOST; }
     scene->bvhBuilder = builder;
+    // the triangle soup on the device: input of the device builders and of the shading-record gather
+    DeviceBuffer<float> devicePositions, deviceNormals, deviceUvs;
+    DeviceBuffer<uint32_t> deviceIndices;
+    DeviceBuffer<int> deviceTriMaterial;
+    auto releaseSoup = [&]() {
+        devicePositions.release(); deviceNormals.release(); deviceUvs.release(); deviceIndices.release(); deviceTriMaterial.release();
+    };
+    if (desc->n_triangles > 0) {
+        const size_t nv = desc->n_vertices, nt = desc->n_triangles;
+        status = devicePositions.allocate(3 * nv);
+        if (status == hipSuccess) { status = deviceNormals.allocate(3 * nv); }
+        if (status == hipSuccess) { status = deviceUvs.allocate(2 * nv); }
+        if (status == hipSuccess) { status = deviceIndices.allocate(3 * nt); }
+        if (status == hipSuccess) { status = deviceTriMaterial.allocate(nt); }
+        if (status == hipSuccess) { status = scene->triShade.allocate((size_t)kTriShadeQuads * nt); }
+        if (status == hipSuccess) { status = hipMemcpy(devicePositions.ptr, desc->positions, 3 * nv * sizeof(float), hipMemcpyHostToDevice); }
+        if (status == hipSuccess) { status = hipMemcpy(deviceNormals.ptr, desc->normals, 3 * nv * sizeof(float), hipMemcpyHostToDevice); }
+        if (status == hipSuccess) { status = hipMemcpy(deviceUvs.ptr, desc->uvs, 2 * nv * sizeof(float), hipMemcpyHostToDevice); }
+        if (status == hipSuccess) { status = hipMemcpy(deviceIndices.ptr, desc->indices, 3 * nt * sizeof(uint32_t), hipMemcpyHostToDevice); }
+        if (status == hipSuccess) { status = hipMemcpy(deviceTriMaterial.ptr, desc->tri_material, nt * sizeof(int), hipMemcpyHostToDevice); }
+        if (status == hipSuccess) {
+            hipLaunchKernelGGL(k_build_tri_shade, dim3((unsigned)((nt + kBlock - 1) / kBlock)), dim3(kBlock), 0, nullptr,
+                               devicePositions.ptr, deviceNormals.ptr, deviceUvs.ptr, deviceIndices.ptr, deviceTriMaterial.ptr,
+                               (uint32_t)nt, scene->triShade.ptr);
+            status = hipGetLastError();
+        }
+        if (status != hipSuccess) { releaseSoup(); return fail_cleanup(status, "upload triangle soup"); }
+    }
+
     if (builder == PATHED_BVH_LBVH_DEVICE || builder == PATHED_BVH_PLOC_DEVICE) {
-        // rtcCommitScene's stand-in on the device (lbvh.h): upload the soup, build, keep the result in place
-        DeviceBuffer<float> devicePositions;
-        DeviceBuffer<uint32_t> deviceIndices;
-        status = devicePositions.allocate((size_t)3 * desc->n_vertices);
-        if (status == hipSuccess) { status = deviceIndices.allocate((size_t)3 * desc->n_triangles); }
-        if (status == hipSuccess) { status = hipMemcpy(devicePositions.ptr, desc->positions, (size_t)3 * desc->n_vertices * sizeof(float), hipMemcpyHostToDevice); }
-        if (status == hipSuccess) { status = hipMemcpy(deviceIndices.ptr, desc->indices, (size_t)3 * desc->n_triangles * sizeof(uint32_t), hipMemcpyHostToDevice); }
+        // rtcCommitScene's stand-in on the device (lbvh.h): build, keep the result in place
         DeviceBvh built;
         std::string message;
-        if (status == hipSuccess) {
-            status = buildBvhOnDevice(builder == PATHED_BVH_PLOC_DEVICE ? kDeviceBuilderPloc : kDeviceBuilderLbvh,
-                                      devicePositions.ptr, deviceIndices.ptr, desc->n_triangles, nullptr, &built, &message);
-        }
-        devicePositions.release();
-        deviceIndices.release();
-        if (status != hipSuccess) { return fail_cleanup(status, message.empty() ? "device BVH build" : message.c_str()); }
+        status = buildBvhOnDevice(builder == PATHED_BVH_PLOC_DEVICE ? kDeviceBuilderPloc : kDeviceBuilderLbvh,
+                                  devicePositions.ptr, deviceIndices.ptr, desc->n_triangles, nullptr, &built, &message);
+        if (status != hipSuccess) { releaseSoup(); return fail_cleanup(status, message.empty() ? "device BVH build" : message.c_str()); }
         scene->nodes.ptr = built.nodes;
         scene->nodes.count = built.nodeCapacity * 8;
         scene->leafTris.ptr = built.leafTris;
@@ -753,10 +751,12 @@ int pathed_hip_scene_create(const PathedSceneDesc *desc, PathedScene **out)
         std::vector<float4> nodes(scene->bvh.nodes.size() / 4), tris(scene->bvh.leafTris.size() / 4);
         std::memcpy(nodes.data(), scene->bvh.nodes.data(), scene->bvh.nodes.size() * sizeof(float));
         std::memcpy(tris.data(), scene->bvh.leafTris.data(), scene->bvh.leafTris.size() * sizeof(float));
-        if ((status = scene->nodes.upload(nodes)) != hipSuccess) { return fail_cleanup(status, "upload nodes"); }
-        if ((status = scene->leafTris.upload(tris)) != hipSuccess) { return fail_cleanup(status, "upload triangles"); }
+        if ((status = scene->nodes.upload(nodes)) != hipSuccess) { releaseSoup(); return fail_cleanup(status, "upload nodes"); }
+        if ((status = scene->leafTris.upload(tris)) != hipSuccess) { releaseSoup(); return fail_cleanup(status, "upload triangles"); }
     }
-    if ((status = scene->triShade.upload(triShade)) != hipSuccess) { return fail_cleanup(status, "upload shading records"); }
+    status = hipDeviceSynchronize();   // the shading-record gather reads the soup
+    releaseSoup();
+    if (status != hipSuccess) { return fail_cleanup(status, "build shading records"); }
     if ((status = scene->spheres.upload(spheres)) != hipSuccess) { return fail_cleanup(status, "upload spheres"); }
     if ((status = scene->materials.upload(materials)) != hipSuccess) { return fail_cleanup(status, "upload materials"); }
     if ((status = scene->lights.upload(lights)) != hipSuccess) { return fail_cleanup(status, "upload lights"); }
