@@ -70,7 +70,12 @@ int runJob(const std::string &jobPath, const std::string &assetRootOverride)
         Image image(width, height, job.outputDirectory());
 
         const std::string assetRoot = !assetRootOverride.empty() ? assetRootOverride : job.assetRoot();
+        const std::string builder = job.bvhBuilder();
+        const int builderCode = builder == "ploc" ? PATHED_BVH_PLOC_DEVICE : builder == "lbvh" ? PATHED_BVH_LBVH_DEVICE : PATHED_BVH_SAH_HOST;
+        if (builder != "sah" && builder != "lbvh" && builder != "ploc") { throw std::runtime_error("job: unknown bvh_builder: " + builder); }
+        pathed_hip_set_bvh_builder(builderCode);
         Scene scene(loadScene(job.scene(), width, height, assetRoot), job.gpu());
+        pathed_hip_set_bvh_builder(PATHED_BVH_SAH_HOST);
 
         std::shared_ptr<Integrator> integrator = job.integrator();
         integrator->configure(job.spp(), job.seed(), job.sppPerLaunch(), job.outputDirectory());

@@ -2,7 +2,8 @@
 // Same keys as the reference (spp, integrator, scene, startBounce, lastBounce,
 // output_directory, output_name, showUI, force, width, height); job-file numbers are real
 // JSON numbers.  Optional extra keys with defaults, so reference job files run unchanged:
-//   "seed" (1), "spp_per_launch" (64), "gpu" (0), "asset_root" (directory paths resolve in).
+//   "seed" (1), "spp_per_launch" (64), "gpu" (0), "asset_root" (directory paths resolve in),
+//   "bvh_builder" ("sah" | "lbvh" | "ploc": include/pathed_hip.h PATHED_BVH_*).
 #pragma once
 
 #include "bounce_controller.h"
@@ -48,6 +49,7 @@ public:
     int sppPerLaunch() const { return m_json["spp_per_launch"].isNumber() ? m_json["spp_per_launch"].asInt() : 64; }
     int gpu() const { return m_json["gpu"].isNumber() ? m_json["gpu"].asInt() : 0; }
     std::string assetRoot() const { return m_json["asset_root"].isString() ? m_json["asset_root"].asString() : ""; }
+    std::string bvhBuilder() const { return m_json["bvh_builder"].isString() ? m_json["bvh_builder"].asString() : "sah"; }
 
     // string -> class factory, src/job.cpp:65-97; only the hot-path integrators exist here
     std::shared_ptr<Integrator> integrator() const;

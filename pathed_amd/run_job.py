@@ -63,7 +63,7 @@ def main(argv=None):
             json.dump(job, handle, indent=4)
 
     scene = LoadedScene(job["scene"], width, height, asset_root if asset_root is not None else job.get("asset_root"))
-    gpu = HipScene(scene.desc, device=local_rank)
+    gpu = HipScene(scene.desc, device=local_rank, bvh_builder=job.get("bvh_builder", "sah"))
     host = _capi.load_host()
     stream = torch.cuda.current_stream().cuda_stream
 
