@@ -628,6 +628,84 @@ int main(int argc, char **argv)
         }
     }
 
+    /* ---- PIZ-compressed EXR files, written AND read back by the reference's vendored tinyexr ---- */
+    /* The reference reads environment maps through tinyexr LoadEXR (src/environment_light.cpp:14-28),
+     * which accepts PIZ.  Two fixture files are written next to the texture fixtures (data, generated
+     * by the reference's own code) and what LoadEXR returns for them is dumped:
+     * exr_piz_image: in = file index   out = width height, then the RGBA floats of LoadEXR */
+    {
+        const std::string directory = (argc > 3) ? argv[3] : "tests/golden/textures";
+        struct Spec { const char *name; int width, height, pixelType; };
+        const Spec specs[2] = {
+            { "piz_float_45x70.exr", 45, 70, TINYEXR_PIXELTYPE_FLOAT },   /* > 2 blocks of 32 lines, odd sizes, 16-bit wavelet */
+            { "piz_half_33x40.exr", 33, 40, TINYEXR_PIXELTYPE_HALF },     /* few distinct values: 14-bit wavelet */
+        };
+        for (int f = 0; f < 2; f++) {
+            const Spec &spec = specs[f];
+            const size_t pixels = (size_t)spec.width * spec.height;
+            std::vector<float> planes[4];   /* A B G R: the channel order tinyexr wants */
+            for (int c = 0; c < 4; c++) { planes[c].resize(pixels); }
+            for (int y = 0; y < spec.height; y++) {
+                for (int x = 0; x < spec.width; x++) {
+                    const size_t i = (size_t)y * spec.width + x;
+                    if (f == 0) {
+                        const float sun = (x > 30 && x < 36 && y > 10 && y < 15) ? 4000.f : 0.f;
+                        planes[3][i] = 0.2f + 0.01f * x + 0.3f * uniform01() + sun;        /* R */
+                        planes[2][i] = 0.1f + 0.005f * y + 0.1f * uniform01() + sun;      /* G */
+                        planes[1][i] = (y < 35) ? 0.7f + 0.2f * uniform01() : 0.f;          /* B: exact zeros */
+                        planes[0][i] = 1.f;                                                   /* A */
+                    } else {
+                        planes[3][i] = 0.25f * (float)((x / 4 + y / 4) % 4);
+                        planes[2][i] = 0.5f * (float)((x / 8) % 2);
+                        planes[1][i] = (float)(y % 3);
+                        planes[0][i] = 1.f;
+                    }
+                }
+            }
+            EXRHeader header;
+            InitEXRHeader(&header);
+            EXRImage image;
+            InitEXRImage(&image);
+            image.num_channels = 4;
+            unsigned char *pointers[4] = {
+                (unsigned char *)planes[0].data(), (unsigned char *)planes[1].data(),
+                (unsigned char *)planes[2].data(), (unsigned char *)planes[3].data() };
+            image.images = pointers;
+            image.width = spec.width;
+            image.height = spec.height;
+            header.num_channels = 4;
+            EXRChannelInfo channelInfo[4];
+            memset(channelInfo, 0, sizeof channelInfo);
+            const char *names[4] = { "A", "B", "G", "R" };
+            int inputTypes[4], outputTypes[4];
+            for (int c = 0; c < 4; c++) {
+                strncpy(channelInfo[c].name, names[c], 255);
+                inputTypes[c] = TINYEXR_PIXELTYPE_FLOAT;
+                outputTypes[c] = spec.pixelType;
+            }
+            header.channels = channelInfo;
+            header.pixel_types = inputTypes;
+            header.requested_pixel_types = outputTypes;
+            header.compression_type = TINYEXR_COMPRESSIONTYPE_PIZ;
+            const std::string path = directory + "/" + spec.name;
+            const char *message = nullptr;
+            if (SaveEXRImageToFile(&image, &header, path.c_str(), &message) != TINYEXR_SUCCESS) {
+                fprintf(stderr, "cannot write %s: %s\n", path.c_str(), message ? message : "?");
+                continue;
+            }
+            float *loaded = nullptr;
+            int width = 0, height = 0;
+            if (LoadEXR(&loaded, &width, &height, path.c_str(), &message) != TINYEXR_SUCCESS) {
+                fprintf(stderr, "cannot read back %s: %s\n", path.c_str(), message ? message : "?");
+                continue;
+            }
+            std::vector<float> out = { (float)width, (float)height };
+            out.insert(out.end(), loaded, loaded + (size_t)4 * width * height);
+            free(loaded);
+            emit("exr_piz_image", { (float)f }, out);
+        }
+    }
+
     if (g_out != stdout) { fclose(g_out); }
     return 0;
 }

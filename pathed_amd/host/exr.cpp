@@ -243,6 +243,268 @@ struct ChannelInfo {
     int pixelType;
 };
 
+// ---- PIZ (OpenEXR compression 4): range compaction by bitmap, 2-D Haar-like wavelet on 16-bit
+// words, canonical Huffman with a run-length symbol.  Needed for environment maps written by tools
+// whose default is PIZ; the reference reads them through tinyexr (src/environment_light.cpp:14-28).
+// Restated from the published format; checked against a file written by the reference's tinyexr
+// (tests/golden/env_piz.exr).
+
+struct PizBits {
+    const unsigned char *at, *end;
+    uint64_t hold = 0;
+    int held = 0;
+
+    // n <= 32; reads past the end yield zero bits
+    uint32_t take(int n)
+    {
+        while (held < n) {
+            hold = (hold << 8) | (at < end ? *at++ : 0u);
+            held += 8;
+        }
+        held -= n;
+        return (uint32_t)((hold >> held) & ((1ull << n) - 1ull));
+    }
+};
+
+bool pizHuffmanDecode(const unsigned char *in, size_t inLength, std::vector<uint16_t> *out, std::string *why)
+{
+    const int kSymbols = (1 << 16) + 1;   // 16-bit literals plus the run-length symbol
+    if (inLength < 20) { *why = "piz: truncated huffman header"; return false; }
+    uint32_t header[5];
+    std::memcpy(header, in, 20);
+    const uint32_t first = header[0], last = header[1], bitCount = header[3];
+    if (first >= (uint32_t)kSymbols || last >= (uint32_t)kSymbols || first > last) { *why = "piz: bad symbol range"; return false; }
+
+    // code lengths: 6 bits each, 59..62 = a run of 2..5 zero lengths, 63 = 8 more bits, run of 6..261
+    std::vector<unsigned char> length((size_t)kSymbols, 0);
+    PizBits table { in + 20, in + inLength };
+    for (uint32_t symbol = first; symbol <= last; symbol++) {
+        const uint32_t l = table.take(6);
+        if (l == 63u) {
+            const uint32_t run = table.take(8) + 6u;
+            if (symbol + run > last + 1u) { *why = "piz: bad zero run"; return false; }
+            symbol += run - 1u;
+        } else if (l >= 59u) {
+            const uint32_t run = l - 59u + 2u;
+            if (symbol + run > last + 1u) { *why = "piz: bad zero run"; return false; }
+            symbol += run - 1u;
+        } else {
+            length[symbol] = (unsigned char)l;
+        }
+    }
+    const unsigned char *stream = table.at;   // the bit stream starts on the next byte
+    if (stream > in + inLength || (uint64_t)bitCount > 8ull * (uint64_t)(in + inLength - stream)) { *why = "piz: truncated huffman data"; return false; }
+
+    // canonical codes: within a length symbols take consecutive codes in symbol order; the longest
+    // codes are numerically lowest (base[l] = (base[l + 1] + count[l + 1]) >> 1)
+    uint64_t count[59] = { 0 }, base[60] = { 0 };
+    for (int symbol = 0; symbol < kSymbols; symbol++) { count[length[(size_t)symbol]]++; }
+    {
+        uint64_t code = 0;
+        for (int l = 58; l > 0; l--) {
+            base[l] = code;
+            code = (code + count[l]) >> 1;
+        }
+    }
+    std::vector<uint32_t> start(60, 0), ordered;   // symbols sorted by (length, symbol)
+    {
+        uint32_t total = 0;
+        for (int l = 1; l <= 58; l++) { start[(size_t)l] = total; total += (uint32_t)count[l]; }
+        ordered.resize(total);
+        std::vector<uint32_t> cursor(start);
+        for (int symbol = 0; symbol < kSymbols; symbol++) {
+            const int l = length[(size_t)symbol];
+            if (l > 0) { ordered[cursor[(size_t)l]++] = (uint32_t)symbol; }
+        }
+    }
+    // short codes resolve with one table access
+    const int kFast = 12;
+    std::vector<uint32_t> fast((size_t)1 << kFast, 0);   // symbol << 6 | length, 0 = longer code
+    for (int l = 1; l <= kFast; l++) {
+        for (uint64_t k = 0; k < count[l]; k++) {
+            const uint64_t code = base[l] + k;
+            const uint32_t entry = (ordered[start[(size_t)l] + (uint32_t)k] << 6) | (uint32_t)l;
+            const uint64_t low = code << (kFast - l);
+            for (uint64_t fill = 0; fill < (1ull << (kFast - l)); fill++) { fast[(size_t)(low + fill)] = entry; }
+        }
+    }
+
+    const uint32_t runSymbol = last;
+    PizBits bits { stream, in + inLength };
+    uint64_t remaining = bitCount;
+    size_t produced = 0;
+    const size_t wanted = out->size();
+    while (remaining > 0) {
+        uint32_t symbol = 0;
+        int used = 0;
+        // peek up to kFast bits without consuming more than remain
+        const int peek = remaining < (uint64_t)kFast ? (int)remaining : kFast;
+        while (bits.held < peek) {
+            bits.hold = (bits.hold << 8) | (bits.at < bits.end ? *bits.at++ : 0u);
+            bits.held += 8;
+        }
+        const uint32_t window = (uint32_t)((bits.hold >> (bits.held - peek)) & ((1ull << peek) - 1ull)) << (kFast - peek);
+        const uint32_t entry = fast[window];
+        if (entry != 0 && (int)(entry & 63u) <= peek) {
+            used = (int)(entry & 63u);
+            symbol = entry >> 6;
+            bits.held -= used;
+        } else {
+            // longer than the table: extend bit by bit
+            uint64_t code = 0;
+            bool found = false;
+            while ((uint64_t)used < remaining && used < 58) {
+                code = (code << 1) | bits.take(1);
+                used++;
+                if (count[used] && code >= base[used] && code - base[used] < count[used]) {
+                    symbol = ordered[start[(size_t)used] + (uint32_t)(code - base[used])];
+                    found = true;
+                    break;
+                }
+            }
+            if (!found) { *why = "piz: invalid huffman code"; return false; }
+        }
+        remaining -= (uint64_t)used;
+        if (symbol == runSymbol) {
+            if (remaining < 8 || produced == 0) { *why = "piz: bad run"; return false; }
+            const uint32_t run = bits.take(8);
+            remaining -= 8;
+            if (produced + run > wanted) { *why = "piz: run past the end"; return false; }
+            const uint16_t value = (*out)[produced - 1];
+            for (uint32_t k = 0; k < run; k++) { (*out)[produced++] = value; }
+        } else {
+            if (produced >= wanted) { *why = "piz: too much data"; return false; }
+            (*out)[produced++] = (uint16_t)symbol;
+        }
+    }
+    if (produced != wanted) { *why = "piz: not enough data"; return false; }
+    return true;
+}
+
+// inverse of the two wavelet butterflies (14-bit exact variant, 16-bit modulo variant)
+inline void pizUnbutterfly(bool exact14, uint16_t low, uint16_t high, uint16_t *a, uint16_t *b)
+{
+    if (exact14) {
+        const int l = (int16_t)low, h = (int16_t)high;
+        const int first = l + (h & 1) + (h >> 1);
+        *a = (uint16_t)(int16_t)first;
+        *b = (uint16_t)(int16_t)(first - h);
+    } else {
+        const int m = low, d = high;
+        const int second = (m - (d >> 1)) & 0xFFFF;
+        *a = (uint16_t)((d + second - 0x8000) & 0xFFFF);
+        *b = (uint16_t)second;
+    }
+}
+
+// in-place inverse 2-D wavelet over an nx x ny grid with element strides sx, sy
+void pizWaveletDecode(uint16_t *data, int nx, int sx, int ny, int sy, uint16_t maxValue)
+{
+    const bool exact14 = maxValue < (1 << 14);
+    const int n = nx < ny ? nx : ny;
+    int step = 1;
+    while (step <= n) { step <<= 1; }
+    step >>= 1;           // coarsest level: distance between the pairs' first elements is 2 * half
+    int half = step >> 1;
+    for (; half >= 1; step = half, half >>= 1) {
+        const int rowLimit = ny - step, columnLimit = nx - step;
+        int y = 0;
+        for (; y <= rowLimit; y += step) {
+            uint16_t *row = data + (size_t)y * sy;
+            int x = 0;
+            for (; x <= columnLimit; x += step) {
+                uint16_t *p00 = row + (size_t)x * sx;
+                uint16_t *p01 = p00 + (size_t)half * sx;
+                uint16_t *p10 = p00 + (size_t)half * sy;
+                uint16_t *p11 = p10 + (size_t)half * sx;
+                uint16_t a, b, c, d;
+                pizUnbutterfly(exact14, *p00, *p10, &a, &c);
+                pizUnbutterfly(exact14, *p01, *p11, &b, &d);
+                pizUnbutterfly(exact14, a, b, p00, p01);
+                pizUnbutterfly(exact14, c, d, p10, p11);
+            }
+            if (nx & half) {   // odd column: vertical pair only
+                uint16_t *p00 = row + (size_t)x * sx;
+                uint16_t *p10 = p00 + (size_t)half * sy;
+                uint16_t a;
+                pizUnbutterfly(exact14, *p00, *p10, &a, p10);
+                *p00 = a;
+            }
+        }
+        if (ny & half) {       // odd row: horizontal pairs only
+            uint16_t *row = data + (size_t)y * sy;
+            for (int x = 0; x <= columnLimit; x += step) {
+                uint16_t *p00 = row + (size_t)x * sx;
+                uint16_t *p01 = p00 + (size_t)half * sx;
+                uint16_t a;
+                pizUnbutterfly(exact14, *p00, *p01, &a, p01);
+                *p00 = a;
+            }
+        }
+    }
+}
+
+// one PIZ block -> the raw scanline layout (per line, per channel, little-endian samples)
+bool pizDecodeBlock(const unsigned char *in, size_t inLength, const std::vector<ChannelInfo> &channels, int width, int lines,
+                    std::vector<unsigned char> *raw, std::string *why)
+{
+    if (inLength < 4) { *why = "piz: truncated block"; return false; }
+    uint16_t minNonZero, maxNonZero;
+    std::memcpy(&minNonZero, in, 2);
+    std::memcpy(&maxNonZero, in + 2, 2);
+    size_t at = 4;
+    std::vector<unsigned char> bitmap(8192, 0);
+    if (maxNonZero >= 8192) { *why = "piz: bad bitmap range"; return false; }
+    if (minNonZero <= maxNonZero) {
+        const size_t bytes = (size_t)maxNonZero - minNonZero + 1;
+        if (at + bytes > inLength) { *why = "piz: truncated bitmap"; return false; }
+        std::memcpy(bitmap.data() + minNonZero, in + at, bytes);
+        at += bytes;
+    }
+    // the values present (plus zero), in order: word k of the coded data stands for table[k]
+    std::vector<uint16_t> table(65536, 0);
+    int present = 0;
+    for (int value = 0; value < 65536; value++) {
+        if (value == 0 || (bitmap[(size_t)value >> 3] & (1 << (value & 7)))) { table[(size_t)present++] = (uint16_t)value; }
+    }
+    const uint16_t maxValue = (uint16_t)(present - 1);
+
+    if (at + 4 > inLength) { *why = "piz: truncated block"; return false; }
+    int32_t huffmanLength;
+    std::memcpy(&huffmanLength, in + at, 4);
+    at += 4;
+    if (huffmanLength < 0 || at + (size_t)huffmanLength > inLength) { *why = "piz: bad huffman length"; return false; }
+
+    size_t words = 0;
+    for (const ChannelInfo &channel : channels) { words += (size_t)width * lines * (channel.pixelType == 1 ? 1 : 2); }
+    std::vector<uint16_t> data(words);
+    if (!pizHuffmanDecode(in + at, (size_t)huffmanLength, &data, why)) { return false; }
+
+    // channel planes follow each other; a 32-bit sample is two interleaved 16-bit planes
+    size_t plane = 0;
+    std::vector<size_t> planeStart;
+    for (const ChannelInfo &channel : channels) {
+        const int wordsPerSample = channel.pixelType == 1 ? 1 : 2;
+        planeStart.push_back(plane);
+        for (int part = 0; part < wordsPerSample; part++) {
+            pizWaveletDecode(data.data() + plane + part, width, wordsPerSample, lines, width * wordsPerSample, maxValue);
+        }
+        plane += (size_t)width * lines * wordsPerSample;
+    }
+    for (uint16_t &word : data) { word = table[word]; }
+
+    raw->resize(words * 2);
+    size_t cursor = 0;
+    for (int line = 0; line < lines; line++) {
+        for (size_t c = 0; c < channels.size(); c++) {
+            const size_t rowWords = (size_t)width * (channels[c].pixelType == 1 ? 1 : 2);
+            std::memcpy(raw->data() + cursor, data.data() + planeStart[c] + (size_t)line * rowWords, rowWords * 2);
+            cursor += rowWords * 2;
+        }
+    }
+    return true;
+}
+
 }  // namespace
 
 bool readExrRGBA(
@@ -308,8 +570,8 @@ bool readExrRGBA(
     }
     if (!reader.ok) { return fail("truncated header"); }
     if (channels.empty()) { return fail("no channels"); }
-    if (compression != 0 && compression != 2 && compression != 3) {
-        return fail("compression type " + std::to_string(compression) + " unsupported (NONE/ZIPS/ZIP only)");
+    if (compression != 0 && compression != 2 && compression != 3 && compression != 4) {
+        return fail("compression type " + std::to_string(compression) + " unsupported (NONE / ZIPS / ZIP / PIZ only)");
     }
     (void)lineOrder;
 
@@ -323,7 +585,7 @@ bool readExrRGBA(
         bytesPerLine += (size_t)w * (channel.pixelType == 1 ? 2 : 4);
     }
 
-    const int linesPerBlock = (compression == 3) ? 16 : 1;
+    const int linesPerBlock = (compression == 4) ? 32 : (compression == 3) ? 16 : 1;
     const int blockCount = (h + linesPerBlock - 1) / linesPerBlock;
 
     std::vector<uint64_t> offsets((size_t)blockCount);
@@ -351,6 +613,10 @@ bool readExrRGBA(
         if (compression == 0 || (size_t)size == expected) {
             raw.assign(data.begin() + (long)pos, data.begin() + (long)(pos + (size_t)size));
             if (raw.size() != expected) { return fail("bad uncompressed block"); }
+        } else if (compression == 4) {
+            std::string why;
+            if (!pizDecodeBlock(data.data() + pos, (size_t)size, channels, w, lines, &raw, &why)) { return fail(why); }
+            if (raw.size() != expected) { return fail("piz: block size mismatch"); }
         } else {
             scratch.resize(expected);
             uLongf destLength = (uLongf)expected;

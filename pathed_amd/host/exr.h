@@ -3,8 +3,8 @@
 //          stored HALF, uncompressed, increasing-Y scanlines.
 //   read:  reference EnvironmentLight ctor (src/environment_light.cpp:14-28) uses
 //          tinyexr LoadEXR -> float RGBA, row 0 = first scanline.  Supported here:
-//          scanline files with NONE / ZIPS / ZIP compression and HALF / FLOAT
-//          channels (PIZ and tiled files are rejected with a clear error).
+//          scanline files with NONE / ZIPS / ZIP / PIZ compression and HALF / FLOAT
+//          channels (tiled, deep and the lossy codecs are rejected with a clear error).
 #pragma once
 
 #include <string>

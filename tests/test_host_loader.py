@@ -188,3 +188,40 @@ def test_one_pixel_env_map_matches_reference_decode():
     nonzero = np.argwhere(data[..., :3].sum(-1) != 0)
     assert nonzero.tolist() == [[239, 753]]
     assert data[239, 753, :3].tolist() == [10000.0, 10000.0, 10000.0]
+
+
+@pytest.mark.parametrize("index,name", [(0, "piz_float_45x70.exr"), (1, "piz_half_33x40.exr")])
+def test_piz_compressed_exr_matches_reference_decode(index, name):
+    """PIZ (range bitmap + wavelet + Huffman) environment maps: the fixture files were written by the
+    reference's vendored tinyexr through oracle/_ref/refdump, and `exr_piz_image` holds what its LoadEXR
+    returned for them (FLOAT channels spanning > 2 blocks with the 16-bit wavelet; HALF channels with few
+    distinct values, i.e. the 14-bit wavelet).  This reader must return the same floats exactly."""
+    import json
+    expected = None
+    with open(os.path.join(_capi.REPO_ROOT, "tests", "golden", "reference_functions.jsonl")) as handle:
+        for line in handle:
+            if '"exr_piz_image"' in line:
+                record = json.loads(line)
+                if int(record["in"][0]) == index:
+                    out = record["out"]
+                    expected = np.array(out[2:], dtype=np.float64).reshape(int(out[1]), int(out[0]), 4)
+    assert expected is not None
+    host = _capi.load_host()
+    w, h = C.c_int(), C.c_int()
+    path = os.path.join(_capi.REPO_ROOT, "tests", "golden", "textures", name).encode()
+    assert host.pathed_host_read_exr_rgba(path, C.byref(w), C.byref(h), None, 0) == 0, host.pathed_host_last_error()
+    assert (h.value, w.value) == expected.shape[:2]
+    data = np.zeros((h.value, w.value, 4), dtype=np.float32)
+    assert host.pathed_host_read_exr_rgba(path, C.byref(w), C.byref(h), data.ctypes.data_as(C.POINTER(C.c_float)), data.size) == 0
+    # the dump prints 9 significant digits: float32 round-trips exactly
+    assert np.array_equal(data, expected.astype(np.float32))
+    assert data[..., :3].max() > (1000.0 if index == 0 else 1.5)
+
+
+def test_truncated_piz_file_is_rejected(tmp_path):
+    host = _capi.load_host()
+    blob = open(os.path.join(_capi.REPO_ROOT, "tests", "golden", "textures", "piz_half_33x40.exr"), "rb").read()
+    broken = tmp_path / "broken.exr"
+    broken.write_bytes(blob[: len(blob) - 200])
+    w, h = C.c_int(), C.c_int()
+    assert host.pathed_host_read_exr_rgba(str(broken).encode(), C.byref(w), C.byref(h), None, 0) != 0
