@@ -84,3 +84,28 @@ def test_python_job_runner_matches_the_executable(tmp_path):
         outputs[name] = _read_exr(os.path.join(out_dir, "auto-00008spp.exr"))
     # the executable renders 8 samples as 1+1+2+4 launches, the runner as 1+1+2+4 too: same sums
     assert np.allclose(outputs["cpp"], outputs["py"], rtol=1e-3, atol=1e-4)
+
+
+def test_bvh_builder_job_key_changes_the_build_not_the_image(tmp_path):
+    """job.json "bvh_builder": the on-GPU PLOC / LBVH builds give the checkpoint the host SAH build gives,
+    byte for byte (hits do not depend on the tree); an unknown name is an error."""
+    from pathed_amd import _capi
+    job = json.load(open(os.path.join(_capi.REPO_ROOT, "jobs", "cornell-c1.json")))
+    job["scene"] = "scenes/cornell-glossy.json"   # > 64 triangles: a BVH is built and walked
+    job["width"] = job["height"] = 48
+    job["spp"] = 4
+    exe = os.path.join(_capi.REPO_ROOT, "pathed_amd", "bin", "pathed")
+    files = {}
+    for builder in ("sah", "ploc", "lbvh", "octree"):
+        out_dir = str(tmp_path / builder)
+        job["output_directory"] = out_dir
+        job["bvh_builder"] = builder
+        job_path = str(tmp_path / (builder + ".json"))
+        json.dump(job, open(job_path, "w"))
+        result = subprocess.run([exe, job_path, _capi.REPO_ROOT], capture_output=True, text=True, cwd=str(tmp_path))
+        if builder == "octree":
+            assert result.returncode != 0 and "bvh_builder" in (result.stdout + result.stderr)
+            continue
+        assert result.returncode == 0, result.stdout + result.stderr
+        files[builder] = open(os.path.join(out_dir, "auto-00004spp.exr"), "rb").read()
+    assert files["sah"] == files["ploc"] == files["lbvh"]
