@@ -1,0 +1,114 @@
+"""Randomised scenes: the HIP path against the CPU oracle on inputs nobody hand-picked.
+
+Each seed builds a triangle soup with the awkward cases mixed in (zero-area and duplicated triangles,
+needle triangles, coordinates from 1e-3 to 1e3), every material kind with random parameters, emitters,
+spheres, sometimes an environment map and an image texture.  Checks: closest-hit and any-hit queries are
+bit-exact against the oracle, the three BVH builders give identical hits and images, and the rendered
+image is within the stated tolerance of the oracle's.
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def build_scene(seed, size=40):
+    from pathed_amd import _capi
+    from scene_builder import BuiltScene
+    rng = np.random.default_rng(seed)
+    scale = float(10.0 ** rng.uniform(-1.0, 2.0))
+    built = BuiltScene(size, size, (0, 0.3 * scale, 3.0 * scale), (0, 0, 0), fov_degrees=50.0)
+
+    texture = built.texture(rng.integers(0, 256, (5, 9, 3), dtype=np.uint8)) if seed % 2 == 0 else None
+    materials = [
+        built.material(_capi.MAT_LAMBERTIAN, diffuse=rng.uniform(0.1, 0.9, 3)),
+        built.material(_capi.MAT_LAMBERTIAN, checker=((0.8, 0.7, 0.6), (0.2, 0.2, 0.3), (4.0, 7.0))),
+        built.material(_capi.MAT_OREN_NAYAR, diffuse=rng.uniform(0.1, 0.9, 3), sigma=float(rng.uniform(0.1, 0.9))),
+        built.material(_capi.MAT_MICROFACET, alpha=float(rng.uniform(0.05, 0.5))),
+        built.material(_capi.MAT_PLASTIC, diffuse=rng.uniform(0.1, 0.6, 3), alpha=float(rng.uniform(0.05, 0.4))),
+        built.material(_capi.MAT_GLASS, ior=float(rng.uniform(1.2, 1.8))),
+        built.material(_capi.MAT_MIRROR),
+    ]
+    if texture is not None:
+        materials.append(built.material(_capi.MAT_LAMBERTIAN, texture=texture))
+    light = built.material(_capi.MAT_LAMBERTIAN, diffuse=(0, 0, 0), emit=rng.uniform(2.0, 12.0, 3))
+
+    n = int(rng.integers(80, 1500))
+    centres = rng.normal(size=(n, 3)) * scale
+    spans = scale * 10.0 ** rng.uniform(-2.0, -0.3, size=(n, 1, 1))
+    corners = centres[:, None, :] + rng.normal(size=(n, 3, 3)) * spans
+    corners[0:5, 2] = corners[0:5, 1]                       # zero-area: two coincident corners
+    corners[5:10, 2] = 0.5 * (corners[5:10, 0] + corners[5:10, 1])   # zero-area: collinear
+    corners[10:20] = corners[20:30]                         # exact duplicates (tie: lower primitive id wins)
+    corners[30:35, 1] = corners[30:35, 0] + (corners[30:35, 1] - corners[30:35, 0]) * 1e-4   # needles
+    vertices = corners.reshape(-1, 3).astype(np.float32)
+    faces = np.arange(3 * n).reshape(n, 3)
+    uvs = rng.uniform(-2.0, 3.0, size=(3 * n, 2)).astype(np.float32)
+    normals = np.zeros((3 * n, 3), dtype=np.float32)
+    smooth = rng.random(n) < 0.3                             # a third of the faces carry vertex normals
+    face_normal = np.cross(corners[:, 1] - corners[:, 0], corners[:, 2] - corners[:, 0])
+    length = np.linalg.norm(face_normal, axis=1, keepdims=True)
+    face_normal = np.where(length > 0, face_normal / np.maximum(length, 1e-30), 0.0)
+    for k in np.nonzero(smooth)[0]:
+        normals[3 * k:3 * k + 3] = face_normal[k] + rng.normal(size=(3, 3)) * 0.1
+    # one mesh per material so that every kind is used
+    order = rng.integers(0, len(materials), size=n)
+    for index, material in enumerate(materials):
+        chosen = np.nonzero(order == index)[0]
+        if chosen.size == 0:
+            continue
+        picked = faces[chosen].reshape(-1)
+        built.mesh(vertices[picked], np.arange(picked.size).reshape(-1, 3), material,
+                   normals=normals[picked], uvs=uvs[picked])
+    top = 2.5 * scale
+    built.quad([(-scale, top, -scale), (scale, top, -scale), (scale, top, scale), (-scale, top, scale)], light)
+    for _ in range(int(rng.integers(0, 3))):
+        built.sphere(tuple(rng.normal(size=3) * scale), float(scale * rng.uniform(0.1, 0.5)), materials[int(rng.integers(0, len(materials)))])
+    if seed % 3 == 0:
+        env = rng.uniform(0.0, 1.0, size=(8, 16, 4)).astype(np.float32)
+        env[2, 5, :3] = 40.0
+        env[6] = 0.0                                          # an empty row in the theta distribution
+        built.environment(env, scale=float(rng.uniform(0.5, 2.0)))
+    return built, built.finish(), scale
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_scene_parity(seed):
+    import oracle_lib
+    from pathed_amd.integrator import HipScene
+    built, desc, scale = build_scene(seed)
+    size = 40
+    gpu, cpu = HipScene(desc, device=0), oracle_lib.OracleScene(desc)
+
+    rng = np.random.default_rng(100 + seed)
+    rays = np.zeros((40000, 8), dtype=np.float32)
+    rays[:, 0:3] = rng.normal(size=(40000, 3)) * 2.0 * scale
+    direction = rng.normal(size=(40000, 3))
+    direction[:2000, 0] = 0.0                                 # axis-aligned and zero-component directions
+    direction[2000:3000, 1:] = 0.0
+    rays[:, 4:7] = direction / np.linalg.norm(direction, axis=1, keepdims=True)
+    rays[:, 3] = 1e-3
+    rays[:, 7] = 1e5
+    rays[3000:6000, 7] = rng.uniform(0.1, 3.0, 3000) * scale  # short intervals
+    hits = gpu.trace(rays)
+    assert np.array_equal(hits.view(np.int32), cpu.trace(rays).view(np.int32))
+    occluded = gpu.trace(rays, any_hit=True)
+    assert np.array_equal(occluded, cpu.trace(rays, any_hit=True))
+
+    image = gpu.render(7, 0, 8, 0, 6)
+    if desc.contents.n_triangles > 64:
+        for builder in ("ploc", "lbvh"):
+            other = HipScene(desc, device=0, bvh_builder=builder)
+            assert np.array_equal(other.trace(rays).view(np.int32), hits.view(np.int32)), builder
+            assert np.array_equal(other.render(7, 0, 8, 0, 6), image), builder
+
+    expected, _ = cpu.render(size, size, 7, 0, 8, 0, 6, threads=os.cpu_count(), chunk=4)
+    assert np.isfinite(image).all()
+    rel = float(np.linalg.norm(image - expected) / max(np.linalg.norm(expected), 1e-30))
+    bad = float((np.abs(image - expected) > 1e-2 * np.maximum(np.abs(expected), 1e-3)).any(axis=2).mean())
+    # glass is in every scene: the glass tolerance of SURVEY.md §8d applies
+    assert rel <= 1e-2 and bad <= 5e-3, (seed, rel, bad)
+    stats = gpu.stats()
+    assert stats["dropped_samples"] <= 0.02 * size * size * 8
