@@ -306,6 +306,10 @@ bool pizHuffmanDecode(const unsigned char *in, size_t inLength, std::vector<uint
             code = (code + count[l]) >> 1;
         }
     }
+    // a consistent length table never assigns a code that does not fit its length
+    for (int l = 1; l <= 58; l++) {
+        if (count[l] && base[l] + count[l] > (1ull << l)) { *why = "piz: inconsistent huffman code lengths"; return false; }
+    }
     std::vector<uint32_t> start(60, 0), ordered;   // symbols sorted by (length, symbol)
     {
         uint32_t total = 0;
@@ -578,6 +582,7 @@ bool readExrRGBA(
     const int w = window[2] - window[0] + 1;
     const int h = window[3] - window[1] + 1;
     if (w <= 0 || h <= 0) { return fail("bad data window"); }
+    if ((uint64_t)w * (uint64_t)h > (1ull << 28)) { return fail("image larger than 2^28 pixels"); }
 
     size_t bytesPerLine = 0;
     for (const ChannelInfo &channel : channels) {

@@ -56,6 +56,7 @@ bool decodePng(const std::vector<uint8_t> &file, int *width, int *height, std::v
     }
     if (!sawHeader) { return fail("no IHDR"); }
     if (w == 0 || h == 0 || w > 65535 || h > 65535) { return fail("image size out of range (1..65535)"); }
+    if ((uint64_t)w * h > (1ull << 28)) { return fail("image larger than 2^28 pixels"); }
     if (interlace != 0) { return fail("interlaced (Adam7) files are not supported: re-save without interlacing"); }
     int channels;
     switch (colorType) {
@@ -162,6 +163,7 @@ bool decodePnm(const std::vector<uint8_t> &file, int *width, int *height, std::v
     if (values[0] < 1 || values[1] < 1 || values[0] > 65535 || values[1] > 65535) { return fail("image size out of range (1..65535)"); }
     if (values[2] < 1 || values[2] > 255) { return fail("only maxval <= 255 is supported"); }
     const size_t count = (size_t)values[0] * values[1];
+    if (count > ((size_t)1 << 28)) { return fail("image larger than 2^28 pixels"); }
     if (at + count * channels > file.size()) { return fail("truncated pixel data"); }
     rgb->resize(3 * count);
     for (size_t k = 0; k < count; k++) {
