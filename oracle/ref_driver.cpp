@@ -41,6 +41,8 @@
 /* the reference defines the stb_image implementation in its executables (app/main.cpp:16) */
 #define STB_IMAGE_IMPLEMENTATION
 #include "stb_image.h"
+#define STB_IMAGE_WRITE_IMPLEMENTATION
+#include "stb_image_write.h"
 
 #define private public
 #define protected public
@@ -703,6 +705,25 @@ int main(int argc, char **argv)
             out.insert(out.end(), loaded, loaded + (size_t)4 * width * height);
             free(loaded);
             emit("exr_piz_image", { (float)f }, out);
+        }
+    }
+
+    /* ---- Image::write -> stbi_write_bmp (src/image.cpp:156-161) ------------------------- */
+    /* bmp_bytes: in = width height, then 3*width*height RGB bytes   out = the file stb wrote, byte by byte */
+    {
+        const int sizes[3][2] = { { 5, 3 }, { 4, 2 }, { 7, 1 } };   /* row padding 1, 0, 3 */
+        for (int k = 0; k < 3; k++) {
+            const int width = sizes[k][0], height = sizes[k][1];
+            std::vector<unsigned char> pixels((size_t)3 * width * height);
+            std::vector<float> in = { (float)width, (float)height };
+            for (size_t i = 0; i < pixels.size(); i++) { pixels[i] = (unsigned char)(uniform01() * 255.99f); in.push_back((float)pixels[i]); }
+            const char *path = "/tmp/pathed_refdump.bmp";
+            stbi_write_bmp(path, width, height, 3, pixels.data());
+            std::ifstream file(path, std::ios::binary);
+            std::vector<float> out;
+            char byte;
+            while (file.get(byte)) { out.push_back((float)(unsigned char)byte); }
+            emit("bmp_bytes", in, out);
         }
     }
 

@@ -239,6 +239,9 @@ def load_host():
     if hasattr(lib, "pathed_host_write_exr_half_bgr"):
         lib.pathed_host_write_exr_half_bgr.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_float)]
         lib.pathed_host_write_exr_half_bgr.restype = C.c_int
+    if hasattr(lib, "pathed_host_write_bmp_rgb8"):
+        lib.pathed_host_write_bmp_rgb8.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_uint8)]
+        lib.pathed_host_write_bmp_rgb8.restype = C.c_int
     if hasattr(lib, "pathed_host_load_image_rgb8"):
         lib.pathed_host_load_image_rgb8.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_uint8), C.c_size_t]
         lib.pathed_host_load_image_rgb8.restype = C.c_int

@@ -51,6 +51,7 @@ void pathed_host_free_scene(void *handle)
 // ---- job runner (shared by the `pathed` executable and the Python harness) ----------
 
 #include "exr.h"
+#include "image.h"
 #include "image_decode.h"
 #include "integrator.h"
 #include "job.h"
@@ -131,6 +132,13 @@ int pathed_host_read_exr_rgba(const char *path, int *width, int *height, float *
         if (capacity < data.size()) { g_hostError = "buffer too small"; return 2; }
         std::memcpy(rgba, data.data(), data.size() * sizeof(float));
     }
+    return 0;
+}
+
+// the reference's BMP preview writer (Image::write -> stbi_write_bmp); rgb is top-down interleaved
+int pathed_host_write_bmp_rgb8(const char *path, int width, int height, const unsigned char *rgb)
+{
+    if (!pathed::writeBmpRgb8(path, width, height, rgb)) { g_hostError = std::string("cannot write ") + path; return 1; }
     return 0;
 }
 

@@ -65,4 +65,35 @@ void Image::save(const std::string &filestem, bool saveCheckpoint)
     }
 }
 
+// src/image.cpp:156-161 -> stbi_write_bmp(path, w, h, 3, data): 14 + 40 byte headers, rows bottom-up,
+// pixels B G R, rows padded to four bytes
+bool writeBmpRgb8(const std::string &path, int width, int height, const unsigned char *rgb)
+{
+    FILE *file = fopen(path.c_str(), "wb");
+    if (!file) { return false; }
+    const int pad = (-width * 3) & 3;
+    auto put16 = [&](unsigned int v) { fputc(v & 0xFF, file); fputc((v >> 8) & 0xFF, file); };
+    auto put32 = [&](unsigned int v) { put16(v & 0xFFFF); put16(v >> 16); };
+    fputc('B', file); fputc('M', file);
+    put32(14u + 40u + (unsigned int)(width * 3 + pad) * (unsigned int)height);
+    put16(0); put16(0); put32(14u + 40u);
+    put32(40u); put32((unsigned int)width); put32((unsigned int)height); put16(1); put16(24);
+    put32(0); put32(0); put32(0); put32(0); put32(0); put32(0);
+    for (int row = height - 1; row >= 0; row--) {
+        const unsigned char *line = rgb + (size_t)3 * row * width;
+        for (int col = 0; col < width; col++) {
+            fputc(line[3 * col + 2], file);
+            fputc(line[3 * col + 1], file);
+            fputc(line[3 * col + 0], file);
+        }
+        for (int k = 0; k < pad; k++) { fputc(0, file); }
+    }
+    return fclose(file) == 0;
+}
+
+void Image::write(const std::string &filename)
+{
+    writeBmpRgb8(m_outputDirectory + filename, m_width, m_height, m_data.data());
+}
+
 }  // namespace pathed

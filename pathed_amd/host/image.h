@@ -18,6 +18,9 @@ public:
 
     void save(const std::string &filestem);
     void saveCheckpoint(const std::string &filestem);
+    // <outdir>/<filename>: the 8-bit preview as a 24-bit BMP, byte for byte what stbi_write_bmp
+    // writes (reference src/image.cpp:156-161)
+    void write(const std::string &filename);
 
     std::mutex &getLock() { return m_lock; }
     const std::vector<unsigned char> &data() const { return m_data; }
@@ -35,5 +38,8 @@ private:
     std::vector<float> m_raw;           // interleaved RGB, top scanline first
     std::mutex m_lock;
 };
+
+// 24-bit BMP of top-down interleaved RGB, the layout stbi_write_bmp produces
+bool writeBmpRgb8(const std::string &path, int width, int height, const unsigned char *rgb);
 
 }  // namespace pathed

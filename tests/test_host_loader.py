@@ -225,3 +225,23 @@ def test_truncated_piz_file_is_rejected(tmp_path):
     broken.write_bytes(blob[: len(blob) - 200])
     w, h = C.c_int(), C.c_int()
     assert host.pathed_host_read_exr_rgba(str(broken).encode(), C.byref(w), C.byref(h), None, 0) != 0
+
+
+def test_bmp_preview_is_what_stb_image_write_writes(tmp_path):
+    """Image::write (reference src/image.cpp:156-161) goes through stbi_write_bmp; `bmp_bytes` records hold
+    the files stb wrote for three small images (row padding 1, 0 and 3 bytes)."""
+    import json
+    host = _capi.load_host()
+    seen = 0
+    with open(os.path.join(_capi.REPO_ROOT, "tests", "golden", "reference_functions.jsonl")) as handle:
+        for line in handle:
+            if '"bmp_bytes"' not in line:
+                continue
+            record = json.loads(line)
+            width, height = int(record["in"][0]), int(record["in"][1])
+            pixels = np.array(record["in"][2:], dtype=np.uint8)
+            path = str(tmp_path / ("preview%d.bmp" % seen))
+            assert host.pathed_host_write_bmp_rgb8(path.encode(), width, height, pixels.ctypes.data_as(C.POINTER(C.c_uint8))) == 0
+            assert open(path, "rb").read() == bytes(int(v) for v in record["out"])
+            seen += 1
+    assert seen == 3
