@@ -92,7 +92,8 @@ static const int kStatRefillCycles = 16;   // shader clocks spent refilling lane
 static const int kStatInnerCycles = 17;
 static const int kStatLeafCycles = 18;
 static const int kStatInnerSteps = 19;
-static const int kStatCount = 24;
+static const int kStatShadeProfile = 24;   // PATHED_SHADE_PROFILE builds: (waves, lanes) per k_shade region, 2 words each
+static const int kStatCount = 48;
 
 // state word (rayD.w): bits 0..15 vertex that spawned the ray (0 = camera ray),
 // 16 eligible, 17 delta, 18 continue (device_scene.h), 19..25 sample index inside the unit
@@ -929,6 +930,21 @@ __global__ __launch_bounds__(kBlock) void k_resolve(RenderParams p)
     out[2] = b;
 }
 
+// Tuning builds only (-DPATHED_SHADE_PROFILE): how many waves enter a region of k_shade and with how
+// many lanes -- lane utilisation per region (tools/shade_profile.py prints the table).
+#ifdef PATHED_SHADE_PROFILE
+#define SHADE_REGION(index, predicate)                                                                        \
+    do {                                                                                                      \
+        const unsigned long long mask_ = __ballot(predicate);                                                 \
+        if (mask_ != 0ull && (threadIdx.x & 63) == __ffsll((long long)mask_) - 1) {                           \
+            atomicAdd(&p.stats[kStatShadeProfile + 2 * (index)], 1ull);                                       \
+            atomicAdd(&p.stats[kStatShadeProfile + 2 * (index) + 1], (unsigned long long)__popcll(mask_));    \
+        }                                                                                                     \
+    } while (0)
+#else
+#define SHADE_REGION(index, predicate) do { } while (0)
+#endif
+
 template <bool LDS_MATERIALS>
 struct MaterialAccess {
     const DMaterial *table;
@@ -1009,6 +1025,8 @@ __global__ __launch_bounds__(kBlock) void k_shade(RenderParams p)
     float4 outPend = make_float4(0.f, 0.f, 0.f, 0.f);
     Rgb result = rgb(0.f);
 
+    SHADE_REGION(0, true);        // every wave, 64 lanes
+    SHADE_REGION(1, active);      // slots with work
     if (active) {
         const float4 ro = roIn;
         const float4 resIn = resIn0;
@@ -1035,7 +1053,10 @@ __global__ __launch_bounds__(kBlock) void k_shade(RenderParams p)
         // ONE inlined copy of the intersection record, ahead of the bounce-0 / later-bounce split:
         // the lanes of a wave sit at different path depths, and code inlined in both branches is
         // executed twice by every mixed wave
+        SHADE_REGION(2, !miss);   // makeIsect
         if (!miss) { isect = makeIsect(scene, o, d, h); }
+        SHADE_REGION(3, rayBounce == 0);
+        SHADE_REGION(4, rayBounce != 0 && (st & kStEligible) != 0);   // finishes the previous vertex's MIS term
 
         if (rayBounce == 0) {
             // SampleIntegrator::samplePixel, src/sample_integrator.cpp:18-59
@@ -1107,6 +1128,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(RenderParams p)
 
         outMod = make_float4(modulation.r, modulation.g, modulation.b, 1.f);
 
+        SHADE_REGION(5, haveVertex);
         if (haveVertex) {
             // PathTracer::L: sample the BSDF, then direct(), src/path_tracer.cpp:30-36, 60-73
             const DMaterial &material = materials[isect.material];
@@ -1122,6 +1144,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(RenderParams p)
             const bool wantContinue = !checkDone(p.lastBounce, vertex + 1);
 
             Rgb lightTerm = rgb(0.f);
+            SHADE_REGION(6, wantDirect);
             if (wantDirect) {
                 random.dimension = vertexBase(vertex) + 3;
                 lightTerm = sampleLightsTerm(scene, materials, isect, material, random, &shadow);
@@ -1153,6 +1176,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(RenderParams p)
     bool needUnit = false;
     bool startNext = false;       // the slot starts a camera ray: one inlined copy of startSample below
     uint32_t nextPixel = 0, nextSample = 0;
+    SHADE_REGION(7, active && finished);
     if (active && finished) {
         // radianceLookup += color, src/sample_integrator.cpp:61-63; non-finite samples dropped
         float4 partial = p.state.acc[slot];
@@ -1199,6 +1223,8 @@ __global__ __launch_bounds__(kBlock) void k_shade(RenderParams p)
         }
     }
 
+    SHADE_REGION(8, startNext);
+    SHADE_REGION(9, shadow.push);
     if (startNext) { startSample(p, nextPixel, nextSample, sampleInUnit, &outRayO, &outRayD); }
 
     if (active) {
