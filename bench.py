@@ -36,6 +36,8 @@ def parse_args():
     parser.add_argument("--last-bounce", type=int, default=10)
     parser.add_argument("--seed", type=int, default=1)
     parser.add_argument("--no-cpu-baseline", action="store_true")
+    parser.add_argument("--time-every-launch", action="store_true",
+                        help="HIP events around every trace / shade launch instead of every 8th")
     parser.add_argument("--no-kernel-timing", action="store_true",
                         help="skip the HIP-event timing of every trace launch (roofline.achieved becomes null)")
     return parser.parse_args()
@@ -121,7 +123,10 @@ def main():
         step(index)
     accum.zero_()
 
-    gpu.set_stats_mode(count=False, time_kernels=not args.no_kernel_timing)
+    # HIP-event pairs around every 8th launch of each pool: timing every launch keeps a pool's kernels from
+    # running back to back and costs ~6 % of the rate (--time-every-launch restores it)
+    gpu.set_stats_mode(count=False, time_kernels=(not args.no_kernel_timing) and args.time_every_launch,
+                       time_sampled=(not args.no_kernel_timing) and not args.time_every_launch)
     gpu.reset_stats()
 
     torch.cuda.synchronize()
@@ -155,10 +160,12 @@ def main():
         roofline = None
         if per_step_stats is not None:
             bytes_per_step = algorithmic_bytes(per_step_stats)
-            launches = timed_stats["trace_launches"]
+            timed_launches = timed_stats["trace_launches"]          # launches bracketed by HIP events
+            launches = timed_stats["trace_launches_all"]            # all trace launches of the timed region
             trace_ms = timed_stats["trace_ms"]
             total_bytes = bytes_per_step * args.steps
-            achieved = (total_bytes / (trace_ms * 1e-3) / 1e9) if trace_ms > 0 else None
+            # bytes per launch / average duration of the timed launches
+            achieved = ((total_bytes / launches) / (trace_ms / timed_launches * 1e-3) / 1e9) if trace_ms > 0 and launches else None
             traffic = None
             traffic_path = os.path.join(REPO_ROOT, "profiles", "hbm_traffic.json")
             if os.path.exists(traffic_path):
@@ -202,13 +209,14 @@ def main():
                 "traffic": traffic,
                 "algorithmic_bytes_per_launch": (total_bytes / launches) if launches else None,
                 "algorithmic_bytes_per_sample": bytes_per_step / (args.width * args.height * spp),
-                "avg_launch_ms": (trace_ms / launches) if launches else None,
+                "avg_launch_ms": (trace_ms / timed_launches) if timed_launches else None,
                 "launches": launches,
+                "timed_launches": timed_launches,
                 "rays_per_sample": (per_step_stats["closest_rays"] + per_step_stats["shadow_rays"])
                 / (args.width * args.height * spp),
                 "bvh_resident": ["HBM", "LDS", "none (<= 64 triangles: every ray tests all, scalar loads)"][per_step_stats["scene_in_lds"]],
-                "trace_ms_total": trace_ms,
-                "shade_ms_total": timed_stats["shade_ms"],
+                "trace_ms_timed": trace_ms,
+                "shade_ms_timed": timed_stats["shade_ms"],
                 "valu": valu,
             }
 

@@ -192,7 +192,7 @@ typedef struct PathedStats {
     uint64_t parked_rays;          /* rays a trace launch handed on to the next one unfinished — stats mode */
     double   bvh_build_ms;         /* scene_create's BVH build: host wall time (SAH) or HIP-event time (LBVH) */
     uint32_t bvh_builder;          /* PATHED_BVH_* the scene was built with                 */
-    uint32_t reserved0;
+    uint32_t trace_launches_all;   /* trace launches since reset_stats, timed or not (trace_launches counts the timed ones) */
 } PathedStats;
 
 /* ---- life cycle ---------------------------------------------------------- */
@@ -264,8 +264,10 @@ int pathed_hip_set_samples_per_unit(PathedScene *scene, int samples);
 int pathed_hip_trace(PathedScene *scene, const float *rays, size_t n,
                      int any_hit, void *hits);
 
-/* Enable/disable the counting variants of the trace kernel (nodes_visited /
- * tris_tested).  Off by default: the timed path never counts. */
+/* Bit 0: the counting variants of the trace kernel (nodes_visited / tris_tested); off by default, the
+ * timed path never counts.  Bit 1: HIP-event pairs around every trace and shade launch (trace_ms,
+ * shade_ms, trace_launches).  Bit 2: ... around every 8th launch only: the event pairs keep a pool's
+ * kernels from running back to back and cost ~6 % of the rate when every launch is timed. */
 int pathed_hip_set_stats_mode(PathedScene *scene, int enabled);
 int pathed_hip_get_stats(PathedScene *scene, PathedStats *out);
 int pathed_hip_reset_stats(PathedScene *scene);

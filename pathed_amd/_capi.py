@@ -122,7 +122,7 @@ class PathedStats(C.Structure):
         ("parked_rays", C.c_uint64),
         ("bvh_build_ms", C.c_double),
         ("bvh_builder", C.c_uint32),
-        ("reserved0", C.c_uint32),
+        ("trace_launches_all", C.c_uint32),
     ]
 
 

@@ -96,8 +96,9 @@ class HipScene:
         _check(self._lib, self._lib.pathed_hip_set_samples_per_unit(self._handle, int(samples)),
                "pathed_hip_set_samples_per_unit")
 
-    def set_stats_mode(self, count=False, time_kernels=False):
-        mode = (1 if count else 0) | (2 if time_kernels else 0)
+    def set_stats_mode(self, count=False, time_kernels=False, time_sampled=False):
+        """time_kernels: HIP events around every launch; time_sampled: around every 8th (cheaper, same averages)."""
+        mode = (1 if count else 0) | (2 if time_kernels else 0) | (4 if time_sampled else 0)
         _check(self._lib, self._lib.pathed_hip_set_stats_mode(self._handle, mode), "pathed_hip_set_stats_mode")
 
     def reset_stats(self):

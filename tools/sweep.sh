@@ -8,5 +8,5 @@ for lib in "$@"; do
   python3 $ROOT/tools/dragon_render.py 2>&1 | tail -1
   python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline 2>&1 | tail -1 | python3 -c "
 import sys,json
-j=json.loads(sys.stdin.read()); r=j['roofline']; print('cornell %.1f Msamples/s trace %.3f ms/launch shade_total %.0f' % (j['value'], r['avg_launch_ms'], r['shade_ms_total']))"
+j=json.loads(sys.stdin.read()); r=j['roofline']; print('cornell %.1f Msamples/s trace %.3f ms/launch shade_total %.0f' % (j['value'], r['avg_launch_ms'], r['shade_ms_timed']))"
 done
