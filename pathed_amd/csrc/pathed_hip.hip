@@ -130,6 +130,8 @@ struct EventRing {
 
 }  // namespace
 
+static const int kMaxPools = 4;
+
 struct PathedScene {
     DScene device;
     int width = 0, height = 0;
@@ -152,9 +154,9 @@ struct PathedScene {
     size_t chunkCapacity = 0;     // float4 entries of chunkBuf
     int samplesPerUnit = 4;       // "chunk": samples a slot sums before it publishes a partial
     int maxSlots = 1 << 20;
-    int pools = 2;                // independent slot pools on separate streams (trace || shade)
-    hipStream_t poolStreams[2] = { nullptr, nullptr };
-    hipEvent_t poolDone[2] = { nullptr, nullptr };
+    int pools = 2;                // independent slot pools on separate streams (trace || shade); PATHED_POOLS = 1..kMaxPools
+    hipStream_t poolStreams[kMaxPools] = { nullptr, nullptr, nullptr, nullptr };
+    hipEvent_t poolDone[kMaxPools] = { nullptr, nullptr, nullptr, nullptr };
     hipEvent_t callerReady = nullptr;
     DeviceBuffer<float4> rayO, rayD, hit, mod, thr, res, pend, acc, shO, shD, chunkBuf;
     DeviceBuffer<unsigned int> counters;
@@ -194,7 +196,7 @@ struct PathedScene {
         counters.release(); stats.release();
         suspendMask.release(); suspendData.release(); stackOverflow.release();
         if (hostRemaining) { (void)hipHostFree(hostRemaining); }
-        for (int h = 0; h < 2; h++) {
+        for (int h = 0; h < kMaxPools; h++) {
             if (poolStreams[h]) { (void)hipStreamDestroy(poolStreams[h]); }
             if (poolDone[h]) { (void)hipEventDestroy(poolDone[h]); }
         }
@@ -363,20 +365,20 @@ int ensureRenderState(PathedScene *scene, int nSlots, size_t chunkEntries)
         HIP_TRY(scene->chunkBuf.allocate(chunkEntries));
         scene->chunkCapacity = chunkEntries;
     }
-    if (!scene->counters.ptr) { HIP_TRY(scene->counters.allocate(2 * kCtrCount)); }
+    if (!scene->counters.ptr) { HIP_TRY(scene->counters.allocate(kMaxPools * kCtrCount)); }
     if (!scene->suspendMask.ptr && !scene->bruteForce) {
         const size_t waves = (size_t)scene->traceGrid * kWavesPerBlock;
-        HIP_TRY(scene->suspendMask.allocate(2 * waves));
-        HIP_TRY(scene->suspendData.allocate(2 * waves * (size_t)(kSaveWords + scene->maxStack) * 64));
+        HIP_TRY(scene->suspendMask.allocate((size_t)scene->pools * waves));
+        HIP_TRY(scene->suspendData.allocate((size_t)scene->pools * waves * (size_t)(kSaveWords + scene->maxStack) * 64));
         const size_t overflowRows = (size_t)(scene->maxStack > scene->stackRows ? scene->maxStack - scene->stackRows : 0);
-        HIP_TRY(scene->stackOverflow.allocate(2 * (size_t)scene->traceGrid * kBlock * (overflowRows ? overflowRows : 1)));
+        HIP_TRY(scene->stackOverflow.allocate((size_t)scene->pools * (size_t)scene->traceGrid * kBlock * (overflowRows ? overflowRows : 1)));
     }
     if (!scene->stats.ptr) {
         HIP_TRY(scene->stats.allocate(kStatCount));
         HIP_TRY(hipMemset(scene->stats.ptr, 0, kStatCount * sizeof(unsigned long long)));
     }
     if (!scene->hostRemaining) {
-        HIP_TRY(hipHostMalloc((void **)&scene->hostRemaining, 64 * sizeof(unsigned int), hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc((void **)&scene->hostRemaining, kMaxPools * 32 * sizeof(unsigned int), hipHostMallocDefault));
     }
     return PATHED_OK;
 }
@@ -787,7 +789,10 @@ int pathed_hip_scene_create(const PathedSceneDesc *desc, PathedScene **out)
     d.env.thetaGuide = scene->thetaGuide.ptr;
     d.env.phiGuide = scene->phiGuide.ptr;
 
-    if (const char *poolCount = getenv("PATHED_POOLS")) { scene->pools = atoi(poolCount) >= 2 ? 2 : 1; }
+    if (const char *poolCount = getenv("PATHED_POOLS")) {
+        const int value = atoi(poolCount);
+        scene->pools = value < 1 ? 1 : value > kMaxPools ? kMaxPools : value;
+    }
     configureTrace(scene);
     scene->bruteForce = scene->device.nTris <= kBruteForceMaxTris && !getenv("PATHED_NO_BRUTE_FORCE");
     // BVH scenes: more slots = more rays per persistent wave to refill finished lanes from
@@ -844,7 +849,7 @@ static int renderPass(PathedScene *scene, uint64_t seed, uint32_t begin, uint32_
     int code = ensureRenderState(scene, nSlots, (size_t)nUnits);
     if (code != PATHED_OK) { return code; }
     if (pools > 1 && !scene->poolStreams[0]) {
-        for (int h = 0; h < 2; h++) {
+        for (int h = 0; h < kMaxPools; h++) {
             HIP_TRY(hipStreamCreateWithFlags(&scene->poolStreams[h], hipStreamNonBlocking));
             HIP_TRY(hipEventCreateWithFlags(&scene->poolDone[h], hipEventDisableTiming));
         }
@@ -854,8 +859,8 @@ static int renderPass(PathedScene *scene, uint64_t seed, uint32_t begin, uint32_
     const int blocksPerPool = slotsPerPool / kBlock;
     const int nQueues = blocksPerPool < kUnitQueues ? blocksPerPool : kUnitQueues;
 
-    RenderParams params[2];
-    hipStream_t streams[2] = { stream, stream };
+    RenderParams params[kMaxPools];
+    hipStream_t streams[kMaxPools] = { stream, stream, stream, stream };
     for (int h = 0; h < pools; h++) {
         RenderParams &q = params[h];
         const size_t slotBase = (size_t)h * slotsPerPool;
@@ -925,7 +930,7 @@ static int renderPass(PathedScene *scene, uint64_t seed, uint32_t begin, uint32_
     // a lag of one chunk of launches so the GPU never waits for the host.
     const int launchChunk = 8;
     const int ringSize = 32;
-    hipEvent_t pollEvents[2][2];
+    hipEvent_t pollEvents[kMaxPools][2];
     for (int h = 0; h < pools; h++) {
         HIP_TRY(hipEventCreateWithFlags(&pollEvents[h][0], hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&pollEvents[h][1], hipEventDisableTiming));
@@ -933,8 +938,9 @@ static int renderPass(PathedScene *scene, uint64_t seed, uint32_t begin, uint32_
     unsigned long long iteration = 0;
     int pollIndex = 0;
     bool havePending = false;
-    bool poolDone[2] = { false, pools < 2 };
-    while (!(poolDone[0] && poolDone[1])) {
+    bool poolDone[kMaxPools];
+    for (int h = 0; h < kMaxPools; h++) { poolDone[h] = h >= pools; }
+    while (!(poolDone[0] && poolDone[1] && poolDone[2] && poolDone[3])) {
         for (int k = 0; k < launchChunk; k++) {
             for (int h = 0; h < pools; h++) {
                 if (poolDone[h]) { continue; }
