@@ -288,8 +288,9 @@ def test_result_does_not_depend_on_scheduling_or_intersector_variant(libs):
     fixed by the unit decomposition, not by which slot happened to render which unit."""
     base, base_stats = _render_with_env(libs, {"PATHED_POOLS": "1"}, "scenes/cornell.json", 160, 11, 12)
     assert base_stats["scene_in_lds"] == 2
-    two_pools, _ = _render_with_env(libs, {"PATHED_POOLS": "2"}, "scenes/cornell.json", 160, 11, 12)
-    assert np.array_equal(base, two_pools)
+    for pools in ("2", "3", "4"):
+        several, _ = _render_with_env(libs, {"PATHED_POOLS": pools}, "scenes/cornell.json", 160, 11, 12)
+        assert np.array_equal(base, several), pools
     bvh, bvh_stats = _render_with_env(libs, {"PATHED_NO_BRUTE_FORCE": "1"}, "scenes/cornell.json", 160, 11, 12)
     assert bvh_stats["scene_in_lds"] == 1
     assert np.array_equal(base, bvh)
@@ -298,8 +299,9 @@ def test_result_does_not_depend_on_scheduling_or_intersector_variant(libs):
     # a BVH scene (1 112 triangles, nodes in HBM/L2), one pool vs two
     glass_one, stats = _render_with_env(libs, {"PATHED_POOLS": "1"}, "scenes/cornell-glass.json", 128, 3, 8)
     assert stats["scene_in_lds"] == 0
-    glass_two, _ = _render_with_env(libs, {"PATHED_POOLS": "2", "PATHED_MAX_SLOTS": "20000"}, "scenes/cornell-glass.json", 128, 3, 8)
-    assert np.array_equal(glass_one, glass_two)
+    for pools in ("2", "3"):
+        glass_several, _ = _render_with_env(libs, {"PATHED_POOLS": pools, "PATHED_MAX_SLOTS": "20000"}, "scenes/cornell-glass.json", 128, 3, 8)
+        assert np.array_equal(glass_one, glass_several), pools
 
 
 def _render_counted(libs, env, scene_path, size, seed, spp):
