@@ -245,6 +245,20 @@ static void dumpMaterial(const MaterialSpec &spec, int cases, bool allowBackside
 
 int main(int argc, char **argv)
 {
+    /* refdump --image-hash <file>...: size and FNV-1a hash of stbi_load(file, .., 3), for spot checks of the
+     * host decoder on image files too large to keep as fixtures */
+    if (argc > 2 && std::string(argv[1]) == "--image-hash") {
+        for (int a = 2; a < argc; a++) {
+            int width = 0, height = 0, channels = 0;
+            unsigned char *data = stbi_load(argv[a], &width, &height, &channels, 3);
+            if (!data) { printf("%s: cannot load\n", argv[a]); continue; }
+            unsigned long long hash = 1469598103934665603ull;
+            for (size_t i = 0; i < (size_t)3 * width * height; i++) { hash = (hash ^ data[i]) * 1099511628211ull; }
+            printf("%s %d %d %016llx\n", argv[a], width, height, hash);
+            stbi_image_free(data);
+        }
+        return 0;
+    }
     if (argc > 1) {
         g_out = fopen(argv[1], "w");
         if (!g_out) { fprintf(stderr, "cannot open %s\n", argv[1]); return 1; }
@@ -724,6 +738,24 @@ int main(int argc, char **argv)
             char byte;
             while (file.get(byte)) { out.push_back((float)(unsigned char)byte); }
             emit("bmp_bytes", in, out);
+        }
+    }
+
+    /* ---- JPEG texture files through the reference's stb_image (texture_image records, index 100+) ---- */
+    {
+        const std::string directory = (argc > 3) ? argv[3] : "tests/golden/textures";
+        const char *files[] = { "jpeg_444_37x29.jpg", "jpeg_420_37x29.jpg", "jpeg_422_37x29.jpg", "jpeg_progressive_420_37x29.jpg",
+                                "jpeg_progressive_444_37x29.jpg", "jpeg_noise_420_26x21.jpg", "jpeg_grey_37x29.jpg",
+                                "jpeg_420_1x9.jpg", "jpeg_restart_420_100x70.jpg" };
+        for (int f = 0; f < 9; f++) {
+            const std::string path = directory + "/" + files[f];
+            std::ifstream probe(path);
+            if (!probe.good()) { fprintf(stderr, "texture fixture missing: %s\n", path.c_str()); continue; }
+            Texture texture(path);
+            texture.load();
+            std::vector<float> image = { (float)texture.m_width, (float)texture.m_height };
+            for (int i = 0; i < 3 * texture.m_width * texture.m_height; i++) { image.push_back((float)texture.m_data[i]); }
+            emit("texture_image", { (float)(100 + f) }, image);
         }
     }
 

@@ -1,9 +1,10 @@
 // 8-bit RGB image files for image-texture albedos: what the reference gets from
-// stbi_load(path, &w, &h, &channels, 3) (src/texture.cpp:12-31).  Lossless formats only, where
-// any conforming decoder returns the same bytes as stb_image: PNG (non-interlaced; grey, RGB,
-// palette, with or without alpha, 1-16 bits) and binary PNM (P5 / P6, maxval <= 255).
-// JPEG is rejected with a message: its decoded bytes depend on the decoder's IDCT and
-// upsampling, so a second implementation would not reproduce stb_image's texels.
+// stbi_load(path, &w, &h, &channels, 3) (src/texture.cpp:12-31).
+//   PNG   non-interlaced; grey, RGB, palette, with or without alpha, 1-16 bits
+//   PNM   binary P5 / P6, maxval <= 255
+//   JPEG  baseline and progressive, 8-bit, greyscale or three components.  A JPEG's decoded bytes depend
+//         on the decoder's IDCT, chroma upsampling and colour conversion, so those follow stb_image's
+//         arithmetic; the output is checked byte for byte against stb_image (tests/test_textures.py).
 #pragma once
 
 #include <cstdint>

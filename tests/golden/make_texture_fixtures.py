@@ -100,3 +100,33 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+def jpeg_fixtures():
+    """JPEG files written by Pillow (libjpeg): the sampling factors, scan types and edge cases the decoder
+    must reproduce stb_image's bytes for."""
+    from PIL import Image
+    rng = np.random.default_rng(11)
+    y, x = np.mgrid[0:29, 0:37]
+    smooth = np.stack([128 + 100 * np.sin(x / 3.0 + y / 7.0), 100 + 80 * np.cos(y / 2.5), 60 + 50 * np.sin((x - y) / 4.0)], axis=2)
+    smooth = np.clip(smooth + rng.normal(0, 6, smooth.shape), 0, 255).astype(np.uint8)
+    noisy = rng.integers(0, 256, (21, 26, 3), dtype=np.uint8)          # clamping, large coefficients
+    noisy[5:12, 4:15] = [255, 0, 0]
+    colour = Image.fromarray(smooth, "RGB")
+    colour.save(os.path.join(OUT, "jpeg_444_37x29.jpg"), quality=92, subsampling=0)
+    colour.save(os.path.join(OUT, "jpeg_420_37x29.jpg"), quality=75, subsampling=2)
+    colour.save(os.path.join(OUT, "jpeg_422_37x29.jpg"), quality=80, subsampling=1, optimize=True)
+    colour.save(os.path.join(OUT, "jpeg_progressive_420_37x29.jpg"), quality=85, subsampling=2, progressive=True)
+    colour.save(os.path.join(OUT, "jpeg_progressive_444_37x29.jpg"), quality=60, subsampling=0, progressive=True, optimize=True)
+    Image.fromarray(noisy, "RGB").save(os.path.join(OUT, "jpeg_noise_420_26x21.jpg"), quality=95, subsampling=2)
+    Image.fromarray(smooth[:, :, 0], "L").save(os.path.join(OUT, "jpeg_grey_37x29.jpg"), quality=80)
+    Image.fromarray(smooth[:9, :1], "RGB").save(os.path.join(OUT, "jpeg_420_1x9.jpg"), quality=85, subsampling=2)
+    big = np.kron(smooth, np.ones((3, 3, 1), dtype=np.uint8))[:70, :100]
+    try:
+        Image.fromarray(big, "RGB").save(os.path.join(OUT, "jpeg_restart_420_100x70.jpg"), quality=70, subsampling=2, restart_marker_blocks=3)
+    except TypeError:
+        Image.fromarray(big, "RGB").save(os.path.join(OUT, "jpeg_restart_420_100x70.jpg"), quality=70, subsampling=2)
+
+
+if __name__ == "__main__":
+    jpeg_fixtures()

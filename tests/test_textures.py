@@ -22,6 +22,10 @@ GOLDEN = os.path.join(ROOT, "tests", "golden", "reference_functions.jsonl")
 TEXTURES = os.path.join(ROOT, "tests", "golden", "textures")
 FILES = ["rgb8_7x5.png", "rgba16_4x3.png", "greyalpha8_3x4.png", "grey2_5x6.png", "palette4_5x4.png",
          "rgb_2x3.ppm", "wood_48x32.png"]
+# JPEG files written by Pillow / libjpeg (tests/golden/make_texture_fixtures.py); record index = 100 + position
+JPEG_FILES = ["jpeg_444_37x29.jpg", "jpeg_420_37x29.jpg", "jpeg_422_37x29.jpg", "jpeg_progressive_420_37x29.jpg",
+              "jpeg_progressive_444_37x29.jpg", "jpeg_noise_420_26x21.jpg", "jpeg_grey_37x29.jpg", "jpeg_420_1x9.jpg",
+              "jpeg_restart_420_100x70.jpg"]
 
 
 def _records():
@@ -56,7 +60,7 @@ def load_image(path):
 
 
 def test_golden_file_has_the_texture_records():
-    assert sorted(IMAGES) == list(range(len(FILES)))
+    assert sorted(IMAGES) == list(range(len(FILES))) + [100 + k for k in range(len(JPEG_FILES))]
     assert len(LOOKUPS) >= 200
 
 
@@ -65,6 +69,16 @@ def test_decoder_returns_the_bytes_stb_image_returns(index):
     decoded = load_image(os.path.join(TEXTURES, FILES[index]))
     assert decoded.shape == IMAGES[index].shape
     assert np.array_equal(decoded, IMAGES[index])
+
+
+@pytest.mark.parametrize("index", range(len(JPEG_FILES)))
+def test_jpeg_decoder_returns_the_bytes_stb_image_returns(index):
+    """A JPEG's decoded bytes depend on the decoder (IDCT, chroma upsampling, colour conversion): the host
+    decoder follows stb_image's arithmetic and must reproduce its output exactly — baseline 4:4:4 / 4:2:2 /
+    4:2:0, progressive, greyscale, optimised Huffman tables, restart intervals, one-pixel-wide images."""
+    decoded = load_image(os.path.join(TEXTURES, JPEG_FILES[index]))
+    assert decoded.shape == IMAGES[100 + index].shape
+    assert np.array_equal(decoded, IMAGES[100 + index])
 
 
 def test_lookup_matches_the_reference():
@@ -81,9 +95,13 @@ def test_lookup_matches_the_reference():
 
 def test_decoder_errors_are_loud(tmp_path):
     jpeg = tmp_path / "a.jpg"
-    jpeg.write_bytes(b"\xff\xd8\xff\xe0" + b"\0" * 32)
-    with pytest.raises(RuntimeError, match="JPEG"):
+    jpeg.write_bytes(open(os.path.join(TEXTURES, JPEG_FILES[1]), "rb").read()[:300])
+    with pytest.raises(RuntimeError, match="jpeg"):
         load_image(str(jpeg))
+    unknown = tmp_path / "a.gif"
+    unknown.write_bytes(b"GIF89a" + b"\0" * 32)
+    with pytest.raises(RuntimeError, match="unknown image format"):
+        load_image(str(unknown))
     broken = tmp_path / "b.png"
     broken.write_bytes(open(os.path.join(TEXTURES, FILES[0]), "rb").read()[:60])
     with pytest.raises(RuntimeError, match="png"):
