@@ -11,7 +11,7 @@ ARCH     ?= gfx950
 # fused multiply-adds appear only where the source says fmaf().
 # x86-64-v3 (AVX2+FMA) rather than -march=native: the objects are built in one
 # container and run on another host.
-CPUFLAGS  = -std=c++17 -O2 -fPIC -ffp-contract=off -march=x86-64-v3 -Wall -Wextra -Iinclude
+CPUFLAGS  = -std=c++17 -O2 -fPIC -ffp-contract=off -fwrapv -march=x86-64-v3 -Wall -Wextra -Iinclude
 HIPFLAGS  = -std=c++17 -O3 -fPIC -ffp-contract=off --offload-arch=$(ARCH) -Iinclude -Wall -Wno-unused-parameter
 
 LIBDIR    = pathed_amd/lib
