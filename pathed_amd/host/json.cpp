@@ -24,6 +24,17 @@ public:
 private:
     const std::string &m_text;
     size_t m_pos;
+    int m_depth = 0;
+    static const int kMaxDepth = 256;   // nesting of arrays / objects: the parser recurses
+
+    struct Nested {
+        JsonParser &parser;
+        explicit Nested(JsonParser &p) : parser(p)
+        {
+            if (++parser.m_depth > kMaxDepth) { parser.fail("nesting deeper than 256 levels"); }
+        }
+        ~Nested() { parser.m_depth--; }
+    };
 
     [[noreturn]] void fail(const std::string &what) const
     {
@@ -55,8 +66,8 @@ private:
     Json parseValue()
     {
         char c = peek();
-        if (c == '{') { return parseObject(); }
-        if (c == '[') { return parseArray(); }
+        if (c == '{') { Nested level(*this); return parseObject(); }
+        if (c == '[') { Nested level(*this); return parseArray(); }
         if (c == '"') {
             Json j;
             j.m_type = Json::Type::String;

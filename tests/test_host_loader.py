@@ -245,3 +245,10 @@ def test_bmp_preview_is_what_stb_image_write_writes(tmp_path):
             assert open(path, "rb").read() == bytes(int(v) for v in record["out"])
             seen += 1
     assert seen == 3
+
+
+def test_deeply_nested_json_is_an_error_not_a_stack_overflow(tmp_path):
+    bad = tmp_path / "deep.json"
+    bad.write_text("[" * 200000)
+    with pytest.raises(RuntimeError, match="nesting"):
+        LoadedScene(str(bad), 8, 8, asset_root="")
