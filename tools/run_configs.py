@@ -39,6 +39,8 @@ def main():
     parser.add_argument("--only", default="")
     parser.add_argument("--full", action="store_true", help="render the spp BASELINE.json names (C2 4096, C3 1024, C4 2048, C5 8192) on this one GPU")
     parser.add_argument("--builder", default="sah", choices=["sah", "lbvh", "ploc"])
+    parser.add_argument("--parity-full", type=int, default=0, metavar="SPP",
+                        help="also compare GPU and CPU oracle at the configuration's FULL resolution with this many spp")
     args = parser.parse_args()
     full_spp = {"C1": 16, "C2": 4096, "C3": 1024, "C4": 2048, "C5": 8192}
     subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_assets.py"), "--dragon", str(args.dragon)], check=True,
@@ -89,6 +91,17 @@ def main():
         g2, o2 = HipScene(small.desc, device=0), oracle_lib.OracleScene(small.desc)
         image = g2.render(1, 0, 16, 0, 10)
         expected, _ = o2.render(pw, ph, 1, 0, 16, 0, 10, threads=cores, chunk=4)
+        full_parity = None
+        if args.parity_full > 0:
+            n = args.parity_full
+            image_full = gpu.render(1, 0, n, 0, 10)
+            expected_full, _ = oracle.render(w, h, 1, 0, n, 0, 10, threads=cores, chunk=4)
+            difference = np.abs(image_full - expected_full)
+            full_parity = {
+                "spp": n, "relL2": "%.2e" % relative_l2(image_full, expected_full),
+                "pixels_bit_identical": round(float((image_full == expected_full).all(axis=2).mean()), 4),
+                "pixels_off_by_more_than_1_percent": round(float((difference > 1e-2 * np.maximum(np.abs(expected_full), 1e-3)).any(axis=2).mean()), 6),
+            }
         rows.append({
             "config": name, "scene": path, "res": "%dx%d" % (w, h), "spp": spp, "note": note,
             "triangles": scene.n_triangles, "scene_create_s": round(setup, 2), "bvh_builder": args.builder,
@@ -101,6 +114,7 @@ def main():
             "cpu_oracle_Msamples_s": round(w * h * cpu_spp / cpu_elapsed / 1e6, 2), "cpu_cores": cores,
             "relL2_vs_oracle_%dx%d_16spp" % (pw, ph): "%.2e" % relative_l2(image, expected),
             "mean_rgb": [round(float(v), 4) for v in (accum / spp).mean(dim=(0, 1)).tolist()],
+            "parity_at_full_resolution": full_parity,
         })
         print(json.dumps(rows[-1]), flush=True)
     return rows
