@@ -746,8 +746,9 @@ int main(int argc, char **argv)
         const std::string directory = (argc > 3) ? argv[3] : "tests/golden/textures";
         const char *files[] = { "jpeg_444_37x29.jpg", "jpeg_420_37x29.jpg", "jpeg_422_37x29.jpg", "jpeg_progressive_420_37x29.jpg",
                                 "jpeg_progressive_444_37x29.jpg", "jpeg_noise_420_26x21.jpg", "jpeg_grey_37x29.jpg",
-                                "jpeg_420_1x9.jpg", "jpeg_restart_420_100x70.jpg" };
-        for (int f = 0; f < 9; f++) {
+                                "jpeg_420_1x9.jpg", "jpeg_restart_420_100x70.jpg",
+                                "adam7_rgb8_13x11.png", "adam7_grey4_10x9.png", "adam7_rgba16_3x2.png" };
+        for (int f = 0; f < 12; f++) {
             const std::string path = directory + "/" + files[f];
             std::ifstream probe(path);
             if (!probe.good()) { fprintf(stderr, "texture fixture missing: %s\n", path.c_str()); continue; }

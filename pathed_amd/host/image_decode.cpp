@@ -57,7 +57,7 @@ bool decodePng(const std::vector<uint8_t> &file, int *width, int *height, std::v
     if (!sawHeader) { return fail("no IHDR"); }
     if (w == 0 || h == 0 || w > 65535 || h > 65535) { return fail("image size out of range (1..65535)"); }
     if ((uint64_t)w * h > (1ull << 28)) { return fail("image larger than 2^28 pixels"); }
-    if (interlace != 0) { return fail("interlaced (Adam7) files are not supported: re-save without interlacing"); }
+    if (interlace > 1) { return fail("unknown interlace method"); }
     int channels;
     switch (colorType) {
     case 0: channels = 1; break;
@@ -73,70 +73,92 @@ bool decodePng(const std::vector<uint8_t> &file, int *width, int *height, std::v
     if (!depthOk) { return fail("bit depth not allowed for the colour type"); }
     if (colorType == 3 && palette.size() < 3) { return fail("palette image without PLTE"); }
 
-    const size_t rowBytes = ((size_t)w * channels * depth + 7) / 8;
     const size_t pixelBytes = (size_t)(channels * depth + 7) / 8;   // filter distance, >= 1
-    std::vector<uint8_t> raw((rowBytes + 1) * h);
+    auto rowBytesFor = [&](uint32_t pixels) { return ((size_t)pixels * channels * depth + 7) / 8; };
+
+    // Adam7: seven reduced images, each filtered on its own (PNG specification, section 8.2)
+    static const int xOrigin[7] = { 0, 4, 0, 2, 0, 1, 0 }, yOrigin[7] = { 0, 0, 4, 0, 2, 0, 1 };
+    static const int xSpacing[7] = { 8, 8, 4, 4, 2, 2, 1 }, ySpacing[7] = { 8, 8, 8, 4, 4, 2, 2 };
+    struct Pass { uint32_t w, h; int x0, y0, dx, dy; };
+    std::vector<Pass> passes;
+    if (interlace == 0) {
+        passes.push_back({ w, h, 0, 0, 1, 1 });
+    } else {
+        for (int k = 0; k < 7; k++) {
+            const uint32_t pw = (w - (uint32_t)xOrigin[k] + (uint32_t)xSpacing[k] - 1) / (uint32_t)xSpacing[k];
+            const uint32_t ph = (h - (uint32_t)yOrigin[k] + (uint32_t)ySpacing[k] - 1) / (uint32_t)ySpacing[k];
+            if ((uint32_t)xOrigin[k] < w && (uint32_t)yOrigin[k] < h && pw && ph) { passes.push_back({ pw, ph, xOrigin[k], yOrigin[k], xSpacing[k], ySpacing[k] }); }
+        }
+    }
+    size_t rawSizeWanted = 0;
+    for (const Pass &pass : passes) { rawSizeWanted += (rowBytesFor(pass.w) + 1) * pass.h; }
+    std::vector<uint8_t> raw(rawSizeWanted);
     uLongf rawSize = (uLongf)raw.size();
     const int status = uncompress(raw.data(), &rawSize, compressed.data(), (uLong)compressed.size());
     if (status != Z_OK || rawSize != raw.size()) { return fail("corrupt image data (zlib)"); }
-
-    // undo the scanline filters in place
-    std::vector<uint8_t> zeroRow(rowBytes, 0);
-    for (uint32_t y = 0; y < h; y++) {
-        uint8_t *row = &raw[(rowBytes + 1) * y + 1];
-        const uint8_t *above = y ? &raw[(rowBytes + 1) * (y - 1) + 1] : zeroRow.data();
-        const int filter = row[-1];
-        for (size_t i = 0; i < rowBytes; i++) {
-            const int left = i >= pixelBytes ? row[i - pixelBytes] : 0;
-            const int up = above[i];
-            const int upLeft = i >= pixelBytes ? above[i - pixelBytes] : 0;
-            int predicted;
-            switch (filter) {
-            case 0: predicted = 0; break;
-            case 1: predicted = left; break;
-            case 2: predicted = up; break;
-            case 3: predicted = (left + up) >> 1; break;
-            case 4: predicted = paeth(left, up, upLeft); break;
-            default: return fail("unknown scanline filter");
-            }
-            row[i] = (uint8_t)(row[i] + predicted);
-        }
-    }
 
     // expand to 8-bit RGB the way stb_image does for req_comp = 3: 16-bit samples keep their
     // high byte, 1/2/4-bit grey is scaled to 0..255, palette indices are looked up, alpha is dropped
     rgb->resize((size_t)3 * w * h);
     static const int depthScale[9] = { 0, 0xff, 0x55, 0, 0x11, 0, 0, 0, 0x01 };
-    for (uint32_t y = 0; y < h; y++) {
-        const uint8_t *row = &raw[(rowBytes + 1) * y + 1];
-        for (uint32_t x = 0; x < w; x++) {
-            uint8_t sample[4] = { 0, 0, 0, 0 };
-            for (int c = 0; c < channels; c++) {
-                const size_t index = (size_t)x * channels + c;
-                if (depth == 16) { sample[c] = row[2 * index]; }
-                else if (depth == 8) { sample[c] = row[index]; }
-                else {
-                    const size_t bit = index * depth;
-                    const int shift = 8 - depth - (int)(bit & 7);
-                    sample[c] = (uint8_t)((row[bit >> 3] >> shift) & ((1 << depth) - 1));
+    size_t passStart = 0;
+    for (const Pass &pass : passes) {
+        const size_t rowBytes = rowBytesFor(pass.w);
+        // undo the scanline filters in place
+        std::vector<uint8_t> zeroRow(rowBytes, 0);
+        for (uint32_t y = 0; y < pass.h; y++) {
+            uint8_t *row = &raw[passStart + (rowBytes + 1) * y + 1];
+            const uint8_t *above = y ? &raw[passStart + (rowBytes + 1) * (y - 1) + 1] : zeroRow.data();
+            const int filter = row[-1];
+            for (size_t i = 0; i < rowBytes; i++) {
+                const int left = i >= pixelBytes ? row[i - pixelBytes] : 0;
+                const int up = above[i];
+                const int upLeft = i >= pixelBytes ? above[i - pixelBytes] : 0;
+                int predicted;
+                switch (filter) {
+                case 0: predicted = 0; break;
+                case 1: predicted = left; break;
+                case 2: predicted = up; break;
+                case 3: predicted = (left + up) >> 1; break;
+                case 4: predicted = paeth(left, up, upLeft); break;
+                default: return fail("unknown scanline filter");
                 }
-            }
-            uint8_t *out = &(*rgb)[3 * ((size_t)y * w + x)];
-            if (colorType == 3) {
-                const size_t entry = sample[0];
-                if (3 * entry + 2 >= palette.size()) { return fail("palette index out of range"); }
-                out[0] = palette[3 * entry + 0];
-                out[1] = palette[3 * entry + 1];
-                out[2] = palette[3 * entry + 2];
-            } else if (channels <= 2) {
-                const uint8_t grey = depth < 8 ? (uint8_t)(sample[0] * depthScale[depth]) : sample[0];
-                out[0] = out[1] = out[2] = grey;
-            } else {
-                out[0] = sample[0];
-                out[1] = sample[1];
-                out[2] = sample[2];
+                row[i] = (uint8_t)(row[i] + predicted);
             }
         }
+        for (uint32_t y = 0; y < pass.h; y++) {
+            const uint8_t *row = &raw[passStart + (rowBytes + 1) * y + 1];
+            for (uint32_t x = 0; x < pass.w; x++) {
+                uint8_t sample[4] = { 0, 0, 0, 0 };
+                for (int c = 0; c < channels; c++) {
+                    const size_t index = (size_t)x * channels + c;
+                    if (depth == 16) { sample[c] = row[2 * index]; }
+                    else if (depth == 8) { sample[c] = row[index]; }
+                    else {
+                        const size_t bit = index * depth;
+                        const int shift = 8 - depth - (int)(bit & 7);
+                        sample[c] = (uint8_t)((row[bit >> 3] >> shift) & ((1 << depth) - 1));
+                    }
+                }
+                const size_t outX = (size_t)x * pass.dx + pass.x0, outY = (size_t)y * pass.dy + pass.y0;
+                uint8_t *out = &(*rgb)[3 * (outY * w + outX)];
+                if (colorType == 3) {
+                    const size_t entry = sample[0];
+                    if (3 * entry + 2 >= palette.size()) { return fail("palette index out of range"); }
+                    out[0] = palette[3 * entry + 0];
+                    out[1] = palette[3 * entry + 1];
+                    out[2] = palette[3 * entry + 2];
+                } else if (channels <= 2) {
+                    const uint8_t grey = depth < 8 ? (uint8_t)(sample[0] * depthScale[depth]) : sample[0];
+                    out[0] = out[1] = out[2] = grey;
+                } else {
+                    out[0] = sample[0];
+                    out[1] = sample[1];
+                    out[2] = sample[2];
+                }
+            }
+        }
+        passStart += (rowBytes + 1) * pass.h;
     }
     *width = (int)w;
     *height = (int)h;

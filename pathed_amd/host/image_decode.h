@@ -1,6 +1,6 @@
 // 8-bit RGB image files for image-texture albedos: what the reference gets from
 // stbi_load(path, &w, &h, &channels, 3) (src/texture.cpp:12-31).
-//   PNG   non-interlaced; grey, RGB, palette, with or without alpha, 1-16 bits
+//   PNG   grey, RGB, palette, with or without alpha, 1-16 bits, plain or Adam7-interlaced
 //   PNM   binary P5 / P6, maxval <= 255
 //   JPEG  baseline and progressive, 8-bit, greyscale or three components.  A JPEG's decoded bytes depend
 //         on the decoder's IDCT, chroma upsampling and colour conversion, so those follow stb_image's

@@ -54,6 +54,35 @@ def write_png(name, width, height, depth, color_type, rows, bpp, palette=None):
         handle.write(data)
 
 
+def write_png_adam7(name, width, height, depth, color_type, pixel_rows, channels, palette=None):
+    """pixel_rows[y][x] = tuple of samples; writes the seven Adam7 passes, each filtered on its own."""
+    x0, y0 = [0, 4, 0, 2, 0, 1, 0], [0, 0, 4, 0, 2, 0, 1]
+    dx, dy = [8, 8, 4, 4, 2, 2, 1], [8, 8, 8, 4, 4, 2, 2]
+    bpp = max(1, channels * depth // 8)
+    stream = b""
+    for k in range(7):
+        columns = list(range(x0[k], width, dx[k]))
+        lines = list(range(y0[k], height, dy[k]))
+        if not columns or not lines:
+            continue
+        rows = []
+        for y in lines:
+            samples = [s for x in columns for s in pixel_rows[y][x]]
+            if depth == 8:
+                rows.append(bytes(samples))
+            elif depth == 16:
+                rows.append(b"".join(struct.pack(">H", s) for s in samples))
+            else:
+                rows.append(pack_bits(samples, depth))
+        stream += filter_rows(rows, bpp, [(y + k) % 5 for y in range(len(rows))])
+    data = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", width, height, depth, color_type, 0, 0, 1))
+    if palette is not None:
+        data += chunk(b"PLTE", bytes(palette))
+    data += chunk(b"IDAT", zlib.compress(stream, 9)) + chunk(b"IEND", b"")
+    with open(os.path.join(OUT, name), "wb") as handle:
+        handle.write(data)
+
+
 def pack_bits(values, depth):
     out, acc, bits = bytearray(), 0, 0
     for value in values:
@@ -102,6 +131,16 @@ if __name__ == "__main__":
     main()
 
 
+def adam7_fixtures():
+    rng = np.random.default_rng(23)
+    rgb = rng.integers(0, 256, (11, 13, 3), dtype=np.uint8)
+    write_png_adam7("adam7_rgb8_13x11.png", 13, 11, 8, 2, [[tuple(int(v) for v in rgb[y, x]) for x in range(13)] for y in range(11)], 3)
+    grey = rng.integers(0, 16, (9, 10), dtype=np.uint8)
+    write_png_adam7("adam7_grey4_10x9.png", 10, 9, 4, 0, [[(int(grey[y, x]),) for x in range(10)] for y in range(9)], 1)
+    tiny = rng.integers(0, 65536, (2, 3, 4), dtype=np.uint16)   # fewer pixels than passes
+    write_png_adam7("adam7_rgba16_3x2.png", 3, 2, 16, 6, [[tuple(int(v) for v in tiny[y, x]) for x in range(3)] for y in range(2)], 4)
+
+
 def jpeg_fixtures():
     """JPEG files written by Pillow (libjpeg): the sampling factors, scan types and edge cases the decoder
     must reproduce stb_image's bytes for."""
@@ -130,3 +169,4 @@ def jpeg_fixtures():
 
 if __name__ == "__main__":
     jpeg_fixtures()
+    adam7_fixtures()

@@ -25,7 +25,9 @@ FILES = ["rgb8_7x5.png", "rgba16_4x3.png", "greyalpha8_3x4.png", "grey2_5x6.png"
 # JPEG files written by Pillow / libjpeg (tests/golden/make_texture_fixtures.py); record index = 100 + position
 JPEG_FILES = ["jpeg_444_37x29.jpg", "jpeg_420_37x29.jpg", "jpeg_422_37x29.jpg", "jpeg_progressive_420_37x29.jpg",
               "jpeg_progressive_444_37x29.jpg", "jpeg_noise_420_26x21.jpg", "jpeg_grey_37x29.jpg", "jpeg_420_1x9.jpg",
-              "jpeg_restart_420_100x70.jpg"]
+              "jpeg_restart_420_100x70.jpg",
+              # Adam7-interlaced PNGs written by tests/golden/make_texture_fixtures.py (records 109...)
+              "adam7_rgb8_13x11.png", "adam7_grey4_10x9.png", "adam7_rgba16_3x2.png"]
 
 
 def _records():
