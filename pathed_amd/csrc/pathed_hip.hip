@@ -342,8 +342,10 @@ int validate(const PathedSceneDesc *desc)
     return PATHED_OK;
 }
 
-// chunks (units per pixel) rendered per internal pass: bounds chunkBuf to 64 float4 per pixel
-const int kMaxChunksPerPass = 64;
+// chunks (units per pixel) rendered per internal pass: bounds chunkBuf to 256 float4 per pixel (4.3 GB at
+// 1024^2, 8.5 GB at 1080p; further capped at 2^30 units).  Every pass pays the slot pool's ramp-up and tail
+// once: 256 instead of 64 chunks per pass is worth 2-3 % on long renders (tools/pass_sweep.py).
+const int kMaxChunksPerPass = 256;
 
 int ensureRenderState(PathedScene *scene, int nSlots, size_t chunkEntries)
 {
@@ -1021,7 +1023,17 @@ int pathed_hip_render_device(PathedScene *scene, uint64_t seed,
     hipStream_t stream = (hipStream_t)stream_handle;
 
     // passes of at most chunk * kMaxChunksPerPass samples keep the partial-sum buffer bounded
-    const uint32_t perPass = (uint32_t)scene->samplesPerUnit * (uint32_t)kMaxChunksPerPass;
+    int chunksPerPass = kMaxChunksPerPass;
+    {
+        const unsigned long long pixels = (unsigned long long)scene->width * (unsigned long long)scene->height;
+        const unsigned long long cap = (1ull << 30) / (pixels ? pixels : 1ull);
+        if ((unsigned long long)chunksPerPass > cap) { chunksPerPass = cap >= 1ull ? (int)cap : 1; }
+    }
+    if (const char *text = getenv("PATHED_CHUNKS_PER_PASS")) {   // tuning: fewer, longer passes at the cost of a larger partial-sum buffer
+        const int value = atoi(text);
+        if (value >= 1 && value <= 4096) { chunksPerPass = value; }
+    }
+    const uint32_t perPass = (uint32_t)scene->samplesPerUnit * (uint32_t)chunksPerPass;
     uint32_t done = 0;
     while (done < spp_count) {
         const uint32_t count = (spp_count - done < perPass) ? (spp_count - done) : perPass;

@@ -59,7 +59,7 @@ def main():
         accum = torch.zeros((h, w, 3), dtype=torch.float32, device="cuda")
         gpu.render_device(1, 0, min(spp, 16), 0, 10, accum.data_ptr())  # warm-up
         accum.zero_()
-        gpu.set_stats_mode(count=False, time_kernels=True)
+        gpu.set_stats_mode(count=False, time_sampled=True)   # HIP events around every 8th launch
         gpu.reset_stats()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -67,6 +67,11 @@ def main():
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         timed = gpu.stats()
+        if timed["trace_launches"]:
+            # extrapolate the sampled launches to all of them
+            scale = timed["trace_launches_all"] / timed["trace_launches"]
+            timed["trace_ms"] *= scale
+            timed["shade_ms"] *= scale
         gpu.set_stats_mode(count=True)
         gpu.reset_stats()
         scratch = torch.zeros_like(accum)
