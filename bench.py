@@ -35,6 +35,8 @@ def parse_args():
     parser.add_argument("--scene", default="scenes/cornell.json")
     parser.add_argument("--last-bounce", type=int, default=10)
     parser.add_argument("--seed", type=int, default=1)
+    parser.add_argument("--bvh-builder", default="sah", choices=["sah", "lbvh", "ploc"],
+                        help="host binned-SAH build (default) or an on-GPU build; only matters for scenes of more than 64 triangles")
     parser.add_argument("--no-cpu-baseline", action="store_true")
     parser.add_argument("--time-every-launch", action="store_true",
                         help="HIP events around every trace / shade launch instead of every 8th")
@@ -96,7 +98,7 @@ def main():
     from pathed_amd.scene import LoadedScene
 
     scene = LoadedScene(args.scene, args.width, args.height)
-    gpu = HipScene(scene.desc, device=local_rank)
+    gpu = HipScene(scene.desc, device=local_rank, bvh_builder=args.bvh_builder)
     stream = torch.cuda.current_stream().cuda_stream
 
     accum = torch.zeros((args.height, args.width, 3), dtype=torch.float32, device="cuda")
