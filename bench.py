@@ -169,9 +169,11 @@ def main():
             # bytes per launch / average duration of the timed launches
             achieved = ((total_bytes / launches) / (trace_ms / timed_launches * 1e-3) / 1e9) if trace_ms > 0 and launches else None
             traffic = None
-            traffic_path = os.path.join(REPO_ROOT, "profiles", "hbm_traffic.json")
-            if os.path.exists(traffic_path):
-                with open(traffic_path) as handle:
+            # PMC passes exist for two workloads (tools/profile_bench.sh): the default one and the large-BVH scene
+            traffic_files = {("scenes/cornell.json", 2): "hbm_traffic.json", ("scenes/dragon-standin.json", 0): "r1s2dragon_hbm_traffic.json"}
+            traffic_name = traffic_files.get((args.scene, per_step_stats["scene_in_lds"]))
+            if traffic_name and os.path.exists(os.path.join(REPO_ROOT, "profiles", traffic_name)):
+                with open(os.path.join(REPO_ROOT, "profiles", traffic_name)) as handle:
                     traffic = json.load(handle).get("trace_hbm_bytes_per_launch")
             # what a plain streaming kernel reaches on this box: the second denominator
             from pathed_amd.integrator import measure_bandwidth

@@ -15,6 +15,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
+write_default = "--not-default" not in sys.argv   # profiles/hbm_traffic.json is what bench.py reads for the DEFAULT workload
 base = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
 out_dir = os.path.join(ROOT, "profiles")
 os.makedirs(out_dir, exist_ok=True)
@@ -42,7 +43,8 @@ for name, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
         sums[kernel][0] += 1
         sums[kernel][1] += float(row["Counter_Value"])
     for kernel, (count, total) in sums.items():
-        if "pathed::" in kernel and not ("k_trace" in kernel and "true>" in kernel) and count > 4:
+        counting_variant = ("k_trace_small<true>" in kernel) or ("k_trace<" in kernel and kernel.rstrip().endswith("true>"))
+        if "pathed::" in kernel and not counting_variant and count > 4:
             traffic.setdefault(kernel, {})[counter + "_KiB_avg"] = total / count
             traffic[kernel]["launches_" + name] = count
 
@@ -55,6 +57,7 @@ if trace_kernel:
     summary["trace_hbm_bytes_per_launch"] = (2.0 * fetch + write) * 1024.0
     summary["note"] = "2 x FETCH_SIZE + WRITE_SIZE, KiB -> bytes, averaged over the launches of the pmc passes"
 json.dump(summary, open(os.path.join(out_dir, tag + "_hbm_traffic.json"), "w"), indent=1)
-json.dump(summary, open(os.path.join(out_dir, "hbm_traffic.json"), "w"), indent=1)
+if write_default:
+    json.dump(summary, open(os.path.join(out_dir, "hbm_traffic.json"), "w"), indent=1)
 print(json.dumps(summary, indent=1))
 print(open(os.path.join(out_dir, tag + "_kernel_stats.csv")).read()[:1200])
