@@ -13,8 +13,10 @@
 //                       frontier entry carries its subtree's first position in leaf order; subtrees
 //                       of at most four triangles become leaves and write their (v0, prim) (e1) (e2)
 //                       records there.
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 
 #include <hip/hip_runtime.h>
 #include <rocprim/rocprim.hpp>
@@ -498,6 +500,111 @@ __global__ __launch_bounds__(kLbvhBlock) void k_lbvh_wide_emit(
     if (e == m - 1) { *nextCount = base + innerCount[e]; }
 }
 
+// ------------------------------------------------------------------------- SAH top of the tree
+// The last few thousand clusters are joined on the host by a top-down binned-SAH build (weighted by the
+// triangles below each cluster) instead of by more clustering rounds: near the root every ray pays for a
+// bad split, the Morton-order window sees too little there, and a thousand boxes take well under a millisecond.
+// (The same idea as HLBVH's "SAH over treelet roots", Garanzha et al. 2011.)
+struct TopItem {
+    float lo[3], hi[3];
+    unsigned int ref, triangles;
+};
+
+struct TopNodes {
+    std::vector<uint2> children;
+    std::vector<unsigned int> count;
+    std::vector<float4> lo, hi;
+};
+
+// builds the subtree over items[begin, end) (reordered in place); returns its child reference
+unsigned int buildTopSah(std::vector<TopItem> &items, size_t begin, size_t end, unsigned int nodeBase, TopNodes &out)
+{
+    if (end - begin == 1) { return items[begin].ref; }
+    float lo[3] = { 3e38f, 3e38f, 3e38f }, hi[3] = { -3e38f, -3e38f, -3e38f }, clo[3] = { 3e38f, 3e38f, 3e38f }, chi[3] = { -3e38f, -3e38f, -3e38f };
+    unsigned int triangles = 0;
+    for (size_t i = begin; i < end; i++) {
+        for (int a = 0; a < 3; a++) {
+            lo[a] = std::min(lo[a], items[i].lo[a]);
+            hi[a] = std::max(hi[a], items[i].hi[a]);
+            const float centre = 0.5f * (items[i].lo[a] + items[i].hi[a]);
+            clo[a] = std::min(clo[a], centre);
+            chi[a] = std::max(chi[a], centre);
+        }
+        triangles += items[i].triangles;
+    }
+    auto halfArea = [](const float *l, const float *h) {
+        const float dx = h[0] - l[0], dy = h[1] - l[1], dz = h[2] - l[2];
+        return dx >= 0.f ? dx * dy + dy * dz + dz * dx : 0.f;
+    };
+    const int kBins = 16;
+    int bestAxis = -1, bestSplit = -1;
+    float bestCost = 3e38f;
+    for (int axis = 0; axis < 3; axis++) {
+        if (!(chi[axis] > clo[axis])) { continue; }
+        const float scale = (float)kBins / (chi[axis] - clo[axis]);
+        float binLo[kBins][3], binHi[kBins][3];
+        unsigned int binTriangles[kBins];
+        size_t binItems[kBins];
+        for (int b = 0; b < kBins; b++) {
+            for (int a = 0; a < 3; a++) { binLo[b][a] = 3e38f; binHi[b][a] = -3e38f; }
+            binTriangles[b] = 0;
+            binItems[b] = 0;
+        }
+        for (size_t i = begin; i < end; i++) {
+            int b = (int)((0.5f * (items[i].lo[axis] + items[i].hi[axis]) - clo[axis]) * scale);
+            b = b < 0 ? 0 : b > kBins - 1 ? kBins - 1 : b;
+            for (int a = 0; a < 3; a++) { binLo[b][a] = std::min(binLo[b][a], items[i].lo[a]); binHi[b][a] = std::max(binHi[b][a], items[i].hi[a]); }
+            binTriangles[b] += items[i].triangles;
+            binItems[b]++;
+        }
+        float rightArea[kBins];
+        unsigned int rightTriangles[kBins];
+        size_t rightItems[kBins];
+        float accLo[3] = { 3e38f, 3e38f, 3e38f }, accHi[3] = { -3e38f, -3e38f, -3e38f };
+        unsigned int runningTriangles = 0;
+        size_t runningItems = 0;
+        for (int b = kBins - 1; b > 0; b--) {
+            for (int a = 0; a < 3; a++) { accLo[a] = std::min(accLo[a], binLo[b][a]); accHi[a] = std::max(accHi[a], binHi[b][a]); }
+            runningTriangles += binTriangles[b];
+            runningItems += binItems[b];
+            rightArea[b] = halfArea(accLo, accHi);
+            rightTriangles[b] = runningTriangles;
+            rightItems[b] = runningItems;
+        }
+        for (int a = 0; a < 3; a++) { accLo[a] = 3e38f; accHi[a] = -3e38f; }
+        runningTriangles = 0;
+        runningItems = 0;
+        for (int b = 0; b < kBins - 1; b++) {
+            for (int a = 0; a < 3; a++) { accLo[a] = std::min(accLo[a], binLo[b][a]); accHi[a] = std::max(accHi[a], binHi[b][a]); }
+            runningTriangles += binTriangles[b];
+            runningItems += binItems[b];
+            if (runningItems == 0 || rightItems[b + 1] == 0) { continue; }
+            const float cost = halfArea(accLo, accHi) * (float)runningTriangles + rightArea[b + 1] * (float)rightTriangles[b + 1];
+            if (cost < bestCost) { bestCost = cost; bestAxis = axis; bestSplit = b; }
+        }
+    }
+    size_t mid = begin;
+    if (bestAxis >= 0) {
+        const float scale = (float)kBins / (chi[bestAxis] - clo[bestAxis]);
+        const float origin = clo[bestAxis];
+        const int axis = bestAxis, split = bestSplit;
+        auto middle = std::partition(items.begin() + (long)begin, items.begin() + (long)end, [=](const TopItem &item) {
+            int b = (int)((0.5f * (item.lo[axis] + item.hi[axis]) - origin) * scale);
+            b = b < 0 ? 0 : b > kBins - 1 ? kBins - 1 : b;
+            return b <= split;
+        });
+        mid = (size_t)(middle - items.begin());
+    }
+    if (mid == begin || mid == end) { mid = begin + (end - begin) / 2; }   // coincident centres: halve in the given order
+    const unsigned int left = buildTopSah(items, begin, mid, nodeBase, out);
+    const unsigned int right = buildTopSah(items, mid, end, nodeBase, out);
+    out.children.push_back(make_uint2(left, right));
+    out.count.push_back(triangles);
+    out.lo.push_back(make_float4(lo[0], lo[1], lo[2], 0.f));
+    out.hi.push_back(make_float4(hi[0], hi[1], hi[2], 0.f));
+    return nodeBase + (unsigned int)(out.children.size() - 1);
+}
+
 struct Scratch {
     void *pointers[48];
     int used = 0;
@@ -625,8 +732,13 @@ hipError_t buildBvhOnDevice(int builder, const float *positions, const uint32_t 
             if (value >= 1 && value <= kPlocMaxRadius) { radius = value; }
         }
         hipLaunchKernelGGL(k_ploc_init, dim3(blocksFor(n)), dim3(kLbvhBlock), 0, stream, n, sorted, boxLo, boxHi, a);
+        unsigned int topLimit = 1024;   // clusters left to the host's SAH build (0: cluster all the way); 1 024: fewer rounds AND a better top
+        if (const char *text = getenv("PATHED_PLOC_TOP")) {
+            const int value = atoi(text);
+            if (value >= 0 && value <= (1 << 20)) { topLimit = (unsigned int)value; }
+        }
         unsigned int c = n, nodeBase = 0;
-        while (c > 1) {
+        while (c > 1 && c > topLimit) {
             if (++rounds > 4096) { return failed(hipErrorInvalidValue, "clustering does not converge"); }
             hipLaunchKernelGGL(k_ploc_nearest, dim3(blocksFor(c)), dim3(kLbvhBlock), 0, stream, a, c, radius, nearest);
             hipLaunchKernelGGL(k_ploc_flags, dim3(blocksFor(c)), dim3(kLbvhBlock), 0, stream, c, nearest, survives, merges);
@@ -648,6 +760,32 @@ hipError_t buildBvhOnDevice(int builder, const float *positions, const uint32_t 
             const PlocClusters swap = a;
             a = b;
             b = swap;
+        }
+        if (c > 1) {
+            // the top of the tree: SAH over the remaining clusters, on the host
+            std::vector<float4> hostLo(c), hostHi(c);
+            std::vector<unsigned int> hostNode(c), hostCount(c);
+            if ((status = hipMemcpy(hostLo.data(), a.lo, c * sizeof(float4), hipMemcpyDeviceToHost)) != hipSuccess) { return failed(status, "top clusters"); }
+            if ((status = hipMemcpy(hostHi.data(), a.hi, c * sizeof(float4), hipMemcpyDeviceToHost)) != hipSuccess) { return failed(status, "top clusters"); }
+            if ((status = hipMemcpy(hostNode.data(), a.node, c * sizeof(unsigned int), hipMemcpyDeviceToHost)) != hipSuccess) { return failed(status, "top clusters"); }
+            if ((status = hipMemcpy(hostCount.data(), a.count, c * sizeof(unsigned int), hipMemcpyDeviceToHost)) != hipSuccess) { return failed(status, "top clusters"); }
+            std::vector<TopItem> items(c);
+            for (unsigned int i = 0; i < c; i++) {
+                items[i].lo[0] = hostLo[i].x; items[i].lo[1] = hostLo[i].y; items[i].lo[2] = hostLo[i].z;
+                items[i].hi[0] = hostHi[i].x; items[i].hi[1] = hostHi[i].y; items[i].hi[2] = hostHi[i].z;
+                items[i].ref = hostNode[i];
+                items[i].triangles = hostCount[i];
+            }
+            TopNodes top;
+            top.children.reserve(c); top.count.reserve(c); top.lo.reserve(c); top.hi.reserve(c);
+            buildTopSah(items, 0, c, nodeBase, top);
+            const size_t made = top.children.size();
+            if (made != (size_t)c - 1 || (size_t)nodeBase + made != (size_t)n - 1) { return failed(hipErrorInvalidValue, "top build made a wrong node count"); }
+            if ((status = hipMemcpy(children + nodeBase, top.children.data(), made * sizeof(uint2), hipMemcpyHostToDevice)) != hipSuccess) { return failed(status, "top nodes"); }
+            if ((status = hipMemcpy(count + nodeBase, top.count.data(), made * sizeof(unsigned int), hipMemcpyHostToDevice)) != hipSuccess) { return failed(status, "top nodes"); }
+            if ((status = hipMemcpy(nodeLo + nodeBase, top.lo.data(), made * sizeof(float4), hipMemcpyHostToDevice)) != hipSuccess) { return failed(status, "top nodes"); }
+            if ((status = hipMemcpy(nodeHi + nodeBase, top.hi.data(), made * sizeof(float4), hipMemcpyHostToDevice)) != hipSuccess) { return failed(status, "top nodes"); }
+            nodeBase += (unsigned int)made;
         }
         if (nodeBase != n - 1) { return failed(hipErrorInvalidValue, "clustering ended with a wrong node count"); }
         root = n - 2;   // the last node created
