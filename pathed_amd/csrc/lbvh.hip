@@ -7,7 +7,9 @@
 //             k_lbvh_fit        boxes bottom-up: the second thread to reach a node merges its children
 //       PLOC  k_ploc_nearest / _flags / _merge, once per round: mutual nearest neighbours (by the
 //             surface area of their union, within 16 places of the Morton order) merge; compaction
-//             by exclusive scans; ~25 rounds for millions of triangles
+//             by exclusive scans; ~60 rounds for millions of triangles, until 1 024 clusters are left,
+//             which a binned-SAH build on the host joins (buildTopSah: the top of the tree is where a bad
+//             split costs every ray)
 //   6 k_lbvh_wide_*     breadth-first collapse to 4-wide nodes, one level per launch pair; ids are
 //                       handed out by an exclusive scan, so the tree is the same every run.  A
 //                       frontier entry carries its subtree's first position in leaf order; subtrees
