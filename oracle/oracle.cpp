@@ -1214,6 +1214,7 @@ struct BvhNode {
 
 struct Counters {
     uint64_t cameraSamples, closestRays, shadowRays, boxTests, triTests, dropped, vertices;
+    uint64_t shadowRaysNeeded; /* occlusion queries whose light sample has a non-black unoccluded contribution */
 };
 
 struct Bvh {
@@ -1602,20 +1603,35 @@ struct OracleSceneImpl {
         if (dot(lightSample.normal, wiWorld) >= 0.f) { return col(0.f); }
 
         const float lightDistance = length(lightDirection);
-        if (testOcclusion(isect.point, wiWorld, lightDistance, counters)) { return col(0.f); }
-
+        /* The reference queries the occlusion first (:140-141) and evaluates the contribution after; both are
+         * pure, so evaluating first changes nothing -- it only lets the oracle count the queries whose answer
+         * matters. */
         const float pdf = solidAnglePDF(lightSample, isect.point);
         float brdfPDF;
         const Color f = materialF(material, isect, wiWorld, &brdfPDF);
         const float lightWeight = (1 * pdf) / (1 * pdf + 1 * brdfPDF); /* include/mis.h:4-7 */
 
+        /* Shortcut shared with the HIP kernels (deliberate deviation, header): with f exactly black and finite,
+         * positive pdfs the product below is black whatever the occlusion query says; it is not evaluated (only a
+         * non-finite emission could tell the difference).  The query is still made here, as in the reference, but
+         * it does not count as needed. */
+        const bool blackLobe = isBlack(f) && pdf > 0.f && pdf < 3e38f && brdfPDF >= 0.f && brdfPDF < 3e38f;
+        if (blackLobe) {
+            (void)testOcclusion(isect.point, wiWorld, lightDistance, counters);
+            return col(0.f);
+        }
+
         const Vec3 lightWo = -normalized(lightDirection);
 
-        return lightEmit(lightSample.light, lightWo)
+        const Color contribution = lightEmit(lightSample.light, lightWo)
             * lightWeight
             * f
             * fabsf(dot(isect.shadingNormal, wiWorld))
             / pdf;
+        if (counters) { counters->shadowRaysNeeded++; }
+
+        if (testOcclusion(isect.point, wiWorld, lightDistance, counters)) { return col(0.f); }
+        return contribution;
     }
 
     /* -- PathTracer::directSampleBSDF, src/path_tracer.cpp:167-216, given the
@@ -1937,12 +1953,13 @@ int oracle_render_chunked(OracleScene *scene, uint64_t seed, uint32_t spp_begin,
             total.triTests += local.triTests;
             total.dropped += local.dropped;
             total.vertices += local.vertices;
+            total.shadowRaysNeeded += local.shadowRaysNeeded;
         }
     }
     if (stats) {
         stats[0] = total.cameraSamples; stats[1] = total.closestRays; stats[2] = total.shadowRays;
         stats[3] = total.boxTests; stats[4] = total.triTests; stats[5] = total.dropped;
-        stats[6] = total.vertices; stats[7] = 0;
+        stats[6] = total.vertices; stats[7] = total.shadowRaysNeeded;
     }
     return 0;
 }

@@ -32,7 +32,7 @@ const char *oracle_last_error(void);
  * order.  threads <= 1 runs serially; otherwise OpenMP over rows like the
  * reference (src/sample_integrator.cpp:99).  stats (optional, 8 x uint64):
  * camera samples, closest rays, shadow rays, box tests, triangle tests,
- * dropped samples, path vertices, 0. */
+ * dropped samples, path vertices, shadow rays whose light sample has a non-black unoccluded contribution. */
 int oracle_render(OracleScene *scene, uint64_t seed,
                   uint32_t spp_begin, uint32_t spp_count,
                   int start_bounce, int last_bounce,

@@ -807,6 +807,13 @@ __device__ inline Rgb sampleLightsTerm(
     const Rgb f = materialF(material, isect, wiWorld, &brdfPDF);
     const float lightWeight = (1 * pdf) / (1 * pdf + 1 * brdfPDF);  // include/mis.h:4-7
 
+    // The reference asks for the occlusion first and evaluates emitted * weight * f * cos / pdf afterwards.
+    // With f exactly black (the light is below the surface's horizon) and finite, positive pdfs the product is
+    // black whatever the occlusion query says, so neither the emission lookup nor the shadow ray is needed.
+    // (Only a non-finite emission could tell the difference; the oracle takes the same shortcut.  Testing the
+    // finished product instead costs k_shade one more VGPR and with it the second wave next to the trace waves.)
+    if (isBlack(f) && pdf > 0.f && pdf < 3e38f && brdfPDF >= 0.f && brdfPDF < 3e38f) { return rgb(0.f); }
+
     const V3 lightWo = -normalized(lightDirection);
     Rgb emitted;
     if (light.kind == 2) { emitted = envEmit(scene.env, lightWo); }
@@ -818,11 +825,12 @@ __device__ inline Rgb sampleLightsTerm(
     shadow->direction = wiWorld;
     shadow->tfar = lightDistance - 1e-3f;
 
-    return emitted
+    const Rgb contribution = emitted
         * lightWeight
         * f
         * fabsf(dot(isect.shadingNormal, wiWorld))
         / pdf;
+    return contribution;
 }
 
 // Camera::generateRay(int,int), src/camera.cpp:49-55, for (pixel, sample)

@@ -80,7 +80,7 @@ class OracleScene:
                                               _fptr(accum), threads, stats, chunk)
         if code != 0:
             raise RuntimeError("oracle_render failed")
-        names = ["camera_samples", "closest_rays", "shadow_rays", "box_tests", "tri_tests", "dropped", "vertices"]
+        names = ["camera_samples", "closest_rays", "shadow_rays", "box_tests", "tri_tests", "dropped", "vertices", "shadow_rays_needed"]
         return accum, dict(zip(names, list(stats)))
 
     def sample_pixel(self, seed, row, col, sample, start_bounce, last_bounce):

@@ -208,7 +208,10 @@ def test_stats_mode_counts_match_the_oracle(libs):
     assert stats["camera_samples"] == cpu_stats["camera_samples"] == 48 * 48 * 4
     # same estimator, same random stream: ray counts agree up to the rare decision flip
     assert abs(stats["closest_rays"] - cpu_stats["closest_rays"]) <= 0.002 * cpu_stats["closest_rays"]
-    assert abs(stats["shadow_rays"] - cpu_stats["shadow_rays"]) <= 0.002 * cpu_stats["shadow_rays"]
+    # the HIP path skips the occlusion query of a light sample that contributes exactly black either way;
+    # the oracle asks like the reference does and counts the queries that matter separately
+    assert cpu_stats["shadow_rays_needed"] < cpu_stats["shadow_rays"]
+    assert abs(stats["shadow_rays"] - cpu_stats["shadow_rays_needed"]) <= 0.002 * cpu_stats["shadow_rays_needed"]
     # Cornell (36 triangles) takes the all-triangles kernel: no boxes, 36 tests per closest ray
     assert stats["tris_tested"] > 0
     if stats["scene_in_lds"] == 2:
