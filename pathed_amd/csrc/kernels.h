@@ -1153,6 +1153,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(RenderParams p)
 
             Rgb lightTerm = rgb(0.f);
             SHADE_REGION(6, wantDirect);
+            SHADE_REGION(10, isBlack(bsdfSample.throughput));   // the continuation ray cannot contribute
             if (wantDirect) {
                 random.dimension = vertexBase(vertex) + 3;
                 lightTerm = sampleLightsTerm(scene, materials, isect, material, random, &shadow);

@@ -1173,9 +1173,10 @@ int pathed_hip_get_stats(PathedScene *scene, PathedStats *out)
     out->bvh_builder = (uint32_t)scene->bvhBuilder;
     out->trace_launches_all = (uint32_t)scene->traceLaunchesAll;
     if (getenv("PATHED_SHADE_PROFILE")) {   // counters exist in -DPATHED_SHADE_PROFILE builds only
-        static const char *regions[10] = { "all waves", "active slots", "makeIsect (hit)", "camera-ray vertex", "finish previous MIS term",
-                                           "new vertex: BSDF sample", "light sampling", "sample finished", "startSample (regeneration)", "shadow ray pushed" };
-        for (int r = 0; r < 10; r++) {
+        static const char *regions[11] = { "all waves", "active slots", "makeIsect (hit)", "camera-ray vertex", "finish previous MIS term",
+                                           "new vertex: BSDF sample", "light sampling", "sample finished", "startSample (regeneration)", "shadow ray pushed",
+                                           "BSDF sample with black throughput" };
+        for (int r = 0; r < 11; r++) {
             const unsigned long long waves = device[kStatShadeProfile + 2 * r], lanes = device[kStatShadeProfile + 2 * r + 1];
             fprintf(stderr, "[pathed] k_shade region %-28s waves %12llu  (%.3f of all)  lanes per wave %.1f\n", regions[r], waves,
                     device[kStatShadeProfile] ? (double)waves / (double)device[kStatShadeProfile] : 0.0, waves ? (double)lanes / (double)waves : 0.0);
