@@ -1590,8 +1590,10 @@ struct OracleSceneImpl {
 
     /* -- PathTracer::directSampleLights, src/path_tracer.cpp:113-165 ---------- */
 
-    Color directSampleLights(const Intersection &isect, const Material &material, Rng &random, Counters *counters) const
+    Color directSampleLights(const Intersection &isect, const Material &material, Rng &random, Counters *counters,
+                             bool *queryMatters = nullptr) const
     {
+        if (queryMatters) { *queryMatters = false; }
         if (isDelta(material)) { return col(0.f); }
         if (lights.empty()) { return col(0.f); } /* the reference would index an empty vector */
 
@@ -1629,6 +1631,7 @@ struct OracleSceneImpl {
             * fabsf(dot(isect.shadingNormal, wiWorld))
             / pdf;
         if (counters) { counters->shadowRaysNeeded++; }
+        if (queryMatters) { *queryMatters = true; }
 
         if (testOcclusion(isect.point, wiWorld, lightDistance, counters)) { return col(0.f); }
         return contribution;
@@ -1724,12 +1727,20 @@ struct OracleSceneImpl {
             const bool wantContinue = !checkDone(lastBounce, bounce + 1);
 
             Color lightTerm = col(0.f);
+            bool queryMatters = false;
             if (wantDirect) {
                 random.dimension = vertexBase(bounce) + 3;
-                lightTerm = directSampleLights(last, material, random, counters);
+                lightTerm = directSampleLights(last, material, random, counters, &queryMatters);
             }
 
             if (!wantDirect && !wantContinue) { break; }
+
+            /* Shortcut shared with the HIP kernels (deliberate deviation, header): nothing pending at this vertex
+             * and a BSDF sample of exactly black throughput.  The reference traces the continuation ray, finds its
+             * MIS term and the new modulation black, and stops with the same result (only a non-finite emission or
+             * light pdf on that ray could tell the difference). */
+            if (isBlack(bsdfSample.throughput) && bsdfSample.pdf > 0.f && bsdfSample.pdf < 3e38f
+                && !queryMatters && isBlack(lightTerm)) { break; }
 
             const Intersection next = testIntersect(last.point, bsdfSample.wiWorld, counters);
 

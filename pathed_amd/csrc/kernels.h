@@ -1159,7 +1159,13 @@ __global__ __launch_bounds__(kBlock) void k_shade(RenderParams p)
                 lightTerm = sampleLightsTerm(scene, materials, isect, material, random, &shadow);
             }
 
-            if (!wantDirect && !wantContinue) {
+            // A vertex with nothing pending (no light term, no shadow ray) whose BSDF sample has exactly black
+            // throughput ends the sample here: the reference would trace the continuation ray, multiply the
+            // modulation by that black throughput and stop, with the same result (paths that land on a
+            // black-bodied emitter: 10 % of the vertices of the Veach scene).
+            const bool deadEnd = isBlack(bsdfSample.throughput) && bsdfSample.pdf > 0.f && bsdfSample.pdf < 3e38f
+                && !shadow.push && isBlack(lightTerm);
+            if ((!wantDirect && !wantContinue) || deadEnd) {
                 finished = true;
                 Rgb first = rgb(0.f);
                 if (firstEmitMaterial >= 0) { first = first + matEmit(materials[firstEmitMaterial]); }
