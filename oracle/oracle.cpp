@@ -48,6 +48,12 @@
  *   - non-finite samples are dropped (and counted) instead of poisoning the pixel.
  *   - closest-hit ties (equal t) resolve to the lower primitive index so the result
  *     does not depend on BVH shape.
+ *   - two shortcuts shared with the HIP kernels, both value-preserving unless an emission or
+ *     a light pdf is itself non-finite: a light sample whose BSDF value is exactly black (finite,
+ *     positive pdfs) contributes black without its emission being evaluated; a vertex with nothing
+ *     pending whose BSDF sample has exactly black throughput ends the sample without the
+ *     continuation ray.  (The occlusion query of the first case is still made here, as in the
+ *     reference; the kernels skip it.)
  *
  * Build: g++ -std=c++17 -O2 -ffp-contract=off -fopenmp (see oracle/Makefile); the
  * intersection helpers use explicit fmaf so they round like the GPU's v_fma_f32.
