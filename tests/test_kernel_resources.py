@@ -1,0 +1,40 @@
+"""Register budgets the two-pool overlap depends on ("Two slot pools"): three 96-VGPR trace waves and
+two k_shade waves share a SIMD only while k_shade stays at 104 VGPRs or fewer; one register more cost 6-8 % on the
+mesh scenes every time it was tried (profiles/r1s2_ab_*.log).  Compile-only: hipcc reports the usage per kernel."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = "/opt/rocm/bin/hipcc"
+
+
+def test_vgpr_budgets_of_the_hot_kernels(tmp_path):
+    if not os.path.exists(HIPCC) and shutil.which("hipcc") is None:
+        pytest.skip("no hipcc")
+    compiler = HIPCC if os.path.exists(HIPCC) else shutil.which("hipcc")
+    result = subprocess.run(
+        [compiler, "-std=c++17", "-O3", "-fPIC", "-ffp-contract=off", "--offload-arch=gfx950", "-Iinclude",
+         "-Rpass-analysis=kernel-resource-usage", "-c", "pathed_amd/csrc/pathed_hip.hip", "-o", str(tmp_path / "probe.o")],
+        cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert result.returncode == 0, result.stderr[-2000:]
+    usage = {}
+    name = None
+    for line in result.stderr.splitlines():
+        found = re.search(r"Function Name: (\S+)", line)
+        if found:
+            name = found.group(1)
+            usage[name] = {}
+        for key in ("VGPRs", "ScratchSize \\[bytes/lane\\]", "Occupancy \\[waves/SIMD\\]"):
+            value = re.search(key + r": (\d+)", line)
+            if value and name:
+                usage[name][key.split(" ")[0]] = int(value.group(1))
+    shade = [v for k, v in usage.items() if "k_shadeILb1" in k]
+    assert shade and shade[0]["VGPRs"] <= 104 and shade[0]["ScratchSize"] == 0, shade
+    traces = [v for k, v in usage.items() if re.search(r"k_traceILi\d+ELb[01]ELb0", k)]   # the non-counting variants
+    assert len(traces) == 6 and all(v["VGPRs"] <= 96 for v in traces), traces
+    small = [v for k, v in usage.items() if "k_trace_smallILb0" in k]
+    assert small and small[0]["VGPRs"] <= 64 and small[0]["ScratchSize"] == 0, small
