@@ -1,20 +1,30 @@
 #!/usr/bin/env python3
 """Headline benchmark: Msamples/s of the GPU PathTracer on scenes/cornell.json, 1024x1024.
 
-A "step" renders `--spp-per-step` camera samples (default 1024: one internal pass of the library) for every
-pixel through the C ABI (pathed_hip_render_device) into a device-resident radiance-sum buffer; 4 steps are
-the 4096-spp configuration BASELINE.json quotes.  With N ranks each rank renders its own,
-disjoint range of sample indices (weak scaling: per-GPU work is fixed) and the sums are
-reduced to rank 0 over RCCL once, inside the timed region.
+A "step" renders `--spp-per-step` camera samples (default 1024: one internal pass of the library) for
+every pixel through the C ABI (pathed_hip_render_device) into device-resident radiance sums; 4 steps are
+the 4096-spp configuration BASELINE.json quotes.
 
-Prints ONE JSON line on rank 0 (contract in the task statement), including
-  roofline      algorithmic bytes of the BVH-traversal kernel / its HIP-event time
-  cpu_baseline  the CPU oracle (a port of the reference estimator; the reference binary
-                cannot be built) timed on the host cores, bounded sample
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: one process per GPU.  Under torch.distributed.run (WORLD_SIZE in the environment) this process IS
+a rank; started plainly with --gpus N it spawns the N ranks itself, as children of a parent that never
+touches the GPU.  Scaling is STRONG by default (north star: Cornell 1024^2 x 4096 spp split over the
+GPUs): the samples of every step are split over the ranks (pathed_amd/parallel.strong_range), each rank
+adds into its own sums, and ONE RCCL reduce to rank 0 closes the timed region.  --scaling weak fixes the
+per-GPU work instead.
+
+Rank 0 prints ONE JSON line (contract in the task statement) with, besides the headline value:
+  roofline      what bounds the pipeline on this workload, with a denominator measured on this box
+  cpu_baseline  the CPU oracle (a port of the reference estimator; the reference binary cannot be
+                built) timed on the host cores, bounded sample   [N = 1 only]
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -22,6 +32,7 @@ REPO_ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO_ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+STATE_BYTES_PER_VERTEX = 112 + 128   # k_shade's path-state streams: read + written per shaded vertex
 
 
 def parse_args():
@@ -29,6 +40,8 @@ def parse_args():
     parser.add_argument("--gpus", type=int, default=1)
     parser.add_argument("--steps", type=int, default=4)
     parser.add_argument("--warmup", type=int, default=2)
+    parser.add_argument("--scaling", choices=["strong", "weak"], default="strong",
+                        help="strong: the samples of a step are split over the GPUs (total work fixed); weak: every GPU renders a full step")
     parser.add_argument("--spp-per-step", type=int, default=1024)
     parser.add_argument("--width", type=int, default=1024)
     parser.add_argument("--height", type=int, default=1024)
@@ -38,18 +51,96 @@ def parse_args():
     parser.add_argument("--bvh-builder", default="sah", choices=["sah", "lbvh", "ploc"],
                         help="host binned-SAH build (default) or an on-GPU build; only matters for scenes of more than 64 triangles")
     parser.add_argument("--no-cpu-baseline", action="store_true")
+    parser.add_argument("--no-large-bvh", action="store_true",
+                        help="skip the second, BVH-traversal-bound workload (scenes/dragon-standin.json) behind roofline.large_bvh")
+    parser.add_argument("--large-bvh-subdiv", type=int, default=9, help="icosphere subdivisions of the stand-in mesh: 9 = 5.2 M triangles")
     parser.add_argument("--time-every-launch", action="store_true",
                         help="HIP events around every trace / shade launch instead of every 8th")
     parser.add_argument("--no-kernel-timing", action="store_true",
-                        help="skip the HIP-event timing of every trace launch (roofline.achieved becomes null)")
+                        help="no HIP-event timing of kernel launches (the roofline block becomes null)")
     return parser.parse_args()
 
+
+# --------------------------------------------------------------------------- launcher (no GPU call)
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as child processes.  The parent makes
+    no HIP call (counting devices does not initialise the GPU on this image) and never re-executes itself."""
+    import torch
+    visible = torch.cuda.device_count()
+    if visible < args.gpus:
+        raise SystemExit("bench.py --gpus %d: this machine shows %d GPU(s)" % (args.gpus, visible))
+    with socket.socket() as probe:
+        probe.bind(("127.0.0.1", 0))
+        port = probe.getsockname()[1]
+    children = []
+    for rank in range(args.gpus):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        children.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    code = 0
+    try:
+        pending = list(children)
+        while pending:
+            for child in list(pending):
+                status = child.poll()
+                if status is None:
+                    continue
+                pending.remove(child)
+                if status != 0:
+                    code = code or status
+                    for other in pending:   # a rank died: the others would wait in a collective forever
+                        other.terminate()
+            time.sleep(0.05)
+    finally:
+        for child in children:
+            if child.poll() is None:
+                child.kill()
+    return code
+
+
+# --------------------------------------------------------------------------- measurement helpers
 
 def algorithmic_bytes(stats):
     """per ray 32 B of ray + S_hit (16 closest / 4 any-hit) + 32 B per child box
     tested + 48 B per leaf triangle tested."""
     return (48 * stats["closest_rays"] + 36 * stats["shadow_rays"]
             + 32 * stats["nodes_visited"] + 48 * stats["tris_tested"])
+
+
+def kernel_sources_digest():
+    """Identifies the kernel sources a committed PMC summary was collected on."""
+    digest = hashlib.sha1()
+    directory = os.path.join(REPO_ROOT, "pathed_amd", "csrc")
+    for name in sorted(os.listdir(directory)):
+        with open(os.path.join(directory, name), "rb") as handle:
+            digest.update(handle.read())
+    return digest.hexdigest()[:16]
+
+
+def pmc_per_sample(workload):
+    """Per-camera-sample counter totals of a workload from the committed rocprofv3 --pmc passes
+    (tools/pmc_per_sample.sh -> profiles/pmc_per_sample.json); None when there is no such pass."""
+    path = os.path.join(REPO_ROOT, "profiles", "pmc_per_sample.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as handle:
+        entry = json.load(handle).get(workload)
+    if entry is not None:
+        entry = dict(entry, stale=(entry.get("kernel_sources") != kernel_sources_digest()))
+    return entry
+
+
+def scene_description(scene, stats):
+    """What the workload is, read off the loaded scene (not a hard-coded string)."""
+    desc = scene.desc.contents
+    kinds = ["Lambertian", "Oren-Nayar", "Microfacet", "Plastic", "Glass", "Mirror"]
+    used = sorted({desc.materials[i].type for i in range(desc.n_materials)})
+    lights = "environment light" if bool(desc.env) else "area lights"
+    intersector = ["4-wide BVH in HBM", "4-wide BVH staged in LDS", "all-triangles kernel (<= 64 triangles)"][stats["scene_in_lds"]]
+    return "%d triangles, %d spheres, materials {%s}, %s; %s" % (
+        desc.n_triangles, desc.n_spheres, ", ".join(kinds[k] for k in used), lights, intersector)
 
 
 def cpu_baseline(scene, args):
@@ -77,9 +168,98 @@ def cpu_baseline(scene, args):
     }
 
 
-def main():
-    args = parse_args()
+def kernel_rates(counted, counted_samples, timed, timed_samples):
+    """Per-kernel algorithmic rates of a timed region.  `counted`: statistics of a counting pass over
+    counted_samples camera samples (exact ray / box / triangle counts; never part of a timed region);
+    `timed`: statistics of the timed region (HIP-event time of the sampled launches, launch counts)."""
+    if not timed["trace_launches"] or timed["trace_ms"] <= 0:
+        return None
+    scale = timed_samples / float(counted_samples)
+    launches = timed["trace_launches_all"]
+    trace_avg_ms = timed["trace_ms"] / timed["trace_launches"]
+    shade_avg_ms = timed["shade_ms"] / timed["trace_launches"]
+    trace_bytes = algorithmic_bytes(counted) * scale / launches
+    # every closest-hit result is one slot visit of k_shade: state in (112 B), state out (128 B)
+    shade_bytes = STATE_BYTES_PER_VERTEX * counted["closest_rays"] * scale / launches
+    return {
+        "launches": launches,
+        "timed_launches": timed["trace_launches"],
+        "trace": {"algorithmic_bytes_per_launch": trace_bytes, "avg_launch_us": trace_avg_ms * 1e3,
+                  "achieved": trace_bytes / (trace_avg_ms * 1e-3) / 1e9, "frac": trace_bytes / (trace_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+        "shade": {"algorithmic_bytes_per_launch": shade_bytes, "avg_launch_us": shade_avg_ms * 1e3,
+                  "achieved": shade_bytes / (shade_avg_ms * 1e-3) / 1e9, "frac": shade_bytes / (shade_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+        "rays_per_sample": (counted["closest_rays"] + counted["shadow_rays"]) / float(counted_samples),
+        "vertices_per_sample": counted["closest_rays"] / float(counted_samples),
+        "algorithmic_bytes_per_sample": {"trace": algorithmic_bytes(counted) / float(counted_samples),
+                                         "shade": STATE_BYTES_PER_VERTEX * counted["closest_rays"] / float(counted_samples)},
+    }
 
+
+def large_bvh_leg(args, torch, stream):
+    """The workload the north-star roofline target is about: BVH traversal over a tree that does not fit the
+    256 MB Infinity Cache (scenes/dragon-standin.json, procedural mesh, 1920x1080), timed in this very run."""
+    from pathed_amd.integrator import HipScene
+    from pathed_amd.scene import LoadedScene
+
+    mesh = os.path.join(REPO_ROOT, "assets", "dragon-standin.ply")
+    wanted = 20 * 4 ** args.large_bvh_subdiv
+    have = 0
+    if os.path.exists(mesh):
+        with open(mesh, "rb") as handle:
+            for line in handle.read(400).split(b"\n"):
+                if line.startswith(b"element face"):
+                    have = int(line.split()[2])
+    if have != wanted:   # generated on the box: the 100 MB file does not travel with the snapshot
+        subprocess.run([sys.executable, os.path.join(REPO_ROOT, "tools", "make_assets.py"), "--dragon", str(args.large_bvh_subdiv)],
+                       check=True, stdout=subprocess.DEVNULL)
+    width, height = 1920, 1080
+    count_spp, warm_spp, timed_spp = 16, 32, 256
+    t0 = time.perf_counter()
+    scene = LoadedScene("scenes/dragon-standin.json", width, height)
+    gpu = HipScene(scene.desc, device=torch.cuda.current_device(), bvh_builder=args.bvh_builder)
+    setup_s = time.perf_counter() - t0
+    accum = torch.zeros((height, width, 3), dtype=torch.float32, device="cuda")
+    gpu.render_device(args.seed, 0, warm_spp, 0, args.last_bounce, accum.data_ptr(), stream)
+    gpu.set_stats_mode(count=True)
+    gpu.reset_stats()
+    gpu.render_device(args.seed, 1000, count_spp, 0, args.last_bounce, accum.data_ptr(), stream)
+    torch.cuda.synchronize()
+    counted = gpu.stats()
+    gpu.set_stats_mode(count=False, time_sampled=True)
+    gpu.reset_stats()
+    accum.zero_()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    gpu.render_device(args.seed, 2000, timed_spp, 0, args.last_bounce, accum.data_ptr(), stream)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    timed = gpu.stats()
+    rates = kernel_rates(counted, width * height * count_spp, timed, width * height * timed_spp)
+    pmc = pmc_per_sample("large_bvh")
+    traffic = None
+    if pmc and rates:
+        traffic = {name: pmc["hbm_bytes_per_sample"][name] * width * height * timed_spp / rates["launches"]
+                   for name in ("trace", "shade") if name in pmc.get("hbm_bytes_per_sample", {})}
+    result = {
+        "workload": "scenes/dragon-standin.json %dx%d, %d spp timed (%d spp counted), bounces 0..%d; %s" % (
+            width, height, timed_spp, count_spp, args.last_bounce, scene_description(scene, timed)),
+        "bvh_bytes": timed["bvh_bytes"], "bvh_builder": args.bvh_builder, "bvh_build_ms": timed["bvh_build_ms"],
+        "setup_s": setup_s, "msamples_per_s": width * height * timed_spp / elapsed / 1e6,
+        "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "k_trace": rates["trace"] if rates else None,
+        "k_shade": rates["shade"] if rates else None,
+        "rays_per_sample": rates["rays_per_sample"] if rates else None,
+        "traffic": traffic,
+        "traffic_source": None if not pmc else {"file": "profiles/pmc_per_sample.json", "stale": pmc["stale"]},
+        "image_mean_rgb": (accum / float(timed_spp)).mean(dim=(0, 1)).tolist(),
+    }
+    gpu.close()
+    return result
+
+
+# --------------------------------------------------------------------------- one rank
+
+def run_rank(args):
     import torch
     import torch.distributed as dist
 
@@ -93,8 +273,10 @@ def main():
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        world_size = dist.get_world_size()   # the ranks RCCL actually sees
 
-    from pathed_amd.integrator import HipScene
+    from pathed_amd import parallel
+    from pathed_amd.integrator import HipScene, measure_bandwidth, measure_valu
     from pathed_amd.scene import LoadedScene
 
     scene = LoadedScene(args.scene, args.width, args.height)
@@ -103,21 +285,34 @@ def main():
 
     accum = torch.zeros((args.height, args.width, 3), dtype=torch.float32, device="cuda")
     spp = args.spp_per_step
-    # rank r owns sample indices [r * (W+K) * spp, (r+1) * (W+K) * spp): disjoint streams
-    base = rank * (args.warmup + args.steps) * spp
+    strong = args.scaling == "strong"
+
+    def step_range(index):
+        """Sample indices this rank renders in step `index` (warm-up steps first)."""
+        if strong:   # the step's samples [index * spp, (index + 1) * spp) split over the ranks
+            return parallel.strong_range(rank, world_size, index * spp, spp)
+        # weak: every rank renders spp samples of its own, disjoint stream
+        return parallel.weak_range(rank, (args.warmup + args.steps) * spp, first=index * spp)[0], spp
 
     def step(index):
-        gpu.render_device(args.seed, base + index * spp, spp, 0, args.last_bounce, accum.data_ptr(), stream)
+        begin, count = step_range(index)
+        if count > 0:
+            gpu.render_device(args.seed, begin, count, 0, args.last_bounce, accum.data_ptr(), stream)
 
-    # one untimed, counting pass over the first step's samples: exact ray / box / triangle counts
-    per_step_stats = None
-    if rank == 0:
+    # one untimed, counting pass over the first timed step's samples: exact ray / box / triangle counts
+    counted = None
+    counted_samples = 0
+    timing = not args.no_kernel_timing
+    if rank == 0 and timing:   # (a PMC run passes --no-kernel-timing: nothing but the timed path's kernels then)
         gpu.set_stats_mode(count=True)
         gpu.reset_stats()
         scratch = torch.zeros_like(accum)
-        gpu.render_device(args.seed, base + args.warmup * spp, spp, 0, args.last_bounce, scratch.data_ptr(), stream)
+        begin, count = step_range(args.warmup)
+        count = max(count, 1)
+        gpu.render_device(args.seed, begin, count, 0, args.last_bounce, scratch.data_ptr(), stream)
         torch.cuda.synchronize()
-        per_step_stats = gpu.stats()
+        counted = gpu.stats()
+        counted_samples = args.width * args.height * count
         del scratch
     gpu.set_stats_mode(count=False)
 
@@ -127,8 +322,8 @@ def main():
 
     # HIP-event pairs around every 8th launch of each pool: timing every launch keeps a pool's kernels from
     # running back to back and costs ~6 % of the rate (--time-every-launch restores it)
-    gpu.set_stats_mode(count=False, time_kernels=(not args.no_kernel_timing) and args.time_every_launch,
-                       time_sampled=(not args.no_kernel_timing) and not args.time_every_launch)
+    gpu.set_stats_mode(count=False, time_kernels=timing and args.time_every_launch,
+                       time_sampled=timing and not args.time_every_launch)
     gpu.reset_stats()
 
     torch.cuda.synchronize()
@@ -138,117 +333,97 @@ def main():
     t0 = time.perf_counter()
     for index in range(args.steps):
         step(args.warmup + index)
+    torch.cuda.synchronize()
+    rendered = time.perf_counter() - t0
     if distributed:
         # the path's one exchange step: per-GPU radiance sums -> rank 0 (RCCL reduce over xGMI)
         dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
     torch.cuda.synchronize()
+    reduced = time.perf_counter() - t0
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
 
+    per_rank = [[rendered, reduced - rendered, elapsed]]
     if distributed:
-        slowest = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(slowest, op=dist.ReduceOp.MAX)
-        elapsed = float(slowest.item())
+        mine = torch.tensor(per_rank[0], dtype=torch.float64, device="cuda")
+        gathered = [torch.zeros_like(mine) for _ in range(world_size)]
+        dist.all_gather(gathered, mine)
+        per_rank = [g.tolist() for g in gathered]
+        elapsed = max(row[2] for row in per_rank)   # MAX over ranks
 
-    timed_stats = gpu.stats()
+    timed = gpu.stats()
 
     if rank == 0:
-        samples_per_rank = args.width * args.height * spp * args.steps
-        total_samples = samples_per_rank * world_size
+        pixels = args.width * args.height
+        total_spp = spp * args.steps * (1 if strong else world_size)
+        total_samples = pixels * total_spp
         value = total_samples / elapsed / 1e6
+        my_samples = pixels * sum(step_range(args.warmup + index)[1] for index in range(args.steps))
 
         roofline = None
-        if per_step_stats is not None:
-            bytes_per_step = algorithmic_bytes(per_step_stats)
-            timed_launches = timed_stats["trace_launches"]          # launches bracketed by HIP events
-            launches = timed_stats["trace_launches_all"]            # all trace launches of the timed region
-            trace_ms = timed_stats["trace_ms"]
-            total_bytes = bytes_per_step * args.steps
-            # bytes per launch / average duration of the timed launches
-            achieved = ((total_bytes / launches) / (trace_ms / timed_launches * 1e-3) / 1e9) if trace_ms > 0 and launches else None
-            traffic = None
-            # PMC passes exist for two workloads (tools/profile_bench.sh): the default one and the large-BVH scene
-            traffic_files = {("scenes/cornell.json", 2): "hbm_traffic.json", ("scenes/dragon-standin.json", 0): "r1s2dragon_hbm_traffic.json"}
-            traffic_name = traffic_files.get((args.scene, per_step_stats["scene_in_lds"]))
-            if traffic_name and os.path.exists(os.path.join(REPO_ROOT, "profiles", traffic_name)):
-                with open(os.path.join(REPO_ROOT, "profiles", traffic_name)) as handle:
-                    traffic = json.load(handle).get("trace_hbm_bytes_per_launch")
-            # what a plain streaming kernel reaches on this box: the second denominator
-            from pathed_amd.integrator import measure_bandwidth
+        if timing and counted is not None:
+            rates = kernel_rates(counted, counted_samples, timed, my_samples)
             measured_read, measured_copy = measure_bandwidth(gib=2.0, repeats=10)
-            # Secondary bound for the all-triangles scenes ("FP32 VALU issue rate"):
-            # wave instructions per launch from the committed PMC pass of this very workload
-            # (profiles/r1s2_pmc_cornell.json, SQ_INSTS_VALU), launches and time measured live.
-            # A wave64 VALU instruction occupies its SIMD for 4 cycles; 4 SIMDs per CU.
-            valu = None
-            pmc_path = os.path.join(REPO_ROOT, "profiles", "r1s2_pmc_cornell.json")
-            if os.path.exists(pmc_path) and per_step_stats["scene_in_lds"] == 2 and args.scene == "scenes/cornell.json" \
-                    and (args.width, args.height) == (1024, 1024) and spp >= 256:
-                with open(pmc_path) as handle:
-                    pmc = json.load(handle)["kernels"]
-                trace_instructions = pmc["void pathed::k_trace_small<false>"]["SQ_INSTS_VALU"]
-                shade_instructions = pmc["void pathed::k_shade<true>"]["SQ_INSTS_VALU"]
-                simds = 4 * torch.cuda.get_device_properties(local_rank).multi_processor_count
-                clock_hz = 2.4e9  # MI355X peak engine clock, /opt/skills/guides/MI355X_MICROARCH.md
-                issued = launches * (trace_instructions + shade_instructions)
-                valu = {
-                    "bound": "valu issue",
-                    "wave_instructions_per_launch": {"k_trace_small": trace_instructions, "k_shade": shade_instructions},
-                    "achieved": issued / elapsed / 1e9, "peak": simds * clock_hz / 4 / 1e9, "unit": "G wave-instructions/s",
-                    "frac": issued * 4 / (simds * clock_hz * elapsed),
-                    "note": "whole pipeline (both kernels, both pools) over the timed region; per-launch counts from the PMC pass at 256 spp per call (profiles/r1s2_pmc_cornell.json)",
+            workload_key = "cornell_1024" if (args.scene, args.width, args.height) == ("scenes/cornell.json", 1024, 1024) else None
+            pmc = pmc_per_sample(workload_key) if workload_key else None
+            traffic = None
+            if pmc and rates and "hbm_bytes_per_sample" in pmc:
+                traffic = sum(pmc["hbm_bytes_per_sample"].values()) * my_samples / rates["launches"]
+            hbm = None
+            if rates:
+                # the kernel that takes the larger share of the timed region is the dominant one
+                dominant = "shade" if timed["shade_ms"] >= timed["trace_ms"] else "trace"
+                hbm = {
+                    "dominant_kernel": {"shade": "k_shade (path-state streams, 112 B read + 128 B written per shaded vertex)",
+                                        "trace": "k_trace (BVH traversal + triangle/sphere intersect)"}[dominant],
+                    "k_shade": rates["shade"], "k_trace": rates["trace"] if counted["scene_in_lds"] == 0 else None,
+                    "peak_measured": {"stream_read": measured_read, "stream_copy": measured_copy, "unit": "GB/s",
+                                      "note": "2 GiB probe, 16 B per lane, HIP events (pathed_hip_measure_bandwidth)"},
+                    "k_shade_frac_of_measured_copy": rates["shade"]["achieved"] / measured_copy,
+                    "trace_ms_timed": timed["trace_ms"], "shade_ms_timed": timed["shade_ms"],
+                    "rays_per_sample": rates["rays_per_sample"], "vertices_per_sample": rates["vertices_per_sample"],
                 }
-            # k_shade is bound by its state streams: HBM bytes per launch from the same PMC passes,
-            # launch duration live, against the read-plus-write rate the bandwidth probe reaches on this box
-            shade_streams = None
-            shade_launches = timed_stats["trace_launches"]   # one k_shade per timed k_trace launch
-            if traffic_name and shade_launches and timed_stats["shade_ms"] > 0:
-                with open(os.path.join(REPO_ROOT, "profiles", traffic_name)) as handle:
-                    kernels = json.load(handle).get("kernels", {})
-                shade_entry = next((v for k, v in kernels.items() if "k_shade" in k), None)
-                if shade_entry and "FETCH_SIZE_KiB_avg" in shade_entry and "WRITE_SIZE_KiB_avg" in shade_entry:
-                    shade_bytes = (2.0 * shade_entry["FETCH_SIZE_KiB_avg"] + shade_entry["WRITE_SIZE_KiB_avg"]) * 1024.0
-                    shade_avg_ms = timed_stats["shade_ms"] / shade_launches
-                    shade_rate = shade_bytes / (shade_avg_ms * 1e-3) / 1e9
-                    shade_streams = {
-                        "kernel": "k_shade (path state streams: read 8 x 16 B, write 6 x 16 B per slot)",
-                        "hbm_bytes_per_launch": shade_bytes, "avg_launch_ms": shade_avg_ms, "achieved": shade_rate, "unit": "GB/s",
-                        "frac_of_measured_copy": shade_rate / measured_copy,
-                        "note": "while sharing the chip with the other pool's trace kernel; alone it reaches 3.6 TB/s",
-                    }
-            roofline = {
-                "bound": "hbm",
-                "kernel": "k_trace (BVH traversal + triangle/sphere intersect, closest + any-hit)",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
-                "peak_measured": {"stream_read": measured_read, "stream_copy": measured_copy, "unit": "GB/s",
-                                  "note": "2 GiB probe, 16 B per lane, HIP events (pathed_hip_measure_bandwidth)"},
-                "frac_of_measured_read": (achieved / measured_read) if achieved else None,
-                "traffic": traffic,
-                "algorithmic_bytes_per_launch": (total_bytes / launches) if launches else None,
-                "algorithmic_bytes_per_sample": bytes_per_step / (args.width * args.height * spp),
-                "avg_launch_ms": (trace_ms / timed_launches) if timed_launches else None,
-                "launches": launches,
-                "timed_launches": timed_launches,
-                "rays_per_sample": (per_step_stats["closest_rays"] + per_step_stats["shadow_rays"])
-                / (args.width * args.height * spp),
-                "bvh_resident": ["HBM", "LDS", "none (<= 64 triangles: every ray tests all, scalar loads)"][per_step_stats["scene_in_lds"]],
-                "trace_ms_timed": trace_ms,
-                "shade_ms_timed": timed_stats["shade_ms"],
-                "valu": valu,
-                "shade_streams": shade_streams,
-            }
+            if counted["scene_in_lds"] == 2:
+                # All-triangles scenes (<= 64 triangles: every ray query runs out of registers and scalar loads):
+                # neither HBM nor MFMA bounds the pipeline, VALU issue does.  Denominator: what independent
+                # v_fma_f32 streams reach on THIS box at the pipeline's occupancy (pathed_hip_measure_valu);
+                # numerator: SQ_INSTS_VALU per camera sample from the committed PMC pass x samples / s live.
+                fma4, mixed4 = measure_valu(waves_per_simd=4, repeats=10)
+                fma1, _ = measure_valu(waves_per_simd=1, repeats=10)
+                issued = pmc["valu_wave_instructions_per_sample"] * total_samples / world_size if pmc else None
+                roofline = {
+                    "bound": "valu",
+                    "kernel": "whole pipeline (k_trace_small + k_shade, both pools): all-triangles scene, ray queries never leave the registers",
+                    "achieved": (issued / elapsed / 1e9) if issued else None,
+                    "peak": fma4 / 1e9,
+                    "unit": "G wave-instr/s",
+                    "frac": (issued / elapsed / fma4) if issued else None,
+                    "traffic": traffic,
+                    "peak_note": "v_fma_f32 wave-instructions/s measured on this box at 4 waves/SIMD, independent chains "
+                                 "(1 wave/SIMD: %.0f G/s; with a v_rcp/v_sqrt pair per 6 fma: %.0f G/s)" % (fma1 / 1e9, mixed4 / 1e9),
+                    "instructions_source": None if not pmc else {
+                        "file": "profiles/pmc_per_sample.json", "valu_wave_instructions_per_sample": pmc["valu_wave_instructions_per_sample"],
+                        "stale": pmc["stale"]},
+                    "hbm": hbm,
+                }
+            elif rates:
+                dominant = "shade" if timed["shade_ms"] >= timed["trace_ms"] else "trace"
+                roofline = {
+                    "bound": "hbm", "kernel": hbm["dominant_kernel"],
+                    "achieved": rates[dominant]["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": rates[dominant]["frac"],
+                    "traffic": traffic, "hbm": hbm,
+                }
+            if roofline is not None and world_size == 1 and not args.no_large_bvh and args.scene == "scenes/cornell.json":
+                roofline["large_bvh"] = large_bvh_leg(args, torch, stream)
 
         baseline = None
         # the CPU oracle is timed on rank 0 of the single-GPU run only
         if not args.no_cpu_baseline and world_size == 1:
             baseline = cpu_baseline(scene, args)
 
-        mean = (accum / float(spp * args.steps * world_size)).mean(dim=(0, 1)).tolist()
+        mean = (accum / float(total_spp)).mean(dim=(0, 1)).tolist()
         line = {
             "metric": "Msamples/s (pixels x spp / s), PathTracer radiance loop",
             "value": value,
@@ -258,28 +433,40 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic camera samples on scenes/cornell.json (the reference's own scene file)",
+            "data": "synthetic camera samples (counter-based random stream, seed %d) on %s, the reference's own scene file: %s" % (
+                args.seed, args.scene, scene_description(scene, timed)),
             "config": {
-                "workload": "%s %dx%d, %d spp per step x %d steps per GPU (the 4096-spp configuration = 4 steps of 1024), "
-                            "Lambertian, bounces 0..%d, seed %d" % (
-                                args.scene, args.width, args.height, spp, args.steps, args.last_bounce, args.seed),
+                "workload": "%s %dx%d, %d spp per step x %d steps = %d spp%s, bounces 0..%d, seed %d" % (
+                    args.scene, args.width, args.height, spp, args.steps, total_spp,
+                    " (the 4096-spp configuration = 4 steps of 1024)" if (spp, args.steps) == (1024, 4) and strong else "",
+                    args.last_bounce, args.seed),
                 "spp_per_step": spp,
-                "samples_per_gpu": samples_per_rank,
-                "parallelism": "spp sharded over %d GPU(s), one RCCL reduce of 3*W*H fp32" % world_size,
+                "total_samples": total_samples,
+                "parallelism": ("the samples of every step split over %d GPU(s)" if strong else "a full step on each of %d GPU(s)") % world_size
+                               + ", one RCCL reduce of 3*W*H fp32 sums to rank 0 inside the timed region",
             },
+            "per_rank_s": {"render": [row[0] for row in per_rank], "reduce": [row[1] for row in per_rank], "total": [row[2] for row in per_rank]},
             "roofline": roofline,
             "cpu_baseline": baseline,
             "image_mean_rgb": mean,
-            "dropped_samples": timed_stats["dropped_samples"],
+            "dropped_samples": timed["dropped_samples"],
         }
         print(json.dumps(line), flush=True)
 
     if distributed:
         dist.destroy_process_group()
+    return 0
+
+
+def main():
+    args = parse_args()
+    if "WORLD_SIZE" in os.environ or args.gpus <= 1:
+        return run_rank(args)      # a rank of torch.distributed.run / of our own launcher, or the single-GPU run
+    return launch_ranks(args)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -34,6 +34,9 @@ extern "C" {
 #endif
 
 #define PATHED_ABI_VERSION 2   /* 2: image-texture albedo (PathedTexture, PathedMaterial.texture) */
+/* Additions that leave PathedSceneDesc unchanged (no version bump): PathedSceneOptions /
+ * pathed_hip_scene_create_ex (per-scene device and tuning), pathed_hip_measure_valu,
+ * pathed_hip_accum_add / pathed_hip_accum_copy_peer (multi-GPU fan-in of the radiance sums). */
 
 /* error codes */
 #define PATHED_OK            0
@@ -221,6 +224,32 @@ int pathed_hip_set_bvh_builder(int builder);
 int pathed_hip_scene_create(const PathedSceneDesc *desc, PathedScene **out);
 void pathed_hip_scene_destroy(PathedScene *scene);
 
+/* Per-scene options.  Zero-initialise, set struct_size = sizeof(PathedSceneOptions), then set only
+ * what you need: every field's "automatic" value is 0 except where stated, so a zeroed struct
+ * means "all defaults" -- EXCEPT `device`, where 0 is device 0; use PATHED_DEVICE_CURRENT (-1) for
+ * the device of pathed_hip_init.  The device is part of the scene: every call that takes the
+ * PathedScene selects it first (hipSetDevice is per host thread), so a host may drive several
+ * scenes on several GPUs from one thread per GPU (reference app/main.cpp:93-98 runs the
+ * integrator on its own std::thread).  The PATHED_* environment variables remain as overrides
+ * for tuning experiments; tests and hosts use this struct. */
+#define PATHED_DEVICE_CURRENT (-1)
+typedef struct PathedSceneOptions {
+    uint32_t struct_size;       /* sizeof(PathedSceneOptions)                                  */
+    int32_t device;             /* HIP device id, or PATHED_DEVICE_CURRENT                     */
+    int32_t bvh_builder;        /* PATHED_BVH_* + 1 (0 = the process default of set_bvh_builder) */
+    int32_t stack_rows;         /* LDS rows of the traversal stack: 8, 16 or 22 (0 = by tree depth); deeper entries spill to HBM */
+    int32_t pools;              /* independent slot pools, 1..4 (0 = 2)                        */
+    int32_t suspend_lanes;      /* park a trace wave's tail below this many rays, 1..64; -1 = never (0 = 32) */
+    int32_t suspend_patience;   /* ... after this many steps without a new card, >= 1; -1 = none (0 = 24)     */
+    int32_t park_min_cards;     /* ... while the pool has this many cards per wave, >= 1; -1 = always (0 = 1)  */
+    int32_t max_slots;          /* path slots (0 = 1 Mi for all-triangles scenes, 4 Mi for BVH scenes)         */
+    int32_t intersector;        /* 0 automatic, 1 always walk the BVH (never the all-triangles kernel)         */
+    int32_t trace_blocks_per_cu;/* persistent trace blocks per CU (0 = automatic)              */
+    int32_t reserved[5];        /* must be 0                                                   */
+} PathedSceneOptions;
+int pathed_hip_scene_create_ex(const PathedSceneDesc *desc, const PathedSceneOptions *options, PathedScene **out);
+int pathed_hip_scene_device(const PathedScene *scene);   /* the HIP device the scene lives on, or a negative error */
+
 /* ---- the hot path -------------------------------------------------------- */
 
 /* Render camera samples [spp_begin, spp_begin+spp_count) of every pixel and ADD
@@ -289,6 +318,31 @@ int pathed_hip_scene_export_bvh(PathedScene *scene,
  * read kernel and of a copy kernel with HIP events.  read_gbs = bytes read / s; copy_gbs counts
  * bytes read + bytes written. */
 int pathed_hip_measure_bandwidth(size_t bytes, int repeats, double *read_gbs, double *copy_gbs);
+
+/* Measurement aid: the VALU issue rate THIS device sustains, in wave-instructions per second, as the
+ * denominator of the "VALU issue" bound quoted for the scenes whose ray queries never leave the
+ * registers (<= 64 triangles).  Runs `waves_per_simd` waves (1..8) on every SIMD of the chip, each
+ * issuing `instructions_per_wave` INDEPENDENT v_fma_f32 (eight accumulator chains per lane, so no
+ * wave ever waits on its own result), timed with HIP events over `repeats` launches.
+ * fma_rate = v_fma_f32 wave-instructions / s; mixed_rate = the same with one v_rcp_f32 / v_sqrt_f32
+ * pair per six v_fma_f32 (the quarter-rate instructions a path tracer's normalisations issue). */
+int pathed_hip_measure_valu(int waves_per_simd, int repeats, double *fma_rate, double *mixed_rate);
+
+/* ---- multi-GPU fan-in ------------------------------------------------------ */
+/* The path's one exchange step: per-GPU radiance sums -> one buffer (the reference's
+ * waves are additive, src/integrator.cpp:42-51).  A host that drives several scenes in one process
+ * (one worker thread per GPU) uses these two instead of RCCL:
+ *   pathed_hip_accum_copy_peer  copies `count` floats from src (on src_scene's device) into dst (on
+ *                               dst_scene's device) over xGMI (hipMemcpyPeer); blocking.
+ *   pathed_hip_accum_add        dst[i] += src[i] on dst_scene's device; blocking. */
+int pathed_hip_accum_copy_peer(PathedScene *dst_scene, float *dst, PathedScene *src_scene, const float *src, size_t count);
+int pathed_hip_accum_add(PathedScene *dst_scene, float *dst, const float *src, size_t count);
+/* Device memory for such buffers, on the scene's device (hipMalloc / hipFree / hipMemcpy wrappers so a
+ * plain C++ host needs no HIP headers). */
+int pathed_hip_accum_alloc(PathedScene *scene, size_t count, float **out);   /* zero-filled */
+int pathed_hip_accum_free(PathedScene *scene, float *buffer);
+int pathed_hip_accum_download(PathedScene *scene, const float *buffer, size_t count, float *host);
+int pathed_hip_accum_upload(PathedScene *scene, float *buffer, size_t count, const float *host);
 
 const char *pathed_hip_last_error(void);
 const char *pathed_hip_version(void);

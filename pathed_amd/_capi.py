@@ -126,11 +126,32 @@ class PathedStats(C.Structure):
     ]
 
 
+class PathedSceneOptions(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("device", C.c_int32),
+        ("bvh_builder", C.c_int32),
+        ("stack_rows", C.c_int32),
+        ("pools", C.c_int32),
+        ("suspend_lanes", C.c_int32),
+        ("suspend_patience", C.c_int32),
+        ("park_min_cards", C.c_int32),
+        ("max_slots", C.c_int32),
+        ("intersector", C.c_int32),
+        ("trace_blocks_per_cu", C.c_int32),
+        ("reserved", C.c_int32 * 5),
+    ]
+
+
+DEVICE_CURRENT = -1
+
 # every symbol include/pathed_hip.h declares; tests check that the library exports all
 HIP_SYMBOLS = [
     "pathed_hip_init",
     "pathed_hip_set_bvh_builder",
     "pathed_hip_scene_create",
+    "pathed_hip_scene_create_ex",
+    "pathed_hip_scene_device",
     "pathed_hip_scene_destroy",
     "pathed_hip_render",
     "pathed_hip_render_device",
@@ -141,6 +162,13 @@ HIP_SYMBOLS = [
     "pathed_hip_reset_stats",
     "pathed_hip_scene_export_bvh",
     "pathed_hip_measure_bandwidth",
+    "pathed_hip_measure_valu",
+    "pathed_hip_accum_copy_peer",
+    "pathed_hip_accum_add",
+    "pathed_hip_accum_alloc",
+    "pathed_hip_accum_free",
+    "pathed_hip_accum_download",
+    "pathed_hip_accum_upload",
     "pathed_hip_last_error",
     "pathed_hip_version",
 ]
@@ -180,6 +208,25 @@ def load_hip():
     lib.pathed_hip_set_bvh_builder.restype = C.c_int
     lib.pathed_hip_scene_create.argtypes = [C.POINTER(PathedSceneDesc), C.POINTER(vp)]
     lib.pathed_hip_scene_create.restype = C.c_int
+    lib.pathed_hip_scene_create_ex.argtypes = [C.POINTER(PathedSceneDesc), C.POINTER(PathedSceneOptions), C.POINTER(vp)]
+    lib.pathed_hip_scene_create_ex.restype = C.c_int
+    lib.pathed_hip_scene_device.argtypes = [vp]
+    lib.pathed_hip_scene_device.restype = C.c_int
+    lib.pathed_hip_measure_valu.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    lib.pathed_hip_measure_valu.restype = C.c_int
+    fp = C.POINTER(C.c_float)
+    lib.pathed_hip_accum_copy_peer.argtypes = [vp, vp, vp, vp, C.c_size_t]
+    lib.pathed_hip_accum_copy_peer.restype = C.c_int
+    lib.pathed_hip_accum_add.argtypes = [vp, vp, vp, C.c_size_t]
+    lib.pathed_hip_accum_add.restype = C.c_int
+    lib.pathed_hip_accum_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
+    lib.pathed_hip_accum_alloc.restype = C.c_int
+    lib.pathed_hip_accum_free.argtypes = [vp, vp]
+    lib.pathed_hip_accum_free.restype = C.c_int
+    lib.pathed_hip_accum_download.argtypes = [vp, vp, C.c_size_t, fp]
+    lib.pathed_hip_accum_download.restype = C.c_int
+    lib.pathed_hip_accum_upload.argtypes = [vp, vp, C.c_size_t, fp]
+    lib.pathed_hip_accum_upload.restype = C.c_int
     lib.pathed_hip_scene_destroy.argtypes = [vp]
     lib.pathed_hip_scene_destroy.restype = None
     lib.pathed_hip_render.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.POINTER(C.c_float)]

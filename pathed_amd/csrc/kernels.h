@@ -1331,4 +1331,45 @@ __global__ __launch_bounds__(kBlock) void k_stream_copy(const float4 *source, fl
     for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < count; i += stride) { target[i] = source[i]; }
 }
 
+// ------------------------------------------------------------------------- VALU issue-rate probe
+// Denominator of the "VALU issue" bound (pathed_hip_measure_valu).  Every lane keeps eight
+// independent accumulator chains, so consecutive v_fma_f32 never wait for each other; inline asm
+// keeps the compiler from folding or vectorising them.  MIXED adds one v_rcp_f32 + v_sqrt_f32 pair per
+// six v_fma_f32 (a path tracer's normalisations; those two issue at a quarter of the FMA rate).
+static const int kValuProbeUnroll = 48;   // VALU instructions per loop iteration
+template <bool MIXED>
+__global__ __launch_bounds__(kBlock) void k_valu_probe(int iterations, float seed, float *sink)
+{
+    float a0 = seed + threadIdx.x, a1 = a0 + 1.f, a2 = a0 + 2.f, a3 = a0 + 3.f;
+    float a4 = a0 + 4.f, a5 = a0 + 5.f, a6 = a0 + 6.f, a7 = a0 + 7.f;
+    const float m = 0.999f, c = 0.001f;
+    for (int i = 0; i < iterations; i++) {
+        #pragma unroll
+        for (int k = 0; k < kValuProbeUnroll / 8; k++) {
+            if (MIXED) {
+                asm volatile(
+                    "v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %1, %1, %8, %9\n v_fma_f32 %2, %2, %8, %9\n"
+                    "v_fma_f32 %3, %3, %8, %9\n v_fma_f32 %4, %4, %8, %9\n v_fma_f32 %5, %5, %8, %9\n"
+                    "v_rcp_f32 %6, %6\n v_sqrt_f32 %7, %7\n"
+                    : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "v"(c));
+            } else {
+                asm volatile(
+                    "v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %1, %1, %8, %9\n v_fma_f32 %2, %2, %8, %9\n"
+                    "v_fma_f32 %3, %3, %8, %9\n v_fma_f32 %4, %4, %8, %9\n v_fma_f32 %5, %5, %8, %9\n"
+                    "v_fma_f32 %6, %6, %8, %9\n v_fma_f32 %7, %7, %8, %9\n"
+                    : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "v"(c));
+            }
+        }
+    }
+    const float total = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
+    if (total == 12345.678f) { *sink = total; }   // keeps the chains alive
+}
+
+// dst[i] += src[i]: the fan-in of per-GPU radiance sums inside one process (pathed_hip_accum_add)
+__global__ __launch_bounds__(kBlock) void k_accum_add(float *dst, const float *src, size_t count)
+{
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < count; i += stride) { dst[i] += src[i]; }
+}
+
 }  // namespace pathed

@@ -38,6 +38,9 @@ int fail(int code, const std::string &message)
         }                                                                                  \
     } while (0)
 
+// hipSetDevice is per host thread: every entry point that takes a scene selects the scene's device first
+#define SELECT_DEVICE(scene) HIP_TRY(hipSetDevice((scene)->deviceId))
+
 template <typename T>
 struct DeviceBuffer {
     T *ptr = nullptr;
@@ -135,6 +138,8 @@ static const int kMaxPools = 4;
 struct PathedScene {
     DScene device;
     int width = 0, height = 0;
+    int deviceId = 0;             // the HIP device every buffer of this scene lives on
+    PathedSceneOptions options;   // as passed to scene_create_ex (zeroed = defaults)
 
     // host copy kept for export / introspection (a device-built tree is downloaded on demand)
     FlatBvh bvh;
@@ -433,7 +438,9 @@ void configureTrace(PathedScene *scene)
     // deeper entries spill to HBM.
     scene->maxStack = 3 * scene->bvh.maxDepth + 1;
     scene->stackRows = scene->maxStack <= 8 ? 8 : scene->maxStack <= 16 ? 16 : 22;
-    if (const char *override = getenv("PATHED_STACK_ROWS")) {   // tests: force the HBM spill path
+    const PathedSceneOptions &options = scene->options;
+    if (options.stack_rows == 8 || options.stack_rows == 16 || options.stack_rows == 22) { scene->stackRows = options.stack_rows; }
+    if (const char *override = getenv("PATHED_STACK_ROWS")) {   // experiments: force the HBM spill path
         const int value = atoi(override);
         if (value == 8 || value == 16 || value == 22) { scene->stackRows = value; }
     }
@@ -452,11 +459,15 @@ void configureTrace(PathedScene *scene)
     // 5: 1192 / 1292); a single pool wants all five the LDS allows (1266 / 1316).
     if (!scene->sceneInLds) { blocksPerCu = scene->pools > 1 ? (blocksPerCu < 3 ? blocksPerCu : 3) : (blocksPerCu < 5 ? blocksPerCu : 5); }
     if (blocksPerCu < 1) { blocksPerCu = 1; }
+    if (options.trace_blocks_per_cu >= 1 && options.trace_blocks_per_cu <= 16) { blocksPerCu = options.trace_blocks_per_cu; }
     if (const char *override = getenv("PATHED_TRACE_BLOCKS_PER_CU")) {
         const int value = atoi(override);
         if (value >= 1 && value <= 16) { blocksPerCu = value; }
     }
     scene->traceGrid = scene->computeUnits * blocksPerCu;
+    if (options.park_min_cards != 0) { scene->parkMinCards = options.park_min_cards < 0 ? 0 : (options.park_min_cards > 1024 ? 1024 : options.park_min_cards); }
+    if (options.suspend_patience != 0) { scene->suspendPatience = options.suspend_patience < 0 ? 0 : (options.suspend_patience > 4096 ? 4096 : options.suspend_patience); }
+    if (options.suspend_lanes != 0) { scene->suspendLanes = options.suspend_lanes < 0 ? 0 : (options.suspend_lanes > 64 ? 64 : options.suspend_lanes); }
     if (const char *override = getenv("PATHED_PARK_MIN_CARDS")) {
         const int value = atoi(override);
         if (value >= 0 && value <= 1024) { scene->parkMinCards = value; }
@@ -545,6 +556,116 @@ int pathed_hip_measure_bandwidth(size_t bytes, int repeats, double *read_gbs, do
     return PATHED_OK;
 }
 
+int pathed_hip_measure_valu(int waves_per_simd, int repeats, double *fma_rate, double *mixed_rate)
+{
+    if (!fma_rate || !mixed_rate || repeats < 1 || repeats > 1000) { return fail(PATHED_E_INVALID, "bad argument"); }
+    if (waves_per_simd < 1 || waves_per_simd > 8) { return fail(PATHED_E_INVALID, "waves_per_simd must be 1..8"); }
+    if (g_device < 0) {
+        const int code = pathed_hip_init(0);
+        if (code != PATHED_OK) { return code; }
+    }
+    int device = 0;
+    HIP_TRY(hipGetDevice(&device));
+    hipDeviceProp_t properties;
+    int units = 256;
+    if (hipGetDeviceProperties(&properties, device) == hipSuccess && properties.multiProcessorCount > 0) { units = properties.multiProcessorCount; }
+    float *sink = nullptr;
+    hipEvent_t start = nullptr, stop = nullptr;
+    hipError_t status = hipMalloc((void **)&sink, sizeof(float));
+    if (status == hipSuccess) { status = hipEventCreate(&start); }
+    if (status == hipSuccess) { status = hipEventCreate(&stop); }
+    // one 256-thread block = one wave on each of a CU's four SIMDs; k blocks per CU = k waves per SIMD
+    const dim3 grid((unsigned)(units * waves_per_simd)), block(kBlock);
+    const int iterations = 4096;   // 196 608 instructions per wave and launch: ~0.2-0.4 ms
+    float fmaMs = 0.f, mixedMs = 0.f;
+    if (status == hipSuccess) {
+        hipLaunchKernelGGL((k_valu_probe<false>), grid, block, 0, nullptr, iterations, 1.f, sink);   // warm-up
+        hipLaunchKernelGGL((k_valu_probe<true>), grid, block, 0, nullptr, iterations, 1.f, sink);
+        (void)hipEventRecord(start, nullptr);
+        for (int r = 0; r < repeats; r++) { hipLaunchKernelGGL((k_valu_probe<false>), grid, block, 0, nullptr, iterations, 1.f, sink); }
+        (void)hipEventRecord(stop, nullptr);
+        status = hipEventSynchronize(stop);
+        if (status == hipSuccess) { status = hipEventElapsedTime(&fmaMs, start, stop); }
+        (void)hipEventRecord(start, nullptr);
+        for (int r = 0; r < repeats; r++) { hipLaunchKernelGGL((k_valu_probe<true>), grid, block, 0, nullptr, iterations, 1.f, sink); }
+        (void)hipEventRecord(stop, nullptr);
+        if (status == hipSuccess) { status = hipEventSynchronize(stop); }
+        if (status == hipSuccess) { status = hipEventElapsedTime(&mixedMs, start, stop); }
+        if (status == hipSuccess) { status = hipGetLastError(); }
+    }
+    if (sink) { (void)hipFree(sink); }
+    if (start) { (void)hipEventDestroy(start); }
+    if (stop) { (void)hipEventDestroy(stop); }
+    if (status != hipSuccess || !(fmaMs > 0.f) || !(mixedMs > 0.f)) {
+        return fail(PATHED_E_DEVICE, std::string("VALU probe: ") + hipGetErrorString(status));
+    }
+    const double issued = (double)grid.x * kWavesPerBlock * (double)iterations * kValuProbeUnroll * repeats;
+    *fma_rate = issued / (fmaMs * 1e-3);
+    *mixed_rate = issued / (mixedMs * 1e-3);
+    return PATHED_OK;
+}
+
+int pathed_hip_accum_alloc(PathedScene *scene, size_t count, float **out)
+{
+    if (!scene || !out || count == 0) { return fail(PATHED_E_INVALID, "bad argument"); }
+    SELECT_DEVICE(scene);
+    float *buffer = nullptr;
+    HIP_TRY(hipMalloc((void **)&buffer, count * sizeof(float)));
+    const hipError_t status = hipMemset(buffer, 0, count * sizeof(float));
+    if (status != hipSuccess) { (void)hipFree(buffer); return fail(PATHED_E_DEVICE, hipGetErrorString(status)); }
+    *out = buffer;
+    return PATHED_OK;
+}
+
+int pathed_hip_accum_free(PathedScene *scene, float *buffer)
+{
+    if (!scene) { return fail(PATHED_E_INVALID, "null scene"); }
+    SELECT_DEVICE(scene);
+    if (buffer) { HIP_TRY(hipFree(buffer)); }
+    return PATHED_OK;
+}
+
+int pathed_hip_accum_download(PathedScene *scene, const float *buffer, size_t count, float *host)
+{
+    if (!scene || !buffer || !host) { return fail(PATHED_E_INVALID, "null argument"); }
+    SELECT_DEVICE(scene);
+    HIP_TRY(hipMemcpy(host, buffer, count * sizeof(float), hipMemcpyDeviceToHost));
+    return PATHED_OK;
+}
+
+int pathed_hip_accum_upload(PathedScene *scene, float *buffer, size_t count, const float *host)
+{
+    if (!scene || !buffer || !host) { return fail(PATHED_E_INVALID, "null argument"); }
+    SELECT_DEVICE(scene);
+    HIP_TRY(hipMemcpy(buffer, host, count * sizeof(float), hipMemcpyHostToDevice));
+    return PATHED_OK;
+}
+
+int pathed_hip_accum_copy_peer(PathedScene *dst_scene, float *dst, PathedScene *src_scene, const float *src, size_t count)
+{
+    if (!dst_scene || !src_scene || !dst || !src) { return fail(PATHED_E_INVALID, "null argument"); }
+    SELECT_DEVICE(dst_scene);
+    if (dst_scene->deviceId == src_scene->deviceId) {
+        HIP_TRY(hipMemcpy(dst, src, count * sizeof(float), hipMemcpyDeviceToDevice));
+    } else {
+        HIP_TRY(hipMemcpyPeer(dst, dst_scene->deviceId, src, src_scene->deviceId, count * sizeof(float)));
+    }
+    return PATHED_OK;
+}
+
+int pathed_hip_accum_add(PathedScene *dst_scene, float *dst, const float *src, size_t count)
+{
+    if (!dst_scene || !dst || !src) { return fail(PATHED_E_INVALID, "null argument"); }
+    SELECT_DEVICE(dst_scene);
+    if (count == 0) { return PATHED_OK; }
+    size_t blocks = (count + kBlock - 1) / kBlock;
+    if (blocks > (size_t)dst_scene->computeUnits * 16) { blocks = (size_t)dst_scene->computeUnits * 16; }
+    hipLaunchKernelGGL(k_accum_add, dim3((unsigned)blocks), dim3(kBlock), 0, nullptr, dst, src, count);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    return PATHED_OK;
+}
+
 int pathed_hip_set_bvh_builder(int builder)
 {
     if (builder != PATHED_BVH_SAH_HOST && builder != PATHED_BVH_LBVH_DEVICE && builder != PATHED_BVH_PLOC_DEVICE) {
@@ -556,22 +677,61 @@ int pathed_hip_set_bvh_builder(int builder)
 
 int pathed_hip_scene_create(const PathedSceneDesc *desc, PathedScene **out)
 {
+    return pathed_hip_scene_create_ex(desc, nullptr, out);
+}
+
+int pathed_hip_scene_device(const PathedScene *scene)
+{
+    if (!scene) { return fail(PATHED_E_INVALID, "null scene"); }
+    return scene->deviceId;
+}
+
+int pathed_hip_scene_create_ex(const PathedSceneDesc *desc, const PathedSceneOptions *optionsIn, PathedScene **out)
+{
     if (!out) { return fail(PATHED_E_INVALID, "out pointer is null"); }
     *out = nullptr;
     int code = validate(desc);
     if (code != PATHED_OK) { return code; }
-    if (g_device < 0) {
-        code = pathed_hip_init(0);
-        if (code != PATHED_OK) { return code; }
+    PathedSceneOptions options;
+    std::memset(&options, 0, sizeof options);
+    options.device = PATHED_DEVICE_CURRENT;
+    if (optionsIn) {
+        if (optionsIn->struct_size != sizeof(PathedSceneOptions)) { return fail(PATHED_E_INVALID, "PathedSceneOptions.struct_size mismatch"); }
+        options = *optionsIn;
+        for (int k = 0; k < 5; k++) {
+            if (options.reserved[k] != 0) { return fail(PATHED_E_INVALID, "PathedSceneOptions.reserved must be zero"); }
+        }
+        if (options.bvh_builder < 0 || options.bvh_builder > PATHED_BVH_PLOC_DEVICE + 1) { return fail(PATHED_E_INVALID, "unknown BVH builder"); }
+        if (options.pools < 0 || options.pools > kMaxPools) { return fail(PATHED_E_INVALID, "pools must be 0..4"); }
+        if (options.stack_rows != 0 && options.stack_rows != 8 && options.stack_rows != 16 && options.stack_rows != 22) {
+            return fail(PATHED_E_INVALID, "stack_rows must be 0, 8, 16 or 22");
+        }
+        if (options.max_slots < 0 || (options.max_slots != 0 && options.max_slots < kBlock)) { return fail(PATHED_E_INVALID, "max_slots must be 0 or >= 256"); }
     }
+    int deviceId = options.device;
+    if (deviceId == PATHED_DEVICE_CURRENT) {
+        if (g_device < 0) {
+            code = pathed_hip_init(0);
+            if (code != PATHED_OK) { return code; }
+        }
+        deviceId = g_device;
+    } else {
+        int count = 0;
+        const hipError_t counted = hipGetDeviceCount(&count);
+        if (counted != hipSuccess || count == 0) { return fail(PATHED_E_NO_DEVICE, std::string("no HIP device: ") + hipGetErrorString(counted)); }
+        if (deviceId < 0 || deviceId >= count) { return fail(PATHED_E_INVALID, "device id out of range"); }
+    }
+    HIP_TRY(hipSetDevice(deviceId));
 
     PathedScene *scene = new PathedScene();
     std::memset(&scene->device, 0, sizeof scene->device);
+    scene->deviceId = deviceId;
+    scene->options = options;
     scene->width = desc->camera.width;
     scene->height = desc->camera.height;
 
     hipDeviceProp_t properties;
-    if (hipGetDeviceProperties(&properties, g_device) == hipSuccess) {
+    if (hipGetDeviceProperties(&properties, deviceId) == hipSuccess) {
         scene->computeUnits = properties.multiProcessorCount > 0 ? properties.multiProcessorCount : 256;
     }
 
@@ -697,7 +857,7 @@ int pathed_hip_scene_create(const PathedSceneDesc *desc, PathedScene **out)
     };
 
     hipError_t status;
-    int builder = g_bvhBuilder;
+    int builder = options.bvh_builder > 0 ? options.bvh_builder - 1 : g_bvhBuilder;
     if (const char *text = getenv("PATHED_BVH_BUILDER")) {
         if (!strcmp(text, "lbvh")) { builder = PATHED_BVH_LBVH_DEVICE; }
         else if (!strcmp(text, "ploc")) { builder = PATHED_BVH_PLOC_DEVICE; }
@@ -791,12 +951,13 @@ int pathed_hip_scene_create(const PathedSceneDesc *desc, PathedScene **out)
     d.env.thetaGuide = scene->thetaGuide.ptr;
     d.env.phiGuide = scene->phiGuide.ptr;
 
+    if (options.pools > 0) { scene->pools = options.pools; }
     if (const char *poolCount = getenv("PATHED_POOLS")) {
         const int value = atoi(poolCount);
         scene->pools = value < 1 ? 1 : value > kMaxPools ? kMaxPools : value;
     }
     configureTrace(scene);
-    scene->bruteForce = scene->device.nTris <= kBruteForceMaxTris && !getenv("PATHED_NO_BRUTE_FORCE");
+    scene->bruteForce = scene->device.nTris <= kBruteForceMaxTris && options.intersector != 1 && !getenv("PATHED_NO_BRUTE_FORCE");
     // BVH scenes: more slots = more rays per persistent wave to refill finished lanes from
     // (ray cost is heavy-tailed); the all-triangles kernel has uniform cost and prefers the
     // smaller, Infinity-Cache-resident state
@@ -814,6 +975,7 @@ int pathed_hip_scene_create(const PathedSceneDesc *desc, PathedScene **out)
             }
         }
     }
+    if (options.max_slots >= kBlock) { scene->maxSlots = options.max_slots; }
     if (const char *slots = getenv("PATHED_MAX_SLOTS")) {
         const long value = atol(slots);
         if (value >= kBlock) { scene->maxSlots = (int)value; }
@@ -824,6 +986,7 @@ int pathed_hip_scene_create(const PathedSceneDesc *desc, PathedScene **out)
 
 void pathed_hip_scene_destroy(PathedScene *scene)
 {
+    if (scene) { (void)hipSetDevice(scene->deviceId); }
     delete scene;
 }
 
@@ -932,7 +1095,22 @@ static int renderPass(PathedScene *scene, uint64_t seed, uint32_t begin, uint32_
     // a lag of one chunk of launches so the GPU never waits for the host.
     const int launchChunk = 8;
     const int ringSize = 32;
-    hipEvent_t pollEvents[kMaxPools][2];
+    // the poll events are destroyed and the pool streams drained on every way out, error or not
+    struct PollGuard {
+        hipEvent_t events[kMaxPools][2] = {};
+        hipStream_t *streams = nullptr;
+        int pools = 0;
+        ~PollGuard()
+        {
+            for (int h = 0; h < pools; h++) { (void)hipStreamSynchronize(streams[h]); }
+            for (int h = 0; h < kMaxPools; h++) {
+                for (int k = 0; k < 2; k++) { if (events[h][k]) { (void)hipEventDestroy(events[h][k]); } }
+            }
+        }
+    } guard;
+    guard.streams = streams;
+    guard.pools = pools;
+    hipEvent_t (&pollEvents)[kMaxPools][2] = guard.events;
     for (int h = 0; h < pools; h++) {
         HIP_TRY(hipEventCreateWithFlags(&pollEvents[h][0], hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&pollEvents[h][1], hipEventDisableTiming));
@@ -992,10 +1170,6 @@ static int renderPass(PathedScene *scene, uint64_t seed, uint32_t begin, uint32_
     hipLaunchKernelGGL(k_resolve, pixelGrid, block, 0, stream, params[0]);
     for (int h = 0; h < pools; h++) { HIP_TRY(hipStreamSynchronize(streams[h])); }
     HIP_TRY(hipStreamSynchronize(stream));
-    for (int h = 0; h < pools; h++) {
-        (void)hipEventDestroy(pollEvents[h][0]);
-        (void)hipEventDestroy(pollEvents[h][1]);
-    }
     HIP_TRY(hipGetLastError());
 
     scene->iterations += iteration;
@@ -1015,6 +1189,7 @@ int pathed_hip_render_device(PathedScene *scene, uint64_t seed,
     }
     if (spp_count == 0) { return PATHED_OK; }
     if ((uint64_t)spp_begin + spp_count > 0x7fffffffull) { return fail(PATHED_E_INVALID, "sample index overflow"); }
+    SELECT_DEVICE(scene);
 
     if (scene->timeKernels) {
         HIP_TRY(scene->traceEvents.create());
@@ -1062,6 +1237,7 @@ int pathed_hip_render(PathedScene *scene, uint64_t seed,
                       float *accum_rgb_sum)
 {
     if (!scene || !accum_rgb_sum) { return fail(PATHED_E_INVALID, "null scene or accumulation buffer"); }
+    SELECT_DEVICE(scene);
     const size_t count = (size_t)3 * scene->width * scene->height;
     float *deviceAccum = nullptr;
     HIP_TRY(hipMalloc((void **)&deviceAccum, count * sizeof(float)));
@@ -1085,6 +1261,7 @@ int pathed_hip_trace(PathedScene *scene, const float *rays, size_t n, int any_hi
     if (n == 0) { return PATHED_OK; }
     if (!rays || !hits) { return fail(PATHED_E_INVALID, "null ray or hit buffer"); }
     if (n > (size_t)1 << 28) { return fail(PATHED_E_INVALID, "too many rays in one call"); }
+    SELECT_DEVICE(scene);
 
     float4 *deviceRays = nullptr;
     float4 *deviceHits = nullptr;
@@ -1106,8 +1283,9 @@ int pathed_hip_trace(PathedScene *scene, const float *rays, size_t n, int any_hi
             case 16: hipLaunchKernelGGL((k_trace_rays<16>), grid, block, lds, 0, scene->device, deviceRays, (int)n, any_hit, deviceHits, deviceOccluded, deviceOverflow, scene->maxStack); break;
             default: hipLaunchKernelGGL((k_trace_rays<22>), grid, block, lds, 0, scene->device, deviceRays, (int)n, any_hit, deviceHits, deviceOccluded, deviceOverflow, scene->maxStack); break;
             }
+            status = hipGetLastError();
+            if (status == hipSuccess) { status = hipDeviceSynchronize(); }
         }
-        status = hipDeviceSynchronize();
     }
     if (status == hipSuccess) {
         status = any_hit
@@ -1134,6 +1312,7 @@ int pathed_hip_set_stats_mode(PathedScene *scene, int enabled)
 int pathed_hip_reset_stats(PathedScene *scene)
 {
     if (!scene) { return fail(PATHED_E_INVALID, "null scene"); }
+    SELECT_DEVICE(scene);
     if (scene->stats.ptr) { HIP_TRY(hipMemset(scene->stats.ptr, 0, kStatCount * sizeof(unsigned long long))); }
     scene->iterations = 0;
     scene->traceLaunchesAll = 0;
@@ -1148,6 +1327,7 @@ int pathed_hip_reset_stats(PathedScene *scene)
 int pathed_hip_get_stats(PathedScene *scene, PathedStats *out)
 {
     if (!scene || !out) { return fail(PATHED_E_INVALID, "null argument"); }
+    SELECT_DEVICE(scene);
     std::memset(out, 0, sizeof *out);
     unsigned long long device[kStatCount] = { 0 };
     if (scene->stats.ptr) {
@@ -1200,6 +1380,7 @@ int pathed_hip_get_stats(PathedScene *scene, PathedStats *out)
 int pathed_hip_scene_export_bvh(PathedScene *scene, float *nodes, size_t *n_nodes, float *tris, size_t *n_tris)
 {
     if (!scene || !n_nodes || !n_tris) { return fail(PATHED_E_INVALID, "null argument"); }
+    SELECT_DEVICE(scene);
     if (!scene->bvhOnHost) {
         // a device-built tree: fetch it once
         scene->bvh.nodes.resize((size_t)scene->bvh.nodeCount * kNodeFloats);

@@ -56,6 +56,9 @@ void pathed_host_free_scene(void *handle)
 #include "integrator.h"
 #include "job.h"
 
+#include <chrono>
+#include <fstream>
+#include <iomanip>
 #include <iostream>
 #include <thread>
 
@@ -74,12 +77,18 @@ int runJob(const std::string &jobPath, const std::string &assetRootOverride)
         const std::string builder = job.bvhBuilder();
         const int builderCode = builder == "ploc" ? PATHED_BVH_PLOC_DEVICE : builder == "lbvh" ? PATHED_BVH_LBVH_DEVICE : PATHED_BVH_SAH_HOST;
         if (builder != "sah" && builder != "lbvh" && builder != "ploc") { throw std::runtime_error("job: unknown bvh_builder: " + builder); }
-        pathed_hip_set_bvh_builder(builderCode);
-        Scene scene(loadScene(job.scene(), width, height, assetRoot), job.gpu());
-        pathed_hip_set_bvh_builder(PATHED_BVH_SAH_HOST);
+        const std::vector<int> devices = job.devices();
+        const auto loadBegin = std::chrono::steady_clock::now();
+        FlatScene flat = loadScene(job.scene(), width, height, assetRoot);
+        const auto uploadBegin = std::chrono::steady_clock::now();
+        // one replica of the scene per device; the device travels with the scene handle, so the
+        // render thread below (and its per-device workers) need no device selection of their own
+        Scene scene(std::move(flat), devices, builderCode);
+        const auto uploadEnd = std::chrono::steady_clock::now();
 
         std::shared_ptr<Integrator> integrator = job.integrator();
         integrator->configure(job.spp(), job.seed(), job.sppPerLaunch(), job.outputDirectory());
+        integrator->setStateFile(job.outputDirectory() + "auto.state", job.resume());
 
         // the reference renders on a dedicated thread while the UI owns the main thread
         // (app/main.cpp:98); kept so `quit` and the Image lock behave the same
@@ -90,10 +99,40 @@ int runJob(const std::string &jobPath, const std::string &assetRootOverride)
                 integrator->run(image, scene, [](RenderStatus) {}, &quit);
             } catch (const std::exception &error) {
                 failure = error.what();
+                if (failure.empty()) { failure = "render failed"; }
             }
         });
         renderThread.join();
         if (!failure.empty()) { throw std::runtime_error(failure); }
+
+        // <outdir>/metrics.json: what this run did and how fast
+        {
+            const RenderMetrics &m = integrator->metrics();
+            PathedStats stats;
+            std::memset(&stats, 0, sizeof stats);
+            pathed_hip_get_stats(scene.handle(), &stats);
+            const double samples = (double)m.width * m.height * (double)(m.lastSample - m.firstSample);
+            std::ofstream out(job.outputDirectory() + "metrics.json");
+            out << std::setprecision(9);
+            out << "{\n";
+            out << "  \"width\": " << m.width << ", \"height\": " << m.height << ",\n";
+            out << "  \"first_sample\": " << m.firstSample << ", \"last_sample\": " << m.lastSample << ",\n";
+            out << "  \"devices\": [";
+            for (size_t i = 0; i < devices.size(); i++) { out << (i ? ", " : "") << devices[i]; }
+            out << "],\n";
+            out << "  \"scene_load_seconds\": " << std::chrono::duration<double>(uploadBegin - loadBegin).count() << ",\n";
+            out << "  \"scene_upload_seconds\": " << std::chrono::duration<double>(uploadEnd - uploadBegin).count() << ",\n";
+            out << "  \"bvh_builder\": \"" << builder << "\", \"bvh_build_ms\": " << stats.bvh_build_ms
+                << ", \"bvh_bytes\": " << stats.bvh_bytes << ", \"bvh_nodes\": " << stats.bvh_nodes << ",\n";
+            out << "  \"render_seconds\": " << m.loopSeconds << ",\n";
+            out << "  \"msamples_per_second\": " << (m.loopSeconds > 0.0 ? samples / m.loopSeconds / 1e6 : 0.0) << ",\n";
+            out << "  \"reduce_seconds\": " << m.reduceSeconds << ", \"reduces\": " << m.reduces << ",\n";
+            out << "  \"replica_seconds\": [";
+            for (size_t i = 0; i < m.replicaSeconds.size(); i++) { out << (i ? ", " : "") << m.replicaSeconds[i]; }
+            out << "],\n";
+            out << "  \"dropped_samples\": " << stats.dropped_samples << "\n";
+            out << "}\n";
+        }
         return 0;
     } catch (const std::exception &error) {
         g_hostError = error.what();

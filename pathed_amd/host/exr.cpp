@@ -603,12 +603,12 @@ bool readExrRGBA(
     std::vector<unsigned char> scratch;
     for (int block = 0; block < blockCount; block++) {
         size_t pos = (size_t)offsets[(size_t)block];
-        if (pos + 8 > data.size()) { return fail("bad block offset"); }
+        if (pos > data.size() || data.size() - pos < 8) { return fail("bad block offset"); }   // no wrap for offsets near 2^64
         int32_t y, size;
         std::memcpy(&y, data.data() + pos, 4);
         std::memcpy(&size, data.data() + pos + 4, 4);
         pos += 8;
-        if (size < 0 || pos + (size_t)size > data.size()) { return fail("bad block size"); }
+        if (size < 0 || (size_t)size > data.size() - pos) { return fail("bad block size"); }
 
         const int firstLine = y - window[1];
         const int lines = std::min(linesPerBlock, h - firstLine);

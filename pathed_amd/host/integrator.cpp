@@ -2,31 +2,114 @@
 
 #include <chrono>
 #include <cstdio>
+#include <cstring>
+#include <fstream>
 #include <iomanip>
 #include <iostream>
 #include <sstream>
 #include <stdexcept>
+#include <thread>
 
 namespace pathed {
 
-Scene::Scene(FlatScene flat, int device)
-    : m_flat(std::move(flat)), m_handle(nullptr)
+namespace {
+
+std::string hipError(const char *what)
 {
-    if (pathed_hip_init(device) != PATHED_OK) {
-        throw std::runtime_error(std::string("pathed_hip_init: ") + pathed_hip_last_error());
+    return std::string(what) + ": " + pathed_hip_last_error();
+}
+
+// run `work(replica)` for every replica, each on its own host thread (one worker per device);
+// the first failure is rethrown on the caller's thread
+template <typename Work>
+void forEachReplica(size_t replicas, Work work)
+{
+    if (replicas == 1) { work((size_t)0); return; }
+    std::vector<std::string> failures(replicas);
+    std::vector<std::thread> workers;
+    for (size_t r = 0; r < replicas; r++) {
+        workers.emplace_back([&, r]() {
+            try { work(r); } catch (const std::exception &error) { failures[r] = error.what(); if (failures[r].empty()) { failures[r] = "unknown error"; } }
+        });
     }
+    for (std::thread &worker : workers) { worker.join(); }
+    for (const std::string &failure : failures) {
+        if (!failure.empty()) { throw std::runtime_error(failure); }
+    }
+}
+
+// The sidecar a resumed job continues from: the fp32 radiance SUMS and how many samples they hold.
+// Because the random stream is a pure function of (seed, pixel, sample, dimension), "the next
+// sample" needs no generator state: a resumed run is the straight run, bit for bit, as long as the
+// interruption fell on a batch boundary (it always does: the file is written after a batch).
+struct StateHeader {
+    char magic[8];            // "PATHEDS1"
+    int32_t width, height;
+    int32_t done;             // samples per pixel already in the sums
+    int32_t startBounce, lastBounce;
+    uint64_t seed;
+};
+
+}  // namespace
+
+Scene::Scene(FlatScene flat, int device)
+    : m_flat(std::move(flat)), m_devices(1, device)
+{
+    upload(0);
+}
+
+Scene::Scene(FlatScene flat, const std::vector<int> &devices, int bvhBuilder)
+    : m_flat(std::move(flat)), m_devices(devices)
+{
+    if (m_devices.empty()) { throw std::runtime_error("Scene: no device"); }
+    upload(bvhBuilder + 1);
+}
+
+void Scene::upload(int bvhBuilderPlusOne)
+{
+    m_handles.assign(m_devices.size(), nullptr);
     const PathedSceneDesc desc = m_flat.desc();
-    if (pathed_hip_scene_create(&desc, &m_handle) != PATHED_OK) {
-        throw std::runtime_error(std::string("pathed_hip_scene_create: ") + pathed_hip_last_error());
+    try {
+        // every device builds / uploads its own replica, in parallel
+        forEachReplica(m_devices.size(), [&](size_t r) {
+            PathedSceneOptions options;
+            std::memset(&options, 0, sizeof options);
+            options.struct_size = sizeof options;
+            options.device = m_devices[r];
+            options.bvh_builder = bvhBuilderPlusOne;
+            if (pathed_hip_scene_create_ex(&desc, &options, &m_handles[r]) != PATHED_OK) {
+                throw std::runtime_error(hipError("pathed_hip_scene_create_ex"));
+            }
+        });
+    } catch (...) {
+        for (PathedScene *handle : m_handles) { pathed_hip_scene_destroy(handle); }
+        throw;
     }
 }
 
 Scene::~Scene()
 {
-    pathed_hip_scene_destroy(m_handle);
+    for (PathedScene *handle : m_handles) { pathed_hip_scene_destroy(handle); }
 }
 
-// reference src/integrator.cpp:19-106
+void Integrator::configure(int spp, unsigned long long seed, int sppPerLaunch, const std::string &logPrefix)
+{
+    if (sppPerLaunch < 1) { throw std::runtime_error("spp_per_launch must be >= 1"); }
+    if (spp < 1) { throw std::runtime_error("spp must be >= 1"); }
+    m_spp = spp;
+    m_seed = seed;
+    m_sppPerLaunch = sppPerLaunch;
+    m_logPrefix = logPrefix;
+}
+
+// reference src/integrator.cpp:19-106.  The reference adds one sample per pixel per wave to a host
+// vector; here the sums stay on the devices (one buffer per replica) and come to the host only when
+// an image is due: at the power-of-two checkpoints (src/integrator.cpp:87-92), at the end, and when
+// `quit` is raised.  With G replicas the samples of a batch [done, done + count) are split
+// G ways (contiguous shares, strongRange), every replica adds its share into its own buffer on its
+// own host thread, and an image is  sum over replicas  / done: waves are additive
+// (src/integrator.cpp:42-51), so the union over replicas of what they have rendered is always
+// exactly the samples [0, done) -- the single-GPU image up to fp32 summation order.
 void Integrator::run(
     Image &image,
     Scene &scene,
@@ -36,24 +119,73 @@ void Integrator::run(
     const int width = scene.width();
     const int height = scene.height();
     const int primarySamples = m_spp;
+    const size_t replicas = scene.replicas();
+    const size_t floats = (size_t)3 * width * height;
 
     printf("Beginning pre-process...\n");
     preprocess(scene);
     printf("Pre-process complete (0.0s elapsed)\n");
 
-    std::vector<float> radianceLookup((size_t)3 * width * height, 0.f);
+    std::vector<float *> deviceSums(replicas, nullptr);
+    float *staging = nullptr;   // on replica 0's device: a peer's sums on their way into the total
+    float *total = nullptr;     // on replica 0's device: sum over replicas (G > 1 only)
+    struct Cleanup {
+        Scene &scene;
+        std::vector<float *> &sums;
+        float *&staging;
+        float *&total;
+        ~Cleanup()
+        {
+            for (size_t r = 0; r < sums.size(); r++) { if (sums[r]) { pathed_hip_accum_free(scene.handle(r), sums[r]); } }
+            if (staging) { pathed_hip_accum_free(scene.handle(0), staging); }
+            if (total) { pathed_hip_accum_free(scene.handle(0), total); }
+        }
+    } cleanup{ scene, deviceSums, staging, total };
+    for (size_t r = 0; r < replicas; r++) {
+        if (pathed_hip_accum_alloc(scene.handle(r), floats, &deviceSums[r]) != PATHED_OK) { throw std::runtime_error(hipError("pathed_hip_accum_alloc")); }
+    }
+    if (replicas > 1) {
+        if (pathed_hip_accum_alloc(scene.handle(0), floats, &staging) != PATHED_OK) { throw std::runtime_error(hipError("pathed_hip_accum_alloc")); }
+        if (pathed_hip_accum_alloc(scene.handle(0), floats, &total) != PATHED_OK) { throw std::runtime_error(hipError("pathed_hip_accum_alloc")); }
+    }
 
+    std::vector<float> radianceLookup(floats, 0.f);
     int done = 0;
+    if (m_resume) {
+        done = loadState(radianceLookup, width, height);
+        if (done > 0) {
+            // the sums so far continue on replica 0
+            if (pathed_hip_accum_upload(scene.handle(0), deviceSums[0], floats, radianceLookup.data()) != PATHED_OK) {
+                throw std::runtime_error(hipError("pathed_hip_accum_upload"));
+            }
+            std::cout << "[" << m_logPrefix << "] resuming at sample " << done << "/" << primarySamples << std::endl;
+        }
+    }
+
+    m_metrics = RenderMetrics();
+    m_metrics.replicas = (int)replicas;
+    m_metrics.firstSample = done;
+    m_metrics.replicaSeconds.assign(replicas, 0.0);
+    const auto loopBegin = std::chrono::steady_clock::now();
+
     while (done < primarySamples) {
         // batches end on powers of two so checkpoints appear exactly where the reference
         // writes them (src/integrator.cpp:87-92)
         int nextPower = 1;
         while (nextPower <= done) { nextPower *= 2; }
-        int count = std::min(m_sppPerLaunch, primarySamples - done);
+        long long limit = (long long)m_sppPerLaunch * (long long)replicas;
+        int count = (int)std::min<long long>(limit, primarySamples - done);
         count = std::min(count, nextPower - done);
 
         const auto begin = std::chrono::steady_clock::now();
-        sampleImage(radianceLookup, scene, (unsigned)done, (unsigned)count);
+        forEachReplica(replicas, [&](size_t r) {
+            unsigned first = 0, mine = 0;
+            strongRange((unsigned)r, (unsigned)replicas, (unsigned)done, (unsigned)count, &first, &mine);
+            if (mine == 0) { return; }
+            const auto replicaBegin = std::chrono::steady_clock::now();
+            sampleImage(deviceSums[r], scene, r, first, mine);
+            m_metrics.replicaSeconds[r] += std::chrono::duration<double>(std::chrono::steady_clock::now() - replicaBegin).count();
+        });
         const auto end = std::chrono::steady_clock::now();
         done += count;
 
@@ -64,7 +196,24 @@ void Integrator::run(
         status.elapsedSeconds = std::chrono::duration<double>(end - begin).count();
         if (callback) { callback(status); }
 
-        {
+        const bool checkpoint = (done & (done - 1)) == 0;
+        const bool stopping = quit && *quit;
+        if (checkpoint || done == primarySamples || stopping) {
+            const auto reduceBegin = std::chrono::steady_clock::now();
+            const float *source = deviceSums[0];
+            if (replicas > 1) {
+                // the path's one exchange step: per-device sums -> replica 0, over xGMI
+                if (pathed_hip_accum_copy_peer(scene.handle(0), total, scene.handle(0), deviceSums[0], floats) != PATHED_OK) { throw std::runtime_error(hipError("pathed_hip_accum_copy_peer")); }
+                for (size_t r = 1; r < replicas; r++) {
+                    if (pathed_hip_accum_copy_peer(scene.handle(0), staging, scene.handle(r), deviceSums[r], floats) != PATHED_OK) { throw std::runtime_error(hipError("pathed_hip_accum_copy_peer")); }
+                    if (pathed_hip_accum_add(scene.handle(0), total, staging, floats) != PATHED_OK) { throw std::runtime_error(hipError("pathed_hip_accum_add")); }
+                }
+                source = total;
+            }
+            if (pathed_hip_accum_download(scene.handle(0), source, floats, radianceLookup.data()) != PATHED_OK) { throw std::runtime_error(hipError("pathed_hip_accum_download")); }
+            m_metrics.reduceSeconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - reduceBegin).count();
+            m_metrics.reduces++;
+
             std::lock_guard<std::mutex> guard(image.getLock());
             image.setSpp(done);
             for (int row = 0; row < height; row++) {
@@ -77,7 +226,8 @@ void Integrator::run(
                         radianceLookup[index + 2] / done);
                 }
             }
-            if ((done & (done - 1)) == 0) { image.saveCheckpoint("auto"); }
+            if (checkpoint) { image.saveCheckpoint("auto"); }
+            saveState(radianceLookup, width, height, done);
         }
 
         std::ostringstream line;
@@ -86,18 +236,63 @@ void Integrator::run(
              << " (" << status.elapsedSeconds << "s elapsed)";
         std::cout << line.str() << std::endl;
 
-        if (quit && *quit) { return; }
+        if (stopping) { break; }
     }
+    m_metrics.lastSample = done;
+    m_metrics.loopSeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - loopBegin).count();
+    m_metrics.width = width;
+    m_metrics.height = height;
 }
 
-void HipPathTracer::sampleImage(std::vector<float> &radianceLookup, Scene &scene, unsigned begin, unsigned count)
+void Integrator::saveState(const std::vector<float> &sums, int width, int height, int done) const
 {
-    const int code = pathed_hip_render(
-        scene.handle(), m_seed, begin, count,
+    if (m_statePath.empty()) { return; }
+    StateHeader header;
+    std::memset(&header, 0, sizeof header);
+    std::memcpy(header.magic, "PATHEDS1", 8);
+    header.width = width;
+    header.height = height;
+    header.done = done;
+    header.startBounce = stateStartBounce();
+    header.lastBounce = stateLastBounce();
+    header.seed = m_seed;
+    // write beside, then rename: an interrupted write never leaves a truncated state behind
+    const std::string scratch = m_statePath + ".tmp";
+    {
+        std::ofstream out(scratch, std::ios::binary | std::ios::trunc);
+        out.write(reinterpret_cast<const char *>(&header), sizeof header);
+        out.write(reinterpret_cast<const char *>(sums.data()), (std::streamsize)(sums.size() * sizeof(float)));
+        if (!out) { fprintf(stderr, "pathed: cannot write %s\n", scratch.c_str()); return; }
+    }
+    if (std::rename(scratch.c_str(), m_statePath.c_str()) != 0) { fprintf(stderr, "pathed: cannot rename %s\n", scratch.c_str()); }
+}
+
+int Integrator::loadState(std::vector<float> &sums, int width, int height) const
+{
+    if (m_statePath.empty()) { return 0; }
+    std::ifstream in(m_statePath, std::ios::binary);
+    if (!in) { return 0; }   // nothing to resume from: start at sample 0
+    StateHeader header;
+    in.read(reinterpret_cast<char *>(&header), sizeof header);
+    if (!in || std::memcmp(header.magic, "PATHEDS1", 8) != 0) { throw std::runtime_error("resume: " + m_statePath + " is not a pathed state file"); }
+    if (header.width != width || header.height != height) { throw std::runtime_error("resume: state file has another resolution"); }
+    if (header.seed != m_seed || header.startBounce != stateStartBounce() || header.lastBounce != stateLastBounce()) {
+        throw std::runtime_error("resume: state file was rendered with another seed or bounce window");
+    }
+    if (header.done < 0 || header.done > m_spp) { throw std::runtime_error("resume: state file holds more samples than the job asks for"); }
+    in.read(reinterpret_cast<char *>(sums.data()), (std::streamsize)(sums.size() * sizeof(float)));
+    if (!in) { throw std::runtime_error("resume: state file is truncated"); }
+    return header.done;
+}
+
+void HipPathTracer::sampleImage(float *deviceSums, Scene &scene, size_t replica, unsigned begin, unsigned count)
+{
+    const int code = pathed_hip_render_device(
+        scene.handle(replica), m_seed, begin, count,
         m_bounceController.startBounce(), m_bounceController.lastBounce(),
-        radianceLookup.data());
+        deviceSums, nullptr, 1);
     if (code != PATHED_OK) {
-        throw std::runtime_error(std::string("pathed_hip_render: ") + pathed_hip_last_error());
+        throw std::runtime_error(std::string("pathed_hip_render_device: ") + pathed_hip_last_error());
     }
 }
 

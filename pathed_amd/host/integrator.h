@@ -24,24 +24,54 @@ struct RenderStatus {
     double elapsedSeconds = 0.0;
 };
 
+// what a render leaves behind for <outdir>/metrics.json
+struct RenderMetrics {
+    int width = 0, height = 0;
+    int replicas = 1;
+    int firstSample = 0, lastSample = 0;   // samples [first, last) were rendered by this run
+    double loopSeconds = 0.0;              // the render loop, checkpoints included
+    double reduceSeconds = 0.0;            // fan-in of the per-device sums + download
+    int reduces = 0;
+    std::vector<double> replicaSeconds;    // time each replica spent inside sampleImage
+};
+
 // Host-side Scene: the parsed description plus its upload (reference include/scene.h:83-130
 // owns the Embree scene the same way).
+// With several devices the description is uploaded to each of them (scene + BVH replicated,
+// SURVEY.md §8e); handle(r) is the replica on devices()[r].  The same id may appear twice: two
+// replicas on one GPU, which is how the fan-out is tested on a one-GPU box.
 class Scene {
 public:
     Scene(FlatScene flat, int device);
+    Scene(FlatScene flat, const std::vector<int> &devices, int bvhBuilder);
     ~Scene();
     Scene(const Scene &) = delete;
     Scene &operator=(const Scene &) = delete;
 
-    PathedScene *handle() const { return m_handle; }
+    PathedScene *handle() const { return m_handles[0]; }
+    PathedScene *handle(size_t replica) const { return m_handles[replica]; }
+    size_t replicas() const { return m_handles.size(); }
+    const std::vector<int> &devices() const { return m_devices; }
     const FlatScene &flat() const { return m_flat; }
     int width() const { return m_flat.camera.width; }
     int height() const { return m_flat.camera.height; }
 
 private:
+    void upload(int bvhBuilder);
+
     FlatScene m_flat;
-    PathedScene *m_handle;
+    std::vector<int> m_devices;
+    std::vector<PathedScene *> m_handles;
 };
+
+// Samples [first, first + count) split over `parts` (total work fixed): part r gets a contiguous
+// share, the first count % parts parts one sample more.  Same rule as pathed_amd/parallel.py.
+inline void strongRange(unsigned part, unsigned parts, unsigned first, unsigned count, unsigned *begin, unsigned *mine)
+{
+    const unsigned base = count / parts, extra = count % parts;
+    *begin = first + part * base + (part < extra ? part : extra);
+    *mine = base + (part < extra ? 1u : 0u);
+}
 
 class Integrator {
 public:
@@ -57,23 +87,31 @@ public:
     virtual void preprocess(const Scene &) {}
     virtual void postwave(const Scene &, int /*waveCount*/) {}
 
-    void configure(int spp, unsigned long long seed, int sppPerLaunch, const std::string &logPrefix)
-    {
-        m_spp = spp;
-        m_seed = seed;
-        m_sppPerLaunch = sppPerLaunch;
-        m_logPrefix = logPrefix;
-    }
+    void configure(int spp, unsigned long long seed, int sppPerLaunch, const std::string &logPrefix);
+
+    // <outdir>/auto.state: fp32 radiance sums + sample count, rewritten whenever an image is published.
+    // With resume the run continues from it (a missing file means "start at 0").
+    void setStateFile(const std::string &path, bool resume) { m_statePath = path; m_resume = resume; }
+    const RenderMetrics &metrics() const { return m_metrics; }
 
 protected:
-    // adds `count` samples of every pixel, starting at sample index `begin`, to radianceLookup
-    // (reference sampleImage adds exactly one)
-    virtual void sampleImage(std::vector<float> &radianceLookup, Scene &scene, unsigned begin, unsigned count) = 0;
+    // adds `count` samples of every pixel, starting at sample index `begin`, to the radiance sums
+    // `deviceSums` that live on replica `replica`'s device (reference sampleImage adds exactly one
+    // sample to radianceLookup)
+    virtual void sampleImage(float *deviceSums, Scene &scene, size_t replica, unsigned begin, unsigned count) = 0;
 
     int m_spp = 1;
     unsigned long long m_seed = 1;
+    virtual int stateStartBounce() const { return 0; }
+    virtual int stateLastBounce() const { return -1; }
+    void saveState(const std::vector<float> &sums, int width, int height, int done) const;
+    int loadState(std::vector<float> &sums, int width, int height) const;
+
     int m_sppPerLaunch = 64;
+    bool m_resume = false;
+    std::string m_statePath;
     std::string m_logPrefix;
+    RenderMetrics m_metrics;
 };
 
 class HipPathTracer : public Integrator {
@@ -83,7 +121,9 @@ public:
     {}
 
 protected:
-    void sampleImage(std::vector<float> &radianceLookup, Scene &scene, unsigned begin, unsigned count) override;
+    void sampleImage(float *deviceSums, Scene &scene, size_t replica, unsigned begin, unsigned count) override;
+    int stateStartBounce() const override { return m_bounceController.startBounce(); }
+    int stateLastBounce() const override { return m_bounceController.lastBounce(); }
 
 private:
     BounceController m_bounceController;

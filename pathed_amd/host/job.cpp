@@ -36,6 +36,21 @@ void Job::init()
     report << m_json.dump(4) << std::endl;
 }
 
+std::vector<int> Job::devices() const
+{
+    const Json &gpus = m_json["gpus"];
+    std::vector<int> ids;
+    if (gpus.isArray()) {
+        for (size_t i = 0; i < gpus.size(); i++) { ids.push_back(gpus[i].asInt()); }
+    } else {
+        const int count = gpus.isNumber() ? gpus.asInt() : 1;
+        for (int i = 0; i < count; i++) { ids.push_back(gpu() + i); }
+    }
+    if (ids.empty() || ids.size() > 64) { throw std::runtime_error("job: \"gpus\" must name 1..64 devices"); }
+    for (int id : ids) { if (id < 0) { throw std::runtime_error("job: negative device id in \"gpus\""); } }
+    return ids;
+}
+
 std::shared_ptr<Integrator> Job::integrator() const
 {
     const std::string name = integratorName();

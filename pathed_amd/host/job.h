@@ -3,14 +3,19 @@
 // output_directory, output_name, showUI, force, width, height); job-file numbers are real
 // JSON numbers.  Optional extra keys with defaults, so reference job files run unchanged:
 //   "seed" (1), "spp_per_launch" (64), "gpu" (0), "asset_root" (directory paths resolve in),
-//   "bvh_builder" ("sah" | "lbvh" | "ploc": include/pathed_hip.h PATHED_BVH_*).
+//   "bvh_builder" ("sah" | "lbvh" | "ploc": include/pathed_hip.h PATHED_BVH_*),
+//   "gpus" (1): a count N -> devices gpu .. gpu+N-1, or an explicit list of device ids (an id may
+//               repeat: several replicas on one GPU); the samples of every batch are split over them,
+//   "resume" (false): continue from <output_directory>/auto.state if it exists.
 #pragma once
 
 #include "bounce_controller.h"
 #include "json.h"
 
 #include <memory>
+#include <stdexcept>
 #include <string>
+#include <vector>
 
 namespace pathed {
 
@@ -46,7 +51,15 @@ public:
     BounceController bounceController() const { return m_bounceController; }
 
     unsigned long long seed() const { return m_json["seed"].isNumber() ? (unsigned long long)m_json["seed"].asNumber() : 1ull; }
-    int sppPerLaunch() const { return m_json["spp_per_launch"].isNumber() ? m_json["spp_per_launch"].asInt() : 64; }
+    int sppPerLaunch() const
+    {
+        if (!m_json["spp_per_launch"].isNumber()) { return 64; }
+        const double value = m_json["spp_per_launch"].asNumber();
+        if (!(value >= 1.0) || value > 1e6) { throw std::runtime_error("job: spp_per_launch must be in [1, 1000000]"); }
+        return (int)value;
+    }
+    bool resume() const { return m_json["resume"].isBool() && m_json["resume"].asBool(); }
+    std::vector<int> devices() const;
     int gpu() const { return m_json["gpu"].isNumber() ? m_json["gpu"].asInt() : 0; }
     std::string assetRoot() const { return m_json["asset_root"].isString() ? m_json["asset_root"].asString() : ""; }
     std::string bvhBuilder() const { return m_json["bvh_builder"].isString() ? m_json["bvh_builder"].asString() : "sah"; }

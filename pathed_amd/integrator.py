@@ -33,22 +33,43 @@ def measure_bandwidth(gib=2.0, repeats=10):
     return read.value, copy.value
 
 
+def measure_valu(waves_per_simd=4, repeats=10):
+    """(v_fma_f32, fma + rcp/sqrt mix) wave-instructions per second the device sustains (pathed_hip_measure_valu)."""
+    lib = _capi.load_hip()
+    fma, mixed = C.c_double(0.0), C.c_double(0.0)
+    _check(lib, lib.pathed_hip_measure_valu(int(waves_per_simd), int(repeats), C.byref(fma), C.byref(mixed)),
+           "pathed_hip_measure_valu")
+    return fma.value, mixed.value
+
+
 class HipScene:
-    """A scene uploaded to one GPU (PathedScene handle)."""
+    """A scene uploaded to one GPU (PathedScene handle).
+
+    Keyword options map onto PathedSceneOptions (include/pathed_hip.h): stack_rows, pools,
+    suspend_lanes, suspend_patience, park_min_cards, max_slots, intersector ("auto" | "bvh"),
+    trace_blocks_per_cu.  `device=None` keeps the device of an earlier pathed_hip_init.
+    """
 
     BVH_BUILDERS = {"sah": 0, "lbvh": 1, "ploc": 2}  # PATHED_BVH_SAH_HOST / _LBVH_DEVICE / _PLOC_DEVICE
 
-    def __init__(self, desc_pointer, device=None, bvh_builder="sah"):
+    def __init__(self, desc_pointer, device=None, bvh_builder="sah", **options):
         self._lib = _capi.load_hip()
-        if device is not None:
-            _check(self._lib, self._lib.pathed_hip_init(int(device)), "pathed_hip_init")
+        packed = _capi.PathedSceneOptions()
+        packed.struct_size = C.sizeof(_capi.PathedSceneOptions)
+        packed.device = _capi.DEVICE_CURRENT if device is None else int(device)
+        packed.bvh_builder = self.BVH_BUILDERS[bvh_builder] + 1
+        intersector = options.pop("intersector", "auto")
+        packed.intersector = {"auto": 0, "bvh": 1}[intersector]
+        for name in ("stack_rows", "pools", "suspend_lanes", "suspend_patience", "park_min_cards", "max_slots", "trace_blocks_per_cu"):
+            if name in options:
+                setattr(packed, name, int(options.pop(name)))
+        if options:
+            raise TypeError("unknown scene options: %s" % sorted(options))
         handle = C.c_void_p()
-        _check(self._lib, self._lib.pathed_hip_set_bvh_builder(self.BVH_BUILDERS[bvh_builder]), "pathed_hip_set_bvh_builder")
-        try:
-            _check(self._lib, self._lib.pathed_hip_scene_create(desc_pointer, C.byref(handle)), "pathed_hip_scene_create")
-        finally:
-            self._lib.pathed_hip_set_bvh_builder(0)
+        _check(self._lib, self._lib.pathed_hip_scene_create_ex(desc_pointer, C.byref(packed), C.byref(handle)),
+               "pathed_hip_scene_create_ex")
         self._handle = handle
+        self.device = int(self._lib.pathed_hip_scene_device(handle))
         self.width = int(desc_pointer.contents.camera.width)
         self.height = int(desc_pointer.contents.camera.height)
 
@@ -154,7 +175,9 @@ class PathTracer:
         self.bounce_controller = bounce_controller
         self.spp = spp
         self.seed = seed
-        self.spp_per_launch = spp_per_launch
+        if int(spp_per_launch) < 1:
+            raise PathedError("spp_per_launch must be >= 1")
+        self.spp_per_launch = int(spp_per_launch)
 
     def run(self, image, scene, callback=None, quit_flag=None):
         """image: float32 (H, W, 3) array that receives the running mean; scene: HipScene."""

@@ -8,9 +8,10 @@ of one node (one process per GPU, RCCL reduce of the radiance sums to rank 0).
 
 Same job.json keys, output files and log lines as the reference (src/job.cpp:33-63,
 src/integrator.cpp:69-102): <output_directory>/report.json, auto.exr, auto-%05dspp.exr at every
-power-of-two sample count, "[<outdir>/] sample: i/N (Xs elapsed)".  Between two checkpoints rank r
-renders a contiguous share of the sample indices (pathed_amd/parallel.py), so the final sums equal
-the single-GPU sums up to fp32 summation order.
+power-of-two sample count (and only there, like the reference), "[<outdir>/] sample: i/N (Xs elapsed)".
+Every batch of samples is split over the ranks (contiguous shares, pathed_amd/parallel.py) and each rank
+keeps adding into its own sums; they are reduced only when a checkpoint is due, so the image at every
+checkpoint holds exactly the samples [0, n): the single-GPU image up to fp32 summation order.
 """
 import ctypes as C
 import json
@@ -53,46 +54,67 @@ def main(argv=None):
         raise SystemExit("Unimplemented")  # the reference throws "Unimplemented" (src/job.cpp:96)
     out_dir = job["output_directory"] + "/"
 
+    # rank 0 decides whether the job may run (output directory rules, src/job.cpp:33-63) and tells the
+    # others BEFORE anyone builds a scene or enters a collective: every rank leaves with the same code
+    go = 1
     if rank == 0:
         if os.path.isdir(out_dir):
             print("Output directory already exists: %s" % out_dir)
             if not job.get("force", False):
-                raise SystemExit(1)
-        os.makedirs(out_dir, exist_ok=True)
-        with open(os.path.join(out_dir, "report.json"), "w") as handle:
-            json.dump(job, handle, indent=4)
+                go = 0
+        if go:
+            os.makedirs(out_dir, exist_ok=True)
+            with open(os.path.join(out_dir, "report.json"), "w") as handle:
+                json.dump(job, handle, indent=4)
+    if world_size > 1:
+        decision = torch.tensor([go], dtype=torch.int32, device="cuda")
+        dist.broadcast(decision, src=0)
+        go = int(decision.item())
+    if not go:
+        if world_size > 1:
+            dist.destroy_process_group()
+        return 1
+
+    spp_per_launch = int(job.get("spp_per_launch", 64))
+    if spp_per_launch < 1:
+        raise SystemExit("spp_per_launch must be >= 1")
 
     scene = LoadedScene(job["scene"], width, height, asset_root if asset_root is not None else job.get("asset_root"))
     gpu = HipScene(scene.desc, device=local_rank, bvh_builder=job.get("bvh_builder", "sah"))
     host = _capi.load_host()
     stream = torch.cuda.current_stream().cuda_stream
 
-    accum = torch.zeros((height, width, 3), dtype=torch.float32, device="cuda")   # this rank's sums
-    total = torch.zeros_like(accum) if rank == 0 else None                         # reduced sums so far
+    # this rank's sums; they keep growing, and are reduced only when an image is due: at the power-of-two
+    # checkpoints (src/integrator.cpp:87-92) and at the end.  The union over ranks of what has been
+    # rendered is always exactly the samples [0, done).
+    accum = torch.zeros((height, width, 3), dtype=torch.float32, device="cuda")
+    total = torch.zeros_like(accum)
     done = 0
     while done < spp:
         next_power = 1
         while next_power <= done:
             next_power *= 2
-        count = min(next_power, spp) - done          # up to the next checkpoint
+        count = min(next_power, spp, done + spp_per_launch * world_size) - done
         begin, mine = parallel.strong_range(rank, world_size, done, count)
         t0 = time.perf_counter()
-        accum.zero_()
         if mine > 0:
             gpu.render_device(seed, begin, mine, bounces.start_bounce, bounces.last_bounce, accum.data_ptr(), stream)
-        parallel.reduce_to_root(accum, root=0)
+        done += count
+        checkpoint = (done & (done - 1)) == 0
+        if checkpoint or done == spp:
+            total.copy_(accum)
+            parallel.reduce_to_root(total, root=0)
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
-        done += count
         if rank == 0:
-            total += accum
-            mean = (total / float(done)).cpu().numpy()
-            pointer = mean.ctypes.data_as(C.POINTER(C.c_float))
-            for name in ("auto.exr", "auto-%05dspp.exr" % done):
-                path = os.path.join(out_dir, name)
-                if host.pathed_host_write_exr_half_bgr(path.encode(), width, height, pointer) != 0:
-                    raise RuntimeError(host.pathed_host_last_error().decode())
-                print("Saved exr file. [ %s ] " % path)
+            if checkpoint:
+                mean = (total / float(done)).cpu().numpy()
+                pointer = mean.ctypes.data_as(C.POINTER(C.c_float))
+                for name in ("auto.exr", "auto-%05dspp.exr" % done):
+                    path = os.path.join(out_dir, name)
+                    if host.pathed_host_write_exr_half_bgr(path.encode(), width, height, pointer) != 0:
+                        raise RuntimeError(host.pathed_host_last_error().decode())
+                    print("Saved exr file. [ %s ] " % path)
             print("[%s] sample: %d/%d (%.1fs elapsed)" % (out_dir, done, spp, elapsed), flush=True)
 
     if world_size > 1:

@@ -31,8 +31,9 @@ def test_struct_sizes_match_the_header():
     import tempfile
     source = (
         '#include "pathed_hip.h"\n#include <stdio.h>\n'
-        'int main(void){printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(PathedCamera), sizeof(PathedMaterial),'
-        ' sizeof(PathedSphere), sizeof(PathedGeom), sizeof(PathedEnvLight), sizeof(PathedSceneDesc), sizeof(PathedStats));return 0;}\n'
+        'int main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(PathedCamera), sizeof(PathedMaterial),'
+        ' sizeof(PathedSphere), sizeof(PathedGeom), sizeof(PathedEnvLight), sizeof(PathedSceneDesc), sizeof(PathedStats),'
+        ' sizeof(PathedSceneOptions));return 0;}\n'
     )
     with tempfile.TemporaryDirectory() as tmp:
         c_file = os.path.join(tmp, "sizes.c")
@@ -41,7 +42,7 @@ def test_struct_sizes_match_the_header():
         subprocess.run(["gcc", "-I", os.path.join(_capi.REPO_ROOT, "include"), c_file, "-o", exe], check=True)
         sizes = [int(x) for x in subprocess.run([exe], check=True, capture_output=True, text=True).stdout.split()]
     expected = [C.sizeof(t) for t in (_capi.PathedCamera, _capi.PathedMaterial, _capi.PathedSphere, _capi.PathedGeom,
-                                      _capi.PathedEnvLight, _capi.PathedSceneDesc, _capi.PathedStats)]
+                                      _capi.PathedEnvLight, _capi.PathedSceneDesc, _capi.PathedStats, _capi.PathedSceneOptions)]
     assert sizes == expected
 
 

@@ -109,3 +109,79 @@ def test_bvh_builder_job_key_changes_the_build_not_the_image(tmp_path):
         assert result.returncode == 0, result.stdout + result.stderr
         files[builder] = open(os.path.join(out_dir, "auto-00004spp.exr"), "rb").read()
     assert files["sah"] == files["ploc"] == files["lbvh"]
+
+
+def _read_state(path):
+    """<outdir>/auto.state: 40-byte header (magic, w, h, done, startBounce, lastBounce, seed) + fp32 sums."""
+    blob = open(path, "rb").read()
+    assert blob[:8] == b"PATHEDS1"
+    width, height, done, start, last = np.frombuffer(blob, dtype="<i4", count=5, offset=8)
+    sums = np.frombuffer(blob, dtype="<f4", offset=40).reshape(height, width, 3)
+    return int(done), sums
+
+
+def _run_job(tmp_path, name, job):
+    from pathed_amd import _capi
+    out_dir = str(tmp_path / name)
+    job = dict(job, output_directory=out_dir)
+    job_path = str(tmp_path / (name + ".json"))
+    json.dump(job, open(job_path, "w"))
+    exe = os.path.join(_capi.REPO_ROOT, "pathed_amd", "bin", "pathed")
+    result = subprocess.run([exe, job_path, _capi.REPO_ROOT], capture_output=True, text=True, cwd=str(tmp_path))
+    return out_dir, result
+
+
+def test_gpus_job_key_fans_the_samples_out_and_sums_them_back(tmp_path):
+    """job.json "gpus": the C++ host renders every batch on several scene replicas (one worker thread
+    each) and sums their buffers on replica 0.  Two replicas on the one GPU of this box ([0, 0])
+    against one: the same samples [0, n) at every checkpoint, so the fp32 sums agree to summation order;
+    three replicas leave a ragged split (16 = 6 + 5 + 5)."""
+    from pathed_amd import _capi
+    job = json.load(open(os.path.join(_capi.REPO_ROOT, "jobs", "cornell-c1.json")))
+    job["scene"] = "scenes/cornell-glossy.json"
+    job["width"], job["height"], job["spp"] = 80, 64, 16
+    single_dir, result = _run_job(tmp_path, "single", job)
+    assert result.returncode == 0, result.stdout + result.stderr
+    done, single = _read_state(os.path.join(single_dir, "auto.state"))
+    assert done == 16
+    for name, gpus in (("two", [0, 0]), ("three", [0, 0, 0])):
+        out_dir, result = _run_job(tmp_path, name, dict(job, gpus=gpus))
+        assert result.returncode == 0, result.stdout + result.stderr
+        done, several = _read_state(os.path.join(out_dir, "auto.state"))
+        assert done == 16
+        rel = np.linalg.norm(several - single) / np.linalg.norm(single)
+        assert rel < 1e-6, (name, rel)
+        for spp in (1, 2, 4, 8, 16):
+            assert os.path.exists(os.path.join(out_dir, "auto-%05dspp.exr" % spp))
+        metrics = json.load(open(os.path.join(out_dir, "metrics.json")))
+        assert metrics["devices"] == gpus and len(metrics["replica_seconds"]) == len(gpus)
+        assert metrics["last_sample"] == 16 and metrics["msamples_per_second"] > 0 and metrics["reduces"] == 5
+    # a device this box does not have is an error, not a crash
+    _, result = _run_job(tmp_path, "absent", dict(job, gpus=[0, 63]))
+    assert result.returncode != 0 and "device" in (result.stdout + result.stderr)
+
+
+def test_resumed_job_continues_bit_identically(tmp_path):
+    """"resume": true reloads <outdir>/auto.state (fp32 sums + sample count) and goes on from there.  The random
+    stream is a function of (seed, pixel, sample, dimension), so 8 samples now + 8 later are the 16-sample
+    run bit for bit; a state file from another seed is refused."""
+    from pathed_amd import _capi
+    job = json.load(open(os.path.join(_capi.REPO_ROOT, "jobs", "cornell-c1.json")))
+    job["width"], job["height"] = 72, 56
+    straight_dir, result = _run_job(tmp_path, "straight", dict(job, spp=16))
+    assert result.returncode == 0, result.stdout + result.stderr
+    first_dir, result = _run_job(tmp_path, "resumed", dict(job, spp=8))
+    assert result.returncode == 0, result.stdout + result.stderr
+    assert _read_state(os.path.join(first_dir, "auto.state"))[0] == 8
+    second_dir, result = _run_job(tmp_path, "resumed", dict(job, spp=16, resume=True))
+    assert result.returncode == 0, result.stdout + result.stderr
+    assert "resuming at sample 8/16" in result.stdout and "sample: 16/16" in result.stdout and "sample: 4/16" not in result.stdout
+    done, resumed = _read_state(os.path.join(second_dir, "auto.state"))
+    done_straight, straight = _read_state(os.path.join(straight_dir, "auto.state"))
+    assert done == done_straight == 16
+    assert np.array_equal(resumed, straight)
+    assert open(os.path.join(second_dir, "auto-00016spp.exr"), "rb").read() == open(os.path.join(straight_dir, "auto-00016spp.exr"), "rb").read()
+    _, result = _run_job(tmp_path, "resumed", dict(job, spp=32, resume=True, seed=5))
+    assert result.returncode != 0 and "seed" in (result.stdout + result.stderr)
+    _, result = _run_job(tmp_path, "bad-launch", dict(job, spp_per_launch=0))
+    assert result.returncode != 0 and "spp_per_launch" in (result.stdout + result.stderr)

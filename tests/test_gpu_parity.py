@@ -267,62 +267,58 @@ def test_full_size_properties(libs):
     assert lit.shape[0] > 1000 and torch.equal(lit, torch.tensor([17.0, 12.0, 4.0], device="cuda").expand_as(lit))
 
 
-def _render_with_env(libs, env, scene_path, size, seed, spp):
-    """Scene-creation-time switches (PATHED_POOLS, PATHED_NO_BRUTE_FORCE, ...) are read from the
-    environment when the scene is created."""
+def _render_with_options(libs, options, scene_path, size, seed, spp, count=False):
+    """Scene-creation-time switches travel in PathedSceneOptions (include/pathed_hip.h)."""
     _, HipScene, LoadedScene = libs
-    saved = {key: os.environ.get(key) for key in env}
-    os.environ.update(env)
-    try:
-        scene = LoadedScene(scene_path, size, size)
-        gpu = HipScene(scene.desc, device=0)
-        return gpu.render(seed, 0, spp, 0, 10), gpu.stats()
-    finally:
-        for key, value in saved.items():
-            if value is None:
-                os.environ.pop(key, None)
-            else:
-                os.environ[key] = value
+    scene = LoadedScene(scene_path, size, size)
+    gpu = HipScene(scene.desc, device=0, **options)
+    if count:
+        gpu.set_stats_mode(count=True)
+        gpu.reset_stats()
+    return gpu.render(seed, 0, spp, 0, 10), gpu.stats()
 
 
 def test_result_does_not_depend_on_scheduling_or_intersector_variant(libs):
     """One pool or two, all-triangles kernel or LDS-resident BVH walk: the image is bit-identical,
     because hits follow an order-independent acceptance rule and the per-pixel summation order is
     fixed by the unit decomposition, not by which slot happened to render which unit."""
-    base, base_stats = _render_with_env(libs, {"PATHED_POOLS": "1"}, "scenes/cornell.json", 160, 11, 12)
+    base, base_stats = _render_with_options(libs, {"pools": 1}, "scenes/cornell.json", 160, 11, 12)
     assert base_stats["scene_in_lds"] == 2
-    for pools in ("2", "3", "4"):
-        several, _ = _render_with_env(libs, {"PATHED_POOLS": pools}, "scenes/cornell.json", 160, 11, 12)
+    for pools in (2, 3, 4):
+        several, _ = _render_with_options(libs, {"pools": pools}, "scenes/cornell.json", 160, 11, 12)
         assert np.array_equal(base, several), pools
-    bvh, bvh_stats = _render_with_env(libs, {"PATHED_NO_BRUTE_FORCE": "1"}, "scenes/cornell.json", 160, 11, 12)
+    bvh, bvh_stats = _render_with_options(libs, {"intersector": "bvh"}, "scenes/cornell.json", 160, 11, 12)
     assert bvh_stats["scene_in_lds"] == 1
     assert np.array_equal(base, bvh)
-    few_slots, _ = _render_with_env(libs, {"PATHED_MAX_SLOTS": "4096"}, "scenes/cornell.json", 160, 11, 12)
+    few_slots, _ = _render_with_options(libs, {"max_slots": 4096}, "scenes/cornell.json", 160, 11, 12)
     assert np.array_equal(base, few_slots)
     # a BVH scene (1 112 triangles, nodes in HBM/L2), one pool vs two
-    glass_one, stats = _render_with_env(libs, {"PATHED_POOLS": "1"}, "scenes/cornell-glass.json", 128, 3, 8)
+    glass_one, stats = _render_with_options(libs, {"pools": 1}, "scenes/cornell-glass.json", 128, 3, 8)
     assert stats["scene_in_lds"] == 0
-    for pools in ("2", "3"):
-        glass_several, _ = _render_with_env(libs, {"PATHED_POOLS": pools, "PATHED_MAX_SLOTS": "20000"}, "scenes/cornell-glass.json", 128, 3, 8)
+    for pools in (2, 3):
+        glass_several, _ = _render_with_options(libs, {"pools": pools, "max_slots": 20000}, "scenes/cornell-glass.json", 128, 3, 8)
         assert np.array_equal(glass_one, glass_several), pools
 
 
-def _render_counted(libs, env, scene_path, size, seed, spp):
+def test_scene_options_are_validated(libs):
+    """PathedSceneOptions: wrong struct size, unknown builder, bad stack rows are PATHED_E_INVALID, not a crash."""
+    import ctypes as C
+    from pathed_amd import _capi
+    from pathed_amd.integrator import PathedError
     _, HipScene, LoadedScene = libs
-    saved = {key: os.environ.get(key) for key in env}
-    os.environ.update(env)
-    try:
-        scene = LoadedScene(scene_path, size, size)
-        gpu = HipScene(scene.desc, device=0)
-        gpu.set_stats_mode(count=True)
-        gpu.reset_stats()
-        return gpu.render(seed, 0, spp, 0, 10), gpu.stats()
-    finally:
-        for key, value in saved.items():
-            if value is None:
-                os.environ.pop(key, None)
-            else:
-                os.environ[key] = value
+    scene = LoadedScene("scenes/cornell.json", 16, 16)
+    with pytest.raises(PathedError):
+        HipScene(scene.desc, device=0, stack_rows=9)
+    with pytest.raises(PathedError):
+        HipScene(scene.desc, device=0, pools=7)
+    with pytest.raises(PathedError):
+        HipScene(scene.desc, device=4096)
+    lib = _capi.load_hip()
+    options = _capi.PathedSceneOptions()
+    options.struct_size = 12
+    handle = C.c_void_p()
+    assert lib.pathed_hip_scene_create_ex(scene.desc, C.byref(options), C.byref(handle)) == -1
+    assert HipScene(scene.desc, device=0).device == 0
 
 
 def test_rays_carried_over_between_trace_launches_change_nothing(libs):
@@ -330,14 +326,14 @@ def test_rays_carried_over_between_trace_launches_change_nothing(libs):
     traversal stack) to the next launch instead of idling on them.  With that switched off, on, or
     set so eagerly that most waves hand rays on every launch, the image is the same bit for bit."""
     # one block per CU: each wave draws enough cards to run well past the minimum step count
-    few_waves = {"PATHED_TRACE_BLOCKS_PER_CU": "1"}
-    off, off_stats = _render_counted(libs, dict(few_waves, PATHED_SUSPEND_LANES="0"), "scenes/cornell-glass.json", 384, 5, 8)
+    few_waves = {"trace_blocks_per_cu": 1}
+    off, off_stats = _render_with_options(libs, dict(few_waves, suspend_lanes=-1), "scenes/cornell-glass.json", 384, 5, 8, count=True)
     assert off_stats["scene_in_lds"] == 0 and off_stats["parked_rays"] == 0
-    default, default_stats = _render_counted(libs, few_waves, "scenes/cornell-glass.json", 384, 5, 8)
+    default, default_stats = _render_with_options(libs, few_waves, "scenes/cornell-glass.json", 384, 5, 8, count=True)
     assert default_stats["parked_rays"] > 0
     assert np.array_equal(off, default)
-    eager, eager_stats = _render_counted(libs, dict(few_waves, PATHED_SUSPEND_LANES="64", PATHED_SUSPEND_PATIENCE="0"),
-                                         "scenes/cornell-glass.json", 384, 5, 8)
+    eager, eager_stats = _render_with_options(libs, dict(few_waves, suspend_lanes=64, suspend_patience=-1),
+                                              "scenes/cornell-glass.json", 384, 5, 8, count=True)
     assert eager_stats["parked_rays"] > default_stats["parked_rays"]
     assert np.array_equal(off, eager)
     assert eager_stats["closest_rays"] == off_stats["closest_rays"]
@@ -351,29 +347,18 @@ def test_traversal_stack_spill_to_hbm_changes_nothing(libs):
     spills for a large share of the rays, in the test hook, in the render kernel and in the
     records of parked rays: hits and image stay bit-identical."""
     oracle_lib, HipScene, LoadedScene = libs
-    saved = os.environ.get("PATHED_STACK_ROWS")
-    try:
-        os.environ["PATHED_STACK_ROWS"] = "8"
-        scene = LoadedScene("scenes/teapot.json", 96, 96)
-        spilling = HipScene(scene.desc, device=0)
-        assert spilling.stats()["bvh_max_depth"] * 3 + 1 > 8
-        rays = _rays(100000, 21, (0, 4, 0), 9.0)
-        hits = spilling.trace(rays)
-        occluded = spilling.trace(rays, any_hit=True)
-        few_waves = {"PATHED_TRACE_BLOCKS_PER_CU": "1", "PATHED_SUSPEND_LANES": "64", "PATHED_SUSPEND_PATIENCE": "0",
-                     "PATHED_PARK_MIN_CARDS": "0"}  # park although the pool is small
-        os.environ.update(few_waves)
-        parked_scene = HipScene(scene.desc, device=0)
-        parked_scene.set_stats_mode(count=True)
-        image = parked_scene.render(3, 0, 8, 0, 8)
-        assert parked_scene.stats()["parked_rays"] > 0
-    finally:
-        for key in ("PATHED_TRACE_BLOCKS_PER_CU", "PATHED_SUSPEND_LANES", "PATHED_SUSPEND_PATIENCE", "PATHED_PARK_MIN_CARDS"):
-            os.environ.pop(key, None)
-        if saved is None:
-            os.environ.pop("PATHED_STACK_ROWS", None)
-        else:
-            os.environ["PATHED_STACK_ROWS"] = saved
+    scene = LoadedScene("scenes/teapot.json", 96, 96)
+    spilling = HipScene(scene.desc, device=0, stack_rows=8)
+    assert spilling.stats()["bvh_max_depth"] * 3 + 1 > 8
+    rays = _rays(100000, 21, (0, 4, 0), 9.0)
+    hits = spilling.trace(rays)
+    occluded = spilling.trace(rays, any_hit=True)
+    # park although the pool is small
+    parked_scene = HipScene(scene.desc, device=0, stack_rows=8, trace_blocks_per_cu=1, suspend_lanes=64,
+                            suspend_patience=-1, park_min_cards=-1)
+    parked_scene.set_stats_mode(count=True)
+    image = parked_scene.render(3, 0, 8, 0, 8)
+    assert parked_scene.stats()["parked_rays"] > 0
     cpu = oracle_lib.OracleScene(scene.desc)
     assert np.array_equal(hits.view(np.int32), cpu.trace(rays).view(np.int32))
     assert np.array_equal(occluded, cpu.trace(rays, any_hit=True))

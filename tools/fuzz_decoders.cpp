@@ -43,6 +43,25 @@ int main(int argc, char **argv) {
             good ? ok++ : failed++;
         }
     }
+    // directed case: every 8-byte field in the head of an EXR file (among them the entries of the block-offset
+    // table) replaced by a value just below 2^64 -- an offset check written `pos + 8 > size` wraps and passes
+    for (int a = 2; a < argc; a++) {
+        if (std::string(argv[a]).find(".exr") == std::string::npos) { continue; }
+        std::ifstream in(argv[a], std::ios::binary);
+        const std::vector<unsigned char> original((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+        if (original.size() > (1u << 20)) { continue; }
+        const size_t span = original.size() < 8 ? 0 : (original.size() - 8 < 1024 ? original.size() - 8 : 1024);
+        for (size_t at = 0; at < span; at++) {
+            std::vector<unsigned char> data = original;
+            const unsigned char huge[8] = { 0xFA, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF };   // little-endian 0xFFFFFFFFFFFFFFFA
+            for (int k = 0; k < 8; k++) { data[at + k] = huge[k]; }
+            { std::ofstream out(scratch.c_str(), std::ios::binary); out.write((const char *)data.data(), (std::streamsize)data.size()); }
+            std::string error;
+            int w = 0, h = 0;
+            std::vector<float> rgba;
+            pathed::readExrRGBA(scratch.c_str(), &w, &h, &rgba, &error) ? ok++ : failed++;
+        }
+    }
     remove(scratch.c_str());
     printf("decoded %ld, rejected %ld, no crash\n", ok, failed);
     return 0;

@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""Condenses the passes of tools/pmc_per_sample.sh (gpurun_out/pmcps_<tag>/) into profiles/pmc_per_sample.json:
+per workload and per camera sample, the VALU wave-instructions issued and the HBM bytes moved (2 x FETCH_SIZE +
+WRITE_SIZE, KiB -> bytes: on gfx950 FETCH_SIZE reports half the bytes of wide coalesced reads, MI355X_MICROARCH.md
+§HBM), split into the trace kernels and everything else of the pipeline ("shade": stage, init and resolve kernels).
+Also keeps the per-kernel per-launch averages the totals come from.  Usage: tools/summarize_pmc_per_sample.py <tag>"""
+import collections
+import csv
+import glob
+import hashlib
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r2"
+base = os.path.join(ROOT, "gpurun_out", "pmcps_" + tag)
+
+
+def digest():
+    sha = hashlib.sha1()
+    directory = os.path.join(ROOT, "pathed_amd", "csrc")
+    for name in sorted(os.listdir(directory)):
+        sha.update(open(os.path.join(directory, name), "rb").read())
+    return sha.hexdigest()[:16]
+
+
+def totals(name):
+    """{counter: {kernel: [launches, total]}} over the pathed:: kernels of one pass"""
+    out = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
+    for path in glob.glob(os.path.join(base, name, "*", "*_counter_collection.csv")):
+        for row in csv.DictReader(open(path)):
+            kernel = row["Kernel_Name"].split("(")[0]
+            if "pathed::" not in kernel:
+                continue
+            entry = out[row["Counter_Name"]][kernel]
+            entry[0] += 1
+            entry[1] += float(row["Counter_Value"])
+    return out
+
+
+def kernel_class(kernel):
+    return "trace" if "k_trace" in kernel else "shade"
+
+
+def workload(prefix, samples, with_valu):
+    entry = {"samples": samples, "kernel_sources": digest()}
+    per_kernel = collections.defaultdict(dict)
+    if with_valu:
+        valu = totals(prefix + "_valu")
+        entry["valu_wave_instructions_per_sample"] = sum(v[1] for v in valu["SQ_INSTS_VALU"].values()) / samples
+        lanes = sum(v[1] for v in valu["SQ_THREAD_CYCLES_VALU"].values())
+        active = sum(v[1] for v in valu["SQ_ACTIVE_INST_VALU"].values())
+        if active > 0:
+            # SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU = lanes active per VALU issue cycle group: lane utilisation of 64
+            entry["valu_lane_utilisation"] = lanes / active / 64.0
+        for counter, kernels in valu.items():
+            for kernel, (launches, total) in kernels.items():
+                per_kernel[kernel][counter + "_per_launch"] = total / launches
+                per_kernel[kernel]["launches"] = launches
+    fetch = totals(prefix + "_fetch")["FETCH_SIZE"]
+    write = totals(prefix + "_write")["WRITE_SIZE"]
+    classes = collections.defaultdict(float)
+    for kernel, (launches, total) in fetch.items():
+        classes[kernel_class(kernel)] += 2.0 * total * 1024.0
+        per_kernel[kernel]["FETCH_SIZE_KiB_per_launch"] = total / launches
+        per_kernel[kernel]["launches"] = launches
+    for kernel, (launches, total) in write.items():
+        classes[kernel_class(kernel)] += total * 1024.0
+        per_kernel[kernel]["WRITE_SIZE_KiB_per_launch"] = total / launches
+    entry["hbm_bytes_per_sample"] = {name: value / samples for name, value in sorted(classes.items())}
+    entry["kernels"] = {kernel: dict(sorted(values.items())) for kernel, values in sorted(per_kernel.items())}
+    return entry
+
+
+summary = {
+    "note": "rocprofv3 --pmc passes of tools/pmc_per_sample.sh, one counter group per pass, over exactly the timed path's kernels; "
+            "HBM bytes = 2 x FETCH_SIZE + WRITE_SIZE (gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md)",
+    "tag": tag,
+    "cornell_1024": workload("cornell", 1024 * 1024 * 256, True),
+    "large_bvh": workload("dragon", 1920 * 1080 * 64, False),
+}
+out = os.path.join(ROOT, "profiles", "pmc_per_sample.json")
+json.dump(summary, open(out, "w"), indent=1)
+for name in ("cornell_1024", "large_bvh"):
+    entry = summary[name]
+    print(name, {k: v for k, v in entry.items() if k not in ("kernels",)})
