@@ -276,7 +276,7 @@ def run_rank(args):
         world_size = dist.get_world_size()   # the ranks RCCL actually sees
 
     from pathed_amd import parallel
-    from pathed_amd.integrator import HipScene, measure_bandwidth, measure_valu
+    from pathed_amd.integrator import HipScene, measure_bandwidth
     from pathed_amd.scene import LoadedScene
 
     scene = LoadedScene(args.scene, args.width, args.height)
@@ -364,13 +364,15 @@ def run_rank(args):
 
         roofline = None
         if timing and counted is not None:
-            rates = kernel_rates(counted, counted_samples, timed, my_samples)
+            fused = counted["path_kernel"] == 3
+            rates = None if fused else kernel_rates(counted, counted_samples, timed, my_samples)
             measured_read, measured_copy = measure_bandwidth(gib=2.0, repeats=10)
             workload_key = "cornell_1024" if (args.scene, args.width, args.height) == ("scenes/cornell.json", 1024, 1024) else None
             pmc = pmc_per_sample(workload_key) if workload_key else None
+            launches = timed["trace_launches_all"]
             traffic = None
-            if pmc and rates and "hbm_bytes_per_sample" in pmc:
-                traffic = sum(pmc["hbm_bytes_per_sample"].values()) * my_samples / rates["launches"]
+            if pmc and launches and "hbm_bytes_per_sample" in pmc:
+                traffic = sum(pmc["hbm_bytes_per_sample"].values()) * my_samples / launches
             hbm = None
             if rates:
                 # the kernel that takes the larger share of the timed region is the dominant one
@@ -387,22 +389,30 @@ def run_rank(args):
                 }
             if counted["scene_in_lds"] == 2:
                 # All-triangles scenes (<= 64 triangles: every ray query runs out of registers and scalar loads):
-                # neither HBM nor MFMA bounds the pipeline, VALU issue does.  Denominator: what independent
-                # v_fma_f32 streams reach on THIS box at the pipeline's occupancy (pathed_hip_measure_valu);
-                # numerator: SQ_INSTS_VALU per camera sample from the committed PMC pass x samples / s live.
-                fma4, mixed4 = measure_valu(waves_per_simd=4, repeats=10)
-                fma1, _ = measure_valu(waves_per_simd=1, repeats=10)
-                issued = pmc["valu_wave_instructions_per_sample"] * total_samples / world_size if pmc else None
+                # neither HBM nor MFMA bounds the path, VALU issue does.  Denominator: the best rate any occupancy
+                # reaches on THIS box with independent v_fma_f32 on VGPR operands (pathed_hip_measure_valu_modes);
+                # numerator: SQ_INSTS_VALU per camera sample from the committed PMC pass x the samples of the timed
+                # region / the kernels' own time, measured live with HIP events (fused kernel: every launch).
+                from pathed_amd.integrator import VALU_MODES, measure_valu_modes
+                probes = {waves: measure_valu_modes(waves, repeats=5) for waves in (1, 4, 8)}
+                peak = max(row[2] for row in probes.values())
+                issued = pmc["valu_wave_instructions_per_sample"] * my_samples if pmc else None
+                kernel_s = (timed["trace_ms"] * 1e-3) if fused and timed["trace_ms"] > 0 else rendered
                 roofline = {
                     "bound": "valu",
-                    "kernel": "whole pipeline (k_trace_small + k_shade, both pools): all-triangles scene, ray queries never leave the registers",
-                    "achieved": (issued / elapsed / 1e9) if issued else None,
-                    "peak": fma4 / 1e9,
+                    "kernel": "k_path_small (fused: camera ray .. termination in registers, one persistent launch per pass)" if fused
+                              else "whole wavefront pipeline (k_trace_small + shade kernel, both pools)",
+                    "achieved": (issued / kernel_s / 1e9) if issued else None,
+                    "peak": peak / 1e9,
                     "unit": "G wave-instr/s",
-                    "frac": (issued / elapsed / fma4) if issued else None,
+                    "frac": (issued / kernel_s / peak) if issued else None,
                     "traffic": traffic,
-                    "peak_note": "v_fma_f32 wave-instructions/s measured on this box at 4 waves/SIMD, independent chains "
-                                 "(1 wave/SIMD: %.0f G/s; with a v_rcp/v_sqrt pair per 6 fma: %.0f G/s)" % (fma1 / 1e9, mixed4 / 1e9),
+                    "kernel_seconds": kernel_s, "launches": launches,
+                    "rays_per_sample": (counted["closest_rays"] + counted["shadow_rays"]) / float(counted_samples),
+                    "peak_note": "best of the occupancies probed on this box, v_fma_f32 on three VGPR operands, independent chains; "
+                                 "G wave-instr/s by instruction mix and waves per SIMD below",
+                    "peak_probe": {"modes": list(VALU_MODES),
+                                   "waves_per_simd": {str(waves): [rate / 1e9 for rate in row] for waves, row in probes.items()}},
                     "instructions_source": None if not pmc else {
                         "file": "profiles/pmc_per_sample.json", "valu_wave_instructions_per_sample": pmc["valu_wave_instructions_per_sample"],
                         "stale": pmc["stale"]},

@@ -196,6 +196,9 @@ typedef struct PathedStats {
     double   bvh_build_ms;         /* scene_create's BVH build: host wall time (SAH) or HIP-event time (LBVH) */
     uint32_t bvh_builder;          /* PATHED_BVH_* the scene was built with                 */
     uint32_t trace_launches_all;   /* trace launches since reset_stats, timed or not (trace_launches counts the timed ones) */
+    uint32_t path_kernel;          /* 1 wavefront with the per-slot shade kernel, 2 wavefront with the staged shade kernel,
+                                      3 fused path kernel (tiny scenes: one persistent launch per pass, timed as trace_ms) */
+    uint32_t reserved0;
 } PathedStats;
 
 /* ---- life cycle ---------------------------------------------------------- */
@@ -245,7 +248,11 @@ typedef struct PathedSceneOptions {
     int32_t max_slots;          /* path slots (0 = 1 Mi for all-triangles scenes, 4 Mi for BVH scenes)         */
     int32_t intersector;        /* 0 automatic, 1 always walk the BVH (never the all-triangles kernel)         */
     int32_t trace_blocks_per_cu;/* persistent trace blocks per CU (0 = automatic)              */
-    int32_t reserved[5];        /* must be 0                                                   */
+    int32_t shade_kernel;       /* 0 automatic; 1 wavefront, k_shade (one lane per slot); 2 wavefront, k_shade_staged (dense,
+                                   state-sorted stages per block); 3 k_path_small (fused: whole paths in registers; scenes of
+                                   <= 64 triangles only, their default)                          */
+    int32_t stage_slots;        /* slots per block of the staged kernel: 512 or 1024 (0 = automatic)           */
+    int32_t reserved[3];        /* must be 0                                                   */
 } PathedSceneOptions;
 int pathed_hip_scene_create_ex(const PathedSceneDesc *desc, const PathedSceneOptions *options, PathedScene **out);
 int pathed_hip_scene_device(const PathedScene *scene);   /* the HIP device the scene lives on, or a negative error */
@@ -324,9 +331,13 @@ int pathed_hip_measure_bandwidth(size_t bytes, int repeats, double *read_gbs, do
  * registers (<= 64 triangles).  Runs `waves_per_simd` waves (1..8) on every SIMD of the chip, each
  * issuing `instructions_per_wave` INDEPENDENT v_fma_f32 (eight accumulator chains per lane, so no
  * wave ever waits on its own result), timed with HIP events over `repeats` launches.
- * fma_rate = v_fma_f32 wave-instructions / s; mixed_rate = the same with one v_rcp_f32 / v_sqrt_f32
- * pair per six v_fma_f32 (the quarter-rate instructions a path tracer's normalisations issue). */
+ * fma_rate = v_fma_f32 wave-instructions / s (one VGPR source, scalar multiplier and addend); mixed_rate = the
+ * same with one v_rcp_f32 / v_sqrt_f32 pair per six v_fma_f32 (what a path tracer's normalisations issue). */
 int pathed_hip_measure_valu(int waves_per_simd, int repeats, double *fma_rate, double *mixed_rate);
+/* The same probe over n_modes (<= 5) instruction mixes, rates[mode] in wave-instructions / s:
+ * 0 v_fma_f32 with one VGPR source (scalar multiplier / addend: no register-bank conflicts), 1 six of those + v_rcp_f32 +
+ * v_sqrt_f32, 2 v_fma_f32 with three VGPR sources, 3 v_pk_fma_f32 (two FMAs per lane), 4 v_mul_lo_u32. */
+int pathed_hip_measure_valu_modes(int waves_per_simd, int repeats, double *rates, int n_modes);
 
 /* ---- multi-GPU fan-in ------------------------------------------------------ */
 /* The path's one exchange step: per-GPU radiance sums -> one buffer (the reference's

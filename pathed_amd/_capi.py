@@ -123,6 +123,8 @@ class PathedStats(C.Structure):
         ("bvh_build_ms", C.c_double),
         ("bvh_builder", C.c_uint32),
         ("trace_launches_all", C.c_uint32),
+        ("path_kernel", C.c_uint32),
+        ("reserved0", C.c_uint32),
     ]
 
 
@@ -139,7 +141,9 @@ class PathedSceneOptions(C.Structure):
         ("max_slots", C.c_int32),
         ("intersector", C.c_int32),
         ("trace_blocks_per_cu", C.c_int32),
-        ("reserved", C.c_int32 * 5),
+        ("shade_kernel", C.c_int32),
+        ("stage_slots", C.c_int32),
+        ("reserved", C.c_int32 * 3),
     ]
 
 
@@ -163,6 +167,7 @@ HIP_SYMBOLS = [
     "pathed_hip_scene_export_bvh",
     "pathed_hip_measure_bandwidth",
     "pathed_hip_measure_valu",
+    "pathed_hip_measure_valu_modes",
     "pathed_hip_accum_copy_peer",
     "pathed_hip_accum_add",
     "pathed_hip_accum_alloc",
@@ -214,6 +219,8 @@ def load_hip():
     lib.pathed_hip_scene_device.restype = C.c_int
     lib.pathed_hip_measure_valu.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.pathed_hip_measure_valu.restype = C.c_int
+    lib.pathed_hip_measure_valu_modes.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_double), C.c_int]
+    lib.pathed_hip_measure_valu_modes.restype = C.c_int
     fp = C.POINTER(C.c_float)
     lib.pathed_hip_accum_copy_peer.argtypes = [vp, vp, vp, vp, C.c_size_t]
     lib.pathed_hip_accum_copy_peer.restype = C.c_int

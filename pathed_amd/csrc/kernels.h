@@ -135,6 +135,7 @@ struct RenderParams {
     unsigned int unitBase; // global id of the pool's first unit (pixel / chunk derive from the global id)
     int nQueues;           // min(kUnitQueues, shade blocks): every queue has a consumer
     unsigned int unitsPerQueue;
+    int unitGrab;          // k_path_small: units a wave reserves per atomic
     int chunk;             // samples per unit
     int chunksPerPixel;
     uint32_t seedLo, seedHi;
@@ -478,6 +479,85 @@ struct SmallTris {
 __device__ inline f2 splat2(float v) { f2 r = { v, v }; return r; }
 __device__ inline f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 
+// Phase 1 of the all-triangles intersector for ONE lane's ray (called under wave-uniform control flow):
+// a CONSERVATIVE inside test of every triangle on scalar-loaded records, two triangles per packed
+// instruction, that only RECORDS the candidates in a per-lane bitmask.  A line through the box pierces 4-6
+// triangles, so with 64 lanes "some lane is inside" is true for almost every triangle: doing the division
+// and the acceptance logic there made them two thirds of the instructions.  The test is
+// intersectTriangle()'s predicate with both det signs folded by multiplying through with det:
+// u det >= 0, v det >= 0, (det - u - v) det >= 0, t det >= 0, taken as "not (min < 0)" so that -0,
+// underflow and NaN all err on the side of keeping the candidate; phase 2 decides.  Bits are shifted in
+// (cand = 2 cand + bit), so triangle k of a 32-triangle word ends up at bit 31 - (k & 31).
+__device__ __forceinline__ void smallCandidates(const f2 *pairRecords, int nTris, V3 origin, V3 direction, unsigned int *low, unsigned int *high)
+{
+    const int nPairs = (nTris + 1) / 2;
+    unsigned int candidatesLow = 0, candidatesHigh = 0;
+    const f2 dx = splat2(direction.x), dy = splat2(direction.y), dz = splat2(direction.z);
+    const f2 ox = splat2(origin.x), oy = splat2(origin.y), oz = splat2(origin.z);
+    // one pair of triangles: returns (bit of a) * 2 + bit of b
+    auto testPair = [&](int pair) -> unsigned int {
+        // uniform index into the kernarg segment -> scalar loads, broadcast to the wave
+        const f2 *record = pairRecords + kSmallPairWords * pair;
+        const f2 v0x = record[0], v0y = record[1], v0z = record[2];
+        const f2 e1x = record[3], e1y = record[4], e1z = record[5];
+        const f2 e2x = record[6], e2y = record[7], e2z = record[8];
+        // pvec = d x e2, det = e1 . pvec
+        const f2 px = fma2(dy, e2z, -(dz * e2y));
+        const f2 py = fma2(dz, e2x, -(dx * e2z));
+        const f2 pz = fma2(dx, e2y, -(dy * e2x));
+        const f2 det = fma2(e1x, px, fma2(e1y, py, e1z * pz));
+        const f2 tx = ox - v0x, ty = oy - v0y, tz = oz - v0z;
+        const f2 uScaled = fma2(tx, px, fma2(ty, py, tz * pz));
+        // qvec = tvec x e1
+        const f2 qx = fma2(ty, e1z, -(tz * e1y));
+        const f2 qy = fma2(tz, e1x, -(tx * e1z));
+        const f2 qz = fma2(tx, e1y, -(ty * e1x));
+        const f2 vScaled = fma2(dx, qx, fma2(dy, qy, dz * qz));
+        const f2 tScaled = fma2(e2x, qx, fma2(e2y, qy, e2z * qz));
+        const f2 a = uScaled * det, b = vScaled * det, c = (det - (uScaled + vScaled)) * det, e = tScaled * det;
+        const float worstA = fminf(fminf(a.x, b.x), fminf(c.x, e.x));
+        const float worstB = fminf(fminf(a.y, b.y), fminf(c.y, e.y));
+        return ((worstA < 0.f) ? 0u : 2u) | ((worstB < 0.f) ? 0u : 1u);
+    };
+    const int lowPairs = nPairs < 16 ? nPairs : 16;
+    for (int pair = 0; pair < lowPairs; pair++) { candidatesLow = (candidatesLow << 2) | testPair(pair); }
+    for (int pair = 16; pair < nPairs; pair++) { candidatesHigh = (candidatesHigh << 2) | testPair(pair); }
+    // left-align: the last pair shifted in sits at bit 0; pad pairs and a padding triangle drop out
+    const int lowTris = nTris < 32 ? nTris : 32;
+    const int lowShifted = 2 * (nPairs < 16 ? nPairs : 16);
+    if (lowShifted > 0 && lowShifted < 32) { candidatesLow <<= 32 - lowShifted; }
+    candidatesLow &= lowTris > 0 ? 0xFFFFFFFFu << (32 - lowTris) : 0u;
+    const int highTris = nTris - 32;
+    if (highTris > 0) {
+        const int highShifted = 2 * (nPairs - 16);
+        if (highShifted < 32) { candidatesHigh <<= 32 - highShifted; }
+        candidatesHigh &= 0xFFFFFFFFu << (32 - highTris);
+    } else {
+        candidatesHigh = 0u;
+    }
+    *low = candidatesLow;
+    *high = candidatesHigh;
+}
+
+// Phase 2 (a wave-level loop: call it from wave-uniform control flow, lanes without a ray pass empty masks):
+// the few candidates of each lane go through the ordinary intersector + acceptance rule.
+__device__ __forceinline__ void smallResolve(const TraceGeometry &geometry, LaneRay &ray, unsigned int candidatesLow, unsigned int candidatesHigh)
+{
+    while (__ballot((candidatesLow | candidatesHigh) != 0u) != 0ull) {
+        if ((candidatesLow | candidatesHigh) != 0u) {
+            int k;  // triangle k of a word is bit 31 - (k & 31): take the highest set bit first
+            if (candidatesLow != 0u) { k = __clz((int)candidatesLow); candidatesLow &= ~(0x80000000u >> k); }
+            else { k = __clz((int)candidatesHigh); candidatesHigh &= ~(0x80000000u >> k); k += 32; }
+            const float4 t0 = geometry.tris[3 * k + 0];
+            const float4 t1 = geometry.tris[3 * k + 1];
+            const float4 t2 = geometry.tris[3 * k + 2];
+            bool terminate = false;
+            testLeafTriangle(ray, t0, t1, t2, &terminate);
+            if (terminate) { candidatesLow = 0u; candidatesHigh = 0u; }  // shadow ray occluded
+        }
+    }
+}
+
 template <bool COUNT>
 __global__ __launch_bounds__(kBlock) void k_trace_small(RenderParams p, SmallTris smallTris)
 {
@@ -496,7 +576,6 @@ __global__ __launch_bounds__(kBlock) void k_trace_small(RenderParams p, SmallTri
     const unsigned int shadowCount = p.counters[kCtrShadowCount + (p.parity ^ 1) * kCursorStride];
     const unsigned int totalBatches = slotBatches + (shadowCount + 63u) / 64u;
     const int nTris = p.scene.nTris;
-    const int nPairs = (nTris + 1) / 2;
 
     unsigned int closestRays = 0, shadowRays = 0, trisTested = 0;
 
@@ -537,67 +616,13 @@ __global__ __launch_bounds__(kBlock) void k_trace_small(RenderParams p, SmallTri
         // triangle k of a 32-triangle word ends up at bit 31 - (k & 31).
         unsigned int candidatesLow = 0, candidatesHigh = 0;
         if (valid) {
-            const f2 dx = splat2(ray.d.x), dy = splat2(ray.d.y), dz = splat2(ray.d.z);
-            const f2 ox = splat2(ray.o.x), oy = splat2(ray.o.y), oz = splat2(ray.o.z);
-            // one pair of triangles: returns (bit of a) * 2 + bit of b
-            auto testPair = [&](int pair) -> unsigned int {
-                // uniform index into the kernarg segment -> scalar loads, broadcast to the wave
-                const f2 *record = smallTris.data + kSmallPairWords * pair;
-                const f2 v0x = record[0], v0y = record[1], v0z = record[2];
-                const f2 e1x = record[3], e1y = record[4], e1z = record[5];
-                const f2 e2x = record[6], e2y = record[7], e2z = record[8];
-                // pvec = d x e2, det = e1 . pvec
-                const f2 px = fma2(dy, e2z, -(dz * e2y));
-                const f2 py = fma2(dz, e2x, -(dx * e2z));
-                const f2 pz = fma2(dx, e2y, -(dy * e2x));
-                const f2 det = fma2(e1x, px, fma2(e1y, py, e1z * pz));
-                const f2 tx = ox - v0x, ty = oy - v0y, tz = oz - v0z;
-                const f2 uScaled = fma2(tx, px, fma2(ty, py, tz * pz));
-                // qvec = tvec x e1
-                const f2 qx = fma2(ty, e1z, -(tz * e1y));
-                const f2 qy = fma2(tz, e1x, -(tx * e1z));
-                const f2 qz = fma2(tx, e1y, -(ty * e1x));
-                const f2 vScaled = fma2(dx, qx, fma2(dy, qy, dz * qz));
-                const f2 tScaled = fma2(e2x, qx, fma2(e2y, qy, e2z * qz));
-                const f2 a = uScaled * det, b = vScaled * det, c = (det - (uScaled + vScaled)) * det, e = tScaled * det;
-                const float worstA = fminf(fminf(a.x, b.x), fminf(c.x, e.x));
-                const float worstB = fminf(fminf(a.y, b.y), fminf(c.y, e.y));
-                return ((worstA < 0.f) ? 0u : 2u) | ((worstB < 0.f) ? 0u : 1u);
-            };
-            const int lowPairs = nPairs < 16 ? nPairs : 16;
-            for (int pair = 0; pair < lowPairs; pair++) { candidatesLow = (candidatesLow << 2) | testPair(pair); }
-            for (int pair = 16; pair < nPairs; pair++) { candidatesHigh = (candidatesHigh << 2) | testPair(pair); }
+            smallCandidates(smallTris.data, nTris, ray.o, ray.d, &candidatesLow, &candidatesHigh);
             if (COUNT) { trisTested += (unsigned int)nTris; }
-            // left-align: the last pair shifted in sits at bit 0; pad pairs and a padding triangle drop out
-            const int lowTris = nTris < 32 ? nTris : 32;
-            const int lowShifted = 2 * (nPairs < 16 ? nPairs : 16);
-            if (lowShifted > 0 && lowShifted < 32) { candidatesLow <<= 32 - lowShifted; }
-            candidatesLow &= lowTris > 0 ? 0xFFFFFFFFu << (32 - lowTris) : 0u;
-            const int highTris = nTris - 32;
-            if (highTris > 0) {
-                const int highShifted = 2 * (nPairs - 16);
-                if (highShifted < 32) { candidatesHigh <<= 32 - highShifted; }
-                candidatesHigh &= 0xFFFFFFFFu << (32 - highTris);
-            } else {
-                candidatesHigh = 0u;
-            }
         }
 
         // Phase 2: the few candidates of each lane (typically 1-3) go through the ordinary
         // intersector + acceptance rule, so hits are those of the BVH path bit for bit.
-        while (__ballot((candidatesLow | candidatesHigh) != 0u) != 0ull) {
-            if ((candidatesLow | candidatesHigh) != 0u) {
-                int k;  // triangle k of a word is bit 31 - (k & 31): take the highest set bit first
-                if (candidatesLow != 0u) { k = __clz((int)candidatesLow); candidatesLow &= ~(0x80000000u >> k); }
-                else { k = __clz((int)candidatesHigh); candidatesHigh &= ~(0x80000000u >> k); k += 32; }
-                const float4 t0 = geometry.tris[3 * k + 0];
-                const float4 t1 = geometry.tris[3 * k + 1];
-                const float4 t2 = geometry.tris[3 * k + 2];
-                bool terminate = false;
-                testLeafTriangle(ray, t0, t1, t2, &terminate);
-                if (terminate) { candidatesLow = 0u; candidatesHigh = 0u; }  // shadow ray occluded
-            }
-        }
+        smallResolve(geometry, ray, candidatesLow, candidatesHigh);
 
         if (valid) {
             finishRay(geometry, ray);
@@ -1285,6 +1310,814 @@ __global__ __launch_bounds__(kBlock) void k_shade(RenderParams p)
     }
 }
 
+// ------------------------------------------------------------------------- staged shade
+// k_shade_staged: the same per-slot arithmetic as k_shade, organised as a STAGED, COMPACTED wavefront
+// inside every block (the reference's stage-wise arrays, src/data_parallel_integrator.cpp:307-371:
+// intersections -> direct light -> bounce, each over all pixels; here each stage runs over a dense,
+// state-sorted list of the block's slots).
+//
+// A block owns ROUNDS x 256 consecutive slots and walks them in three phases:
+//   A  classify   one lane per slot, two 16-byte loads (state word, hit).  A slot with a finished ray is
+//                 a MISS (sample ends: regenerate), a TERMINAL hit (the path was not going to continue and
+//                 the hit is no emitter: the sample ends without an intersection record) or a VERTEX.
+//                 Vertices get a key -- 0: an emitter was hit and the BSDF-sampling MIS term has to be
+//                 finished (light pdf, triangle corners), 1 + BSDF type otherwise -- and are counting-
+//                 sorted by it into an LDS list (wave ballots + one wave-level scan, no atomics).
+//   B  vertex     dense over the sorted list: intersection record, previous vertex's MIS term, throughput,
+//                 BSDF sample, light sample, next ray + shadow ray.  Waves are full and (up to one boundary
+//                 wave per key) uniform in what they execute.  A sample that ends here leaves its colour in
+//                 the slot's `res` and joins the regeneration list.
+//   C  regenerate dense over the misses, terminal hits and the samples phase B ended: environment term of a
+//                 miss, colour -> the unit's partial sum, next sample or next unit, camera ray.
+// Only 2-byte slot indices move through LDS; state is read where it is used (the block's lines are in L2
+// from phase A on).  The result cannot depend on the order of the lists: every slot is shaded from its own
+// state with k_shade's operations in k_shade's order (GPU test: images bit-identical to k_shade's).
+static const int kStageKeys = 8;                 // 0 emitter hit with a pending MIS term, 1 + PATHED_MAT_* (0..5), 7 spare
+static const unsigned int kEntrySlotMask = 0x0FFFu;
+static const int kEntryKindShift = 12;
+static const unsigned int kRegenMiss = 0u;       // the ray missed: environment term, then the sample ends
+static const unsigned int kRegenTerminal = 1u;   // last ray of the path hit a non-emitter: pending light term, then the sample ends
+static const unsigned int kRegenColor = 2u;      // phase B ended the sample: its colour is in res.rgb
+
+#ifndef PATHED_STAGED_WAVES
+#define PATHED_STAGED_WAVES 4
+#endif
+template <bool LDS_MATERIALS, int ROUNDS>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_STAGED_WAVES, PATHED_STAGED_WAVES))) void k_shade_staged(RenderParams p)
+{
+    constexpr int kSlots = ROUNDS * kBlock;
+    constexpr int kCountEntries = kStageKeys * ROUNDS * kWavesPerBlock;   // 64 (ROUNDS 2) or 128 (ROUNDS 4)
+    static_assert(kSlots <= (int)kEntrySlotMask + 1, "slot index must fit the list entry");
+    static_assert(kCountEntries % 64 == 0, "one wave scans the key counts");
+    extern __shared__ float4 ldsDynamic[];           // LDS_MATERIALS: the material table, nMaterials x 96 B
+    __shared__ unsigned short vertexList[kSlots];
+    __shared__ unsigned short regenList[kSlots];
+    __shared__ unsigned int keyOffsets[kCountEntries];   // [key][round][wave]: counts, then exclusive offsets
+    __shared__ unsigned int scratch[kWavesPerBlock + 1];
+    __shared__ unsigned int listCounts[2];            // [0] vertices, [1] regenerations
+
+    MaterialAccess<LDS_MATERIALS> materials;
+    if (LDS_MATERIALS) {
+        const int words = p.scene.nMaterials * (int)(sizeof(DMaterial) / 4);
+        const int *source = reinterpret_cast<const int *>(p.scene.materials);
+        int *target = reinterpret_cast<int *>(ldsDynamic);
+        for (int i = threadIdx.x; i < words; i += kBlock) { target[i] = source[i]; }
+        materials.table = reinterpret_cast<const DMaterial *>(ldsDynamic);
+    } else {
+        materials.table = p.scene.materials;
+    }
+    if (threadIdx.x < 2) { listCounts[threadIdx.x] = 0u; }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int blockBase = blockIdx.x * kSlots;
+    const DScene &scene = p.scene;
+
+    // rewind the card cursors for the pool's next trace launch (same stream: it starts after us)
+    if (blockIdx.x == 0 && threadIdx.x < kTraceShards) { p.counters[kCtrTraceCursor + threadIdx.x * kCursorStride] = 0u; }
+    // ... and empty the shadow list the NEXT shade launch will fill (the trace launch that read it is over)
+    if (blockIdx.x == 0 && threadIdx.x == kTraceShards) { p.counters[kCtrShadowCount + (p.parity ^ 1) * kCursorStride] = 0u; }
+
+    // ---------------------------------------------------------------- phase A: classify + sort
+    int myKey[ROUNDS];            // -1: not a vertex
+    unsigned int myRank[ROUNDS];  // position among the wave's lanes with the same key
+    #pragma unroll
+    for (int r = 0; r < ROUNDS; r++) {
+        const int local = r * kBlock + threadIdx.x;
+        const int slot = blockBase + local;
+        const float4 rd = p.state.rayD[slot];
+        const float4 h = p.state.hit[slot];
+        const int st = floatAsInt(rd.w);
+        const int prim = floatAsInt(h.w);
+        int key = -1;
+        int regenKind = -1;
+        if (!(st & kStDone)) {
+            bool parked = false;
+            if (p.suspendLanes > 0) {
+                // a slot with a parked ray (see kSuspendLanes) sits this iteration out, untouched
+                parked = prim == kPrimSuspended;
+                if (!parked && (st & kStEligible)) {
+                    parked = reinterpret_cast<const int *>(p.state.pend + slot)[3] == kShadowSuspended;
+                }
+                if (parked && !(st & kStHold)) { reinterpret_cast<int *>(p.state.rayD + slot)[3] = st | kStHold; }
+            }
+            if (!parked) {
+                if (prim < 0) {
+                    regenKind = (int)kRegenMiss;
+                } else {
+                    int material;
+                    if (prim < scene.nTris) { material = reinterpret_cast<const int *>(scene.triShade + (size_t)kTriShadeQuads * prim)[3]; }
+                    else { material = scene.spheres[prim - scene.nTris].material; }
+                    const DMaterial &hitMaterial = materials[material];
+                    const bool emitter = !(hitMaterial.emit[0] == 0.f && hitMaterial.emit[1] == 0.f && hitMaterial.emit[2] == 0.f);
+                    const int rayBounce = st & kStBounceMask;
+                    const bool pendingTerm = rayBounce != 0 && (st & kStEligible) != 0 && emitter;
+                    if (rayBounce != 0 && !(st & kStContinue) && !pendingTerm) { regenKind = (int)kRegenTerminal; }
+                    else { key = pendingTerm ? 0 : 1 + hitMaterial.type; }
+                }
+            }
+        }
+        // regeneration list: order is irrelevant, one LDS atomic per wave
+        {
+            const unsigned long long mask = __ballot(regenKind >= 0);
+            unsigned int base = 0;
+            if (lane == 0 && mask != 0ull) { base = atomicAdd(&listCounts[1], (unsigned int)__popcll(mask)); }
+            base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
+            if (regenKind >= 0) {
+                const unsigned int rank = __builtin_amdgcn_mbcnt_hi((unsigned int)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)mask, 0u));
+                regenList[base + rank] = (unsigned short)((unsigned int)local | ((unsigned int)regenKind << kEntryKindShift));
+            }
+        }
+        // vertex list: per (key, round, wave) counts now, positions after the scan
+        myKey[r] = key;
+        myRank[r] = 0u;
+        #pragma unroll
+        for (int k = 0; k < kStageKeys; k++) {
+            const unsigned long long mask = __ballot(key == k);
+            if (key == k) { myRank[r] = __builtin_amdgcn_mbcnt_hi((unsigned int)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)mask, 0u)); }
+            if (lane == 0) { keyOffsets[(k * ROUNDS + r) * kWavesPerBlock + wave] = (unsigned int)__popcll(mask); }
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        // exclusive scan of the counts in (key, round, wave) order: every lane owns kItems consecutive entries
+        constexpr int kItems = kCountEntries / 64;
+        unsigned int values[kItems];
+        unsigned int sum = 0u;
+        #pragma unroll
+        for (int k = 0; k < kItems; k++) { values[k] = keyOffsets[lane * kItems + k]; sum += values[k]; }
+        unsigned int inclusive = sum;
+        #pragma unroll
+        for (int delta = 1; delta < 64; delta <<= 1) {
+            const unsigned int other = (unsigned int)__shfl_up((int)inclusive, delta, 64);
+            if (lane >= delta) { inclusive += other; }
+        }
+        unsigned int running = inclusive - sum;
+        #pragma unroll
+        for (int k = 0; k < kItems; k++) { keyOffsets[lane * kItems + k] = running; running += values[k]; }
+        if (lane == 63) { listCounts[0] = inclusive; }
+    }
+    __syncthreads();
+    #pragma unroll
+    for (int r = 0; r < ROUNDS; r++) {
+        if (myKey[r] >= 0) {
+            const unsigned int position = keyOffsets[(myKey[r] * ROUNDS + r) * kWavesPerBlock + wave] + myRank[r];
+            vertexList[position] = (unsigned short)(r * kBlock + threadIdx.x);
+        }
+    }
+    __syncthreads();
+    const unsigned int nVertex = listCounts[0];
+    SHADE_REGION(0, true);
+
+    // ---------------------------------------------------------------- phase B: vertices, dense and key-sorted
+    for (unsigned int listBase = 0; listBase < nVertex; listBase += kBlock) {
+        const unsigned int index = listBase + threadIdx.x;
+        const bool have = index < nVertex;
+        ShadowRequest shadow;
+        shadow.push = false;
+        shadow.origin = v3(0.f, 0.f, 0.f);
+        shadow.direction = v3(0.f, 0.f, 0.f);
+        shadow.tfar = 0.f;
+        bool ended = false;       // the sample ended at this vertex
+        int slot = 0;
+        SHADE_REGION(1, have);
+        if (have) {
+            slot = blockBase + (int)vertexList[index];
+            float4 rd = p.state.rayD[slot];
+            const float4 h = p.state.hit[slot];
+            const float4 ro = p.state.rayO[slot];
+            const float4 resIn = p.state.res[slot];
+            pinLoaded(rd);
+            pinLoaded(h);
+            pinLoaded(ro);
+            pinLoaded(resIn);
+            const int st = floatAsInt(rd.w) & ~kStHold;
+            float4 pendIn = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (st & kStEligible) { pendIn = p.state.pend[slot]; }
+
+            const V3 o = v3(ro.x, ro.y, ro.z);
+            const V3 d = v3(rd.x, rd.y, rd.z);
+            const int rayBounce = st & kStBounceMask;  // vertex that spawned this ray, 0 = camera
+            const int sampleInUnit = (st >> kStSampleShift) & kStSampleMask;
+            const unsigned int unit = (unsigned int)floatAsInt(resIn.w);
+            int firstEmitMaterial = floatAsInt(ro.w);
+
+            uint32_t pixel, firstSample, endSample;
+            unitSamples(p, unit, &pixel, &firstSample, &endSample);
+            const uint32_t sample = firstSample + (uint32_t)sampleInUnit;
+
+            Rgb result = rgb(resIn.x, resIn.y, resIn.z);
+            Rgb modulation = rgb(1.f);
+            Rgb color = rgb(0.f);
+            bool haveVertex = false;
+            const int vertex = rayBounce + 1;
+            const Isect isect = makeIsect(scene, o, d, h);
+
+            if (rayBounce == 0) {
+                // SampleIntegrator::samplePixel, src/sample_integrator.cpp:18-59
+                firstEmitMaterial = -1;
+                if (checkCounts(p.startBounce, p.lastBounce, 0)) {
+                    const Rgb emit = matEmit(materials[isect.material]);
+                    const bool backside = dot(isect.normal, isect.wo) < 0.f;
+                    if (!isBlack(emit) && !backside) { firstEmitMaterial = isect.material; }
+                }
+                result = rgb(0.f);
+                haveVertex = true;
+            } else {
+                // the ray left vertex `rayBounce` along its BSDF sample
+                const float4 modIn = p.state.mod[slot];
+                const float4 thrIn = p.state.thr[slot];
+                modulation = rgb(modIn.x, modIn.y, modIn.z);
+                const float bsdfPdf = modIn.w;
+                const Rgb throughput = rgb(thrIn.x, thrIn.y, thrIn.z);
+                const float cosTheta = thrIn.w;
+
+                if (st & kStEligible) {
+                    // PathTracer::directSampleBSDF, src/path_tracer.cpp:167-216 (the hit branch)
+                    Rgb bsdfTerm = rgb(0.f);
+                    const Rgb emit = matEmit(materials[isect.material]);
+                    if (!isBlack(emit) && dot(isect.wo, isect.shadingNormal) >= 0.f) {
+                        const float lightPDF = lightsPDF(scene, o, isect);
+                        const float brdfWeight = (st & kStDelta)
+                            ? 1.f
+                            : (1 * bsdfPdf) / (1 * bsdfPdf + 1 * lightPDF);
+                        bsdfTerm = emit * brdfWeight * throughput * cosTheta / bsdfPdf;
+                    }
+                    const Rgb Ld = rgb(pendIn.x, pendIn.y, pendIn.z) + bsdfTerm;
+                    if (rayBounce == 1) { result = Ld; }
+                    else { result = result + Ld * modulation; }
+                }
+
+                // PathTracer::L loop body, src/path_tracer.cpp:41-58
+                if (!(st & kStContinue)) {
+                    ended = true;
+                } else {
+                    const float invPDF = 1.f / bsdfPdf;
+                    modulation = modulation * (throughput * cosTheta * invPDF);
+                    if (isBlack(modulation)) { ended = true; }
+                    else { haveVertex = true; }
+                }
+                if (ended) {
+                    Rgb first = rgb(0.f);
+                    if (firstEmitMaterial >= 0) { first = first + matEmit(materials[firstEmitMaterial]); }
+                    color = first + result;
+                }
+            }
+
+            float4 outMod = make_float4(modulation.r, modulation.g, modulation.b, 1.f);
+            float4 outRayO = ro, outRayD = rd;
+            float4 outThr = make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 outPend = make_float4(0.f, 0.f, 0.f, 0.f);
+
+            SHADE_REGION(2, haveVertex);
+            if (haveVertex) {
+                // PathTracer::L: sample the BSDF, then direct(), src/path_tracer.cpp:30-36, 60-73
+                const DMaterial &material = materials[isect.material];
+
+                Rng random;
+                makeKey(((uint64_t)p.seedHi << 32) | p.seedLo, pixel, sample, &random.k0, &random.k1);
+                random.dimension = vertexBase(vertex);
+                const BSDFSample bsdfSample = materialSample(material, isect, random);
+
+                const bool counts = checkCounts(p.startBounce, p.lastBounce, vertex);
+                const bool emissive = !isBlack(matEmit(material));
+                const bool wantDirect = counts && !emissive;  // direct() returns 0 on emitters (:86-90)
+                const bool wantContinue = !checkDone(p.lastBounce, vertex + 1);
+
+                Rgb lightTerm = rgb(0.f);
+                SHADE_REGION(3, wantDirect);
+                if (wantDirect) {
+                    random.dimension = vertexBase(vertex) + 3;
+                    lightTerm = sampleLightsTerm(scene, materials, isect, material, random, &shadow);
+                }
+
+                // see k_shade: a vertex with nothing pending whose BSDF sample has exactly black throughput ends the sample
+                const bool deadEnd = isBlack(bsdfSample.throughput) && bsdfSample.pdf > 0.f && bsdfSample.pdf < 3e38f
+                    && !shadow.push && isBlack(lightTerm);
+                if ((!wantDirect && !wantContinue) || deadEnd) {
+                    ended = true;
+                    Rgb first = rgb(0.f);
+                    if (firstEmitMaterial >= 0) { first = first + matEmit(materials[firstEmitMaterial]); }
+                    color = first + result;
+                    shadow.push = false;
+                } else {
+                    int nextState = vertex | (sampleInUnit << kStSampleShift);
+                    if (wantDirect) { nextState |= kStEligible; }
+                    if (isDelta(material)) { nextState |= kStDelta; }
+                    if (wantContinue) { nextState |= kStContinue; }
+                    outRayO = make_float4(isect.point.x, isect.point.y, isect.point.z, intAsFloat(firstEmitMaterial));
+                    outRayD = make_float4(bsdfSample.wiWorld.x, bsdfSample.wiWorld.y, bsdfSample.wiWorld.z, intAsFloat(nextState));
+                    outMod.w = bsdfSample.pdf;
+                    outThr = make_float4(
+                        bsdfSample.throughput.r, bsdfSample.throughput.g, bsdfSample.throughput.b,
+                        fabsf(dot(isect.shadingNormal, bsdfSample.wiWorld)));
+                    outPend = make_float4(lightTerm.r, lightTerm.g, lightTerm.b, 0.f);
+                }
+            }
+
+            if (ended) {
+                // phase C adds the colour to the unit's partial sum and restarts the slot
+                p.state.res[slot] = make_float4(color.r, color.g, color.b, intAsFloat((int)unit));
+            } else {
+                p.state.rayO[slot] = outRayO;
+                p.state.rayD[slot] = outRayD;
+                p.state.mod[slot] = outMod;
+                p.state.thr[slot] = outThr;
+                p.state.res[slot] = make_float4(result.r, result.g, result.b, intAsFloat((int)unit));
+                p.state.pend[slot] = outPend;
+            }
+        }
+
+        // samples that ended here join the regeneration list
+        {
+            const unsigned long long mask = __ballot(ended);
+            unsigned int base = 0;
+            if (lane == 0 && mask != 0ull) { base = atomicAdd(&listCounts[1], (unsigned int)__popcll(mask)); }
+            base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
+            if (ended) {
+                const unsigned int rank = __builtin_amdgcn_mbcnt_hi((unsigned int)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)mask, 0u));
+                regenList[base + rank] = (unsigned short)((unsigned int)(slot - blockBase) | (kRegenColor << kEntryKindShift));
+            }
+        }
+
+        // shadow-ray list: wave ballot + prefix popcount + LDS block scan, then ONE atomic per block and round
+        {
+            const unsigned long long mask = __ballot(shadow.push);
+            const unsigned int before = (unsigned int)__popcll(mask & ((1ull << lane) - 1ull));
+            if (lane == 0) { scratch[wave] = (unsigned int)__popcll(mask); }
+            __syncthreads();
+            unsigned int offset = 0, total = 0;
+            #pragma unroll
+            for (int w = 0; w < kWavesPerBlock; w++) {
+                const unsigned int count = scratch[w];
+                if (w < wave) { offset += count; }
+                total += count;
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                scratch[kWavesPerBlock] = total ? atomicAdd(&p.counters[kCtrShadowCount + p.parity * kCursorStride], total) : 0u;
+            }
+            __syncthreads();
+            SHADE_REGION(4, shadow.push);
+            if (shadow.push) {
+                const unsigned int at = scratch[kWavesPerBlock] + offset + before;
+                p.state.shO[at] = make_float4(shadow.origin.x, shadow.origin.y, shadow.origin.z, shadow.tfar);
+                p.state.shD[at] = make_float4(shadow.direction.x, shadow.direction.y, shadow.direction.z, intAsFloat(slot));
+            }
+            __syncthreads();   // scratch is reused by the next round
+        }
+    }
+    __syncthreads();
+    const unsigned int nRegen = listCounts[1];
+
+    // ---------------------------------------------------------------- phase C: end of sample, regeneration
+    unsigned int retiredTotal = 0;
+    for (unsigned int listBase = 0; listBase < nRegen; listBase += kBlock) {
+        const unsigned int index = listBase + threadIdx.x;
+        const bool have = index < nRegen;
+        bool needUnit = false, startNext = false;
+        uint32_t nextPixel = 0, nextSample = 0;
+        int sampleInUnit = 0;
+        unsigned int unit = 0xFFFFFFFFu;
+        int slot = 0;
+        float4 outRayO = make_float4(0.f, 0.f, 0.f, 0.f), outRayD = make_float4(0.f, 0.f, 0.f, 0.f);
+        SHADE_REGION(5, have);
+        if (have) {
+            const unsigned int entry = regenList[index];
+            const unsigned int kind = entry >> kEntryKindShift;
+            slot = blockBase + (int)(entry & kEntrySlotMask);
+            const float4 rd = p.state.rayD[slot];
+            const float4 resIn = p.state.res[slot];
+            const float4 partialIn = p.state.acc[slot];
+            const int st = floatAsInt(rd.w) & ~kStHold;
+            outRayD = rd;
+            unit = (unsigned int)floatAsInt(resIn.w);
+            sampleInUnit = (st >> kStSampleShift) & kStSampleMask;
+            Rgb color = rgb(resIn.x, resIn.y, resIn.z);
+            SHADE_REGION(6, kind != kRegenColor);
+            if (kind != kRegenColor) {
+                const float4 ro = p.state.rayO[slot];
+                const V3 d = v3(rd.x, rd.y, rd.z);
+                const int rayBounce = st & kStBounceMask;
+                const int firstEmitMaterial = floatAsInt(ro.w);
+                if (rayBounce == 0) {
+                    // SampleIntegrator::samplePixel: the camera ray missed, src/sample_integrator.cpp:18-31
+                    color = rgb(0.f) + environmentL(scene, d);
+                } else {
+                    Rgb result = rgb(resIn.x, resIn.y, resIn.z);
+                    if (st & kStEligible) {
+                        const float4 pendIn = p.state.pend[slot];
+                        const float4 modIn = p.state.mod[slot];
+                        const float4 thrIn = p.state.thr[slot];
+                        const Rgb modulation = rgb(modIn.x, modIn.y, modIn.z);
+                        const float bsdfPdf = modIn.w;
+                        const Rgb throughput = rgb(thrIn.x, thrIn.y, thrIn.z);
+                        const float cosTheta = thrIn.w;
+                        // PathTracer::directSampleBSDF, src/path_tracer.cpp:167-216: a terminal hit of a non-emitter
+                        // adds nothing, a miss adds the environment's term
+                        Rgb bsdfTerm = rgb(0.f);
+                        if (kind == kRegenMiss) {
+                            const Rgb environmentLight = environmentL(scene, d);
+                            if (!isBlack(environmentLight)) {
+                                // Scene::environmentPDF, src/scene.cpp:494-502
+                                const float lightPDF = envEmitPDF(scene.env, d) / scene.nLights;
+                                const float brdfWeight = (st & kStDelta)
+                                    ? 1.f
+                                    : (1 * bsdfPdf) / (1 * bsdfPdf + 1 * lightPDF);
+                                bsdfTerm = environmentLight * brdfWeight * throughput * cosTheta / bsdfPdf;
+                            }
+                        }
+                        const Rgb Ld = rgb(pendIn.x, pendIn.y, pendIn.z) + bsdfTerm;
+                        if (rayBounce == 1) { result = Ld; }
+                        else { result = result + Ld * modulation; }
+                    }
+                    Rgb first = rgb(0.f);
+                    if (firstEmitMaterial >= 0) { first = first + matEmit(materials[firstEmitMaterial]); }
+                    color = first + result;
+                }
+            }
+
+            // radianceLookup += color, src/sample_integrator.cpp:61-63; non-finite samples dropped
+            float4 partial = partialIn;
+            const bool finite = isfinite(color.r) && isfinite(color.g) && isfinite(color.b);
+            if (finite) {
+                partial.x += color.r;
+                partial.y += color.g;
+                partial.z += color.b;
+            } else {
+                atomicAdd(&p.stats[kStatDropped], 1ull);
+            }
+            uint32_t pixel, firstSample, endSample;
+            unitSamples(p, unit, &pixel, &firstSample, &endSample);
+            sampleInUnit++;
+            if (firstSample + (uint32_t)sampleInUnit < endSample) {
+                startNext = true;
+                nextPixel = pixel;
+                nextSample = firstSample + (uint32_t)sampleInUnit;
+                p.state.acc[slot] = partial;
+            } else {
+                p.state.chunkBuf[unit] = partial;
+                p.state.acc[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
+                needUnit = true;
+            }
+        }
+
+        // block-aggregated grab of the next units (wave ballot + LDS scan, one atomic per block and round)
+        const unsigned int newUnit = grabUnits(p, needUnit, scratch);
+        bool retired = false;
+        if (needUnit) {
+            unit = newUnit;
+            if (newUnit != 0xFFFFFFFFu) {
+                uint32_t endSample;
+                unitSamples(p, newUnit, &nextPixel, &nextSample, &endSample);
+                sampleInUnit = 0;
+                startNext = true;
+            } else {
+                outRayD.w = intAsFloat(kStDone);
+                retired = true;
+            }
+        }
+        SHADE_REGION(7, startNext);
+        if (startNext) { startSample(p, nextPixel, nextSample, sampleInUnit, &outRayO, &outRayD); }
+        if (have) {
+            p.state.rayO[slot] = outRayO;
+            p.state.rayD[slot] = outRayD;
+            p.state.mod[slot] = make_float4(1.f, 1.f, 1.f, 1.f);
+            p.state.thr[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
+            p.state.res[slot] = make_float4(0.f, 0.f, 0.f, intAsFloat((int)unit));
+            p.state.pend[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        retiredTotal += (unsigned int)__popcll(__ballot(retired));
+    }
+    // slots that ran out of units (only at the tail of a render call)
+    if (lane == 0 && retiredTotal != 0u) { atomicSub(&p.counters[kCtrRemaining], retiredTotal); }
+}
+
+// ------------------------------------------------------------------------- fused path kernel (tiny scenes)
+// k_path_small: scenes of <= kBruteForceMaxTris triangles, whose ray queries are two straight-line passes
+// over kernarg-resident triangle records, need no ray or hit buffers at all.  One lane carries one PATH from
+// camera ray to termination with its whole state in registers -- the wavefront iteration
+// "trace, shade, trace shadow, regenerate" becomes the body of one loop -- and waves are persistent: a lane
+// whose sample ended takes the next sample of its work unit, or the next unit from the wave's reserved
+// range (one wave-level atomic per kUnitGrab units on a sharded cursor; a wave whose shard is dealt out
+// moves on to the next).  No path state touches HBM: per unit one 16-byte partial sum is written.
+// Every operation on a path's values is k_shade's, in k_shade's order, and the unit decomposition fixes
+// the summation order, so the radiance sums are the wavefront kernels' bit for bit (GPU test).
+// What the wavefront keeps and this gives up is the DENSE shadow-ray list: the shadow pass runs with
+// the lanes whose vertex asked for one (~70-75 % on Cornell).  Measured, the registers win.
+#ifndef PATHED_FUSED_WAVES
+#define PATHED_FUSED_WAVES 4
+#endif
+template <bool LDS_MATERIALS, bool COUNT>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_FUSED_WAVES, PATHED_FUSED_WAVES))) void k_path_small(RenderParams p, SmallTris smallTris)
+{
+    extern __shared__ float4 ldsDynamic[];           // LDS_MATERIALS: the material table, nMaterials x 96 B
+    MaterialAccess<LDS_MATERIALS> materials;
+    if (LDS_MATERIALS) {
+        const int words = p.scene.nMaterials * (int)(sizeof(DMaterial) / 4);
+        const int *source = reinterpret_cast<const int *>(p.scene.materials);
+        int *target = reinterpret_cast<int *>(ldsDynamic);
+        for (int i = threadIdx.x; i < words; i += kBlock) { target[i] = source[i]; }
+        __syncthreads();
+        materials.table = reinterpret_cast<const DMaterial *>(ldsDynamic);
+    } else {
+        materials.table = p.scene.materials;
+    }
+
+    TraceGeometry geometry;
+    geometry.nodes = nullptr;
+    geometry.tris = p.scene.leafTris;
+    geometry.nNodes = 0;
+    geometry.nTris = p.scene.nTris;
+    geometry.spheres = p.scene.spheres;
+    geometry.nSpheres = p.scene.nSpheres;
+
+    const DScene &scene = p.scene;
+    const int lane = threadIdx.x & 63;
+    const unsigned int waveId = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const int nTris = p.scene.nTris;
+    const uint64_t seed = ((uint64_t)p.seedHi << 32) | p.seedLo;
+
+    // ---- work units: the wave reserves p.unitGrab consecutive units of a queue at a time (wave-uniform state)
+    unsigned int queue = waveId % (unsigned int)p.nQueues, queuesTried = 0;
+    unsigned int reservedNext = 0, reservedEnd = 0;
+    // hands a unit to every lane that wants one, in lane order; 0xFFFFFFFF once the pass is dealt out
+    auto takeUnits = [&](bool want) -> unsigned int {
+        unsigned int mine = 0xFFFFFFFFu;
+        unsigned long long wanting = __ballot(want);
+        while (wanting != 0ull) {
+            if (reservedNext == reservedEnd) {
+                if (queuesTried >= (unsigned int)p.nQueues) { break; }   // every queue is dealt out
+                unsigned int ticket = 0;
+                if (lane == 0) { ticket = atomicAdd(&p.counters[kCtrUnitCursor + queue * kCursorStride], (unsigned int)p.unitGrab); }
+                ticket = (unsigned int)__builtin_amdgcn_readfirstlane((int)ticket);
+                // queue q owns units [q * unitsPerQueue, (q + 1) * unitsPerQueue), clipped to the pool's nUnits
+                unsigned int limit = p.unitsPerQueue;
+                const unsigned long long first = (unsigned long long)queue * p.unitsPerQueue;
+                if (first >= p.nUnits) { limit = 0u; }
+                else if (first + limit > p.nUnits) { limit = (unsigned int)(p.nUnits - first); }
+                if (ticket >= limit) {
+                    queue = (queue + 1u) % (unsigned int)p.nQueues;
+                    queuesTried++;
+                    continue;
+                }
+                reservedNext = ticket;
+                reservedEnd = ticket + (unsigned int)p.unitGrab < limit ? ticket + (unsigned int)p.unitGrab : limit;
+            }
+            const unsigned int available = reservedEnd - reservedNext;
+            const unsigned int rank = __builtin_amdgcn_mbcnt_hi((unsigned int)(wanting >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)wanting, 0u));
+            const bool served = ((wanting >> lane) & 1ull) != 0ull && rank < available;
+            if (served) { mine = queue * p.unitsPerQueue + reservedNext + rank; }
+            const unsigned int count = (unsigned int)__popcll(wanting);
+            reservedNext += count < available ? count : available;
+            wanting &= ~__ballot(served);
+        }
+        return mine;
+    };
+
+    // ---- the path a lane carries
+    bool alive = false;
+    unsigned int unit = 0xFFFFFFFFu;
+    uint32_t pixel = 0, sample = 0, endSample = 0;   // sample: absolute index of the sample in flight
+    Rng random;
+    random.k0 = 0u; random.k1 = 0u; random.dimension = 0u;
+    V3 o = v3(0.f, 0.f, 0.f), d = v3(0.f, 0.f, 1.f);
+    int st = 0;                      // device_scene.h state word: vertex that spawned the ray + eligible / delta / continue
+    int firstEmitMaterial = -1;
+    Rgb result = rgb(0.f), modulation = rgb(1.f), throughput = rgb(0.f), pend = rgb(0.f);
+    float bsdfPdf = 1.f, cosTheta = 0.f;
+    float4 partial = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    unsigned int closestRays = 0, shadowRays = 0, trisTested = 0;
+
+    // Camera::generateRay(int,int) for (pixel, sample), src/camera.cpp:49-55: one inlined copy, reached from the
+    // initial fill and from the end of every sample
+    bool startNext = false;
+    {
+        unit = takeUnits(true);
+        if (unit != 0xFFFFFFFFu) {
+            unitSamples(p, unit, &pixel, &sample, &endSample);
+            alive = true;
+            startNext = true;
+        }
+    }
+
+    while (true) {
+        if (startNext) {
+            makeKey(seed, pixel, sample, &random.k0, &random.k1);
+            random.dimension = 0;
+            const int width = scene.camera.resX;
+            const int row = (int)pixel / width;
+            const int col = (int)pixel - row * width;
+            const float jitterX = random.next() - 0.5f;
+            const float jitterY = random.next() - 0.5f;
+            cameraRay(scene.camera, row + jitterY, col + jitterX, &o, &d);
+            st = 0;
+            firstEmitMaterial = -1;
+            result = rgb(0.f);
+            modulation = rgb(1.f);
+            throughput = rgb(0.f);
+            pend = rgb(0.f);
+            bsdfPdf = 1.f;
+            cosTheta = 0.f;
+            startNext = false;
+        }
+        if (__ballot(alive) == 0ull) { break; }
+
+        // ---- closest hit of the path's ray (Scene::testIntersect's rtcIntersect1)
+        LaneRay ray;
+        laneRayInit(ray, o, d, PATHED_TNEAR, PATHED_TFAR, false);
+        {
+            unsigned int candidatesLow = 0, candidatesHigh = 0;
+            if (alive) {
+                smallCandidates(smallTris.data, nTris, ray.o, ray.d, &candidatesLow, &candidatesHigh);
+                if (COUNT) { trisTested += (unsigned int)nTris; closestRays++; }
+            }
+            smallResolve(geometry, ray, candidatesLow, candidatesHigh);
+            if (alive) { finishRay(geometry, ray); }
+        }
+        const bool miss = ray.bestPrim < 0;
+        const float4 h = make_float4(ray.best, ray.bestU, ray.bestV, intAsFloat(ray.bestPrim));
+
+        // ---- the vertex: k_shade's body on register state
+        ShadowRequest shadow;
+        shadow.push = false;
+        shadow.origin = v3(0.f, 0.f, 0.f);
+        shadow.direction = v3(0.f, 0.f, 1.f);
+        shadow.tfar = 0.f;
+        bool finished = false;
+        Rgb color = rgb(0.f);
+        if (alive) {
+            const int rayBounce = st & kStBounceMask;  // vertex that spawned this ray, 0 = camera
+            bool haveVertex = false;
+            Isect isect;
+            const int vertex = rayBounce + 1;
+            if (!miss) { isect = makeIsect(scene, o, d, h); }
+
+            if (rayBounce == 0) {
+                // SampleIntegrator::samplePixel, src/sample_integrator.cpp:18-59
+                if (miss) {
+                    color = rgb(0.f) + environmentL(scene, d);
+                    finished = true;
+                } else {
+                    firstEmitMaterial = -1;
+                    if (checkCounts(p.startBounce, p.lastBounce, 0)) {
+                        const Rgb emit = matEmit(materials[isect.material]);
+                        const bool backside = dot(isect.normal, isect.wo) < 0.f;
+                        if (!isBlack(emit) && !backside) { firstEmitMaterial = isect.material; }
+                    }
+                    result = rgb(0.f);
+                    haveVertex = true;
+                }
+            } else {
+                // the ray left vertex `rayBounce` along its BSDF sample
+                if (st & kStEligible) {
+                    // PathTracer::directSampleBSDF, src/path_tracer.cpp:167-216
+                    Rgb bsdfTerm = rgb(0.f);
+                    if (!miss) {
+                        const Rgb emit = matEmit(materials[isect.material]);
+                        if (!isBlack(emit) && dot(isect.wo, isect.shadingNormal) >= 0.f) {
+                            const float lightPDF = lightsPDF(scene, o, isect);
+                            const float brdfWeight = (st & kStDelta)
+                                ? 1.f
+                                : (1 * bsdfPdf) / (1 * bsdfPdf + 1 * lightPDF);
+                            bsdfTerm = emit * brdfWeight * throughput * cosTheta / bsdfPdf;
+                        }
+                    } else {
+                        const Rgb environmentLight = environmentL(scene, d);
+                        if (!isBlack(environmentLight)) {
+                            // Scene::environmentPDF, src/scene.cpp:494-502
+                            const float lightPDF = envEmitPDF(scene.env, d) / scene.nLights;
+                            const float brdfWeight = (st & kStDelta)
+                                ? 1.f
+                                : (1 * bsdfPdf) / (1 * bsdfPdf + 1 * lightPDF);
+                            bsdfTerm = environmentLight * brdfWeight * throughput * cosTheta / bsdfPdf;
+                        }
+                    }
+                    const Rgb Ld = pend + bsdfTerm;
+                    if (rayBounce == 1) { result = Ld; }
+                    else { result = result + Ld * modulation; }
+                }
+
+                // PathTracer::L loop body, src/path_tracer.cpp:41-58
+                if (!(st & kStContinue) || miss) {
+                    finished = true;
+                } else {
+                    const float invPDF = 1.f / bsdfPdf;
+                    modulation = modulation * (throughput * cosTheta * invPDF);
+                    if (isBlack(modulation)) { finished = true; }
+                    else { haveVertex = true; }
+                }
+                if (finished) {
+                    Rgb first = rgb(0.f);
+                    if (firstEmitMaterial >= 0) { first = first + matEmit(materials[firstEmitMaterial]); }
+                    color = first + result;
+                }
+            }
+
+            if (haveVertex) {
+                // PathTracer::L: sample the BSDF, then direct(), src/path_tracer.cpp:30-36, 60-73
+                const DMaterial &material = materials[isect.material];
+
+                random.dimension = vertexBase(vertex);
+                const BSDFSample bsdfSample = materialSample(material, isect, random);
+
+                const bool counts = checkCounts(p.startBounce, p.lastBounce, vertex);
+                const bool emissive = !isBlack(matEmit(material));
+                const bool wantDirect = counts && !emissive;  // direct() returns 0 on emitters (:86-90)
+                const bool wantContinue = !checkDone(p.lastBounce, vertex + 1);
+
+                Rgb lightTerm = rgb(0.f);
+                if (wantDirect) {
+                    random.dimension = vertexBase(vertex) + 3;
+                    lightTerm = sampleLightsTerm(scene, materials, isect, material, random, &shadow);
+                }
+
+                // see k_shade: a vertex with nothing pending whose BSDF sample has exactly black throughput ends the sample
+                const bool deadEnd = isBlack(bsdfSample.throughput) && bsdfSample.pdf > 0.f && bsdfSample.pdf < 3e38f
+                    && !shadow.push && isBlack(lightTerm);
+                if ((!wantDirect && !wantContinue) || deadEnd) {
+                    finished = true;
+                    Rgb first = rgb(0.f);
+                    if (firstEmitMaterial >= 0) { first = first + matEmit(materials[firstEmitMaterial]); }
+                    color = first + result;
+                    shadow.push = false;
+                } else {
+                    int nextState = vertex;
+                    if (wantDirect) { nextState |= kStEligible; }
+                    if (isDelta(material)) { nextState |= kStDelta; }
+                    if (wantContinue) { nextState |= kStContinue; }
+                    st = nextState;
+                    o = isect.point;
+                    d = bsdfSample.wiWorld;
+                    bsdfPdf = bsdfSample.pdf;
+                    throughput = bsdfSample.throughput;
+                    cosTheta = fabsf(dot(isect.shadingNormal, bsdfSample.wiWorld));
+                    pend = lightTerm;
+                }
+            }
+        }
+
+        // ---- the vertex's shadow ray (Scene::testOcclusion's rtcOccluded1): an occluded light sample contributes nothing
+        const bool wantShadow = alive && shadow.push;
+        if (__ballot(wantShadow) != 0ull) {
+            LaneRay shadowRay;
+            laneRayInit(shadowRay, shadow.origin, shadow.direction, PATHED_TNEAR, shadow.tfar, true);
+            unsigned int candidatesLow = 0, candidatesHigh = 0;
+            if (wantShadow) {
+                smallCandidates(smallTris.data, nTris, shadowRay.o, shadowRay.d, &candidatesLow, &candidatesHigh);
+                if (COUNT) { trisTested += (unsigned int)nTris; shadowRays++; }
+            }
+            smallResolve(geometry, shadowRay, candidatesLow, candidatesHigh);
+            if (wantShadow) {
+                finishRay(geometry, shadowRay);
+                if (shadowRay.occluded) { pend = rgb(0.f); }
+            }
+        }
+
+        // ---- end of a sample: radianceLookup += color (src/sample_integrator.cpp:61-63; non-finite samples
+        // dropped), then the unit's next sample or the next unit
+        bool needUnit = false;
+        if (alive && finished) {
+            const bool finite = isfinite(color.r) && isfinite(color.g) && isfinite(color.b);
+            if (finite) {
+                partial.x += color.r;
+                partial.y += color.g;
+                partial.z += color.b;
+            } else {
+                atomicAdd(&p.stats[kStatDropped], 1ull);
+            }
+            sample++;
+            if (sample < endSample) {
+                startNext = true;
+            } else {
+                p.state.chunkBuf[unit] = partial;
+                partial = make_float4(0.f, 0.f, 0.f, 0.f);
+                needUnit = true;
+            }
+        }
+        if (__ballot(needUnit) != 0ull) {
+            const unsigned int newUnit = takeUnits(needUnit);
+            if (needUnit) {
+                unit = newUnit;
+                if (newUnit != 0xFFFFFFFFu) {
+                    unitSamples(p, newUnit, &pixel, &sample, &endSample);
+                    startNext = true;
+                } else {
+                    alive = false;
+                }
+            }
+        }
+    }
+
+    if (COUNT) {
+        atomicAdd(&p.stats[kStatTris], (unsigned long long)trisTested);
+        atomicAdd(&p.stats[kStatClosest], (unsigned long long)closestRays);
+        atomicAdd(&p.stats[kStatShadow], (unsigned long long)shadowRays);
+    }
+}
+
 // ------------------------------------------------------------------------- scene set-up
 // The per-triangle shading records (device_scene.h: kTriShadeQuads) gathered on the device from the
 // vertex arrays: pure copies, so the table is the one the host loop used to build, without writing
@@ -1337,31 +2170,57 @@ __global__ __launch_bounds__(kBlock) void k_stream_copy(const float4 *source, fl
 // keeps the compiler from folding or vectorising them.  MIXED adds one v_rcp_f32 + v_sqrt_f32 pair per
 // six v_fma_f32 (a path tracer's normalisations; those two issue at a quarter of the FMA rate).
 static const int kValuProbeUnroll = 48;   // VALU instructions per loop iteration
-template <bool MIXED>
+// MODE 0: v_fma_f32 with one VGPR source (the accumulator) and an SGPR for multiplier and addend: no VGPR bank
+//         conflicts, nothing but issue limits the rate
+// MODE 1: six such v_fma_f32 + one v_rcp_f32 + one v_sqrt_f32 per eight instructions
+// MODE 2: v_fma_f32 with three VGPR sources (accumulator, multiplier, addend in registers)
+// MODE 3: v_pk_fma_f32 (two fp32 FMAs per lane and instruction)
+// MODE 4: v_mul_lo_u32 (the random stream's multiplies)
+template <int MODE>
 __global__ __launch_bounds__(kBlock) void k_valu_probe(int iterations, float seed, float *sink)
 {
     float a0 = seed + threadIdx.x, a1 = a0 + 1.f, a2 = a0 + 2.f, a3 = a0 + 3.f;
     float a4 = a0 + 4.f, a5 = a0 + 5.f, a6 = a0 + 6.f, a7 = a0 + 7.f;
     const float m = 0.999f, c = 0.001f;
+    f2 p0 = { a0, a1 }, p1 = { a2, a3 }, p2 = { a4, a5 }, p3 = { a6, a7 }, p4 = { a1, a0 }, p5 = { a3, a2 }, p6 = { a5, a4 }, p7 = { a7, a6 };
+    const f2 pm = { m, m }, pc = { c, c };
+    unsigned int i0 = threadIdx.x + 1u, i1 = i0 + 1u, i2 = i0 + 2u, i3 = i0 + 3u, i4 = i0 + 4u, i5 = i0 + 5u, i6 = i0 + 6u, i7 = i0 + 7u;
+    const unsigned int im = 0x846ca68bu;
     for (int i = 0; i < iterations; i++) {
         #pragma unroll
         for (int k = 0; k < kValuProbeUnroll / 8; k++) {
-            if (MIXED) {
+            if (MODE == 0) {
                 asm volatile(
-                    "v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %1, %1, %8, %9\n v_fma_f32 %2, %2, %8, %9\n"
-                    "v_fma_f32 %3, %3, %8, %9\n v_fma_f32 %4, %4, %8, %9\n v_fma_f32 %5, %5, %8, %9\n"
+                    "v_fma_f32 %0, %0, %8, %8\n v_fma_f32 %1, %1, %8, %8\n v_fma_f32 %2, %2, %8, %8\n v_fma_f32 %3, %3, %8, %8\n"
+                    "v_fma_f32 %4, %4, %8, %8\n v_fma_f32 %5, %5, %8, %8\n v_fma_f32 %6, %6, %8, %8\n v_fma_f32 %7, %7, %8, %8\n"
+                    : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "s"(m));
+            } else if (MODE == 1) {
+                asm volatile(
+                    "v_fma_f32 %0, %0, %8, %8\n v_fma_f32 %1, %1, %8, %8\n v_fma_f32 %2, %2, %8, %8\n"
+                    "v_fma_f32 %3, %3, %8, %8\n v_fma_f32 %4, %4, %8, %8\n v_fma_f32 %5, %5, %8, %8\n"
                     "v_rcp_f32 %6, %6\n v_sqrt_f32 %7, %7\n"
+                    : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "s"(m));
+            } else if (MODE == 2) {
+                asm volatile(
+                    "v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %1, %1, %8, %9\n v_fma_f32 %2, %2, %8, %9\n v_fma_f32 %3, %3, %8, %9\n"
+                    "v_fma_f32 %4, %4, %8, %9\n v_fma_f32 %5, %5, %8, %9\n v_fma_f32 %6, %6, %8, %9\n v_fma_f32 %7, %7, %8, %9\n"
                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "v"(c));
+            } else if (MODE == 3) {
+                asm volatile(
+                    "v_pk_fma_f32 %0, %0, %8, %9\n v_pk_fma_f32 %1, %1, %8, %9\n v_pk_fma_f32 %2, %2, %8, %9\n v_pk_fma_f32 %3, %3, %8, %9\n"
+                    "v_pk_fma_f32 %4, %4, %8, %9\n v_pk_fma_f32 %5, %5, %8, %9\n v_pk_fma_f32 %6, %6, %8, %9\n v_pk_fma_f32 %7, %7, %8, %9\n"
+                    : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7) : "v"(pm), "v"(pc));
             } else {
                 asm volatile(
-                    "v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %1, %1, %8, %9\n v_fma_f32 %2, %2, %8, %9\n"
-                    "v_fma_f32 %3, %3, %8, %9\n v_fma_f32 %4, %4, %8, %9\n v_fma_f32 %5, %5, %8, %9\n"
-                    "v_fma_f32 %6, %6, %8, %9\n v_fma_f32 %7, %7, %8, %9\n"
-                    : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "v"(c));
+                    "v_mul_lo_u32 %0, %0, %8\n v_mul_lo_u32 %1, %1, %8\n v_mul_lo_u32 %2, %2, %8\n v_mul_lo_u32 %3, %3, %8\n"
+                    "v_mul_lo_u32 %4, %4, %8\n v_mul_lo_u32 %5, %5, %8\n v_mul_lo_u32 %6, %6, %8\n v_mul_lo_u32 %7, %7, %8\n"
+                    : "+v"(i0), "+v"(i1), "+v"(i2), "+v"(i3), "+v"(i4), "+v"(i5), "+v"(i6), "+v"(i7) : "s"(im));
             }
         }
     }
-    const float total = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
+    float total = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
+    total += ((p0.x + p1.y) + (p2.x + p3.y)) + ((p4.x + p5.y) + (p6.x + p7.y));
+    total += (float)(((i0 ^ i1) ^ (i2 ^ i3)) ^ ((i4 ^ i5) ^ (i6 ^ i7)));
     if (total == 12345.678f) { *sink = total; }   // keeps the chains alive
 }
 

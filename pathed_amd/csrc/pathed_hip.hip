@@ -171,6 +171,10 @@ struct PathedScene {
     DeviceBuffer<unsigned long long> stats;
     unsigned int *hostRemaining = nullptr;  // pinned
 
+    bool fusedPath = false;   // tiny scenes: k_path_small, whole paths in registers, no wavefront buffers
+    bool stagedShade = true;  // k_shade_staged (dense, state-sorted stages inside a block) or k_shade (one lane per slot)
+    int stageRounds = 2;      // staged kernel: a block owns stageRounds x 256 slots
+
     int stackRows = 8;    // LDS rows of the per-lane traversal stack (8 / 16 / 22)
     int maxStack = 0;     // the tree's bound on stack entries; entries beyond stackRows spill to stackOverflow
     bool sceneInLds = false;
@@ -423,6 +427,19 @@ void launchTrace(PathedScene *scene, const RenderParams &params, hipStream_t str
 
 void launchShade(PathedScene *scene, const RenderParams &params, hipStream_t stream)
 {
+    if (scene->stagedShade) {
+        const dim3 grid((unsigned)(params.nSlots / (kBlock * scene->stageRounds))), block(kBlock);
+        const bool ldsMaterials = scene->device.nMaterials <= kMaxLdsMaterials;
+        const size_t lds = ldsMaterials ? (size_t)scene->device.nMaterials * sizeof(DMaterial) : 0;
+        if (scene->stageRounds == 4) {
+            if (ldsMaterials) { hipLaunchKernelGGL((k_shade_staged<true, 4>), grid, block, lds, stream, params); }
+            else { hipLaunchKernelGGL((k_shade_staged<false, 4>), grid, block, lds, stream, params); }
+        } else {
+            if (ldsMaterials) { hipLaunchKernelGGL((k_shade_staged<true, 2>), grid, block, lds, stream, params); }
+            else { hipLaunchKernelGGL((k_shade_staged<false, 2>), grid, block, lds, stream, params); }
+        }
+        return;
+    }
     const dim3 grid((unsigned)(params.nSlots / kBlock)), block(kBlock);
     if (scene->device.nMaterials <= kMaxLdsMaterials) {
         hipLaunchKernelGGL((k_shade<true>), grid, block, 0, stream, params);
@@ -558,7 +575,17 @@ int pathed_hip_measure_bandwidth(size_t bytes, int repeats, double *read_gbs, do
 
 int pathed_hip_measure_valu(int waves_per_simd, int repeats, double *fma_rate, double *mixed_rate)
 {
-    if (!fma_rate || !mixed_rate || repeats < 1 || repeats > 1000) { return fail(PATHED_E_INVALID, "bad argument"); }
+    if (!fma_rate || !mixed_rate) { return fail(PATHED_E_INVALID, "bad argument"); }
+    double rates[5] = { 0.0, 0.0, 0.0, 0.0, 0.0 };
+    const int code = pathed_hip_measure_valu_modes(waves_per_simd, repeats, rates, 2);
+    *fma_rate = rates[0];
+    *mixed_rate = rates[1];
+    return code;
+}
+
+int pathed_hip_measure_valu_modes(int waves_per_simd, int repeats, double *rates, int n_modes)
+{
+    if (!rates || repeats < 1 || repeats > 1000 || n_modes < 1 || n_modes > 5) { return fail(PATHED_E_INVALID, "bad argument"); }
     if (waves_per_simd < 1 || waves_per_simd > 8) { return fail(PATHED_E_INVALID, "waves_per_simd must be 1..8"); }
     if (g_device < 0) {
         const int code = pathed_hip_init(0);
@@ -576,32 +603,33 @@ int pathed_hip_measure_valu(int waves_per_simd, int repeats, double *fma_rate, d
     if (status == hipSuccess) { status = hipEventCreate(&stop); }
     // one 256-thread block = one wave on each of a CU's four SIMDs; k blocks per CU = k waves per SIMD
     const dim3 grid((unsigned)(units * waves_per_simd)), block(kBlock);
-    const int iterations = 4096;   // 196 608 instructions per wave and launch: ~0.2-0.4 ms
-    float fmaMs = 0.f, mixedMs = 0.f;
-    if (status == hipSuccess) {
-        hipLaunchKernelGGL((k_valu_probe<false>), grid, block, 0, nullptr, iterations, 1.f, sink);   // warm-up
-        hipLaunchKernelGGL((k_valu_probe<true>), grid, block, 0, nullptr, iterations, 1.f, sink);
+    const int iterations = 8192;   // 393 216 instructions per wave and launch
+    auto launch = [&](int mode) {
+        switch (mode) {
+        case 0: hipLaunchKernelGGL((k_valu_probe<0>), grid, block, 0, nullptr, iterations, 1.f, sink); break;
+        case 1: hipLaunchKernelGGL((k_valu_probe<1>), grid, block, 0, nullptr, iterations, 1.f, sink); break;
+        case 2: hipLaunchKernelGGL((k_valu_probe<2>), grid, block, 0, nullptr, iterations, 1.f, sink); break;
+        case 3: hipLaunchKernelGGL((k_valu_probe<3>), grid, block, 0, nullptr, iterations, 1.f, sink); break;
+        default: hipLaunchKernelGGL((k_valu_probe<4>), grid, block, 0, nullptr, iterations, 1.f, sink); break;
+        }
+    };
+    const double issued = (double)grid.x * kWavesPerBlock * (double)iterations * kValuProbeUnroll * repeats;
+    for (int mode = 0; mode < n_modes && status == hipSuccess; mode++) {
+        float ms = 0.f;
+        launch(mode);   // warm-up
         (void)hipEventRecord(start, nullptr);
-        for (int r = 0; r < repeats; r++) { hipLaunchKernelGGL((k_valu_probe<false>), grid, block, 0, nullptr, iterations, 1.f, sink); }
+        for (int r = 0; r < repeats; r++) { launch(mode); }
         (void)hipEventRecord(stop, nullptr);
         status = hipEventSynchronize(stop);
-        if (status == hipSuccess) { status = hipEventElapsedTime(&fmaMs, start, stop); }
-        (void)hipEventRecord(start, nullptr);
-        for (int r = 0; r < repeats; r++) { hipLaunchKernelGGL((k_valu_probe<true>), grid, block, 0, nullptr, iterations, 1.f, sink); }
-        (void)hipEventRecord(stop, nullptr);
-        if (status == hipSuccess) { status = hipEventSynchronize(stop); }
-        if (status == hipSuccess) { status = hipEventElapsedTime(&mixedMs, start, stop); }
+        if (status == hipSuccess) { status = hipEventElapsedTime(&ms, start, stop); }
         if (status == hipSuccess) { status = hipGetLastError(); }
+        if (status == hipSuccess && !(ms > 0.f)) { status = hipErrorUnknown; }
+        if (status == hipSuccess) { rates[mode] = issued / (ms * 1e-3); }
     }
     if (sink) { (void)hipFree(sink); }
     if (start) { (void)hipEventDestroy(start); }
     if (stop) { (void)hipEventDestroy(stop); }
-    if (status != hipSuccess || !(fmaMs > 0.f) || !(mixedMs > 0.f)) {
-        return fail(PATHED_E_DEVICE, std::string("VALU probe: ") + hipGetErrorString(status));
-    }
-    const double issued = (double)grid.x * kWavesPerBlock * (double)iterations * kValuProbeUnroll * repeats;
-    *fma_rate = issued / (fmaMs * 1e-3);
-    *mixed_rate = issued / (mixedMs * 1e-3);
+    if (status != hipSuccess) { return fail(PATHED_E_DEVICE, std::string("VALU probe: ") + hipGetErrorString(status)); }
     return PATHED_OK;
 }
 
@@ -698,7 +726,7 @@ int pathed_hip_scene_create_ex(const PathedSceneDesc *desc, const PathedSceneOpt
     if (optionsIn) {
         if (optionsIn->struct_size != sizeof(PathedSceneOptions)) { return fail(PATHED_E_INVALID, "PathedSceneOptions.struct_size mismatch"); }
         options = *optionsIn;
-        for (int k = 0; k < 5; k++) {
+        for (int k = 0; k < 3; k++) {
             if (options.reserved[k] != 0) { return fail(PATHED_E_INVALID, "PathedSceneOptions.reserved must be zero"); }
         }
         if (options.bvh_builder < 0 || options.bvh_builder > PATHED_BVH_PLOC_DEVICE + 1) { return fail(PATHED_E_INVALID, "unknown BVH builder"); }
@@ -707,6 +735,8 @@ int pathed_hip_scene_create_ex(const PathedSceneDesc *desc, const PathedSceneOpt
             return fail(PATHED_E_INVALID, "stack_rows must be 0, 8, 16 or 22");
         }
         if (options.max_slots < 0 || (options.max_slots != 0 && options.max_slots < kBlock)) { return fail(PATHED_E_INVALID, "max_slots must be 0 or >= 256"); }
+        if (options.shade_kernel < 0 || options.shade_kernel > 3) { return fail(PATHED_E_INVALID, "shade_kernel must be 0..3"); }
+        if (options.stage_slots != 0 && options.stage_slots != 512 && options.stage_slots != 1024) { return fail(PATHED_E_INVALID, "stage_slots must be 0, 512 or 1024"); }
     }
     int deviceId = options.device;
     if (deviceId == PATHED_DEVICE_CURRENT) {
@@ -962,6 +992,29 @@ int pathed_hip_scene_create_ex(const PathedSceneDesc *desc, const PathedSceneOpt
     // (ray cost is heavy-tailed); the all-triangles kernel has uniform cost and prefers the
     // smaller, Infinity-Cache-resident state
     scene->maxSlots = scene->bruteForce ? (1 << 20) : (1 << 22);
+    // which kernels carry the radiance loop: scenes of <= 64 triangles default to the fused in-register path
+    // kernel, everything else to the wavefront with the per-slot shade kernel (the staged shade kernel is
+    // selectable: it issues fewer instructions but overlaps worse with the other pool's trace kernel)
+    int shadeKernel = options.shade_kernel;
+    if (const char *text = getenv("PATHED_SHADE_KERNEL")) {   // experiments: "per-slot" | "staged" | "fused"
+        if (!strcmp(text, "per-slot")) { shadeKernel = 1; }
+        else if (!strcmp(text, "staged")) { shadeKernel = 2; }
+        else if (!strcmp(text, "fused")) { shadeKernel = 3; }
+    }
+    if (shadeKernel == 3 && !scene->bruteForce) {
+        delete scene;
+        return fail(PATHED_E_INVALID, "the fused path kernel serves scenes of at most 64 triangles that take the all-triangles intersector");
+    }
+    scene->fusedPath = scene->bruteForce && (shadeKernel == 0 || shadeKernel == 3);
+    scene->stagedShade = shadeKernel == 2;
+    // more slots per block = fuller last waves of the dense stages, fewer blocks to fill the chip with:
+    // the 0.5 Mi-slot pools of the all-triangles scenes take 512, the 2 Mi-slot pools of the BVH scenes 1024
+    scene->stageRounds = scene->bruteForce ? 2 : 4;
+    if (options.stage_slots != 0) { scene->stageRounds = options.stage_slots / kBlock; }
+    if (const char *text = getenv("PATHED_STAGE_SLOTS")) {
+        const int value = atoi(text);
+        if (value == 512 || value == 1024) { scene->stageRounds = value / kBlock; }
+    }
     std::memset(&scene->smallTris, 0, sizeof scene->smallTris);
     if (scene->bruteForce) {
         // pairs of leaf-ordered triangles, component-interleaved (kernels.h: SmallTris); the odd
@@ -990,6 +1043,92 @@ void pathed_hip_scene_destroy(PathedScene *scene)
     delete scene;
 }
 
+// One internal pass of the fused path kernel (scenes of <= 64 triangles): a single persistent launch
+// renders every unit of the pass; no slot pool, no iteration loop, no polling.
+static int renderPassFused(PathedScene *scene, uint64_t seed, uint32_t begin, uint32_t count,
+                           int start_bounce, int last_bounce, float *d_accum, hipStream_t stream)
+{
+    const int nPixels = scene->width * scene->height;
+    const int chunk = scene->samplesPerUnit;
+    const int chunksPerPixel = (int)((count + (uint32_t)chunk - 1) / (uint32_t)chunk);
+    const unsigned long long nUnits64 = (unsigned long long)nPixels * (unsigned long long)chunksPerPixel;
+    if (nUnits64 >= 0xFFFFFFF0ull) { return fail(PATHED_E_INVALID, "too many work units in one pass"); }
+    const unsigned int nUnits = (unsigned int)nUnits64;
+
+    if (scene->chunkCapacity < (size_t)nUnits) {
+        HIP_TRY(scene->chunkBuf.allocate((size_t)nUnits));
+        scene->chunkCapacity = (size_t)nUnits;
+    }
+    if (!scene->counters.ptr) { HIP_TRY(scene->counters.allocate(kMaxPools * kCtrCount)); }
+    if (!scene->stats.ptr) {
+        HIP_TRY(scene->stats.allocate(kStatCount));
+        HIP_TRY(hipMemset(scene->stats.ptr, 0, kStatCount * sizeof(unsigned long long)));
+    }
+
+    // persistent grid: what the register budget keeps resident (PATHED_FUSED_WAVES waves per SIMD = blocks per CU),
+    // or fewer when the pass has fewer than 64 units per wave
+    unsigned long long blocks = (unsigned long long)scene->computeUnits * PATHED_FUSED_WAVES;
+    const unsigned long long blocksNeeded = (nUnits64 + (unsigned long long)kBlock - 1) / kBlock;
+    if (blocks > blocksNeeded) { blocks = blocksNeeded; }
+    if (blocks < 1) { blocks = 1; }
+    const unsigned int waves = (unsigned int)blocks * kWavesPerBlock;
+
+    RenderParams params;
+    std::memset(&params, 0, sizeof params);
+    params.scene = scene->device;
+    params.state.chunkBuf = scene->chunkBuf.ptr;
+    params.counters = scene->counters.ptr;
+    params.stats = scene->stats.ptr;
+    params.accum = d_accum;
+    params.nPixels = nPixels;
+    params.nUnits = nUnits;
+    params.unitBase = 0;
+    params.nQueues = (int)(waves < (unsigned int)kUnitQueues ? waves : (unsigned int)kUnitQueues);
+    params.unitsPerQueue = (nUnits + (unsigned int)params.nQueues - 1) / (unsigned int)params.nQueues;
+    {
+        // a wave reserves up to one unit per lane at a time; passes too small for that hand out less per atomic,
+        // so that the last reservations of a queue do not leave most waves idle
+        const unsigned int wavesPerQueue = (waves + (unsigned int)params.nQueues - 1) / (unsigned int)params.nQueues;
+        unsigned int grab = params.unitsPerQueue / (wavesPerQueue * 4u);
+        params.unitGrab = (int)(grab < 1u ? 1u : grab > 64u ? 64u : grab);
+    }
+    params.chunk = chunk;
+    params.chunksPerPixel = chunksPerPixel;
+    params.seedLo = (uint32_t)seed;
+    params.seedHi = (uint32_t)(seed >> 32);
+    params.sppBegin = begin;
+    params.sppEnd = begin + count;
+    params.startBounce = start_bounce;
+    params.lastBounce = last_bounce;
+
+    HIP_TRY(hipMemsetAsync(params.counters, 0, kCtrCount * sizeof(unsigned int), stream));
+    const dim3 grid((unsigned)blocks), block(kBlock);
+    const bool ldsMaterials = scene->device.nMaterials <= kMaxLdsMaterials;
+    const size_t lds = ldsMaterials ? (size_t)scene->device.nMaterials * sizeof(DMaterial) : 0;
+    int timed = -1;
+    if (scene->timeKernels) {
+        timed = scene->traceEvents.acquire();
+        (void)hipEventRecord(scene->traceEvents.start[timed], stream);
+    }
+    if (ldsMaterials) {
+        if (scene->countMode) { hipLaunchKernelGGL((k_path_small<true, true>), grid, block, lds, stream, params, scene->smallTris); }
+        else { hipLaunchKernelGGL((k_path_small<true, false>), grid, block, lds, stream, params, scene->smallTris); }
+    } else {
+        if (scene->countMode) { hipLaunchKernelGGL((k_path_small<false, true>), grid, block, lds, stream, params, scene->smallTris); }
+        else { hipLaunchKernelGGL((k_path_small<false, false>), grid, block, lds, stream, params, scene->smallTris); }
+    }
+    if (timed >= 0) { (void)hipEventRecord(scene->traceEvents.stop[timed], stream); }
+    scene->traceLaunchesAll++;
+    const dim3 pixelGrid((unsigned)((nPixels + kBlock - 1) / kBlock));
+    hipLaunchKernelGGL(k_resolve, pixelGrid, block, 0, stream, params);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(stream));
+
+    scene->iterations += 1;
+    scene->cameraSamples += (unsigned long long)count * (unsigned long long)nPixels;
+    return PATHED_OK;
+}
+
 // One internal pass: samples [begin, begin+count), count <= chunk * kMaxChunksPerPass.
 // The slot pool is split into `pools` independent halves, each with its own unit range,
 // counters and HIP stream: while one half runs its (ALU-bound) trace kernel the other runs its
@@ -1009,7 +1148,9 @@ static int renderPass(PathedScene *scene, uint64_t seed, uint32_t begin, uint32_
     if (nUnits64 < 4ull * kBlock * (unsigned long long)pools) { pools = 1; }
 
     unsigned long long wanted = nUnits64 < (unsigned long long)scene->maxSlots ? nUnits64 : (unsigned long long)scene->maxSlots;
-    const int slotsPerPool = (int)((wanted / pools + kBlock - 1) / kBlock * kBlock);
+    // a block of the staged shade kernel owns stageRounds x 256 slots: pools are whole blocks
+    const unsigned long long slotQuantum = (unsigned long long)kBlock * (scene->stagedShade ? scene->stageRounds : 1);
+    const int slotsPerPool = (int)((wanted / pools + slotQuantum - 1) / slotQuantum * slotQuantum);
     const int nSlots = slotsPerPool * pools;
     int code = ensureRenderState(scene, nSlots, (size_t)nUnits);
     if (code != PATHED_OK) { return code; }
@@ -1022,7 +1163,9 @@ static int renderPass(PathedScene *scene, uint64_t seed, uint32_t begin, uint32_
     }
 
     const int blocksPerPool = slotsPerPool / kBlock;
-    const int nQueues = blocksPerPool < kUnitQueues ? blocksPerPool : kUnitQueues;
+    // every unit queue needs a consumer among the blocks of the shade kernel (a staged block owns stageRounds x 256 slots)
+    const int shadeBlocks = blocksPerPool / (scene->stagedShade ? scene->stageRounds : 1);
+    const int nQueues = shadeBlocks < kUnitQueues ? shadeBlocks : kUnitQueues;
 
     RenderParams params[kMaxPools];
     hipStream_t streams[kMaxPools] = { stream, stream, stream, stream };
@@ -1212,7 +1355,9 @@ int pathed_hip_render_device(PathedScene *scene, uint64_t seed,
     uint32_t done = 0;
     while (done < spp_count) {
         const uint32_t count = (spp_count - done < perPass) ? (spp_count - done) : perPass;
-        const int code = renderPass(scene, seed, spp_begin + done, count, start_bounce, last_bounce, d_accum_rgb_sum, stream);
+        const int code = scene->fusedPath
+            ? renderPassFused(scene, seed, spp_begin + done, count, start_bounce, last_bounce, d_accum_rgb_sum, stream)
+            : renderPass(scene, seed, spp_begin + done, count, start_bounce, last_bounce, d_accum_rgb_sum, stream);
         if (code != PATHED_OK) { return code; }
         done += count;
     }
@@ -1352,6 +1497,7 @@ int pathed_hip_get_stats(PathedScene *scene, PathedStats *out)
     out->bvh_build_ms = scene->bvhBuildMs;
     out->bvh_builder = (uint32_t)scene->bvhBuilder;
     out->trace_launches_all = (uint32_t)scene->traceLaunchesAll;
+    out->path_kernel = scene->fusedPath ? 3u : (scene->stagedShade ? 2u : 1u);
     if (getenv("PATHED_SHADE_PROFILE")) {   // counters exist in -DPATHED_SHADE_PROFILE builds only
         static const char *regions[11] = { "all waves", "active slots", "makeIsect (hit)", "camera-ray vertex", "finish previous MIS term",
                                            "new vertex: BSDF sample", "light sampling", "sample finished", "startSample (regeneration)", "shadow ray pushed",

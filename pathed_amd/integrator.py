@@ -42,12 +42,23 @@ def measure_valu(waves_per_simd=4, repeats=10):
     return fma.value, mixed.value
 
 
+VALU_MODES = ("v_fma_f32 (1 VGPR source)", "6 v_fma_f32 + v_rcp_f32 + v_sqrt_f32", "v_fma_f32 (3 VGPR sources)", "v_pk_fma_f32", "v_mul_lo_u32")
+
+
+def measure_valu_modes(waves_per_simd=4, repeats=5):
+    """wave-instructions per second for each of VALU_MODES (pathed_hip_measure_valu_modes)."""
+    lib = _capi.load_hip()
+    rates = (C.c_double * 5)()
+    _check(lib, lib.pathed_hip_measure_valu_modes(int(waves_per_simd), int(repeats), rates, 5), "pathed_hip_measure_valu_modes")
+    return list(rates)
+
+
 class HipScene:
     """A scene uploaded to one GPU (PathedScene handle).
 
     Keyword options map onto PathedSceneOptions (include/pathed_hip.h): stack_rows, pools,
     suspend_lanes, suspend_patience, park_min_cards, max_slots, intersector ("auto" | "bvh"),
-    trace_blocks_per_cu.  `device=None` keeps the device of an earlier pathed_hip_init.
+    trace_blocks_per_cu, shade_kernel ("auto" | "per-slot" | "staged" | "fused"), stage_slots.  `device=None` keeps the device of an earlier pathed_hip_init.
     """
 
     BVH_BUILDERS = {"sah": 0, "lbvh": 1, "ploc": 2}  # PATHED_BVH_SAH_HOST / _LBVH_DEVICE / _PLOC_DEVICE
@@ -60,7 +71,8 @@ class HipScene:
         packed.bvh_builder = self.BVH_BUILDERS[bvh_builder] + 1
         intersector = options.pop("intersector", "auto")
         packed.intersector = {"auto": 0, "bvh": 1}[intersector]
-        for name in ("stack_rows", "pools", "suspend_lanes", "suspend_patience", "park_min_cards", "max_slots", "trace_blocks_per_cu"):
+        packed.shade_kernel = {"auto": 0, "per-slot": 1, "staged": 2, "fused": 3}[options.pop("shade_kernel", "auto")]
+        for name in ("stack_rows", "pools", "suspend_lanes", "suspend_patience", "park_min_cards", "max_slots", "trace_blocks_per_cu", "stage_slots"):
             if name in options:
                 setattr(packed, name, int(options.pop(name)))
         if options:

@@ -300,6 +300,53 @@ def test_result_does_not_depend_on_scheduling_or_intersector_variant(libs):
         assert np.array_equal(glass_one, glass_several), pools
 
 
+@pytest.mark.parametrize("scene_path,size,spp,last_bounce", [
+    ("scenes/cornell.json", 96, 12, 10),            # all-triangles kernel, emitter hits, paths that run to lastBounce
+    ("scenes/cornell-glass.json", 80, 8, 10),       # BVH walk, glass + Lambertian, parked rays
+    ("scenes/mis-pbrt.json", 96, 8, 6),             # sphere lights, plastic plates: black-bodied emitters end samples
+    ("scenes/teapot.json", 96, 8, 10),              # environment light, glass, checkerboard
+    ("scenes/cornell-oren-nayar.json", 64, 6, 3),   # Oren-Nayar + microfacet, short bounce window
+    ("test_scenes/environment_map_sampling.json", 64, 8, 4),
+])
+def test_shade_kernels_are_bit_identical(libs, scene_path, size, spp, last_bounce):
+    """Three organisations of the same arithmetic.  k_shade: one lane per slot.  k_shade_staged: classify ->
+    key-sorted dense vertex stage -> dense regeneration stage, per block of 512 or 1024 slots.  k_path_small
+    (scenes of <= 64 triangles): whole paths in registers, one persistent launch.  Each performs k_shade's
+    operations in k_shade's order for every path and the unit decomposition fixes the summation order: the
+    radiance sums are the same floats, whatever the block size, pool count or summation granularity."""
+    _, HipScene, LoadedScene = libs
+    scene = LoadedScene(scene_path, size, size)
+    per_slot = HipScene(scene.desc, device=0, shade_kernel="per-slot")
+    expected = per_slot.render(7, 3, spp, 0, last_bounce)
+    assert expected.any() and per_slot.stats()["path_kernel"] == 1
+    for options in ({"stage_slots": 512}, {"stage_slots": 1024}, {"stage_slots": 512, "pools": 1, "max_slots": 4096},
+                    {"stage_slots": 1024, "pools": 3}):
+        staged = HipScene(scene.desc, device=0, shade_kernel="staged", **options)
+        assert np.array_equal(staged.render(7, 3, spp, 0, last_bounce), expected), options
+        assert staged.stats()["path_kernel"] == 2
+    # bounce windows and the exact-reference summation order (one sample per unit)
+    staged = HipScene(scene.desc, device=0, shade_kernel="staged")
+    staged.set_samples_per_unit(1)
+    per_slot.set_samples_per_unit(1)
+    windowed = per_slot.render(2, 0, 3, 1, 2)
+    assert np.array_equal(staged.render(2, 0, 3, 1, 2), windowed)
+    automatic = HipScene(scene.desc, device=0)
+    if automatic.stats()["scene_in_lds"] == 2:
+        # the default for tiny scenes is the fused kernel
+        assert automatic.stats()["path_kernel"] == 3
+        assert np.array_equal(automatic.render(7, 3, spp, 0, last_bounce), expected)
+        automatic.set_samples_per_unit(1)
+        assert np.array_equal(automatic.render(2, 0, 3, 1, 2), windowed)
+        automatic.set_samples_per_unit(7)
+        per_slot.set_samples_per_unit(7)
+        assert np.array_equal(automatic.render(9, 5, 23, 0, last_bounce), per_slot.render(9, 5, 23, 0, last_bounce))   # ragged last unit
+    else:
+        from pathed_amd.integrator import PathedError
+        assert automatic.stats()["path_kernel"] == 1
+        with pytest.raises(PathedError):
+            HipScene(scene.desc, device=0, shade_kernel="fused")
+
+
 def test_scene_options_are_validated(libs):
     """PathedSceneOptions: wrong struct size, unknown builder, bad stack rows are PATHED_E_INVALID, not a crash."""
     import ctypes as C
