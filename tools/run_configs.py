@@ -122,6 +122,21 @@ def main():
             "parity_at_full_resolution": full_parity,
         })
         print(json.dumps(rows[-1]), flush=True)
+    if not args.only or "GT" in args.only.split(","):
+        # the reference's own error metrics (tools/error_reports.py:13-23) against its only rendered image
+        from pathed_amd import gt_metrics
+        gt = gt_metrics.load_gt()
+        scene = LoadedScene(gt_metrics.GT_SCENE, 400, 400)
+        gpu = HipScene(scene.desc, device=0)
+        report = gt_metrics.compare(lambda seed, begin, count: gpu.render(seed, begin, count, 0, gt_metrics.GT_LAST_BOUNCE), gt, 16384)
+        top = report["levels"][-1]
+        rows.append({"config": "GT", "scene": gt_metrics.GT_SCENE + " vs tools/cornell-gt.exr (400x400)", "spp": top["spp"],
+                     "MSE": "%.4e" % top["mse"], "AE": "%.4e" % top["ae"], "MRSE": "%.4e" % top["mrse"],
+                     "MSE_without_light_pixels": "%.3e" % top["mse_dim"], "ground_truth_noise": "%.3e" % report["gt_noise_mse_dim"],
+                     "one_over_spp_law_ratios": [round(r, 2) for r in report["law_ratios"]],
+                     "energy_ratio": round(report["energy_ratio"], 4), "block_rel_p50": round(report["block_rel_p50"], 4),
+                     "block_rel_p95": round(report["block_rel_p95"], 4)})
+        print(json.dumps(rows[-1]), flush=True)
     return rows
 
 
