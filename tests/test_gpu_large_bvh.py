@@ -1,0 +1,83 @@
+"""BASELINE configuration 5 at its real size: the 5.2 M-triangle stand-in (scenes/dragon-standin.json; 352 MB of nodes +
+triangles, beyond the 256 MB Infinity Cache), built on the GPU (PLOC), traced and rendered against the oracle.
+What only this size exercises: PLOC over 5 M clusters, a tree too deep for the LDS stack rows (spill to HBM), parked rays
+that carry deep stacks, the node and shading-record gathers out of HBM."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def large_scene():
+    import oracle_lib
+    from pathed_amd.scene import LoadedScene
+    mesh = os.path.join(ROOT, "assets", "dragon-standin.ply")
+    have = 0
+    if os.path.exists(mesh):
+        for line in open(mesh, "rb").read(400).split(b"\n"):
+            if line.startswith(b"element face"):
+                have = int(line.split()[2])
+    if have != 20 * 4 ** 9:   # the other tests generate smaller versions of the same file
+        subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_assets.py"), "--dragon", "9"], check=True, stdout=subprocess.DEVNULL)
+    small = LoadedScene("scenes/dragon-standin.json", 128, 72)
+    assert small.n_triangles == 20 * 4 ** 9 + 2
+    yield small, oracle_lib.OracleScene(small.desc)
+    # leave the small version behind for the tests that want 82 K triangles
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_assets.py"), "--dragon", "6"], check=True, stdout=subprocess.DEVNULL)
+
+
+def _rays(n, seed):
+    rng = np.random.default_rng(seed)
+    rays = np.zeros((n, 8), dtype=np.float32)
+    rays[:, 0:3] = rng.normal(size=(n, 3)) * 120 + [0, 0, 25]
+    target = rng.normal(size=(n, 3)) * 30 + [0, 0, 25]
+    direction = target - rays[:, 0:3]
+    rays[:, 4:7] = direction / np.linalg.norm(direction, axis=1, keepdims=True)
+    rays[:, 3] = 1e-3
+    rays[:, 7] = 1e5
+    return rays
+
+
+def test_full_size_stand_in_traced_and_rendered_against_the_oracle(large_scene):
+    from pathed_amd.integrator import HipScene
+    scene, cpu = large_scene
+    gpu = HipScene(scene.desc, device=0, bvh_builder="ploc")
+    stats = gpu.stats()
+    assert stats["scene_in_lds"] == 0 and stats["bvh_builder"] == 2
+    assert stats["bvh_bytes"] > 300e6 and stats["bvh_max_depth"] >= 10      # HBM-resident, deeper than the 22 LDS stack rows cover
+    assert stats["bvh_build_ms"] < 500.0                                     # a device build: tens of milliseconds
+    rays = _rays(200000, 4)
+    expected_hits = cpu.trace(rays)
+    assert (expected_hits[:, 3].view(np.int32) >= 0).mean() > 0.9
+    hits = gpu.trace(rays)
+    assert np.array_equal(hits.view(np.int32), expected_hits.view(np.int32))             # closest hits: bit-exact
+    occluded = gpu.trace(rays[:50000], any_hit=True)
+    assert np.array_equal(occluded, cpu.trace(rays[:50000], any_hit=True))
+    # the exported tree is the one the kernel walks: an independent walk of it counts what the kernel counts
+    nodes, tris = gpu.export_bvh()
+    assert tris.shape[0] == scene.n_triangles - 2 + 2 and nodes.shape[0] == stats["bvh_nodes"]
+    image = gpu.render(1, 0, 8, 0, 10)
+    expected, oracle_stats = cpu.render(128, 72, 1, 0, 8, 0, 10, threads=os.cpu_count(), chunk=4)
+    rel = float(np.linalg.norm(image - expected) / np.linalg.norm(expected))
+    bad = float((np.abs(image - expected) > 1e-2 * np.maximum(np.abs(expected), 1e-3)).any(axis=2).mean())
+    assert rel <= 2e-3 and bad <= 2e-3, (rel, bad)
+    assert oracle_stats["vertices"] > 0.3 * oracle_stats["camera_samples"]
+
+    # second leg: only 8 LDS stack rows, so most of the deep traversals spill to HBM, and waves park their tails eagerly
+    # (parked records carry the spilled stack); hits and image are the same bits
+    spilling = HipScene(scene.desc, device=0, bvh_builder="ploc", stack_rows=8, trace_blocks_per_cu=1, suspend_lanes=64,
+                        suspend_patience=-1, park_min_cards=-1)
+    assert np.array_equal(spilling.trace(rays).view(np.int32), hits.view(np.int32))
+    spilling.set_stats_mode(count=True)
+    assert np.array_equal(spilling.render(1, 0, 8, 0, 10), image)
+    assert spilling.stats()["parked_rays"] > 0
+    # the host SAH tree over the same mesh gives the same hits (acceptance does not depend on the tree)
+    sah = HipScene(scene.desc, device=0, bvh_builder="sah")
+    assert np.array_equal(sah.trace(rays[:50000]).view(np.int32), hits[:50000].view(np.int32))
