@@ -80,6 +80,10 @@ const float kInvPi = 0.3183098861837907f;      /* include/util.h:10 INV_PI      
 const float kPi = 3.14159265358979323846f;     /* M_PI narrowed to fp32         */
 const float kTwoPi = 6.283185307179586f;       /* include/util.h:11 M_TWO_PI    */
 
+/* `2 * M_PI * u` exactly as the reference forms it (src/monte_carlo.cpp:28, src/beckmann.cpp:33, src/sphere.cpp:59,97):
+ * in double, narrowed once.  The kernels do the same (pathed_amd/csrc/shading.h: twoPiTimes). */
+inline float twoPiTimes(float u) { return (float)(6.283185307179586476925286766559 * (double)u); }
+
 /* ------------------------------------------------------------------ vectors */
 
 struct Vec3 {
@@ -326,7 +330,7 @@ Vec3 cosineSampleHemisphere(Rng &random)
 {
     const float xi1 = random.next();
     const float r = sqrtf(xi1);
-    const float phi = kTwoPi * random.next();
+    const float phi = twoPiTimes(random.next());
     const float x = r * cosf(phi);
     const float z = r * sinf(phi);
     const float y = sqrtf(1.f - xi1);
@@ -594,7 +598,7 @@ inline float beckmannG(float alpha, Vec3 wo, Vec3 wi)
 /* src/beckmann.cpp:13-43: phi is drawn first, then the tan^2 variate */
 Vec3 beckmannSampleWh(float alpha, Rng &random)
 {
-    const float phi = random.next() * kPi * 2.f;
+    const float phi = twoPiTimes(random.next());
 
     const float xi = random.next();
     float logXi = logf(xi);
@@ -875,7 +879,7 @@ SurfaceSample sphereSampleArea(const Sphere &s, Rng &random)
 {
     const float z = 1 - 2 * random.next();
     const float r = sqrtf(fmaxf(0, 1 - z * z));
-    const float phi = 2 * kPi * random.next();
+    const float phi = twoPiTimes(random.next());
     const Vec3 v = v3(r * cosf(phi), r * sinf(phi), z);
 
     SurfaceSample sample;
@@ -899,7 +903,7 @@ SurfaceSample sphereSample(const Sphere &s, Vec3 referencePoint, Rng &random)
 
     const float xi1 = random.next();
     const float cosTheta = (1.f - xi1) + xi1 * cosThetaMax;
-    const float phi = random.next() * 2.f * kPi;
+    const float phi = twoPiTimes(random.next());
 
     const float sinTheta = sinFromCos(cosTheta);
     const float sideOppositeTheta = centerDistance * sinTheta;
@@ -1060,7 +1064,7 @@ struct EnvLight {
         const float thetaCanonical = (thetaStep + 0.5f) / height;
 
         const float phi = phiCanonical * kTwoPi;
-        const float theta = thetaCanonical * kPi;
+        const float theta = (float)((double)thetaCanonical * 3.14159265358979323846);   /* M_PI is a double: src/environment_light.cpp:92 */
 
         const float pdf = thetaPDF * phiPDF * width * height / (sinf(theta) * kTwoPi * kPi);
 

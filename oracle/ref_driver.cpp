@@ -46,6 +46,7 @@
 
 #define private public
 #define protected public
+#include "mtl_parser.h"
 #include "random_generator.h"
 #include "transform.h"
 #include "environment_light.h"
@@ -73,11 +74,26 @@
 #include "plastic.h"
 #include "ray.h"
 #include "snell.h"
+#include "string_util.h"
 #include "triangle.h"
 #include "util.h"
 #include "vector.h"
 
 static FILE *g_out = stdout;
+
+/* text records: {"fn": name, "text": "...", "tokens": [...]} -- JSON string escaping for the few characters the inputs hold */
+static std::string quoted(const std::string &text)
+{
+    std::string out = "\"";
+    for (char c : text) {
+        if (c == '\\' || c == '"') { out += '\\'; out += c; }
+        else if (c == '\t') { out += "\\t"; }
+        else if (c == '\n') { out += "\\n"; }
+        else if (c == '\r') { out += "\\r"; }
+        else { out += c; }
+    }
+    return out + "\"";
+}
 
 static void emit(const char *fn, const std::vector<float> &in, const std::vector<float> &out)
 {
@@ -757,6 +773,43 @@ int main(int argc, char **argv)
             std::vector<float> image = { (float)texture.m_width, (float)texture.m_height };
             for (int i = 0; i < 3 * texture.m_width * texture.m_height; i++) { image.push_back((float)texture.m_data[i]); }
             emit("texture_image", { (float)(100 + f) }, image);
+        }
+    }
+
+    /* ---- the text layer under the OBJ / MTL readers: src/string_util.cpp, src/mtl_parser.cpp ----
+     * first the reference's own known answers (test/string_util_test.cpp:9-37), then harder lines */
+    {
+        const char *trims[] = { "token", "token  ", "t o  ken", "  token", "  token  ", "  t o  ken", " ", "     ", "",
+                                "\ttoken", " \t token\t", "\t\t" };
+        for (const char *text : trims) {
+            fprintf(g_out, "{\"fn\": \"ltrim\", \"text\": %s, \"result\": %s}\n", quoted(text).c_str(), quoted(lTrim(text)).c_str());
+        }
+        const char *lines[] = { "a b c", " a b c", "  a b c", "a b c ", "  a  b      c    ", "", " ", " \t ",
+                                "newmtl\tname", "Kd 0.1\t0.2  0.3", "f 1/2/3 4//5 6", "\tusemtl  light ", "v  -1.5e-3\t2 3 # no comment syntax",
+                                "single", "trailing\t", "a\t\tb" };
+        for (const char *line : lines) {
+            std::queue<std::string> tokens = tokenize(line);
+            fprintf(g_out, "{\"fn\": \"tokenize\", \"text\": %s, \"tokens\": [", quoted(line).c_str());
+            bool first = true;
+            while (!tokens.empty()) { fprintf(g_out, "%s%s", first ? "" : ", ", quoted(tokens.front()).c_str()); tokens.pop(); first = false; }
+            fprintf(g_out, "]}\n");
+        }
+        /* MtlParser over the two libraries the reference ships and two fixture files; paths relative to the repository root */
+        const std::string root = (argc > 4) ? argv[4] : ".";
+        const char *files[] = { "scenes/CornellBox-Original.mtl", "scenes/cornell-glossy/CornellBox-Glossy.mtl",
+                                "tests/golden/mtl/edge_cases.mtl", "tests/golden/mtl/values_before_newmtl.mtl", "tests/golden/mtl/absent.mtl" };
+        for (const char *file : files) {
+            MtlParser parser(root + "/" + file);
+            parser.parse();
+            fprintf(g_out, "{\"fn\": \"mtl_parse\", \"file\": %s, \"materials\": [", quoted(file).c_str());
+            bool first = true;
+            for (const auto &item : parser.m_mtlLookup) {   /* std::map: name order */
+                const Color kd = item.second.diffuse, ke = item.second.emit;
+                fprintf(g_out, "%s{\"name\": %s, \"Kd\": [%.9g, %.9g, %.9g], \"Ke\": [%.9g, %.9g, %.9g]}", first ? "" : ", ",
+                        quoted(item.first).c_str(), kd.r(), kd.g(), kd.b(), ke.r(), ke.g(), ke.b());
+                first = false;
+            }
+            fprintf(g_out, "], \"baked\": %d}\n", (int)parser.materialLookup().size());
         }
     }
 

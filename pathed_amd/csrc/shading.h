@@ -16,6 +16,11 @@ namespace pathed {
 #define PATHED_PI 3.14159265358979323846f   /* M_PI narrowed to fp32 */
 #define PATHED_TWO_PI 6.283185307179586f    /* include/util.h:11 */
 
+// `2 * M_PI * u` as the reference evaluates it (src/monte_carlo.cpp:28, src/beckmann.cpp:33, src/sphere.cpp:59,97):
+// M_PI is a double, so the product is formed in double and narrowed once.  An fp32 product is an ulp off for
+// a quarter of the inputs, which cosf / sinf turn into relative errors of 1e-5 near their zeros.
+__host__ __device__ inline float twoPiTimes(float u) { return (float)(6.283185307179586476925286766559 * (double)u); }
+
 // ---------------------------------------------------------------------------- rng
 // Counter-based stream u(seed, pixel, sample, dimension); replaces the reference's
 // shared, unseedable mt19937 (src/random_generator.cpp:4-6).  Two bijective 32-bit
@@ -166,7 +171,7 @@ __device__ inline V3 cosineSampleHemisphere(Rng &random)
 {
     const float xi1 = random.next();
     const float r = sqrtf(xi1);
-    const float phi = PATHED_TWO_PI * random.next();
+    const float phi = twoPiTimes(random.next());
     const float x = r * cosf(phi);
     const float z = r * sinf(phi);
     const float y = sqrtf(1.f - xi1);
@@ -396,7 +401,7 @@ __device__ inline float beckmannG(float alpha, V3 wo, V3 wi)
 // src/beckmann.cpp:13-43: phi is drawn first, then the tan^2 variate
 __device__ inline V3 beckmannSampleWh(float alpha, Rng &random)
 {
-    const float phi = random.next() * PATHED_PI * 2.f;
+    const float phi = twoPiTimes(random.next());
 
     const float xi = random.next();
     float logXi = logf(xi);
@@ -665,7 +670,7 @@ __device__ inline SurfaceSample sphereSampleArea(V3 center, float radius, Rng &r
 {
     const float z = 1 - 2 * random.next();
     const float r = sqrtf(fmaxf(0, 1 - z * z));
-    const float phi = 2 * PATHED_PI * random.next();
+    const float phi = twoPiTimes(random.next());
     const V3 v = v3(r * cosf(phi), r * sinf(phi), z);
 
     SurfaceSample sample;
@@ -689,7 +694,7 @@ __device__ inline SurfaceSample sphereSample(V3 center, float radius, V3 referen
 
     const float xi1 = random.next();
     const float cosTheta = (1.f - xi1) + xi1 * cosThetaMax;
-    const float phi = random.next() * 2.f * PATHED_PI;
+    const float phi = twoPiTimes(random.next());
 
     const float sinTheta = sinFromCos(cosTheta);
     const float sideOppositeTheta = centerDistance * sinTheta;
@@ -796,7 +801,7 @@ __device__ inline SurfaceSample envSample(const DEnv &env, V3 point, Rng &random
     const float thetaCanonical = (thetaStep + 0.5f) / env.height;
 
     const float phi = phiCanonical * PATHED_TWO_PI;
-    const float theta = thetaCanonical * PATHED_PI;
+    const float theta = (float)((double)thetaCanonical * 3.14159265358979323846);   // M_PI is a double: src/environment_light.cpp:92
 
     const float pdf = thetaPDF * phiPDF * env.width * env.height / (sinf(theta) * PATHED_TWO_PI * PATHED_PI);
 

@@ -46,6 +46,46 @@ void pathed_host_free_scene(void *handle)
     delete (LoadedScene *)handle;
 }
 
+// tokens of one line, '\n'-separated (reference tokenize / lTrim); returns the token count, -1 if `out` is too small
+int pathed_host_tokenize(const char *line, char *out, size_t capacity)
+{
+    const std::vector<std::string> tokens = pathed::tokenizeLine(line ? line : "");
+    std::string joined;
+    for (size_t i = 0; i < tokens.size(); i++) { joined += (i ? "\n" : "") + tokens[i]; }
+    if (joined.size() + 1 > capacity) { return -1; }
+    std::memcpy(out, joined.c_str(), joined.size() + 1);
+    return (int)tokens.size();
+}
+
+int pathed_host_ltrim(const char *text, char *out, size_t capacity)
+{
+    const std::string trimmed = pathed::leftTrim(text ? text : "");
+    if (trimmed.size() + 1 > capacity) { return -1; }
+    std::memcpy(out, trimmed.c_str(), trimmed.size() + 1);
+    return (int)trimmed.size();
+}
+
+// the materials of an MTL file, one per line in name order: "name\tKd r g b\tKe r g b" (%.9g); returns the count
+int pathed_host_parse_mtl(const char *path, char *out, size_t capacity)
+{
+    try {
+        const std::vector<pathed::MtlMaterial> materials = pathed::parseMtlFile(path ? path : "");
+        std::string text;
+        for (const pathed::MtlMaterial &m : materials) {
+            char line[512];
+            snprintf(line, sizeof line, "%s\tKd %.9g %.9g %.9g\tKe %.9g %.9g %.9g\n", m.name.c_str(),
+                     m.diffuse[0], m.diffuse[1], m.diffuse[2], m.emit[0], m.emit[1], m.emit[2]);
+            text += line;
+        }
+        if (text.size() + 1 > capacity) { g_hostError = "buffer too small"; return -1; }
+        std::memcpy(out, text.c_str(), text.size() + 1);
+        return (int)materials.size();
+    } catch (const std::exception &error) {
+        g_hostError = error.what();
+        return -2;
+    }
+}
+
 }  // extern "C"
 
 // ---- job runner (shared by the `pathed` executable and the Python harness) ----------

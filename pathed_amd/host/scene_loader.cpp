@@ -348,15 +348,11 @@ std::string stripCarriageReturn(std::string line)
     return line;
 }
 
-struct MtlEntry {
-    float diffuse[3] = { 0.f, 0.f, 0.f };
-    float emit[3] = { 0.f, 0.f, 0.f };
-};
-
-std::map<std::string, int> parseMtl(const std::string &path, LoaderContext &context)
+// MtlParser::parse, src/mtl_parser.cpp:16-113: newmtl / Kd / Ke only, a later newmtl of the same name starts
+// over, Kd / Ke ahead of any newmtl land on the material named "".  Entries in std::map (name) order.
+std::vector<MtlMaterial> readMtlFile(const std::string &path)
 {
-    std::map<std::string, MtlEntry> entries;
-    std::vector<std::string> order;
+    std::map<std::string, MtlMaterial> entries;
     std::string current;
 
     std::ifstream file(path);
@@ -368,20 +364,26 @@ std::map<std::string, int> parseMtl(const std::string &path, LoaderContext &cont
         const std::string &command = tokens[0];
         if (command == "newmtl" && tokens.size() >= 2) {
             current = tokens[1];
-            if (!entries.count(current)) { order.push_back(current); }
-            entries[current] = MtlEntry();
+            entries[current] = MtlMaterial();
+            entries[current].name = current;
         } else if (command == "Kd" && tokens.size() >= 4) {
-            if (!entries.count(current)) { order.push_back(current); }
+            entries[current].name = current;
             for (int i = 0; i < 3; i++) { entries[current].diffuse[i] = std::stof(tokens[(size_t)i + 1]); }
         } else if (command == "Ke" && tokens.size() >= 4) {
-            if (!entries.count(current)) { order.push_back(current); }
+            entries[current].name = current;
             for (int i = 0; i < 3; i++) { entries[current].emit[i] = std::stof(tokens[(size_t)i + 1]); }
         }
     }
+    std::vector<MtlMaterial> materials;
+    for (const auto &item : entries) { materials.push_back(item.second); }
+    return materials;
+}
 
+std::map<std::string, int> parseMtl(const std::string &path, LoaderContext &context)
+{
     std::map<std::string, int> lookup;
-    for (const auto &item : entries) {
-        lookup[item.first] = context.addMaterial(makeLambertian(item.second.diffuse, item.second.emit));
+    for (const MtlMaterial &material : readMtlFile(path)) {
+        lookup[material.name] = context.addMaterial(makeLambertian(material.diffuse, material.emit));
     }
     return lookup;
 }
@@ -926,5 +928,9 @@ FlatScene loadScene(
 
     return scene;
 }
+
+std::vector<std::string> tokenizeLine(const std::string &line) { return tokenize(line); }
+std::string leftTrim(const std::string &token) { return lTrim(token); }
+std::vector<MtlMaterial> parseMtlFile(const std::string &path) { return readMtlFile(path); }
 
 }  // namespace pathed

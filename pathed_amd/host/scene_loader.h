@@ -62,4 +62,15 @@ FlatScene loadScene(
 
 PathedMaterial makeLambertian(const float diffuse[3], const float emit[3]);
 
+// The text layer under the OBJ / MTL readers, exposed so the tests can hold it against the reference's own
+// tokenizer and MtlParser (src/string_util.cpp:7-38, src/mtl_parser.cpp:16-113; test/string_util_test.cpp:9-37).
+struct MtlMaterial {
+    std::string name;
+    float diffuse[3] = { 0.f, 0.f, 0.f };
+    float emit[3] = { 0.f, 0.f, 0.f };
+};
+std::vector<std::string> tokenizeLine(const std::string &line);
+std::string leftTrim(const std::string &token);
+std::vector<MtlMaterial> parseMtlFile(const std::string &path);
+
 }  // namespace pathed

@@ -252,3 +252,50 @@ def test_deeply_nested_json_is_an_error_not_a_stack_overflow(tmp_path):
     bad.write_text("[" * 200000)
     with pytest.raises(RuntimeError, match="nesting"):
         LoadedScene(str(bad), 8, 8, asset_root="")
+
+
+def _text_records():
+    import json
+    path = os.path.join(os.path.dirname(__file__), "golden", "reference_functions.jsonl")
+    records = {"ltrim": [], "tokenize": [], "mtl_parse": []}
+    for line in open(path):
+        record = json.loads(line)
+        if record["fn"] in records:
+            records[record["fn"]].append(record)
+    return records
+
+
+def test_tokenizer_and_mtl_reader_match_the_reference_object_code():
+    """The text layer under the OBJ / MTL readers against records dumped from the reference's own string_util.o and
+    mtl_parser.o (oracle/ref_driver.cpp): its known answers (test/string_util_test.cpp:9-37) first, then tabs,
+    repeated blanks, the two material libraries the reference ships and two fixture files with the corner cases
+    (values ahead of any newmtl, a material defined twice, unknown statements, extra tokens, a missing file)."""
+    import ctypes as C
+    from pathed_amd import _capi
+    host = _capi.load_host()
+    host.pathed_host_tokenize.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t]
+    host.pathed_host_ltrim.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t]
+    host.pathed_host_parse_mtl.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t]
+    records = _text_records()
+    assert len(records["ltrim"]) >= 9 and len(records["tokenize"]) >= 8 and len(records["mtl_parse"]) == 5
+    buffer = C.create_string_buffer(1 << 16)
+    for record in records["ltrim"]:
+        assert host.pathed_host_ltrim(record["text"].encode(), buffer, len(buffer)) == len(record["result"])
+        assert buffer.value.decode() == record["result"], record
+    for record in records["tokenize"]:
+        count = host.pathed_host_tokenize(record["text"].encode(), buffer, len(buffer))
+        tokens = buffer.value.decode().split("\n") if count else []
+        assert count == len(record["tokens"]) and tokens == record["tokens"], record
+    for record in records["mtl_parse"]:
+        path = os.path.join(_capi.REPO_ROOT, record["file"])
+        count = host.pathed_host_parse_mtl(path.encode(), buffer, len(buffer))
+        assert count == len(record["materials"]) == record["baked"], record["file"]
+        lines = [line for line in buffer.value.decode().split("\n") if line or count == 1][:count]
+        for line, expected in zip(lines, record["materials"]):
+            name, kd, ke = line.split("\t")
+            assert name == expected["name"]
+            assert [np.float32(v) for v in kd.split()[1:]] == [np.float32(v) for v in expected["Kd"]], (record["file"], name)
+            assert [np.float32(v) for v in ke.split()[1:]] == [np.float32(v) for v in expected["Ke"]], (record["file"], name)
+    # the Cornell library defines its light through Ke (the scene's only emitter)
+    cornell = [r for r in records["mtl_parse"] if r["file"] == "scenes/CornellBox-Original.mtl"][0]
+    assert [m["Ke"] for m in cornell["materials"] if m["name"] == "light"] == [[17.0, 12.0, 4.0]]

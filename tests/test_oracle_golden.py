@@ -2,9 +2,9 @@
 
 tests/golden/reference_functions.jsonl is produced by oracle/_ref/refdump
 (oracle/ref_driver.cpp linked with the reference translation units, see
-oracle/Makefile.ref).  Tolerance: 2e-5 relative / 2e-6 absolute — the oracle keeps the
-reference's operation order but evaluates in fp32 the handful of expressions the
-reference promotes to double through M_PI (oracle/oracle.cpp header).
+oracle/Makefile.ref).  Tolerance: 1e-6 relative / 2e-7 absolute — the oracle keeps the
+reference's operation order; the azimuth `2 * M_PI * u`, which the reference forms in double, is formed in
+double here and in the kernels too (an fp32 product put 27 records between 1e-6 and 3.4e-5 in round 1).
 """
 import json
 import math
@@ -18,8 +18,8 @@ import oracle_lib
 
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "reference_functions.jsonl")
 
-RTOL = 2e-5
-ATOL = 2e-6
+RTOL = 1e-6
+ATOL = 2e-7
 
 
 def _load():
@@ -27,6 +27,8 @@ def _load():
     with open(GOLDEN) as handle:
         for line in handle:
             record = json.loads(line)
+            if "out" not in record:
+                continue   # text records (ltrim / tokenize / mtl_parse): tests/test_host_loader.py holds the host readers against them
             out = [float(v) if not isinstance(v, str) else float(v) for v in record["out"]]
             records[record["fn"]].append((np.array(record["in"], dtype=np.float32), np.array(out, dtype=np.float64)))
     return records
