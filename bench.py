@@ -50,6 +50,10 @@ def parse_args():
     parser.add_argument("--seed", type=int, default=1)
     parser.add_argument("--bvh-builder", default="sah", choices=["sah", "lbvh", "ploc"],
                         help="host binned-SAH build (default) or an on-GPU build; only matters for scenes of more than 64 triangles")
+    parser.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                        help="collective backend: nccl (= RCCL over xGMI); gloo stages the reduce through host memory (rehearsals)")
+    parser.add_argument("--share-gpu", action="store_true",
+                        help="rehearsal on a one-GPU box: every rank renders on device 0 (use with --backend gloo: RCCL refuses two ranks on one device)")
     parser.add_argument("--no-cpu-baseline", action="store_true")
     parser.add_argument("--no-large-bvh", action="store_true",
                         help="skip the second, BVH-traversal-bound workload (scenes/dragon-standin.json) behind roofline.large_bvh")
@@ -68,7 +72,7 @@ def launch_ranks(args):
     no HIP call (counting devices does not initialise the GPU on this image) and never re-executes itself."""
     import torch
     visible = torch.cuda.device_count()
-    if visible < args.gpus:
+    if visible < args.gpus and not args.share_gpu:
         raise SystemExit("bench.py --gpus %d: this machine shows %d GPU(s)" % (args.gpus, visible))
     with socket.socket() as probe:
         probe.bind(("127.0.0.1", 0))
@@ -265,15 +269,19 @@ def run_rank(args):
 
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if args.share_gpu else int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world_size > 1
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
+    staged = args.backend == "gloo"   # collectives on host copies
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-        world_size = dist.get_world_size()   # the ranks RCCL actually sees
+        if staged:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        world_size = dist.get_world_size()   # the ranks the backend actually sees
 
     from pathed_amd import parallel
     from pathed_amd.integrator import HipScene, measure_bandwidth
@@ -337,7 +345,13 @@ def run_rank(args):
     rendered = time.perf_counter() - t0
     if distributed:
         # the path's one exchange step: per-GPU radiance sums -> rank 0 (RCCL reduce over xGMI)
-        dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
+        if staged:
+            host_sums = accum.cpu()
+            dist.reduce(host_sums, dst=0, op=dist.ReduceOp.SUM)
+            if rank == 0:
+                accum.copy_(host_sums)
+        else:
+            dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
     torch.cuda.synchronize()
     reduced = time.perf_counter() - t0
     if distributed:
@@ -347,7 +361,7 @@ def run_rank(args):
 
     per_rank = [[rendered, reduced - rendered, elapsed]]
     if distributed:
-        mine = torch.tensor(per_rank[0], dtype=torch.float64, device="cuda")
+        mine = torch.tensor(per_rank[0], dtype=torch.float64, device="cpu" if staged else "cuda")
         gathered = [torch.zeros_like(mine) for _ in range(world_size)]
         dist.all_gather(gathered, mine)
         per_rank = [g.tolist() for g in gathered]

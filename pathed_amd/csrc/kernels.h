@@ -539,6 +539,77 @@ __device__ __forceinline__ void smallCandidates(const f2 *pairRecords, int nTris
     *high = candidatesHigh;
 }
 
+// Phase 1 for TWO rays that leave the same point (a vertex's continuation ray and its shadow ray): tvec = o - v0,
+// qvec = tvec x e1 and t det = e2 . qvec do not depend on the direction, so the pair costs 12 + 2 x 21 packed
+// operations per two triangles instead of 2 x 33.  Same expressions as smallCandidates, ray by ray.
+__device__ __forceinline__ void smallCandidatesPair(const f2 *pairRecords, int nTris, V3 origin, V3 directionA, V3 directionB,
+                                                    unsigned int *lowA, unsigned int *highA, unsigned int *lowB, unsigned int *highB)
+{
+    const int nPairs = (nTris + 1) / 2;
+    unsigned int aLow = 0, aHigh = 0, bLow = 0, bHigh = 0;
+    const f2 ax = splat2(directionA.x), ay = splat2(directionA.y), az = splat2(directionA.z);
+    const f2 bx = splat2(directionB.x), by = splat2(directionB.y), bz = splat2(directionB.z);
+    const f2 ox = splat2(origin.x), oy = splat2(origin.y), oz = splat2(origin.z);
+    auto testPair = [&](int pair, unsigned int *bitsA, unsigned int *bitsB) {
+        const f2 *record = pairRecords + kSmallPairWords * pair;
+        const f2 v0x = record[0], v0y = record[1], v0z = record[2];
+        const f2 e1x = record[3], e1y = record[4], e1z = record[5];
+        const f2 e2x = record[6], e2y = record[7], e2z = record[8];
+        const f2 tx = ox - v0x, ty = oy - v0y, tz = oz - v0z;
+        // qvec = tvec x e1
+        const f2 qx = fma2(ty, e1z, -(tz * e1y));
+        const f2 qy = fma2(tz, e1x, -(tx * e1z));
+        const f2 qz = fma2(tx, e1y, -(ty * e1x));
+        const f2 tScaled = fma2(e2x, qx, fma2(e2y, qy, e2z * qz));
+        auto oneRay = [&](f2 dx, f2 dy, f2 dz) -> unsigned int {
+            // pvec = d x e2, det = e1 . pvec
+            const f2 px = fma2(dy, e2z, -(dz * e2y));
+            const f2 py = fma2(dz, e2x, -(dx * e2z));
+            const f2 pz = fma2(dx, e2y, -(dy * e2x));
+            const f2 det = fma2(e1x, px, fma2(e1y, py, e1z * pz));
+            const f2 uScaled = fma2(tx, px, fma2(ty, py, tz * pz));
+            const f2 vScaled = fma2(dx, qx, fma2(dy, qy, dz * qz));
+            const f2 a = uScaled * det, b = vScaled * det, c = (det - (uScaled + vScaled)) * det, e = tScaled * det;
+            const float worstA = fminf(fminf(a.x, b.x), fminf(c.x, e.x));
+            const float worstB = fminf(fminf(a.y, b.y), fminf(c.y, e.y));
+            return ((worstA < 0.f) ? 0u : 2u) | ((worstB < 0.f) ? 0u : 1u);
+        };
+        *bitsA = oneRay(ax, ay, az);
+        *bitsB = oneRay(bx, by, bz);
+    };
+    const int lowPairs = nPairs < 16 ? nPairs : 16;
+    for (int pair = 0; pair < lowPairs; pair++) {
+        unsigned int bitsA, bitsB;
+        testPair(pair, &bitsA, &bitsB);
+        aLow = (aLow << 2) | bitsA;
+        bLow = (bLow << 2) | bitsB;
+    }
+    for (int pair = 16; pair < nPairs; pair++) {
+        unsigned int bitsA, bitsB;
+        testPair(pair, &bitsA, &bitsB);
+        aHigh = (aHigh << 2) | bitsA;
+        bHigh = (bHigh << 2) | bitsB;
+    }
+    // left-align as smallCandidates does
+    const int lowTris = nTris < 32 ? nTris : 32;
+    const int lowShifted = 2 * (nPairs < 16 ? nPairs : 16);
+    if (lowShifted > 0 && lowShifted < 32) { aLow <<= 32 - lowShifted; bLow <<= 32 - lowShifted; }
+    const unsigned int lowMask = lowTris > 0 ? 0xFFFFFFFFu << (32 - lowTris) : 0u;
+    aLow &= lowMask;
+    bLow &= lowMask;
+    const int highTris = nTris - 32;
+    if (highTris > 0) {
+        const int highShifted = 2 * (nPairs - 16);
+        if (highShifted < 32) { aHigh <<= 32 - highShifted; bHigh <<= 32 - highShifted; }
+        aHigh &= 0xFFFFFFFFu << (32 - highTris);
+        bHigh &= 0xFFFFFFFFu << (32 - highTris);
+    } else {
+        aHigh = 0u;
+        bHigh = 0u;
+    }
+    *lowA = aLow; *highA = aHigh; *lowB = bLow; *highB = bHigh;
+}
+
 // Phase 2 (a wave-level loop: call it from wave-uniform control flow, lanes without a ray pass empty masks):
 // the few candidates of each lane go through the ordinary intersector + acceptance rule.
 __device__ __forceinline__ void smallResolve(const TraceGeometry &geometry, LaneRay &ray, unsigned int candidatesLow, unsigned int candidatesHigh)
@@ -1804,8 +1875,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_S
 // moves on to the next).  No path state touches HBM: per unit one 16-byte partial sum is written.
 // Every operation on a path's values is k_shade's, in k_shade's order, and the unit decomposition fixes
 // the summation order, so the radiance sums are the wavefront kernels' bit for bit (GPU test).
-// What the wavefront keeps and this gives up is the DENSE shadow-ray list: the shadow pass runs with
-// the lanes whose vertex asked for one (~70-75 % on Cornell).  Measured, the registers win.
+// What the wavefront keeps and this gives up is the DENSE shadow-ray list: a shadow ray is traced by the lane
+// whose vertex asked for it (~70-75 % of the lanes on Cornell).  It leaves the vertex like the continuation ray
+// does, so the two share one pass over the triangles and a third of its arithmetic (smallCandidatesPair).
 #ifndef PATHED_FUSED_WAVES
 #define PATHED_FUSED_WAVES 4
 #endif
@@ -1888,6 +1960,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_F
     Rgb result = rgb(0.f), modulation = rgb(1.f), throughput = rgb(0.f), pend = rgb(0.f);
     float bsdfPdf = 1.f, cosTheta = 0.f;
     float4 partial = make_float4(0.f, 0.f, 0.f, 0.f);
+    bool pendingShadow = false;      // the vertex the ray left asked for an occlusion query along shadowDirection
+    V3 shadowDirection = v3(0.f, 0.f, 1.f);
+    float shadowTfar = 0.f;
 
     unsigned int closestRays = 0, shadowRays = 0, trisTested = 0;
 
@@ -1925,17 +2000,36 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_F
         }
         if (__ballot(alive) == 0ull) { break; }
 
-        // ---- closest hit of the path's ray (Scene::testIntersect's rtcIntersect1)
+        // ---- the path's ray (Scene::testIntersect's rtcIntersect1) and, from the same point, the shadow ray of the
+        // vertex it leaves (Scene::testOcclusion's rtcOccluded1): an occluded light sample contributes nothing
         LaneRay ray;
         laneRayInit(ray, o, d, PATHED_TNEAR, PATHED_TFAR, false);
         {
-            unsigned int candidatesLow = 0, candidatesHigh = 0;
-            if (alive) {
-                smallCandidates(smallTris.data, nTris, ray.o, ray.d, &candidatesLow, &candidatesHigh);
-                if (COUNT) { trisTested += (unsigned int)nTris; closestRays++; }
+            const bool traceShadow = alive && pendingShadow;
+            LaneRay shadowRay;
+            laneRayInit(shadowRay, o, shadowDirection, PATHED_TNEAR, shadowTfar, true);
+            unsigned int candidatesLow = 0, candidatesHigh = 0, shadowLow = 0, shadowHigh = 0;
+            if (__ballot(traceShadow) != 0ull) {
+                if (alive) {
+                    smallCandidatesPair(smallTris.data, nTris, o, d, shadowDirection, &candidatesLow, &candidatesHigh, &shadowLow, &shadowHigh);
+                    if (!traceShadow) { shadowLow = 0u; shadowHigh = 0u; }
+                }
+            } else if (alive) {
+                smallCandidates(smallTris.data, nTris, o, d, &candidatesLow, &candidatesHigh);
+            }
+            if (COUNT && alive) {
+                trisTested += (unsigned int)nTris * (traceShadow ? 2u : 1u);
+                closestRays++;
+                if (traceShadow) { shadowRays++; }
             }
             smallResolve(geometry, ray, candidatesLow, candidatesHigh);
+            smallResolve(geometry, shadowRay, shadowLow, shadowHigh);
             if (alive) { finishRay(geometry, ray); }
+            if (traceShadow) {
+                finishRay(geometry, shadowRay);
+                if (shadowRay.occluded) { pend = rgb(0.f); }
+            }
+            pendingShadow = false;
         }
         const bool miss = ray.bestPrim < 0;
         const float4 h = make_float4(ray.best, ray.bestU, ray.bestV, intAsFloat(ray.bestPrim));
@@ -2059,21 +2153,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_F
             }
         }
 
-        // ---- the vertex's shadow ray (Scene::testOcclusion's rtcOccluded1): an occluded light sample contributes nothing
-        const bool wantShadow = alive && shadow.push;
-        if (__ballot(wantShadow) != 0ull) {
-            LaneRay shadowRay;
-            laneRayInit(shadowRay, shadow.origin, shadow.direction, PATHED_TNEAR, shadow.tfar, true);
-            unsigned int candidatesLow = 0, candidatesHigh = 0;
-            if (wantShadow) {
-                smallCandidates(smallTris.data, nTris, shadowRay.o, shadowRay.d, &candidatesLow, &candidatesHigh);
-                if (COUNT) { trisTested += (unsigned int)nTris; shadowRays++; }
-            }
-            smallResolve(geometry, shadowRay, candidatesLow, candidatesHigh);
-            if (wantShadow) {
-                finishRay(geometry, shadowRay);
-                if (shadowRay.occluded) { pend = rgb(0.f); }
-            }
+        // the vertex's shadow ray leaves isect.point like the continuation ray: both are traced in the next pass
+        if (alive && shadow.push) {
+            pendingShadow = true;
+            shadowDirection = shadow.direction;
+            shadowTfar = shadow.tfar;
         }
 
         // ---- end of a sample: radianceLookup += color (src/sample_integrator.cpp:61-63; non-finite samples

@@ -31,12 +31,14 @@ for name in args.scenes.split(","):
     accum = torch.zeros((h, w, 3), dtype=torch.float32, device="cuda")
     reference = None
     for variant in args.variants.split(","):
-        kernel, _, slots = variant.partition(":")
+        # variant = kernel[:stage slots][/pools], e.g. staged:1024/1
+        spec, _, pools = variant.partition("/")
+        kernel, _, slots = spec.partition(":")
         options = {"shade_kernel": kernel}
         if slots:
             options["stage_slots"] = int(slots)
-        if args.pools:
-            options["pools"] = args.pools
+        if pools or args.pools:
+            options["pools"] = int(pools or args.pools)
         try:
             gpu = HipScene(scene.desc, device=0, **options)
         except Exception as error:
