@@ -28,7 +28,8 @@ namespace bvh_detail {
 
 struct Prim {
     float bmin[3], bmax[3], centroid[3];
-    uint32_t index;
+    uint32_t index;   // triangle id, or triangleCount + sphere index
+    bool sphere;      // a sphere gets a leaf of its own (reference src/sphere.cpp:16-48 gives each one to Embree as a geometry)
 };
 
 struct Box {
@@ -103,7 +104,12 @@ public:
         nodes.push_back(node);
 
         const uint32_t count = end - begin;
+        bool spheresInRange = false;
         if (count <= maxLeafSize()) {
+            for (uint32_t i = begin; i < end; i++) { spheresInRange = spheresInRange || m_prims[i].sphere; }
+        }
+        // leaves are homogeneous: up to maxLeafSize() triangles, or exactly one sphere
+        if (count <= maxLeafSize() && (!spheresInRange || count == 1)) {
             nodes[(size_t)index].first = begin;
             nodes[(size_t)index].count = count;
             *maxDepth = std::max(*maxDepth, depth);
@@ -207,17 +213,35 @@ inline void putInt(float *slot, int value) { std::memcpy(slot, &value, 4); }
 
 }  // namespace bvh_detail
 
-// positions: 3 floats per vertex; indices: 3 per triangle.
-inline FlatBvh buildBvh(const float *positions, const uint32_t *indices, uint32_t triangleCount)
+// positions: 3 floats per vertex; indices: 3 per triangle; spheres: (centre.xyz, radius) each, may be null.
+// Sphere s becomes the leaf reference -(((s + 1) << 3) | 0) - 1: count 0 marks it, trace.h tests it.
+inline FlatBvh buildBvh(const float *positions, const uint32_t *indices, uint32_t triangleCount,
+                        const float *spheres = nullptr, uint32_t sphereCount = 0)
 {
     using namespace bvh_detail;
     FlatBvh out;
-    if (triangleCount == 0) { return out; }
+    const uint32_t primCount = triangleCount + sphereCount;
+    if (primCount == 0) { return out; }
 
-    std::vector<Prim> prims(triangleCount);
+    std::vector<Prim> prims(primCount);
+    for (uint32_t s = 0; s < sphereCount; s++) {
+        Prim &p = prims[triangleCount + s];
+        p.index = triangleCount + s;
+        p.sphere = true;
+        const float radius = std::fabs(spheres[4 * s + 3]);
+        for (int a = 0; a < 3; a++) {
+            // a hit point computed in fp32 may sit an ulp outside centre +- radius: pad by a relative 1e-5 as well
+            const float centre = spheres[4 * s + a];
+            const float reach = radius * 1.00001f + 1e-5f * std::fabs(centre);
+            p.bmin[a] = centre - reach;
+            p.bmax[a] = centre + reach;
+            p.centroid[a] = centre;
+        }
+    }
     for (uint32_t i = 0; i < triangleCount; i++) {
         Prim &p = prims[i];
         p.index = i;
+        p.sphere = false;
         for (int a = 0; a < 3; a++) {
             const float c0 = positions[3 * indices[3 * i + 0] + a];
             const float c1 = positions[3 * indices[3 * i + 1] + a];
@@ -229,7 +253,7 @@ inline FlatBvh buildBvh(const float *positions, const uint32_t *indices, uint32_
     }
 
     Builder builder(prims);
-    builder.nodes.reserve((size_t)triangleCount);
+    builder.nodes.reserve((size_t)primCount);
     int maxDepth = 0;
     // large meshes: the top of the tree here, its subtrees on the host's other cores
     unsigned int hostThreads = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
@@ -237,8 +261,8 @@ inline FlatBvh buildBvh(const float *positions, const uint32_t *indices, uint32_
         const int parsed = atoi(text);
         if (parsed >= 1 && parsed <= 256) { hostThreads = (unsigned int)parsed; }
     }
-    if (triangleCount >= 200000 && hostThreads > 1) { builder.deferThreshold = triangleCount / 256; }
-    const int root = builder.build(0, triangleCount, 0, &maxDepth);
+    if (primCount >= 200000 && hostThreads > 1) { builder.deferThreshold = primCount / 256; }
+    const int root = builder.build(0, primCount, 0, &maxDepth);
     if (!builder.deferred.empty()) {
         const size_t jobs = builder.deferred.size();
         std::vector<std::vector<TempNode>> built(jobs);
@@ -270,14 +294,20 @@ inline FlatBvh buildBvh(const float *positions, const uint32_t *indices, uint32_
         }
     }
 
-    // leaf-ordered triangles: (v0, prim) (e1, 0) (e2, 0)
+    // leaf-ordered triangles: (v0, prim) (e1, 0) (e2, 0); spheres take no slot, so a triangle's place in leaf order
+    // is its place among the triangles of the sorted primitive array
     out.leafTris.resize((size_t)12 * triangleCount);
-    for (uint32_t i = 0; i < triangleCount; i++) {
+    std::vector<uint32_t> trianglePlace(primCount, 0u);
+    uint32_t placed = 0;
+    for (uint32_t i = 0; i < primCount; i++) {
+        trianglePlace[i] = placed;
+        if (prims[i].sphere) { continue; }
         const uint32_t prim = prims[i].index;
         const float *v0 = positions + 3 * indices[3 * prim + 0];
         const float *v1 = positions + 3 * indices[3 * prim + 1];
         const float *v2 = positions + 3 * indices[3 * prim + 2];
-        float *tri = out.leafTris.data() + (size_t)12 * i;
+        float *tri = out.leafTris.data() + (size_t)12 * placed;
+        placed++;
         for (int a = 0; a < 3; a++) {
             tri[a] = v0[a];
             tri[4 + a] = v1[a] - v0[a];
@@ -353,8 +383,10 @@ inline FlatBvh buildBvh(const float *positions, const uint32_t *indices, uint32_
             if (k < wide[n].count) {
                 const TempNode &child = temp[(size_t)wide[n].child[k]];
                 padBox(child.box, lo, hi);
-                // leaf: -((first << 3) | count) - 1 (trace.h encodeLeaf); inner: the wide node id
-                ref = child.left < 0 ? -(int)((child.first << 3) | child.count) - 1 : wide[n].id[k];
+                // leaf: -((first << 3) | count) - 1 (trace.h encodeLeaf); a sphere: count 0, first = sphere + 1; inner: the wide node id
+                if (child.left >= 0) { ref = wide[n].id[k]; }
+                else if (prims[child.first].sphere) { ref = -(int)(((prims[child.first].index - triangleCount + 1u) << 3) | 0u) - 1; }
+                else { ref = -(int)((trianglePlace[child.first] << 3) | child.count) - 1; }
             }
             for (int a = 0; a < 3; a++) {
                 node[4 * a + k] = lo[a];

@@ -77,6 +77,7 @@ struct DScene {
     int nTris;
     const DSphere *spheres;
     int nSpheres;
+    int nLinearSpheres;        // spheres the traversal does not reach through leaves: tested one by one after it
 
     // shading
     const float4 *triShade;    // kTriShadeQuads x float4 per original primitive

@@ -182,7 +182,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_T
     geometry.nNodes = p.scene.nNodes;
     geometry.nTris = p.scene.nTris;
     geometry.spheres = p.scene.spheres;
-    geometry.nSpheres = p.scene.nSpheres;
+    geometry.nSpheres = p.scene.nLinearSpheres;
 
     float4 *stageO = ldsRaw + ((STACK + 1) * kBlock) / 4 + (threadIdx.x >> 6) * kCard;  // this wave's kCard entries
     float4 *stageD = stageO + kBlock * kCardRounds;
@@ -463,6 +463,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_T
 // lanes — faster than walking a BVH whose every step diverges.  Hits are identical to the BVH
 // path by the intersector specification (equal-t ties resolve by primitive id, not test order).
 static const int kBruteForceMaxTris = 64;
+static const int kBruteForceMaxSpheres = 16;   // ... and at most this many spheres (each ray tests them one by one)
 
 // The triangle records travel as a KERNEL ARGUMENT (2.3 KB of the 4 KB kernarg segment): kernarg
 // reads are s_load from the constant address space, so a uniform index gives true scalar loads.
@@ -638,7 +639,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_small(RenderParams p, SmallTri
     geometry.nNodes = 0;
     geometry.nTris = p.scene.nTris;
     geometry.spheres = p.scene.spheres;
-    geometry.nSpheres = p.scene.nSpheres;
+    geometry.nSpheres = p.scene.nLinearSpheres;
 
     const int lane = threadIdx.x & 63;
     const unsigned int waveId = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
@@ -732,7 +733,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_rays(
     geometry.nNodes = scene.nNodes;
     geometry.nTris = scene.nTris;
     geometry.spheres = scene.spheres;
-    geometry.nSpheres = scene.nSpheres;
+    geometry.nSpheres = scene.nLinearSpheres;
 
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) { return; }
@@ -1903,7 +1904,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_F
     geometry.nNodes = 0;
     geometry.nTris = p.scene.nTris;
     geometry.spheres = p.scene.spheres;
-    geometry.nSpheres = p.scene.nSpheres;
+    geometry.nSpheres = p.scene.nLinearSpheres;
 
     const DScene &scene = p.scene;
     const int lane = threadIdx.x & 63;

@@ -4,7 +4,7 @@
 //   3 rocprim radix sort of (code, triangle) pairs
 //   4-5 a binary tree over the sorted triangles, with boxes and triangle counts:
 //       LBVH  k_lbvh_hierarchy  Karras' binary radix tree over the codes (ties broken by position)
-//             k_lbvh_fit        boxes bottom-up: the second thread to reach a node merges its children
+//             k_lbvh_fit_pass   boxes bottom-up, one launch per level (kernel boundaries instead of agent-scope fences)
 //       PLOC  k_ploc_nearest / _flags / _merge, once per round: mutual nearest neighbours (by the
 //             surface area of their union, within 16 places of the Morton order) merge; compaction
 //             by exclusive scans; ~60 rounds for millions of triangles, until 1 024 clusters are left,
@@ -185,53 +185,40 @@ __global__ __launch_bounds__(kLbvhBlock) void k_lbvh_hierarchy(
     if (i == 0) { parentOfInternal[0] = -1; }
 }
 
-// a box another thread of this launch may have written: read it past the (non-coherent) vector L1
-__device__ inline float loadCoherent(const float *address)
+// Boxes bottom-up, LEVEL-SYNCHRONOUS: one launch per level of dependency.  A pass gives every internal node whose
+// two children had their boxes BEFORE the pass its own box and marks it in the other copy of the flags; kernel
+// boundaries make a pass's boxes visible to the next (the eight XCDs have separate L2s: inside one launch that
+// visibility cost agent-scope fences and coherent loads, 36 of the build's 45 ms), and the double-buffered flags keep
+// a node from being read in the pass that writes it.  As many passes as the radix tree is high (~45 for 5 M triangles).
+__global__ __launch_bounds__(kLbvhBlock) void k_lbvh_fit_pass(
+    int nInternal, const unsigned int *sorted, const float4 *boxLo, const float4 *boxHi, const uint2 *children,
+    float4 *nodeLo, float4 *nodeHi, const unsigned char *readyIn, unsigned char *readyOut, unsigned int *pending)
 {
-    return __hip_atomic_load(address, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-__global__ __launch_bounds__(kLbvhBlock) void k_lbvh_fit(
-    int n, const unsigned int *sorted, const float4 *boxLo, const float4 *boxHi,
-    const uint2 *children, const int *parentOfInternal, const int *parentOfLeaf,
-    float4 *nodeLo, float4 *nodeHi, unsigned int *arrivals)
-{
-    const int i = blockIdx.x * kLbvhBlock + threadIdx.x;
-    if (i >= n) { return; }
-    int node = parentOfLeaf[i];
-    // every thread either stops at a node it is first to reach or climbs one level: the loop ends
-    while (node >= 0) {
-        __threadfence();                                   // our box below `node` is visible ...
-        const unsigned int earlier = atomicAdd(&arrivals[node], 1u);
-        if (earlier == 0u) { return; }                     // ... the sibling's thread will merge
-        __threadfence();
-        const uint2 pair = children[node];
-        float lo[3], hi[3];
-        #pragma unroll
-        for (int side = 0; side < 2; side++) {
-            const unsigned int ref = side == 0 ? pair.x : pair.y;
-            float clo[3], chi[3];
-            if (ref & kLeafFlag) {
-                const unsigned int tri = sorted[ref & ~kLeafFlag];
-                const float4 a = boxLo[tri], b = boxHi[tri];
-                clo[0] = a.x; clo[1] = a.y; clo[2] = a.z;
-                chi[0] = b.x; chi[1] = b.y; chi[2] = b.z;
+    const int node = blockIdx.x * kLbvhBlock + threadIdx.x;
+    bool waiting = false;
+    if (node < nInternal) {
+        unsigned char ready = readyIn[node];
+        if (!ready) {
+            const uint2 pair = children[node];
+            const bool leftLeaf = (pair.x & kLeafFlag) != 0u, rightLeaf = (pair.y & kLeafFlag) != 0u;
+            const bool leftReady = leftLeaf || readyIn[pair.x] != 0, rightReady = rightLeaf || readyIn[pair.y] != 0;
+            if (leftReady && rightReady) {
+                float4 lo, hi, otherLo, otherHi;
+                if (leftLeaf) { const unsigned int tri = sorted[pair.x & ~kLeafFlag]; lo = boxLo[tri]; hi = boxHi[tri]; }
+                else { lo = nodeLo[pair.x]; hi = nodeHi[pair.x]; }
+                if (rightLeaf) { const unsigned int tri = sorted[pair.y & ~kLeafFlag]; otherLo = boxLo[tri]; otherHi = boxHi[tri]; }
+                else { otherLo = nodeLo[pair.y]; otherHi = nodeHi[pair.y]; }
+                nodeLo[node] = make_float4(fminf(lo.x, otherLo.x), fminf(lo.y, otherLo.y), fminf(lo.z, otherLo.z), 0.f);
+                nodeHi[node] = make_float4(fmaxf(hi.x, otherHi.x), fmaxf(hi.y, otherHi.y), fmaxf(hi.z, otherHi.z), 0.f);
+                ready = 1;
             } else {
-                const float *a = reinterpret_cast<const float *>(nodeLo + ref);
-                const float *b = reinterpret_cast<const float *>(nodeHi + ref);
-                #pragma unroll
-                for (int k = 0; k < 3; k++) { clo[k] = loadCoherent(a + k); chi[k] = loadCoherent(b + k); }
-            }
-            #pragma unroll
-            for (int k = 0; k < 3; k++) {
-                lo[k] = side == 0 ? clo[k] : fminf(lo[k], clo[k]);
-                hi[k] = side == 0 ? chi[k] : fmaxf(hi[k], chi[k]);
+                waiting = true;
             }
         }
-        nodeLo[node] = make_float4(lo[0], lo[1], lo[2], 0.f);
-        nodeHi[node] = make_float4(hi[0], hi[1], hi[2], 0.f);
-        node = parentOfInternal[node];
+        readyOut[node] = ready;
     }
+    const unsigned long long mask = __ballot(waiting);
+    if ((threadIdx.x & 63) == 0 && mask != 0ull) { atomicAdd(pending, (unsigned int)__popcll(mask)); }
 }
 
 // ------------------------------------------------------------------------- PLOC
@@ -702,13 +689,27 @@ hipError_t buildBvhOnDevice(int builder, const float *positions, const uint32_t 
         // 4-5: Karras hierarchy (root = node 0), boxes bottom-up
         int *parentOfInternal = scratch.get<int>(n - 1);
         int *parentOfLeaf = scratch.get<int>(n);
-        unsigned int *arrivals = scratch.get<unsigned int>(n - 1);
+        unsigned char *ready[2] = { scratch.get<unsigned char>(n), scratch.get<unsigned char>(n) };
+        unsigned int *pending = scratch.get<unsigned int>(64);
         if (scratch.status != hipSuccess) { return failed(scratch.status, "scratch allocation"); }
-        if ((status = hipMemsetAsync(arrivals, 0, (size_t)(n - 1) * sizeof(unsigned int), stream)) != hipSuccess) { return failed(status, "memset"); }
+        if ((status = hipMemsetAsync(ready[0], 0, (size_t)n, stream)) != hipSuccess) { return failed(status, "memset"); }
         hipLaunchKernelGGL(k_lbvh_hierarchy, dim3(blocksFor(n - 1)), dim3(kLbvhBlock), 0, stream,
                            keysOut, (int)n, children, count, parentOfInternal, parentOfLeaf);
-        hipLaunchKernelGGL(k_lbvh_fit, dim3(blocksFor(n)), dim3(kLbvhBlock), 0, stream,
-                           (int)n, sorted, boxLo, boxHi, children, parentOfInternal, parentOfLeaf, nodeLo, nodeHi, arrivals);
+        // boxes: one pass per level; the count of nodes still waiting is read back every eighth pass
+        const int passesPerCheck = 8;
+        bool fitted = false;
+        for (int pass = 0; pass < 512 && !fitted; pass += passesPerCheck) {
+            if ((status = hipMemsetAsync(pending, 0, passesPerCheck * sizeof(unsigned int), stream)) != hipSuccess) { return failed(status, "memset"); }
+            for (int k = 0; k < passesPerCheck; k++) {
+                hipLaunchKernelGGL(k_lbvh_fit_pass, dim3(blocksFor(n - 1)), dim3(kLbvhBlock), 0, stream,
+                                   (int)(n - 1), sorted, boxLo, boxHi, children, nodeLo, nodeHi, ready[(pass + k) & 1], ready[(pass + k + 1) & 1], pending + k);
+            }
+            unsigned int waiting[passesPerCheck];
+            if ((status = hipMemcpyAsync(waiting, pending, sizeof waiting, hipMemcpyDeviceToHost, stream)) != hipSuccess) { return failed(status, "read back"); }
+            if ((status = hipStreamSynchronize(stream)) != hipSuccess) { return failed(status, "LBVH box pass"); }
+            for (int k = 0; k < passesPerCheck; k++) { fitted = fitted || waiting[k] == 0u; }
+        }
+        if (!fitted) { return failed(hipErrorUnknown, "LBVH boxes did not converge"); }
         root = 0;
     } else {
         // 4-5 (PLOC): agglomerate along the Morton order until one cluster is left

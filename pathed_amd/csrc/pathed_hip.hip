@@ -171,6 +171,7 @@ struct PathedScene {
     DeviceBuffer<unsigned long long> stats;
     unsigned int *hostRemaining = nullptr;  // pinned
 
+    bool spheresInTree = false;   // the host builder put the spheres into leaves (else they are tested one by one after the traversal)
     bool fusedPath = false;   // tiny scenes: k_path_small, whole paths in registers, no wavefront buffers
     bool stagedShade = true;  // k_shade_staged (dense, state-sorted stages inside a block) or k_shade (one lane per slot)
     int stageRounds = 2;      // staged kernel: a block owns stageRounds x 256 slots
@@ -895,6 +896,8 @@ int pathed_hip_scene_create_ex(const PathedSceneDesc *desc, const PathedSceneOpt
     }
     // tiny meshes take the all-triangles kernel, which wants the host copy of the records
     if (desc->n_triangles <= (uint32_t)kBruteForceMaxTris) { builder = PATHED_BVH_SAH_HOST; }
+    // the device builders take triangles only: scenes with many spheres are built on the host, where spheres become leaves
+    if (desc->n_spheres > (uint32_t)kBruteForceMaxSpheres) { builder = PATHED_BVH_SAH_HOST; }
     scene->bvhBuilder = builder;
     // the triangle soup on the device: input of the device builders and of the shading-record gather
     DeviceBuffer<float> devicePositions, deviceNormals, deviceUvs;
@@ -942,7 +945,19 @@ int pathed_hip_scene_create_ex(const PathedSceneDesc *desc, const PathedSceneOpt
         scene->bvhBuildMs = built.buildMs;
     } else {
         const auto buildStart = std::chrono::steady_clock::now();
-        scene->bvh = buildBvh(desc->positions, desc->indices, desc->n_triangles);
+        // Spheres join the tree as one-sphere leaves (the reference gives each one to Embree as a geometry of its own,
+        // src/sphere.cpp:16-48) unless the scene is small enough for the all-triangles kernel, which tests them one by one.
+        std::vector<float> sphereBounds;
+        const bool tiny = desc->n_triangles <= (uint32_t)kBruteForceMaxTris && desc->n_spheres <= (uint32_t)kBruteForceMaxSpheres
+            && scene->options.intersector != 1 && !getenv("PATHED_NO_BRUTE_FORCE");
+        if (!tiny) {
+            for (uint32_t i = 0; i < desc->n_spheres; i++) {
+                for (int a = 0; a < 3; a++) { sphereBounds.push_back(desc->spheres[i].center_world[a]); }
+                sphereBounds.push_back(desc->spheres[i].radius);
+            }
+        }
+        scene->spheresInTree = !sphereBounds.empty();
+        scene->bvh = buildBvh(desc->positions, desc->indices, desc->n_triangles, sphereBounds.data(), (uint32_t)(sphereBounds.size() / 4));
         scene->bvhBuildMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - buildStart).count();
         std::vector<float4> nodes(scene->bvh.nodes.size() / 4), tris(scene->bvh.leafTris.size() / 4);
         std::memcpy(nodes.data(), scene->bvh.nodes.data(), scene->bvh.nodes.size() * sizeof(float));
@@ -969,6 +984,7 @@ int pathed_hip_scene_create_ex(const PathedSceneDesc *desc, const PathedSceneOpt
     d.nTris = (int)desc->n_triangles;
     d.spheres = scene->spheres.ptr;
     d.nSpheres = (int)desc->n_spheres;
+    d.nLinearSpheres = scene->spheresInTree ? 0 : (int)desc->n_spheres;
     d.triShade = scene->triShade.ptr;
     d.materials = scene->materials.ptr;
     d.nMaterials = (int)desc->n_materials;
@@ -987,7 +1003,8 @@ int pathed_hip_scene_create_ex(const PathedSceneDesc *desc, const PathedSceneOpt
         scene->pools = value < 1 ? 1 : value > kMaxPools ? kMaxPools : value;
     }
     configureTrace(scene);
-    scene->bruteForce = scene->device.nTris <= kBruteForceMaxTris && options.intersector != 1 && !getenv("PATHED_NO_BRUTE_FORCE");
+    scene->bruteForce = scene->device.nTris <= kBruteForceMaxTris && scene->device.nSpheres <= kBruteForceMaxSpheres
+        && options.intersector != 1 && !getenv("PATHED_NO_BRUTE_FORCE");
     // BVH scenes: more slots = more rays per persistent wave to refill finished lanes from
     // (ray cost is heavy-tailed); the all-triangles kernel has uniform cost and prefers the
     // smaller, Infinity-Cache-resident state

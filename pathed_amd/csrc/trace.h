@@ -99,7 +99,7 @@ struct TraceGeometry {
     int nNodes;
     int nTris;
     const DSphere *spheres;
-    int nSpheres;
+    int nSpheres;          // spheres to test AFTER the traversal (those that are not in the tree's leaves)
 };
 
 // One ray in flight on one lane.
@@ -287,7 +287,28 @@ __device__ inline bool innerStep(
     return false;
 }
 
-// Test the lane's pending leaf (<= 7 triangles), then pop the next piece of work.
+// One sphere against the lane's ray, same acceptance rule as the triangles (prim id = nTris + sphere index).
+// Returns true when an any-hit query is decided.
+__device__ inline bool testSphere(const TraceGeometry &g, LaneRay &ray, int index)
+{
+    const DSphere s = g.spheres[index];
+    float t;
+    if (!intersectSphere(ray.o, ray.d, v3(s.centerWorld[0], s.centerWorld[1], s.centerWorld[2]), s.radius, ray.tnear, &t)) { return false; }
+    if (!(t > ray.tnear)) { return false; }
+    const int prim = g.nTris + index;
+    if (ray.anyHit) {
+        if (t <= ray.tfar) { ray.occluded = true; return true; }
+    } else {
+        const bool closer = (ray.bestPrim < 0)
+            ? (t <= ray.best)
+            : (t < ray.best || (t == ray.best && prim < ray.bestPrim));
+        if (closer) { ray.best = t; ray.bestU = 0.f; ray.bestV = 0.f; ray.bestPrim = prim; }
+    }
+    return false;
+}
+
+// Test the lane's pending leaf (<= 7 triangles, or ONE sphere: count 0, first = sphere index + 1 -- reference
+// src/sphere.cpp:16-48 hands its spheres to Embree's tree the same way), then pop the next piece of work.
 // Returns true when the query is complete.
 template <bool COUNT, int ROWS, int STRIDE>
 __device__ inline bool leafStep(const TraceGeometry &g, const LaneStack &stack, LaneRay &ray, TraceCounters *counters)
@@ -295,6 +316,11 @@ __device__ inline bool leafStep(const TraceGeometry &g, const LaneStack &stack, 
     const int first = ray.pendingLeaf >> 3;
     const int count = ray.pendingLeaf & 7;
     ray.pendingLeaf = 0;
+    if (count == 0) {
+        if (COUNT) { counters->tris++; }   // one primitive test
+        if (testSphere(g, ray, first - 1)) { return true; }
+        return popWork<ROWS, STRIDE>(stack, ray);
+    }
     // the next triangle's 48 bytes are in flight while the current one is tested
     float4 t0 = g.tris[3 * first + 0];
     float4 t1 = g.tris[3 * first + 1];
@@ -317,24 +343,13 @@ __device__ inline bool leafStep(const TraceGeometry &g, const LaneStack &stack, 
     return popWork<ROWS, STRIDE>(stack, ray);
 }
 
-// After the BVH: the (few) spheres are tested brute force, then the result is final.
+// After the BVH: the spheres that are not in the tree (g.nSpheres of them: all of a tiny scene's, none when the host
+// builder put them into leaves) are tested one by one, then the result is final.
 __device__ inline void finishRay(const TraceGeometry &g, LaneRay &ray)
 {
     if (ray.anyHit && ray.occluded) { return; }
     for (int i = 0; i < g.nSpheres; i++) {
-        const DSphere s = g.spheres[i];
-        float t;
-        if (!intersectSphere(ray.o, ray.d, v3(s.centerWorld[0], s.centerWorld[1], s.centerWorld[2]), s.radius, ray.tnear, &t)) { continue; }
-        if (!(t > ray.tnear)) { continue; }
-        const int prim = g.nTris + i;
-        if (ray.anyHit) {
-            if (t <= ray.tfar) { ray.occluded = true; return; }
-        } else {
-            const bool closer = (ray.bestPrim < 0)
-                ? (t <= ray.best)
-                : (t < ray.best || (t == ray.best && prim < ray.bestPrim));
-            if (closer) { ray.best = t; ray.bestU = 0.f; ray.bestV = 0.f; ray.bestPrim = prim; }
-        }
+        if (testSphere(g, ray, i)) { return; }
     }
 }
 

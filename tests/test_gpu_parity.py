@@ -501,3 +501,64 @@ def test_bandwidth_probe_reports_a_plausible_rate():
     from pathed_amd.integrator import measure_bandwidth
     read, copy = measure_bandwidth(gib=1.0, repeats=5)
     assert 1000.0 < read < 9000.0 and 1000.0 < copy < 9000.0, (read, copy)   # GB/s on an MI355X (8 TB/s peak)
+
+
+def _sphere_field(count, width=64, height=48, floor=True):
+    """`count` spheres of mixed materials scattered over a floor under an area light."""
+    from pathed_amd import _capi
+    from scene_builder import BuiltScene
+    rng = np.random.default_rng(19)
+    built = BuiltScene(width, height, (0, 6, 14), (0, 1, 0), fov_degrees=40)
+    materials = [built.material(diffuse=(0.7, 0.3, 0.2)), built.material(diffuse=(0.2, 0.6, 0.3)),
+                 built.material(type_=_capi.MAT_MIRROR), built.material(type_=_capi.MAT_GLASS, ior=1.5),
+                 built.material(type_=_capi.MAT_PLASTIC, diffuse=(0.1, 0.2, 0.6), alpha=0.1)]
+    light = built.material(diffuse=(0, 0, 0), emit=(30, 28, 25))
+    if floor:
+        built.quad([(-12, 0, 12), (12, 0, 12), (12, 0, -12), (-12, 0, -12)], built.material(diffuse=(0.6, 0.6, 0.6)))
+        built.quad([(-3, 9, -3), (3, 9, -3), (3, 9, 3), (-3, 9, 3)], light)
+    for index in range(count):
+        radius = float(rng.uniform(0.15, 0.6))
+        centre = (float(rng.uniform(-9, 9)), radius + float(rng.uniform(0.0, 2.5)), float(rng.uniform(-9, 9)))
+        built.sphere(centre, radius, materials[index % len(materials)])
+    if not floor:
+        built.sphere((0.0, 12.0, 0.0), 1.5, light)   # a sphere light: the scene has no triangle at all
+    return built
+
+
+def test_many_spheres_live_in_the_tree_not_in_a_list(libs):
+    """More than 16 spheres: the host builder gives each a leaf of the 4-wide tree (count-0 leaf references), so a ray
+    tests the few it comes near instead of all of them (the reference hands every sphere to Embree's tree,
+    src/sphere.cpp:16-48).  Hits and images: the oracle's, which tests every sphere against every ray."""
+    oracle_lib, HipScene, _ = libs
+    built = _sphere_field(300)
+    desc = built.finish()
+    gpu, cpu = HipScene(desc, device=0), oracle_lib.OracleScene(desc)
+    assert gpu.stats()["scene_in_lds"] == 0
+    rays = _rays(100000, 8, (0, 2, 0), 9.0)
+    expected = cpu.trace(rays)
+    hit_prims = expected[:, 3].view(np.int32)
+    assert (hit_prims >= 4).mean() > 0.08                       # plenty of sphere hits (prim ids 4 ..)
+    assert np.array_equal(gpu.trace(rays).view(np.int32), expected.view(np.int32))
+    assert np.array_equal(gpu.trace(rays, any_hit=True), cpu.trace(rays, any_hit=True))
+    gpu.set_stats_mode(count=True)
+    gpu.reset_stats()
+    image = gpu.render(3, 0, 8, 0, 8)
+    stats = gpu.stats()
+    assert stats["tris_tested"] < 12 * (stats["closest_rays"] + stats["shadow_rays"])   # not 300 sphere tests per ray
+    expected_image, _ = cpu.render(64, 48, 3, 0, 8, 0, 8, threads=os.cpu_count(), chunk=4)
+    rel, bad = _image_metrics(image, expected_image)
+    assert rel <= 1e-2 and bad <= 5e-3, (rel, bad)              # glass and mirror spheres: a flipped decision changes a path
+    # the same tree through the kernel with 8 stack rows and eager parking, and a tree of spheres ONLY (no triangle)
+    again = HipScene(desc, device=0, stack_rows=8, trace_blocks_per_cu=1, suspend_lanes=64, suspend_patience=-1, park_min_cards=-1)
+    assert np.array_equal(again.render(3, 0, 8, 0, 8), image)
+    only = _sphere_field(40, floor=False).finish()
+    gpu_only, cpu_only = HipScene(only, device=0), oracle_lib.OracleScene(only)
+    assert gpu_only.stats()["scene_in_lds"] in (0, 1) and gpu_only.stats()["bvh_nodes"] > 0     # a small tree may be staged in LDS
+    assert np.array_equal(gpu_only.trace(rays).view(np.int32), cpu_only.trace(rays).view(np.int32))
+    image_only = gpu_only.render(5, 0, 8, 0, 6)
+    expected_only, _ = cpu_only.render(64, 48, 5, 0, 8, 0, 6, threads=os.cpu_count(), chunk=4)
+    rel, bad = _image_metrics(image_only, expected_only)
+    assert image_only.any() and rel <= 1e-2 and bad <= 5e-3, (rel, bad)
+    # sixteen spheres or fewer beside a tiny mesh stay with the all-triangles kernels (Veach's scene has five)
+    few = _sphere_field(12).finish()
+    assert HipScene(few, device=0).stats()["scene_in_lds"] == 2
