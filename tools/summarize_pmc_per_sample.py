@@ -2,7 +2,7 @@
 """Condenses the passes of tools/pmc_per_sample.sh (gpurun_out/pmcps_<tag>/) into profiles/pmc_per_sample.json:
 per workload and per camera sample, the VALU wave-instructions issued and the HBM bytes moved (2 x FETCH_SIZE +
 WRITE_SIZE, KiB -> bytes: on gfx950 FETCH_SIZE reports half the bytes of wide coalesced reads, MI355X_MICROARCH.md
-§HBM), split into the trace kernels and everything else of the pipeline ("shade": stage, init and resolve kernels).
+§HBM), split into the trace kernels, the fused path kernel ("path") and everything else of the pipeline ("shade": shade, init and resolve kernels).
 Also keeps the per-kernel per-launch averages the totals come from.  Usage: tools/summarize_pmc_per_sample.py <tag>"""
 import collections
 import csv
@@ -40,7 +40,7 @@ def totals(name):
 
 
 def kernel_class(kernel):
-    return "trace" if "k_trace" in kernel else "shade"
+    return "trace" if "k_trace" in kernel else "path" if "k_path" in kernel else "shade"
 
 
 def workload(prefix, samples, with_valu):
