@@ -33,7 +33,8 @@
 extern "C" {
 #endif
 
-#define PATHED_ABI_VERSION 2   /* 2: image-texture albedo (PathedTexture, PathedMaterial.texture) */
+#define PATHED_ABI_VERSION 3   /* 2: image-texture albedo (PathedTexture, PathedMaterial.texture)
+                                * 3: participating media (PathedMedium, PathedGeom.medium, PATHED_MAT_PASSTHROUGH) */
 /* Additions that leave PathedSceneDesc unchanged (no version bump): PathedSceneOptions /
  * pathed_hip_scene_create_ex (per-scene device and tuning), pathed_hip_measure_valu,
  * pathed_hip_accum_add / pathed_hip_accum_copy_peer (multi-GPU fan-in of the radiance sums). */
@@ -55,6 +56,7 @@ extern "C" {
 #define PATHED_MAT_PLASTIC    3
 #define PATHED_MAT_GLASS      4
 #define PATHED_MAT_MIRROR     5
+#define PATHED_MAT_PASSTHROUGH 6 /* reference src/passthrough.cpp: the boundary of a participating medium ("container") */
 
 /* Lambertian albedo source (reference include/albedo.h, src/checkerboard.cpp:9-20) */
 #define PATHED_ALBEDO_CONSTANT     0
@@ -125,7 +127,17 @@ typedef struct PathedGeom {
     int32_t type;   /* PATHED_GEOM_*                                            */
     int32_t first;  /* MESH: first triangle index; SPHERE: index into spheres  */
     int32_t count;  /* MESH: triangle count;       SPHERE: 1                   */
+    int32_t medium; /* the model's "internal_medium" (reference src/scene_parser.cpp:324-337, Surface::getInternalMedium):
+                       index into PathedSceneDesc.media, -1 = none               */
 } PathedGeom;
+
+/* Homogeneous participating medium — reference HomogeneousMedium (src/homogeneous_medium.cpp; scene JSON "media",
+ * src/scene_parser.cpp:221-226).  The reference's transmittance uses all three channels of sigma_t, its distance
+ * sampling the red one (it asserts the three are equal). */
+typedef struct PathedMedium {
+    float sigma_t[3];
+    float sigma_s[3];
+} PathedMedium;
 
 /* Environment light — reference EnvironmentLight (src/environment_light.cpp).
  * rgba is the float RGBA image LoadEXR returns (row 0 = theta 0), map_to_world /
@@ -170,6 +182,9 @@ typedef struct PathedSceneDesc {
 
     uint32_t n_textures;
     const PathedTexture *textures;
+
+    uint32_t n_media;
+    const PathedMedium *media;
 } PathedSceneDesc;
 
 typedef struct PathedScene PathedScene;   /* opaque; owns all device memory     */
@@ -197,7 +212,8 @@ typedef struct PathedStats {
     uint32_t bvh_builder;          /* PATHED_BVH_* the scene was built with                 */
     uint32_t trace_launches_all;   /* trace launches since reset_stats, timed or not (trace_launches counts the timed ones) */
     uint32_t path_kernel;          /* 1 wavefront with the per-slot shade kernel, 2 wavefront with the staged shade kernel,
-                                      3 fused path kernel (tiny scenes: one persistent launch per pass, timed as trace_ms) */
+                                      3 fused path kernel (tiny scenes: one persistent launch per pass, timed as trace_ms),
+                                      4 volume path kernel (PATHED_INTEGRATOR_VOLUME_PATH_TRACER)                        */
     uint32_t reserved0;
 } PathedStats;
 
@@ -282,6 +298,16 @@ int pathed_hip_render_device(PathedScene *scene, uint64_t seed,
                              uint32_t spp_begin, uint32_t spp_count,
                              int start_bounce, int last_bounce,
                              float *d_accum_rgb_sum, void *stream, int blocking);
+
+/* Which of the reference's SampleIntegrator subclasses the render calls run (job.json "integrator", src/job.cpp:65-97):
+ *   PATHED_INTEGRATOR_PATH_TRACER         PathTracer::L (src/path_tracer.cpp:19-216), the default
+ *   PATHED_INTEGRATOR_VOLUME_PATH_TRACER  VolumePathTracer::L (src/volume_path_tracer.cpp:14-131) with
+ *                                         DirectLightingHelper::Ld (src/direct_lighting_helper.cpp:37-187): participating
+ *                                         media behind PATHED_MAT_PASSTHROUGH containers, single scattering per segment.
+ * Scenes that contain PATHED_MAT_PASSTHROUGH materials render with the volume integrator only. */
+#define PATHED_INTEGRATOR_PATH_TRACER 0
+#define PATHED_INTEGRATOR_VOLUME_PATH_TRACER 1
+int pathed_hip_set_integrator(PathedScene *scene, int integrator);
 
 /* Summation granularity.  A pixel's samples are summed in sample order in groups of
  * `samples` (a work unit); the group sums are then added to the pixel in group order.

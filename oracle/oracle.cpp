@@ -455,8 +455,12 @@ Material materialFromDesc(const PathedMaterial &m)
 
 inline bool isDelta(const Material &m)
 {
-    return m.type == PATHED_MAT_GLASS || m.type == PATHED_MAT_MIRROR; /* glass.h:23, mirror.h */
+    /* glass.h:23, mirror.h, passthrough.h:23 */
+    return m.type == PATHED_MAT_GLASS || m.type == PATHED_MAT_MIRROR || m.type == PATHED_MAT_PASSTHROUGH;
 }
+
+/* Material::isContainer, include/passthrough.h:25 */
+inline bool isContainer(const Material &m) { return m.type == PATHED_MAT_PASSTHROUGH; }
 
 /* src/checkerboard.cpp:9-20 */
 Color checkerboardLookup(const Material &m, const Intersection &isect)
@@ -779,6 +783,17 @@ BSDFSample mirrorSample(const Intersection &isect)
     return sample;
 }
 
+/* src/passthrough.cpp:29-43: straight on, pdf 1, throughput 1 / |cos| */
+BSDFSample passthroughSample(const Intersection &isect)
+{
+    const float cosTheta = fabsf(dot(-isect.shadingNormal, -isect.wo));   /* WorldFrame::absCosTheta */
+    BSDFSample sample;
+    sample.wiWorld = -isect.wo;
+    sample.pdf = 1.f;
+    sample.throughput = col(1.f) / cosTheta;
+    return sample;
+}
+
 Color materialF(const Material &m, const Intersection &isect, Vec3 wiWorld, float *pdf)
 {
     switch (m.type) {
@@ -798,6 +813,7 @@ BSDFSample materialSample(const Material &m, const Intersection &isect, Rng &ran
     case PATHED_MAT_MICROFACET: return microfacetSample(m, isect, random);
     case PATHED_MAT_PLASTIC: return plasticSample(m, isect, random);
     case PATHED_MAT_GLASS: return glassSample(m, isect, random);
+    case PATHED_MAT_PASSTHROUGH: return passthroughSample(isect);
     default: return mirrorSample(isect);
     }
 }
@@ -1352,6 +1368,12 @@ struct OracleSceneImpl {
     std::vector<std::vector<unsigned char>> textures; /* copies: the caller owns the description */
     Bvh bvh;
 
+    /* participating media (src/homogeneous_medium.cpp) and the internal medium of every primitive's surface
+     * (Surface::getInternalMedium; -1 = none), triangles first, then spheres */
+    struct Medium { Color sigmaT, sigmaS; };
+    std::vector<Medium> media;
+    std::vector<int> primMedium;
+
     struct Light {
         int kind; /* 0 triangle, 1 sphere, 2 environment */
         int index;
@@ -1459,46 +1481,7 @@ struct OracleSceneImpl {
         if (counters) { counters->closestRays++; }
         HitRecord hit;
         if (!closestHit(o, d, 1e-3f, 1e5f, &hit, counters)) { return isect; }
-
-        Vec3 geometricNormal;
-        Vec3 shadingNormal = v3(0.f, 0.f, 0.f);
-        float uvU = 0.f, uvV = 0.f;
-        int material;
-
-        if (hit.prim < (int)triangles.size()) {
-            const Triangle &tri = triangles[(size_t)hit.prim];
-            const float w = 1.f - hit.u - hit.v;
-            /* rtcInterpolate0 with weights (1-u-v, u, v) */
-            uvU = fmaf(w, tri.uv0[0], fmaf(hit.u, tri.uv1[0], hit.v * tri.uv2[0]));
-            uvV = fmaf(w, tri.uv0[1], fmaf(hit.u, tri.uv1[1], hit.v * tri.uv2[1]));
-            shadingNormal = v3(
-                fmaf(w, tri.n0.x, fmaf(hit.u, tri.n1.x, hit.v * tri.n2.x)),
-                fmaf(w, tri.n0.y, fmaf(hit.u, tri.n1.y, hit.v * tri.n2.y)),
-                fmaf(w, tri.n0.z, fmaf(hit.u, tri.n1.z, hit.v * tri.n2.z)));
-            /* Ng = (v1 - v0) x (v2 - v0) */
-            geometricNormal = normalized(xcross(tri.p1 - tri.p0, tri.p2 - tri.p0));
-            material = tri.material;
-        } else {
-            const Sphere &sphere = spheres[(size_t)hit.prim - triangles.size()];
-            const Vec3 p = o + d * hit.t;
-            geometricNormal = normalized(p - sphere.centerWorld);
-            material = sphere.material;
-        }
-
-        if (length(shadingNormal) == 0.f) { shadingNormal = geometricNormal; }
-
-        isect.hit = true;
-        isect.t = hit.t;
-        isect.point = o + d * hit.t; /* Ray::at, src/ray.cpp:9-12 */
-        isect.wo = -d;
-        isect.normal = geometricNormal;
-        isect.shadingNormal = normalized(shadingNormal);
-        isect.u = uvU;
-        isect.v = uvV;
-        isect.material = material;
-        isect.prim = hit.prim;
-        isect.frame = normalToWorldSpace(isect.shadingNormal, isect.wo);
-        return isect;
+        return makeIntersection(o, d, hit);
     }
 
     /* Scene::testOcclusion, src/scene.cpp:355-381 */
@@ -1686,6 +1669,327 @@ struct OracleSceneImpl {
         return col(0.f);
     }
 
+    /* ======================================================================================================
+     * Participating media: VolumePathTracer (src/volume_path_tracer.cpp), DirectLightingHelper::Ld
+     * (src/direct_lighting_helper.cpp:37-187), VolumeHelper (src/volume_helper.cpp), HomogeneousMedium
+     * (src/homogeneous_medium.cpp) and the two "volumetric" ray queries of Scene (src/scene.cpp:225-353, 383-424).
+     *
+     * PARITY UNPINNED, and in one place DEFINED rather than restated.  The reference makes Embree skip container
+     * surfaces (passthrough material + internal medium) through an intersection filter that records a VolumeEvent
+     * (t, medium) for every container hit Embree reports during its traversal (src/scene.cpp:42-83).  Which hits
+     * those are depends on Embree's traversal order: a container beyond the final opaque hit is reported if it is
+     * met first and culled if it is met later.  Here the events of a closest-hit query are the container hits
+     * with tnear < t < t(final hit), those of an occlusion query the container hits inside the query interval;
+     * equal t are recorded once (scene.cpp:72-77), and the first two in order of t are used (the reference asserts
+     * there are one or two, volume_helper.cpp:43, 83, 101).
+     * ====================================================================================================== */
+
+    struct VolumeEvent { float t; int medium; };
+
+    bool containerPrim(int prim) const
+    {
+        const int material = prim < (int)triangles.size() ? triangles[(size_t)prim].material : spheres[(size_t)prim - triangles.size()].material;
+        return isContainer(materials[(size_t)material]) && primMedium[(size_t)prim] >= 0;
+    }
+
+    /* every primitive (container or not) a ray meets in (tnear, tmax], brute force: the media scenes are small */
+    template <typename Visit>
+    void forEachHit(Vec3 o, Vec3 d, float tnear, Visit visit) const
+    {
+        for (size_t i = 0; i < triangles.size(); i++) {
+            const Triangle &tri = triangles[i];
+            float t, u, v;
+            if (!intersectTriangle(o, d, tri.p0, tri.p1 - tri.p0, tri.p2 - tri.p0, &t, &u, &v)) { continue; }
+            if (!(t > tnear)) { continue; }
+            visit((int)i, t, u, v);
+        }
+        for (size_t i = 0; i < spheres.size(); i++) {
+            float t;
+            if (!intersectSphere(o, d, spheres[i].centerWorld, spheres[i].radius, tnear, &t)) { continue; }
+            if (!(t > tnear)) { continue; }
+            visit((int)(triangles.size() + i), t, 0.f, 0.f);
+        }
+    }
+
+    static void addEvent(std::vector<VolumeEvent> &events, float t, int medium)
+    {
+        for (const VolumeEvent &existing : events) { if (existing.t == t) { return; } }
+        events.push_back({ t, medium });
+    }
+
+    static void sortEvents(std::vector<VolumeEvent> &events)
+    {
+        std::sort(events.begin(), events.end(), [](const VolumeEvent &a, const VolumeEvent &b) { return a.t < b.t; });
+    }
+
+    Intersection makeIntersection(Vec3 o, Vec3 d, const HitRecord &hit) const
+    {
+        Intersection isect;
+        std::memset(&isect, 0, sizeof isect);
+
+        Vec3 geometricNormal;
+        Vec3 shadingNormal = v3(0.f, 0.f, 0.f);
+        float uvU = 0.f, uvV = 0.f;
+        int material;
+
+        if (hit.prim < (int)triangles.size()) {
+            const Triangle &tri = triangles[(size_t)hit.prim];
+            const float w = 1.f - hit.u - hit.v;
+            /* rtcInterpolate0 with weights (1-u-v, u, v) */
+            uvU = fmaf(w, tri.uv0[0], fmaf(hit.u, tri.uv1[0], hit.v * tri.uv2[0]));
+            uvV = fmaf(w, tri.uv0[1], fmaf(hit.u, tri.uv1[1], hit.v * tri.uv2[1]));
+            shadingNormal = v3(
+                fmaf(w, tri.n0.x, fmaf(hit.u, tri.n1.x, hit.v * tri.n2.x)),
+                fmaf(w, tri.n0.y, fmaf(hit.u, tri.n1.y, hit.v * tri.n2.y)),
+                fmaf(w, tri.n0.z, fmaf(hit.u, tri.n1.z, hit.v * tri.n2.z)));
+            /* Ng = (v1 - v0) x (v2 - v0) */
+            geometricNormal = normalized(xcross(tri.p1 - tri.p0, tri.p2 - tri.p0));
+            material = tri.material;
+        } else {
+            const Sphere &sphere = spheres[(size_t)hit.prim - triangles.size()];
+            const Vec3 p = o + d * hit.t;
+            geometricNormal = normalized(p - sphere.centerWorld);
+            material = sphere.material;
+        }
+
+        if (length(shadingNormal) == 0.f) { shadingNormal = geometricNormal; }
+
+        isect.hit = true;
+        isect.t = hit.t;
+        isect.point = o + d * hit.t; /* Ray::at, src/ray.cpp:9-12 */
+        isect.wo = -d;
+        isect.normal = geometricNormal;
+        isect.shadingNormal = normalized(shadingNormal);
+        isect.u = uvU;
+        isect.v = uvV;
+        isect.material = material;
+        isect.prim = hit.prim;
+        isect.frame = normalToWorldSpace(isect.shadingNormal, isect.wo);
+        return isect;
+    }
+
+
+    /* Scene::testVolumetricIntersect, src/scene.cpp:225-353 */
+    Intersection testVolumetricIntersect(Vec3 o, Vec3 d, std::vector<VolumeEvent> *events, Counters *counters) const
+    {
+        if (counters) { counters->closestRays++; }
+        HitRecord best;
+        best.t = 1e5f; best.u = best.v = 0.f; best.prim = -1;
+        forEachHit(o, d, 1e-3f, [&](int prim, float t, float u, float v) {
+            if (containerPrim(prim)) { return; }
+            const bool closer = (best.prim < 0) ? (t <= best.t) : (t < best.t || (t == best.t && prim < best.prim));
+            if (closer) { best.t = t; best.u = u; best.v = v; best.prim = prim; }
+        });
+        events->clear();
+        forEachHit(o, d, 1e-3f, [&](int prim, float t, float, float) {
+            if (containerPrim(prim) && t < best.t) { addEvent(*events, t, primMedium[(size_t)prim]); }
+        });
+        sortEvents(*events);
+        Intersection isect;
+        std::memset(&isect, 0, sizeof isect);
+        isect.hit = false;
+        isect.material = -1;
+        isect.prim = -1;
+        if (best.prim < 0) { return isect; }
+        return makeIntersection(o, d, best);
+    }
+
+    /* Scene::testVolumetricOcclusion, src/scene.cpp:383-424 */
+    bool testVolumetricOcclusion(Vec3 o, Vec3 d, float maxT, std::vector<VolumeEvent> *events, Counters *counters) const
+    {
+        if (counters) { counters->shadowRays++; }
+        const float tfar = maxT - 1e-3f;
+        bool occluded = false;
+        events->clear();
+        forEachHit(o, d, 1e-3f, [&](int prim, float t, float, float) {
+            if (!(t <= tfar)) { return; }
+            if (containerPrim(prim)) { addEvent(*events, t, primMedium[(size_t)prim]); }
+            else { occluded = true; }
+        });
+        sortEvents(*events);
+        return occluded;
+    }
+
+    /* HomogeneousMedium::transmittance, src/homogeneous_medium.cpp:14-18 */
+    Color mediumTransmittance(int medium, Vec3 pointA, Vec3 pointB) const
+    {
+        const Vec3 path = pointB - pointA;
+        const Color sigmaT = media[(size_t)medium].sigmaT;
+        const float distance = length(path);
+        return col(expf(-sigmaT.r * distance), expf(-sigmaT.g * distance), expf(-sigmaT.b * distance));
+    }
+
+    /* VolumeHelper::rayTransmission, src/volume_helper.cpp:71-123 */
+    Color rayTransmission(Vec3 o, Vec3 d, const std::vector<VolumeEvent> &events, int medium) const
+    {
+        Color transmittance = col(1.f);
+        const size_t eventCount = events.size();
+        if (eventCount == 0) { return transmittance; }
+        if (medium >= 0) {
+            if (eventCount == 1) { transmittance = transmittance * mediumTransmittance(medium, o, o + d * events[0].t); }
+            else { transmittance = transmittance * mediumTransmittance(medium, o + d * events[0].t, o + d * events[1].t); }
+        } else {
+            const int eventMedium = events[0].medium;
+            if (eventCount >= 2) { transmittance = transmittance * mediumTransmittance(eventMedium, o + d * events[0].t, o + d * events[1].t); }
+            else { transmittance = transmittance * mediumTransmittance(eventMedium, o, o + d * events[0].t); }
+        }
+        return transmittance;
+    }
+
+    /* VolumeHelper::directSampleLights, src/volume_helper.cpp:12-69 (isotropic phase function 1 / 4 pi) */
+    Color volumeDirectSampleLights(int medium, Vec3 samplePoint, Rng &random, Counters *counters) const
+    {
+        if (lights.empty()) { return col(0.f); }
+        const LightSample lightSample = sampleDirectLights(samplePoint, random);
+        const Vec3 sampleDirection = lightSample.point - samplePoint;
+        const Vec3 wiWorld = normalized(sampleDirection);
+        if (dot(lightSample.normal, wiWorld) >= 0.f) { return col(0.f); }
+        const float lightDistance = length(sampleDirection);
+        std::vector<VolumeEvent> events;
+        if (testVolumetricOcclusion(samplePoint, wiWorld, lightDistance, &events, counters)) { return col(0.f); }
+        const float pdf = solidAnglePDF(lightSample, samplePoint);
+        const Vec3 lightWo = -normalized(sampleDirection);
+        Color shadowTransmittance = col(0.f);
+        if (events.size() == 1) { shadowTransmittance = mediumTransmittance(medium, samplePoint, samplePoint + wiWorld * events[0].t); }
+        else if (events.size() >= 2) { shadowTransmittance = mediumTransmittance(medium, samplePoint + wiWorld * events[0].t, samplePoint + wiWorld * events[1].t); }
+        /* emit * T * 1.f / (4.f * M_PI) / pdf: the product 4 pi is a double, Color::operator/ takes it as a float */
+        const float fourPi = (float)(4.f * 3.14159265358979323846);
+        return lightEmit(lightSample.light, lightWo) * shadowTransmittance * 1.f / fourPi / pdf;
+    }
+
+    /* VolumePathTracer::scatter -> HomogeneousMedium::integrate, src/volume_path_tracer.cpp:114-131,
+     * src/homogeneous_medium.cpp:36-66: one distance sample on the segment; if it lands inside, the in-scattered
+     * light of one light sample there (the path itself goes on undeflected) */
+    Color scatter(int medium, Vec3 entry, Vec3 exit, Rng &random, Counters *counters) const
+    {
+        if (medium < 0) { return col(0.f); }
+        const float sigmaT = media[(size_t)medium].sigmaT.r;
+        const Vec3 travel = exit - entry;
+        const float distance = length(travel);
+        const float xi = random.next();
+        const float sampleT = -logf(1 - xi) / sigmaT;
+        if (sampleT >= distance) { return col(0.f); }
+        const Vec3 samplePoint = entry + normalized(travel) * sampleT;
+        return volumeDirectSampleLights(medium, samplePoint, random, counters);
+    }
+
+    /* DirectLightingHelper::Ld, src/direct_lighting_helper.cpp:37-187 */
+    Color volumeLd(const Intersection &isect, int medium, const Material &material, const BSDFSample &bsdfSample, Rng &random, Counters *counters) const
+    {
+        if (isContainer(material)) { return col(0.f); }
+        if (!isBlack(material.emit)) { return col(0.f); }
+        Color result = col(0.f);
+        /* directSampleLights, :74-134 */
+        Color lightContribution = col(0.f);
+        if (!isDelta(material) && !lights.empty()) {
+            const LightSample lightSample = sampleDirectLights(isect.point, random);
+            const Vec3 lightDirection = lightSample.point - isect.point;
+            const Vec3 wiWorld = normalized(lightDirection);
+            if (!(dot(lightSample.normal, wiWorld) >= 0.f)) {
+                const float lightDistance = length(lightDirection);
+                std::vector<VolumeEvent> events;
+                if (!testVolumetricOcclusion(isect.point, wiWorld, lightDistance, &events, counters)) {
+                    const Color transmittance = rayTransmission(isect.point, wiWorld, events, medium);
+                    const float pdf = solidAnglePDF(lightSample, isect.point);
+                    float brdfPDF;
+                    const Color f = materialF(material, isect, wiWorld, &brdfPDF);
+                    const float lightWeight = (1 * pdf) / (1 * pdf + 1 * brdfPDF);
+                    const Vec3 lightWo = -normalized(lightDirection);
+                    lightContribution = lightEmit(lightSample.light, lightWo)
+                        * transmittance
+                        * lightWeight
+                        * f
+                        * fabsf(dot(isect.shadingNormal, wiWorld))
+                        / pdf;
+                }
+            }
+        }
+        result = result + lightContribution;
+        /* directSampleBSDF, :136-187: the query skips containers; no transmittance is applied (as in the reference) */
+        std::vector<VolumeEvent> events;
+        const Intersection bounce = testVolumetricIntersect(isect.point, bsdfSample.wiWorld, &events, counters);
+        result = result + directSampleBSDF(isect, material, bsdfSample, bounce);
+        return result;
+    }
+
+    /* SampleIntegrator::samplePixel + VolumePathTracer::L, src/sample_integrator.cpp:10-78, src/volume_path_tracer.cpp:14-99.
+     * Random dimensions: the BSDF and light samples of vertex k where PathTracer has them; the distance sample and the
+     * light sample of the medium on the segment that ENDS at vertex k at kMediumDimensions + 4 (k - 1) + {0; 1, 2, 3}. */
+    static uint32_t mediumBase(int vertex) { return 0x4000u + 4u * (uint32_t)(vertex - 1); }
+
+    Color samplePixelVolume(uint64_t seed, int row, int col_, uint32_t sampleIndex, int startBounce, int lastBounce, Counters *counters) const
+    {
+        const uint32_t pixelIndex = (uint32_t)(row * width + col_);
+        Rng random = keyedRng(seed, pixelIndex, sampleIndex);
+        if (counters) { counters->cameraSamples++; }
+        random.dimension = 0;
+        const float jitterX = random.next() - 0.5f;
+        const float jitterY = random.next() - 0.5f;
+        Vec3 rayOrigin, rayDirection;
+        camera.generateRay(row + jitterY, col_ + jitterX, &rayOrigin, &rayDirection);
+
+        Color color = col(0.f);
+        const Intersection intersection = testIntersect(rayOrigin, rayDirection, counters);
+        if (!intersection.hit) { return color + environmentL(rayDirection); }
+
+        if (checkCounts(startBounce, lastBounce, 0)) {
+            const Material &first = materials[(size_t)intersection.material];
+            const bool backside = dot(intersection.normal, intersection.wo) < 0.f;
+            if (!isBlack(first.emit) && !backside) { color = color + first.emit; }
+            if (isContainer(first)) {
+                /* what is seen through the container, src/sample_integrator.cpp:35-51 */
+                std::vector<VolumeEvent> events;
+                const Intersection through = testVolumetricIntersect(rayOrigin, rayDirection, &events, counters);
+                const Color transmittance = rayTransmission(rayOrigin, rayDirection, events, -1);
+                if (through.hit) { color = color + materials[(size_t)through.material].emit * transmittance; }
+                else { color = color + environmentL(rayDirection) * transmittance; }
+            }
+        }
+
+        /* ---- VolumePathTracer::L ---- */
+        int medium = -1;
+        Intersection last = intersection;
+        random.dimension = vertexBase(1);
+        BSDFSample bsdfSample = materialSample(materials[(size_t)last.material], last, random);
+        if (counters) { counters->vertices++; }
+        Color result = col(0.f);
+        if (checkCounts(startBounce, lastBounce, 1)) {
+            random.dimension = vertexBase(1) + 3;
+            result = volumeLd(last, medium, materials[(size_t)last.material], bsdfSample, random, counters);
+        }
+        Color modulation = col(1.f);
+        for (int bounce = 2; !checkDone(lastBounce, bounce); bounce++) {
+            /* refraction: the medium changes (:43-51) */
+            if (dot(last.wo, bsdfSample.wiWorld) < 0.f) {
+                if (dot(last.normal, bsdfSample.wiWorld) < 0.f) { medium = primMedium[(size_t)last.prim]; }
+                else { medium = -1; }
+            }
+            const Intersection next = testIntersect(last.point, bsdfSample.wiWorld, counters);
+            if (!next.hit) { break; }
+            if (counters) { counters->vertices++; }
+            const float invPDF = 1.f / bsdfSample.pdf;
+            const float cosTheta = fabsf(dot(last.shadingNormal, bsdfSample.wiWorld));
+            modulation = modulation * (bsdfSample.throughput * cosTheta * invPDF);
+
+            random.dimension = mediumBase(bounce);
+            const Color Ls = scatter(medium, last.point, next.point, random, counters);
+            result = result + Ls * modulation;
+            if (medium >= 0) { modulation = modulation * mediumTransmittance(medium, last.point, next.point); }
+            else { modulation = modulation * col(1.f); }
+            if (isBlack(modulation)) { break; }
+
+            random.dimension = vertexBase(bounce);
+            bsdfSample = materialSample(materials[(size_t)next.material], next, random);
+            last = next;
+            if (checkCounts(startBounce, lastBounce, bounce)) {
+                random.dimension = vertexBase(bounce) + 3;
+                const Color Ld = volumeLd(next, medium, materials[(size_t)next.material], bsdfSample, random, counters);
+                result = result + Ld * modulation;
+            }
+        }
+        return color + result;
+    }
+
     /* -- SampleIntegrator::samplePixel + PathTracer::L --------------------------
      * src/sample_integrator.cpp:10-78, src/path_tracer.cpp:19-77.  The ray along
      * bsdfSample.wiWorld is traced once and serves both direct()'s BSDF-sampling
@@ -1784,6 +2088,7 @@ inline bool finiteColor(Color c) { return std::isfinite(c.r) && std::isfinite(c.
 
 struct OracleScene {
     OracleSceneImpl impl;
+    int integrator = 0;   /* PATHED_INTEGRATOR_*: 0 PathTracer, 1 VolumePathTracer */
 };
 
 extern "C" {
@@ -1882,11 +2187,34 @@ OracleScene *oracle_scene_create(const PathedSceneDesc *desc)
         impl.lights.push_back({ 2, 0 });
     }
 
+    impl.media.resize(desc->n_media);
+    for (uint32_t i = 0; i < desc->n_media; i++) {
+        impl.media[i].sigmaT = col(desc->media[i].sigma_t[0], desc->media[i].sigma_t[1], desc->media[i].sigma_t[2]);
+        impl.media[i].sigmaS = col(desc->media[i].sigma_s[0], desc->media[i].sigma_s[1], desc->media[i].sigma_s[2]);
+    }
+    impl.primMedium.assign((size_t)desc->n_triangles + desc->n_spheres, -1);
+    for (uint32_t g = 0; g < desc->n_geoms; g++) {
+        const PathedGeom &geom = desc->geoms[g];
+        const int medium = (geom.medium >= 0 && (uint32_t)geom.medium < desc->n_media) ? geom.medium : -1;
+        if (geom.type == PATHED_GEOM_MESH) {
+            for (int i = 0; i < geom.count; i++) { impl.primMedium[(size_t)(geom.first + i)] = medium; }
+        } else {
+            impl.primMedium[(size_t)desc->n_triangles + (size_t)geom.first] = medium;
+        }
+    }
+
     impl.bvh.build(impl.triangles);
     return scene;
 }
 
 void oracle_scene_destroy(OracleScene *scene) { delete scene; }
+
+int oracle_set_integrator(OracleScene *scene, int integrator)
+{
+    if (!scene || (integrator != PATHED_INTEGRATOR_PATH_TRACER && integrator != PATHED_INTEGRATOR_VOLUME_PATH_TRACER)) { return -1; }
+    scene->integrator = integrator;
+    return 0;
+}
 
 int oracle_light_count(OracleScene *scene) { return scene ? (int)scene->impl.lights.size() : -1; }
 
@@ -1924,6 +2252,7 @@ int oracle_render_chunked(OracleScene *scene, uint64_t seed, uint32_t spp_begin,
         /* the reference would divide by a zero light count; nothing to sample */
     }
     const int width = impl.width, height = impl.height;
+    const bool volume = scene->integrator == PATHED_INTEGRATOR_VOLUME_PATH_TRACER;
     Counters total;
     std::memset(&total, 0, sizeof total);
 
@@ -1942,7 +2271,9 @@ int oracle_render_chunked(OracleScene *scene, uint64_t seed, uint32_t spp_begin,
                 float *pixel = accum + 3 * ((size_t)row * width + col_);
                 if (chunk <= 1) {
                     for (uint32_t s = 0; s < spp_count; s++) {
-                        const Color c = impl.samplePixel(seed, row, col_, spp_begin + s, start_bounce, last_bounce, &local);
+                        const Color c = volume
+                            ? impl.samplePixelVolume(seed, row, col_, spp_begin + s, start_bounce, last_bounce, &local)
+                            : impl.samplePixel(seed, row, col_, spp_begin + s, start_bounce, last_bounce, &local);
                         if (!finiteColor(c)) { local.dropped++; continue; }
                         pixel[0] += c.r;
                         pixel[1] += c.g;
@@ -1952,7 +2283,9 @@ int oracle_render_chunked(OracleScene *scene, uint64_t seed, uint32_t spp_begin,
                     for (uint32_t first = 0; first < spp_count; first += (uint32_t)chunk) {
                         float partial[3] = { 0.f, 0.f, 0.f };
                         for (uint32_t s = first; s < spp_count && s < first + (uint32_t)chunk; s++) {
-                            const Color c = impl.samplePixel(seed, row, col_, spp_begin + s, start_bounce, last_bounce, &local);
+                            const Color c = volume
+                                ? impl.samplePixelVolume(seed, row, col_, spp_begin + s, start_bounce, last_bounce, &local)
+                                : impl.samplePixel(seed, row, col_, spp_begin + s, start_bounce, last_bounce, &local);
                             if (!finiteColor(c)) { local.dropped++; continue; }
                             partial[0] += c.r;
                             partial[1] += c.g;

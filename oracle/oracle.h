@@ -76,6 +76,10 @@ int oracle_eval(const char *fn, const float *in, int n_in, float *out, int n_out
 
 int oracle_light_count(OracleScene *scene);
 
+/* PATHED_INTEGRATOR_PATH_TRACER (default) or PATHED_INTEGRATOR_VOLUME_PATH_TRACER: which of the reference's
+ * SampleIntegrator subclasses oracle_render* restate (src/path_tracer.cpp / src/volume_path_tracer.cpp). */
+int oracle_set_integrator(OracleScene *scene, int integrator);
+
 #ifdef __cplusplus
 }
 #endif

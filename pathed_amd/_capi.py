@@ -11,9 +11,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 REPO_ROOT = os.path.dirname(_HERE)
 LIB_DIR = os.path.join(_HERE, "lib")
 
-PATHED_ABI_VERSION = 2
+PATHED_ABI_VERSION = 3
 
-MAT_LAMBERTIAN, MAT_OREN_NAYAR, MAT_MICROFACET, MAT_PLASTIC, MAT_GLASS, MAT_MIRROR = range(6)
+MAT_LAMBERTIAN, MAT_OREN_NAYAR, MAT_MICROFACET, MAT_PLASTIC, MAT_GLASS, MAT_MIRROR, MAT_PASSTHROUGH = range(7)
+INTEGRATOR_PATH_TRACER, INTEGRATOR_VOLUME_PATH_TRACER = 0, 1
 ALBEDO_CONSTANT, ALBEDO_CHECKERBOARD, ALBEDO_TEXTURE = 0, 1, 2
 GEOM_MESH, GEOM_SPHERE = 0, 1
 
@@ -57,7 +58,11 @@ class PathedSphere(C.Structure):
 
 
 class PathedGeom(C.Structure):
-    _fields_ = [("type", C.c_int32), ("first", C.c_int32), ("count", C.c_int32)]
+    _fields_ = [("type", C.c_int32), ("first", C.c_int32), ("count", C.c_int32), ("medium", C.c_int32)]
+
+
+class PathedMedium(C.Structure):
+    _fields_ = [("sigma_t", C.c_float * 3), ("sigma_s", C.c_float * 3)]
 
 
 class PathedEnvLight(C.Structure):
@@ -99,6 +104,8 @@ class PathedSceneDesc(C.Structure):
         ("env", C.POINTER(PathedEnvLight)),
         ("n_textures", C.c_uint32),
         ("textures", C.POINTER(PathedTexture)),
+        ("n_media", C.c_uint32),
+        ("media", C.POINTER(PathedMedium)),
     ]
 
 
@@ -161,6 +168,7 @@ HIP_SYMBOLS = [
     "pathed_hip_render_device",
     "pathed_hip_trace",
     "pathed_hip_set_samples_per_unit",
+    "pathed_hip_set_integrator",
     "pathed_hip_set_stats_mode",
     "pathed_hip_get_stats",
     "pathed_hip_reset_stats",
@@ -244,6 +252,8 @@ def load_hip():
     lib.pathed_hip_trace.restype = C.c_int
     lib.pathed_hip_set_samples_per_unit.argtypes = [vp, C.c_int]
     lib.pathed_hip_set_samples_per_unit.restype = C.c_int
+    lib.pathed_hip_set_integrator.argtypes = [vp, C.c_int]
+    lib.pathed_hip_set_integrator.restype = C.c_int
     lib.pathed_hip_set_stats_mode.argtypes = [vp, C.c_int]
     lib.pathed_hip_set_stats_mode.restype = C.c_int
     lib.pathed_hip_get_stats.argtypes = [vp, C.POINTER(PathedStats)]

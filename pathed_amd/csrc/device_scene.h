@@ -87,6 +87,11 @@ struct DScene {
     int nLights;
     int hasEnv;
     DEnv env;
+
+    // participating media (the volume integrator, volume.h)
+    const struct DMedium *media;
+    const int *primMedium;     // per primitive (triangles, then spheres): its surface's internal medium, -1 none
+    int nMedia;
 };
 
 // path state word (rayD.w)

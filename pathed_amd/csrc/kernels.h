@@ -25,10 +25,12 @@
 
 #include "shading.h"
 #include "trace.h"
+#include "volume.h"
 
 namespace pathed {
 
 static const int kBlock = 256;
+static_assert(kBlock == kVolumeBlock, "volume.h indexes the LDS stack rows with the block size");
 static const int kWavesPerBlock = kBlock / 64;
 static const int kMaxLdsMaterials = 96;  // 96 x 96 B = 9 KiB of LDS
 static const int kUnitQueues = 32;       // sharded work-unit cursors
@@ -2201,6 +2203,332 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_F
         atomicAdd(&p.stats[kStatClosest], (unsigned long long)closestRays);
         atomicAdd(&p.stats[kStatShadow], (unsigned long long)shadowRays);
     }
+}
+
+// ------------------------------------------------------------------------- volume path kernel
+// k_path_volume: SampleIntegrator::samplePixel + VolumePathTracer::L (see volume.h), one path per lane, persistent waves,
+// work units as in k_path_small.  Arithmetic on a path's values follows the reference statement by statement; on a
+// scene without media the result is PathTracer's, bit for bit (the two share their direct-lighting arithmetic; GPU test).
+template <bool LDS_MATERIALS, int STACK>
+__global__ __launch_bounds__(kBlock) void k_path_volume(RenderParams p)
+{
+    extern __shared__ float4 ldsRaw[];
+    // LDS: [STACK + 1][kBlock] traversal stack rows, then (LDS_MATERIALS) the material table
+    MaterialAccess<LDS_MATERIALS> materials;
+    if (LDS_MATERIALS) {
+        float4 *table = ldsRaw + ((STACK + 1) * kBlock) / 4;
+        const int words = p.scene.nMaterials * (int)(sizeof(DMaterial) / 4);
+        const int *source = reinterpret_cast<const int *>(p.scene.materials);
+        int *target = reinterpret_cast<int *>(table);
+        for (int i = threadIdx.x; i < words; i += kBlock) { target[i] = source[i]; }
+        __syncthreads();
+        materials.table = reinterpret_cast<const DMaterial *>(table);
+    } else {
+        materials.table = p.scene.materials;
+    }
+
+    const DScene &scene = p.scene;
+    VolumeContext<MaterialAccess<LDS_MATERIALS>> context;
+    context.geometry.nodes = scene.nodes;
+    context.geometry.tris = scene.leafTris;
+    context.geometry.nNodes = scene.nNodes;
+    context.geometry.nTris = scene.nTris;
+    context.geometry.spheres = scene.spheres;
+    context.geometry.nSpheres = scene.nLinearSpheres;
+    context.stack.lds = reinterpret_cast<int *>(ldsRaw) + threadIdx.x;
+    context.stack.overflowStride = (size_t)gridDim.x * kBlock;
+    context.stack.overflow = p.stackOverflow + ((size_t)blockIdx.x * kBlock + threadIdx.x);
+    context.maxStack = p.maxStack;
+    context.scene = &scene;
+    context.materials = materials;
+    context.primMedium = scene.primMedium;
+    context.media = scene.media;
+
+    const int lane = threadIdx.x & 63;
+    const unsigned int waveId = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const uint64_t seed = ((uint64_t)p.seedHi << 32) | p.seedLo;
+
+    // ---- work units, as in k_path_small
+    unsigned int queue = waveId % (unsigned int)p.nQueues, queuesTried = 0;
+    unsigned int reservedNext = 0, reservedEnd = 0;
+    auto takeUnits = [&](bool want) -> unsigned int {
+        unsigned int mine = 0xFFFFFFFFu;
+        unsigned long long wanting = __ballot(want);
+        while (wanting != 0ull) {
+            if (reservedNext == reservedEnd) {
+                if (queuesTried >= (unsigned int)p.nQueues) { break; }
+                unsigned int ticket = 0;
+                if (lane == 0) { ticket = atomicAdd(&p.counters[kCtrUnitCursor + queue * kCursorStride], (unsigned int)p.unitGrab); }
+                ticket = (unsigned int)__builtin_amdgcn_readfirstlane((int)ticket);
+                unsigned int limit = p.unitsPerQueue;
+                const unsigned long long first = (unsigned long long)queue * p.unitsPerQueue;
+                if (first >= p.nUnits) { limit = 0u; }
+                else if (first + limit > p.nUnits) { limit = (unsigned int)(p.nUnits - first); }
+                if (ticket >= limit) {
+                    queue = (queue + 1u) % (unsigned int)p.nQueues;
+                    queuesTried++;
+                    continue;
+                }
+                reservedNext = ticket;
+                reservedEnd = ticket + (unsigned int)p.unitGrab < limit ? ticket + (unsigned int)p.unitGrab : limit;
+            }
+            const unsigned int available = reservedEnd - reservedNext;
+            const unsigned int rank = __builtin_amdgcn_mbcnt_hi((unsigned int)(wanting >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)wanting, 0u));
+            const bool served = ((wanting >> lane) & 1ull) != 0ull && rank < available;
+            if (served) { mine = queue * p.unitsPerQueue + reservedNext + rank; }
+            const unsigned int count = (unsigned int)__popcll(wanting);
+            reservedNext += count < available ? count : available;
+            wanting &= ~__ballot(served);
+        }
+        return mine;
+    };
+
+    // DirectLightingHelper::Ld, src/direct_lighting_helper.cpp:37-187
+    auto directLighting = [&](const Isect &isect, int medium, const DMaterial &material, const BSDFSample &bsdfSample, Rng &random) -> Rgb {
+        if (material.type == PATHED_MAT_PASSTHROUGH) { return rgb(0.f); }
+        if (!isBlack(matEmit(material))) { return rgb(0.f); }
+        Rgb result = rgb(0.f);
+        // directSampleLights, :74-134
+        Rgb lightContribution = rgb(0.f);
+        if (!volumeIsDelta(material) && scene.nLights != 0) {
+            const int lightCount = scene.nLights;
+            int lightIndex = (int)floorf(random.next() * lightCount);
+            lightIndex = imin(lightIndex, lightCount - 1);
+            const DLight light = scene.lights[lightIndex];
+            SurfaceSample surfaceSample;
+            int lightMaterial = 0;
+            if (light.kind == 0) {
+                const TriShade tri = loadTriCorners(scene, light.index);
+                surfaceSample = triangleSample(tri.p0, tri.p1, tri.p2, random);
+                lightMaterial = tri.material;
+            } else if (light.kind == 1) {
+                const DSphere sphere = scene.spheres[light.index];
+                surfaceSample = sphereSample(v3(sphere.centerSample[0], sphere.centerSample[1], sphere.centerSample[2]), sphere.radius, isect.point, random);
+                lightMaterial = sphere.material;
+            } else {
+                surfaceSample = envSample(scene.env, isect.point, random);
+            }
+            const float lightChoicePDF = 1.f / lightCount;
+            const float invPDF = surfaceSample.invPDF * (1.f / lightChoicePDF);
+            const V3 lightDirection = surfaceSample.point - isect.point;
+            const V3 wiWorld = normalized(lightDirection);
+            if (!(dot(surfaceSample.normal, wiWorld) >= 0.f)) {
+                const float lightDistance = length(lightDirection);
+                VolumeEvents events;
+                RayHit unused;
+                const bool occluded = volumeQuery<STACK>(context, kQueryVolumeOccluded, isect.point, wiWorld, lightDistance - 1e-3f, &unused, &events);
+                if (!occluded) {
+                    const Rgb transmittance = rayTransmission(context.media, isect.point, wiWorld, events, medium);
+                    float pdf;
+                    if (surfaceSample.solidAngle) {
+                        pdf = 1.f / invPDF;
+                    } else {
+                        const V3 lightWoForPdf = -normalized(lightDirection);
+                        const float distance2 = lightDistance * lightDistance;
+                        const float projectedArea = smax(0.f, dot(surfaceSample.normal, lightWoForPdf));
+                        pdf = (1.f / invPDF) * distance2 / projectedArea;
+                    }
+                    float brdfPDF;
+                    const Rgb f = materialF(material, isect, wiWorld, &brdfPDF);
+                    const float lightWeight = (1 * pdf) / (1 * pdf + 1 * brdfPDF);
+                    const V3 lightWo = -normalized(lightDirection);
+                    Rgb emitted;
+                    if (light.kind == 2) { emitted = envEmit(scene.env, lightWo); }
+                    else { emitted = matEmit(materials[lightMaterial]); }
+                    lightContribution = emitted
+                        * transmittance
+                        * lightWeight
+                        * f
+                        * fabsf(dot(isect.shadingNormal, wiWorld))
+                        / pdf;
+                }
+            }
+        }
+        result = result + lightContribution;
+        // directSampleBSDF, :136-187: the query skips containers; no transmittance is applied (as in the reference)
+        Rgb bsdfTerm = rgb(0.f);
+        {
+            RayHit bounceHit;
+            const bool found = volumeQuery<STACK>(context, kQueryVolumeClosest, isect.point, bsdfSample.wiWorld, PATHED_TFAR, &bounceHit, nullptr);
+            if (found) {
+                const Isect bounce = makeIsect(scene, isect.point, bsdfSample.wiWorld,
+                                               make_float4(bounceHit.t, bounceHit.u, bounceHit.v, intAsFloat(bounceHit.prim)));
+                const Rgb emit = matEmit(materials[bounce.material]);
+                if (!isBlack(emit) && dot(bounce.wo, bounce.shadingNormal) >= 0.f) {
+                    const float lightPDF = lightsPDF(scene, isect.point, bounce);
+                    const float brdfWeight = volumeIsDelta(material) ? 1.f : (1 * bsdfSample.pdf) / (1 * bsdfSample.pdf + 1 * lightPDF);
+                    bsdfTerm = emit * brdfWeight * bsdfSample.throughput * fabsf(dot(isect.shadingNormal, bsdfSample.wiWorld)) / bsdfSample.pdf;
+                }
+            } else {
+                const Rgb environmentLight = environmentL(scene, bsdfSample.wiWorld);
+                if (!isBlack(environmentLight)) {
+                    const float lightPDF = envEmitPDF(scene.env, bsdfSample.wiWorld) / scene.nLights;
+                    const float brdfWeight = volumeIsDelta(material) ? 1.f : (1 * bsdfSample.pdf) / (1 * bsdfSample.pdf + 1 * lightPDF);
+                    bsdfTerm = environmentLight * brdfWeight * bsdfSample.throughput * fabsf(dot(isect.shadingNormal, bsdfSample.wiWorld)) / bsdfSample.pdf;
+                }
+            }
+        }
+        result = result + bsdfTerm;
+        return result;
+    };
+
+    // VolumePathTracer::scatter -> HomogeneousMedium::integrate -> VolumeHelper::directSampleLights
+    // (src/volume_path_tracer.cpp:114-131, src/homogeneous_medium.cpp:36-66, src/volume_helper.cpp:12-69)
+    auto scatter = [&](int medium, V3 entry, V3 exitPoint, Rng &random) -> Rgb {
+        if (medium < 0) { return rgb(0.f); }
+        const float sigmaT = context.media[medium].sigmaT[0];
+        const V3 travel = exitPoint - entry;
+        const float distance = length(travel);
+        const float xi = random.next();
+        const float sampleT = -logf(1 - xi) / sigmaT;
+        if (sampleT >= distance) { return rgb(0.f); }
+        const V3 samplePoint = entry + normalized(travel) * sampleT;
+        if (scene.nLights == 0) { return rgb(0.f); }
+        const int lightCount = scene.nLights;
+        int lightIndex = (int)floorf(random.next() * lightCount);
+        lightIndex = imin(lightIndex, lightCount - 1);
+        const DLight light = scene.lights[lightIndex];
+        SurfaceSample surfaceSample;
+        int lightMaterial = 0;
+        if (light.kind == 0) {
+            const TriShade tri = loadTriCorners(scene, light.index);
+            surfaceSample = triangleSample(tri.p0, tri.p1, tri.p2, random);
+            lightMaterial = tri.material;
+        } else if (light.kind == 1) {
+            const DSphere sphere = scene.spheres[light.index];
+            surfaceSample = sphereSample(v3(sphere.centerSample[0], sphere.centerSample[1], sphere.centerSample[2]), sphere.radius, samplePoint, random);
+            lightMaterial = sphere.material;
+        } else {
+            surfaceSample = envSample(scene.env, samplePoint, random);
+        }
+        const float lightChoicePDF = 1.f / lightCount;
+        const float invPDF = surfaceSample.invPDF * (1.f / lightChoicePDF);
+        const V3 sampleDirection = surfaceSample.point - samplePoint;
+        const V3 wiWorld = normalized(sampleDirection);
+        if (dot(surfaceSample.normal, wiWorld) >= 0.f) { return rgb(0.f); }
+        const float lightDistance = length(sampleDirection);
+        VolumeEvents events;
+        RayHit unused;
+        if (volumeQuery<STACK>(context, kQueryVolumeOccluded, samplePoint, wiWorld, lightDistance - 1e-3f, &unused, &events)) { return rgb(0.f); }
+        float pdf;
+        if (surfaceSample.solidAngle) {
+            pdf = 1.f / invPDF;
+        } else {
+            const V3 lightWoForPdf = -normalized(sampleDirection);
+            const float distance2 = lightDistance * lightDistance;
+            const float projectedArea = smax(0.f, dot(surfaceSample.normal, lightWoForPdf));
+            pdf = (1.f / invPDF) * distance2 / projectedArea;
+        }
+        const V3 lightWo = -normalized(sampleDirection);
+        Rgb shadowTransmittance = rgb(0.f);
+        if (events.count == 1) { shadowTransmittance = mediumTransmittance(context.media[medium], samplePoint, samplePoint + wiWorld * events.t0); }
+        else if (events.count >= 2) { shadowTransmittance = mediumTransmittance(context.media[medium], samplePoint + wiWorld * events.t0, samplePoint + wiWorld * events.t1); }
+        Rgb emitted;
+        if (light.kind == 2) { emitted = envEmit(scene.env, lightWo); }
+        else { emitted = matEmit(materials[lightMaterial]); }
+        const float fourPi = (float)(4.f * 3.14159265358979323846);   // `4.f * M_PI` is a double, Color::operator/ takes a float
+        return emitted * shadowTransmittance * 1.f / fourPi / pdf;
+    };
+
+    // one camera sample: SampleIntegrator::samplePixel, src/sample_integrator.cpp:10-78
+    auto samplePixel = [&](uint32_t pixel, uint32_t sample) -> Rgb {
+        Rng random;
+        makeKey(seed, pixel, sample, &random.k0, &random.k1);
+        random.dimension = 0;
+        const int width = scene.camera.resX;
+        const int row = (int)pixel / width;
+        const int col = (int)pixel - row * width;
+        const float jitterX = random.next() - 0.5f;
+        const float jitterY = random.next() - 0.5f;
+        V3 rayOrigin, rayDirection;
+        cameraRay(scene.camera, row + jitterY, col + jitterX, &rayOrigin, &rayDirection);
+
+        Rgb color = rgb(0.f);
+        RayHit hit;
+        if (!volumeQuery<STACK>(context, kQueryRegular, rayOrigin, rayDirection, PATHED_TFAR, &hit, nullptr)) {
+            return color + environmentL(scene, rayDirection);
+        }
+        Isect last = makeIsect(scene, rayOrigin, rayDirection, make_float4(hit.t, hit.u, hit.v, intAsFloat(hit.prim)));
+        if (checkCounts(p.startBounce, p.lastBounce, 0)) {
+            const DMaterial &first = materials[last.material];
+            const bool backside = dot(last.normal, last.wo) < 0.f;
+            if (!isBlack(matEmit(first)) && !backside) { color = color + matEmit(first); }
+            if (first.type == PATHED_MAT_PASSTHROUGH) {
+                // what is seen through the container, src/sample_integrator.cpp:35-51
+                VolumeEvents events;
+                RayHit through;
+                const bool found = volumeQuery<STACK>(context, kQueryVolumeClosest, rayOrigin, rayDirection, PATHED_TFAR, &through, &events);
+                const Rgb transmittance = rayTransmission(context.media, rayOrigin, rayDirection, events, -1);
+                if (found) { color = color + matEmit(materials[primMaterial(context, through.prim)]) * transmittance; }
+                else { color = color + environmentL(scene, rayDirection) * transmittance; }
+            }
+        }
+
+        // ---- VolumePathTracer::L, src/volume_path_tracer.cpp:14-99
+        int medium = -1;
+        random.dimension = vertexBase(1);
+        BSDFSample bsdfSample = volumeMaterialSample(materials[last.material], last, random);
+        Rgb result = rgb(0.f);
+        if (checkCounts(p.startBounce, p.lastBounce, 1)) {
+            random.dimension = vertexBase(1) + 3;
+            result = directLighting(last, medium, materials[last.material], bsdfSample, random);
+        }
+        Rgb modulation = rgb(1.f);
+        for (int bounce = 2; !checkDone(p.lastBounce, bounce); bounce++) {
+            // refraction: the medium changes (:43-51)
+            if (dot(last.wo, bsdfSample.wiWorld) < 0.f) {
+                if (dot(last.normal, bsdfSample.wiWorld) < 0.f) { medium = context.primMedium[last.prim]; }
+                else { medium = -1; }
+            }
+            if (!volumeQuery<STACK>(context, kQueryRegular, last.point, bsdfSample.wiWorld, PATHED_TFAR, &hit, nullptr)) { break; }
+            const Isect next = makeIsect(scene, last.point, bsdfSample.wiWorld, make_float4(hit.t, hit.u, hit.v, intAsFloat(hit.prim)));
+            const float invPDF = 1.f / bsdfSample.pdf;
+            const float cosTheta = fabsf(dot(last.shadingNormal, bsdfSample.wiWorld));
+            modulation = modulation * (bsdfSample.throughput * cosTheta * invPDF);
+
+            random.dimension = mediumBase(bounce);
+            const Rgb Ls = scatter(medium, last.point, next.point, random);
+            result = result + Ls * modulation;
+            if (medium >= 0) { modulation = modulation * mediumTransmittance(context.media[medium], last.point, next.point); }
+            else { modulation = modulation * rgb(1.f); }
+            if (isBlack(modulation)) { break; }
+
+            random.dimension = vertexBase(bounce);
+            bsdfSample = volumeMaterialSample(materials[next.material], next, random);
+            last = next;
+            if (checkCounts(p.startBounce, p.lastBounce, bounce)) {
+                random.dimension = vertexBase(bounce) + 3;
+                const Rgb Ld = directLighting(last, medium, materials[last.material], bsdfSample, random);
+                result = result + Ld * modulation;
+            }
+        }
+        return color + result;
+    };
+
+    unsigned long long samplesDone = 0;
+    while (true) {
+        const unsigned int unit = takeUnits(true);
+        if (__ballot(unit != 0xFFFFFFFFu) == 0ull) { break; }
+        if (unit != 0xFFFFFFFFu) {
+            uint32_t pixel, first, end;
+            unitSamples(p, unit, &pixel, &first, &end);
+            float4 partial = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (uint32_t sample = first; sample < end; sample++) {
+                const Rgb color = samplePixel(pixel, sample);
+                // radianceLookup += color, src/sample_integrator.cpp:61-63; non-finite samples dropped
+                if (isfinite(color.r) && isfinite(color.g) && isfinite(color.b)) {
+                    partial.x += color.r;
+                    partial.y += color.g;
+                    partial.z += color.b;
+                } else {
+                    atomicAdd(&p.stats[kStatDropped], 1ull);
+                }
+                samplesDone++;
+            }
+            p.state.chunkBuf[unit] = partial;
+        }
+    }
+    (void)samplesDone;
 }
 
 // ------------------------------------------------------------------------- scene set-up

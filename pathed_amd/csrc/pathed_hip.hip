@@ -153,6 +153,9 @@ struct PathedScene {
     DeviceBuffer<DLight> lights;
     DeviceBuffer<float> thetaCdf, phiCdf;
     DeviceBuffer<int> phiEmpty, thetaGuide, phiGuide;
+    DeviceBuffer<DMedium> media;
+    DeviceBuffer<int> primMedium;
+    DeviceBuffer<int> volumeOverflow;   // the volume kernel's traversal-stack spill, per thread
 
     // render state, allocated on first use
     int nSlots = 0;
@@ -171,6 +174,8 @@ struct PathedScene {
     DeviceBuffer<unsigned long long> stats;
     unsigned int *hostRemaining = nullptr;  // pinned
 
+    int integrator = PATHED_INTEGRATOR_PATH_TRACER;   // pathed_hip_set_integrator
+    bool hasContainers = false;   // some surface carries the passthrough material: only the volume integrator renders the scene
     bool spheresInTree = false;   // the host builder put the spheres into leaves (else they are tested one by one after the traversal)
     bool fusedPath = false;   // tiny scenes: k_path_small, whole paths in registers, no wavefront buffers
     bool stagedShade = true;  // k_shade_staged (dense, state-sorted stages inside a block) or k_shade (one lane per slot)
@@ -201,6 +206,7 @@ struct PathedScene {
         nodes.release(); leafTris.release(); triShade.release(); envRgba.release(); texels.release();
         spheres.release(); materials.release(); lights.release();
         thetaCdf.release(); phiCdf.release(); phiEmpty.release(); thetaGuide.release(); phiGuide.release();
+        media.release(); primMedium.release(); volumeOverflow.release();
         rayO.release(); rayD.release(); hit.release(); mod.release(); thr.release();
         res.release(); pend.release(); acc.release(); shO.release(); shD.release(); chunkBuf.release();
         counters.release(); stats.release();
@@ -314,7 +320,7 @@ int validate(const PathedSceneDesc *desc)
     }
     for (uint32_t i = 0; i < desc->n_materials; i++) {
         const int type = desc->materials[i].type;
-        if (type < PATHED_MAT_LAMBERTIAN || type > PATHED_MAT_MIRROR) { return fail(PATHED_E_UNSUPPORTED, "unknown material type"); }
+        if (type < PATHED_MAT_LAMBERTIAN || type > PATHED_MAT_PASSTHROUGH) { return fail(PATHED_E_UNSUPPORTED, "unknown material type"); }
         const int albedo = desc->materials[i].albedo_type;
         if (albedo < PATHED_ALBEDO_CONSTANT || albedo > PATHED_ALBEDO_TEXTURE) { return fail(PATHED_E_UNSUPPORTED, "unknown albedo type"); }
         if (albedo == PATHED_ALBEDO_TEXTURE) {
@@ -348,6 +354,12 @@ int validate(const PathedSceneDesc *desc)
     }
     if (desc->env) {
         if (desc->env->width <= 0 || desc->env->height <= 0 || !desc->env->rgba) { return fail(PATHED_E_INVALID, "environment map missing"); }
+    }
+    if (desc->n_media && !desc->media) { return fail(PATHED_E_INVALID, "media array missing"); }
+    for (uint32_t i = 0; i < desc->n_geoms; i++) {
+        if (desc->geoms[i].medium < -1 || (desc->geoms[i].medium >= 0 && (uint32_t)desc->geoms[i].medium >= desc->n_media)) {
+            return fail(PATHED_E_INVALID, "geom medium index out of range");
+        }
     }
     return PATHED_OK;
 }
@@ -446,6 +458,22 @@ void launchShade(PathedScene *scene, const RenderParams &params, hipStream_t str
         hipLaunchKernelGGL((k_shade<true>), grid, block, 0, stream, params);
     } else {
         hipLaunchKernelGGL((k_shade<false>), grid, block, 0, stream, params);
+    }
+}
+
+template <int STACK>
+void launchVolumeStack(const RenderParams &params, dim3 grid, size_t lds, bool ldsMaterials, hipStream_t stream)
+{
+    if (ldsMaterials) { hipLaunchKernelGGL((k_path_volume<true, STACK>), grid, dim3(kBlock), lds, stream, params); }
+    else { hipLaunchKernelGGL((k_path_volume<false, STACK>), grid, dim3(kBlock), lds, stream, params); }
+}
+
+void launchVolume(int stackRows, const RenderParams &params, dim3 grid, size_t lds, bool ldsMaterials, hipStream_t stream)
+{
+    switch (stackRows) {
+    case 8: launchVolumeStack<8>(params, grid, lds, ldsMaterials, stream); break;
+    case 16: launchVolumeStack<16>(params, grid, lds, ldsMaterials, stream); break;
+    default: launchVolumeStack<22>(params, grid, lds, ldsMaterials, stream); break;
     }
 }
 
@@ -971,6 +999,26 @@ int pathed_hip_scene_create_ex(const PathedSceneDesc *desc, const PathedSceneOpt
     if ((status = scene->spheres.upload(spheres)) != hipSuccess) { return fail_cleanup(status, "upload spheres"); }
     if ((status = scene->materials.upload(materials)) != hipSuccess) { return fail_cleanup(status, "upload materials"); }
     if ((status = scene->lights.upload(lights)) != hipSuccess) { return fail_cleanup(status, "upload lights"); }
+    {
+        // participating media and every primitive's internal medium (Surface::getInternalMedium), triangles then spheres
+        std::vector<DMedium> media(desc->n_media);
+        for (uint32_t i = 0; i < desc->n_media; i++) {
+            std::memset(&media[i], 0, sizeof(DMedium));
+            for (int k = 0; k < 3; k++) { media[i].sigmaT[k] = desc->media[i].sigma_t[k]; media[i].sigmaS[k] = desc->media[i].sigma_s[k]; }
+        }
+        std::vector<int> primMedium((size_t)desc->n_triangles + desc->n_spheres, -1);
+        for (uint32_t g = 0; g < desc->n_geoms; g++) {
+            const PathedGeom &geom = desc->geoms[g];
+            if (geom.type == PATHED_GEOM_MESH) {
+                for (int i = 0; i < geom.count; i++) { primMedium[(size_t)(geom.first + i)] = geom.medium; }
+            } else {
+                primMedium[(size_t)desc->n_triangles + (size_t)geom.first] = geom.medium;
+            }
+        }
+        for (uint32_t i = 0; i < desc->n_materials; i++) { scene->hasContainers = scene->hasContainers || desc->materials[i].type == PATHED_MAT_PASSTHROUGH; }
+        if ((status = scene->media.upload(media)) != hipSuccess) { return fail_cleanup(status, "upload media"); }
+        if ((status = scene->primMedium.upload(primMedium)) != hipSuccess) { return fail_cleanup(status, "upload media"); }
+    }
     if ((status = scene->envRgba.upload(envRgba)) != hipSuccess) { return fail_cleanup(status, "upload env map"); }
     if ((status = scene->thetaCdf.upload(thetaCdf)) != hipSuccess) { return fail_cleanup(status, "upload env cdf"); }
     if ((status = scene->phiCdf.upload(phiCdf)) != hipSuccess) { return fail_cleanup(status, "upload env cdf"); }
@@ -990,6 +1038,9 @@ int pathed_hip_scene_create_ex(const PathedSceneDesc *desc, const PathedSceneOpt
     d.nMaterials = (int)desc->n_materials;
     d.lights = scene->lights.ptr;
     d.nLights = (int)lights.size();
+    d.media = scene->media.ptr;
+    d.primMedium = scene->primMedium.ptr;
+    d.nMedia = (int)desc->n_media;
     d.env.rgba = scene->envRgba.ptr;
     d.env.thetaCdf = scene->thetaCdf.ptr;
     d.env.phiCdf = scene->phiCdf.ptr;
@@ -1138,6 +1189,86 @@ static int renderPassFused(PathedScene *scene, uint64_t seed, uint32_t begin, ui
     scene->traceLaunchesAll++;
     const dim3 pixelGrid((unsigned)((nPixels + kBlock - 1) / kBlock));
     hipLaunchKernelGGL(k_resolve, pixelGrid, block, 0, stream, params);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(stream));
+
+    scene->iterations += 1;
+    scene->cameraSamples += (unsigned long long)count * (unsigned long long)nPixels;
+    return PATHED_OK;
+}
+
+// One internal pass of the volume integrator (k_path_volume): like renderPassFused, one persistent launch.
+static int renderPassVolume(PathedScene *scene, uint64_t seed, uint32_t begin, uint32_t count,
+                            int start_bounce, int last_bounce, float *d_accum, hipStream_t stream)
+{
+    const int nPixels = scene->width * scene->height;
+    const int chunk = scene->samplesPerUnit;
+    const int chunksPerPixel = (int)((count + (uint32_t)chunk - 1) / (uint32_t)chunk);
+    const unsigned long long nUnits64 = (unsigned long long)nPixels * (unsigned long long)chunksPerPixel;
+    if (nUnits64 >= 0xFFFFFFF0ull) { return fail(PATHED_E_INVALID, "too many work units in one pass"); }
+    const unsigned int nUnits = (unsigned int)nUnits64;
+
+    if (scene->chunkCapacity < (size_t)nUnits) {
+        HIP_TRY(scene->chunkBuf.allocate((size_t)nUnits));
+        scene->chunkCapacity = (size_t)nUnits;
+    }
+    if (!scene->counters.ptr) { HIP_TRY(scene->counters.allocate(kMaxPools * kCtrCount)); }
+    if (!scene->stats.ptr) {
+        HIP_TRY(scene->stats.allocate(kStatCount));
+        HIP_TRY(hipMemset(scene->stats.ptr, 0, kStatCount * sizeof(unsigned long long)));
+    }
+
+    const bool ldsMaterials = scene->device.nMaterials <= kMaxLdsMaterials;
+    const size_t lds = (size_t)(scene->stackRows + 1) * kBlock * sizeof(int) + (ldsMaterials ? (size_t)scene->device.nMaterials * sizeof(DMaterial) : 0);
+    unsigned long long blocks = (unsigned long long)scene->computeUnits * 2;   // the kernel's registers keep two blocks per CU resident
+    const unsigned long long blocksNeeded = (nUnits64 + (unsigned long long)kBlock - 1) / kBlock;
+    if (blocks > blocksNeeded) { blocks = blocksNeeded; }
+    if (blocks < 1) { blocks = 1; }
+    const unsigned int waves = (unsigned int)blocks * kWavesPerBlock;
+    const size_t overflowRows = (size_t)(scene->maxStack > scene->stackRows ? scene->maxStack - scene->stackRows : 0);
+    const size_t overflowInts = (size_t)blocks * kBlock * (overflowRows ? overflowRows : 1);
+    if (scene->volumeOverflow.count < overflowInts) { HIP_TRY(scene->volumeOverflow.allocate(overflowInts)); }
+
+    RenderParams params;
+    std::memset(&params, 0, sizeof params);
+    params.scene = scene->device;
+    params.state.chunkBuf = scene->chunkBuf.ptr;
+    params.counters = scene->counters.ptr;
+    params.stats = scene->stats.ptr;
+    params.stackOverflow = scene->volumeOverflow.ptr;
+    params.maxStack = scene->maxStack;
+    params.accum = d_accum;
+    params.nPixels = nPixels;
+    params.nUnits = nUnits;
+    params.unitBase = 0;
+    params.nQueues = (int)(waves < (unsigned int)kUnitQueues ? waves : (unsigned int)kUnitQueues);
+    params.unitsPerQueue = (nUnits + (unsigned int)params.nQueues - 1) / (unsigned int)params.nQueues;
+    {
+        const unsigned int wavesPerQueue = (waves + (unsigned int)params.nQueues - 1) / (unsigned int)params.nQueues;
+        unsigned int grab = params.unitsPerQueue / (wavesPerQueue * 4u);
+        params.unitGrab = (int)(grab < 1u ? 1u : grab > 64u ? 64u : grab);
+    }
+    params.chunk = chunk;
+    params.chunksPerPixel = chunksPerPixel;
+    params.seedLo = (uint32_t)seed;
+    params.seedHi = (uint32_t)(seed >> 32);
+    params.sppBegin = begin;
+    params.sppEnd = begin + count;
+    params.startBounce = start_bounce;
+    params.lastBounce = last_bounce;
+
+    HIP_TRY(hipMemsetAsync(params.counters, 0, kCtrCount * sizeof(unsigned int), stream));
+    const dim3 grid((unsigned)blocks);
+    int timed = -1;
+    if (scene->timeKernels) {
+        timed = scene->traceEvents.acquire();
+        (void)hipEventRecord(scene->traceEvents.start[timed], stream);
+    }
+    launchVolume(scene->stackRows, params, grid, lds, ldsMaterials, stream);
+    if (timed >= 0) { (void)hipEventRecord(scene->traceEvents.stop[timed], stream); }
+    scene->traceLaunchesAll++;
+    const dim3 pixelGrid((unsigned)((nPixels + kBlock - 1) / kBlock));
+    hipLaunchKernelGGL(k_resolve, pixelGrid, dim3(kBlock), 0, stream, params);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(stream));
 
@@ -1349,6 +1480,9 @@ int pathed_hip_render_device(PathedScene *scene, uint64_t seed,
     }
     if (spp_count == 0) { return PATHED_OK; }
     if ((uint64_t)spp_begin + spp_count > 0x7fffffffull) { return fail(PATHED_E_INVALID, "sample index overflow"); }
+    if (scene->hasContainers && scene->integrator != PATHED_INTEGRATOR_VOLUME_PATH_TRACER) {
+        return fail(PATHED_E_UNSUPPORTED, "the scene has passthrough (medium container) surfaces: select the VolumePathTracer integrator (pathed_hip_set_integrator)");
+    }
     SELECT_DEVICE(scene);
 
     if (scene->timeKernels) {
@@ -1372,9 +1506,11 @@ int pathed_hip_render_device(PathedScene *scene, uint64_t seed,
     uint32_t done = 0;
     while (done < spp_count) {
         const uint32_t count = (spp_count - done < perPass) ? (spp_count - done) : perPass;
-        const int code = scene->fusedPath
-            ? renderPassFused(scene, seed, spp_begin + done, count, start_bounce, last_bounce, d_accum_rgb_sum, stream)
-            : renderPass(scene, seed, spp_begin + done, count, start_bounce, last_bounce, d_accum_rgb_sum, stream);
+        const int code = scene->integrator == PATHED_INTEGRATOR_VOLUME_PATH_TRACER
+            ? renderPassVolume(scene, seed, spp_begin + done, count, start_bounce, last_bounce, d_accum_rgb_sum, stream)
+            : scene->fusedPath
+                ? renderPassFused(scene, seed, spp_begin + done, count, start_bounce, last_bounce, d_accum_rgb_sum, stream)
+                : renderPass(scene, seed, spp_begin + done, count, start_bounce, last_bounce, d_accum_rgb_sum, stream);
         if (code != PATHED_OK) { return code; }
         done += count;
     }
@@ -1382,6 +1518,16 @@ int pathed_hip_render_device(PathedScene *scene, uint64_t seed,
         scene->traceEvents.harvestAll();
         scene->shadeEvents.harvestAll();
     }
+    return PATHED_OK;
+}
+
+int pathed_hip_set_integrator(PathedScene *scene, int integrator)
+{
+    if (!scene) { return fail(PATHED_E_INVALID, "null scene"); }
+    if (integrator != PATHED_INTEGRATOR_PATH_TRACER && integrator != PATHED_INTEGRATOR_VOLUME_PATH_TRACER) {
+        return fail(PATHED_E_INVALID, "unknown integrator");
+    }
+    scene->integrator = integrator;
     return PATHED_OK;
 }
 
@@ -1514,7 +1660,7 @@ int pathed_hip_get_stats(PathedScene *scene, PathedStats *out)
     out->bvh_build_ms = scene->bvhBuildMs;
     out->bvh_builder = (uint32_t)scene->bvhBuilder;
     out->trace_launches_all = (uint32_t)scene->traceLaunchesAll;
-    out->path_kernel = scene->fusedPath ? 3u : (scene->stagedShade ? 2u : 1u);
+    out->path_kernel = scene->integrator == PATHED_INTEGRATOR_VOLUME_PATH_TRACER ? 4u : scene->fusedPath ? 3u : (scene->stagedShade ? 2u : 1u);
     if (getenv("PATHED_SHADE_PROFILE")) {   // counters exist in -DPATHED_SHADE_PROFILE builds only
         static const char *regions[11] = { "all waves", "active slots", "makeIsect (hit)", "camera-ray vertex", "finish previous MIS term",
                                            "new vertex: BSDF sample", "light sampling", "sample finished", "startSample (regeneration)", "shadow ray pushed",

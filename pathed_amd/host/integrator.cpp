@@ -287,6 +287,9 @@ int Integrator::loadState(std::vector<float> &sums, int width, int height) const
 
 void HipPathTracer::sampleImage(float *deviceSums, Scene &scene, size_t replica, unsigned begin, unsigned count)
 {
+    if (pathed_hip_set_integrator(scene.handle(replica), m_integrator) != PATHED_OK) {
+        throw std::runtime_error(std::string("pathed_hip_set_integrator: ") + pathed_hip_last_error());
+    }
     const int code = pathed_hip_render_device(
         scene.handle(replica), m_seed, begin, count,
         m_bounceController.startBounce(), m_bounceController.lastBounce(),

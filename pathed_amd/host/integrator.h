@@ -116,8 +116,10 @@ protected:
 
 class HipPathTracer : public Integrator {
 public:
-    explicit HipPathTracer(BounceController bounceController)
-        : m_bounceController(bounceController)
+    // integrator: PATHED_INTEGRATOR_PATH_TRACER (reference PathTracer) or PATHED_INTEGRATOR_VOLUME_PATH_TRACER
+    // (reference VolumePathTracer, src/volume_path_tracer.cpp: participating media)
+    explicit HipPathTracer(BounceController bounceController, int integrator = PATHED_INTEGRATOR_PATH_TRACER)
+        : m_bounceController(bounceController), m_integrator(integrator)
     {}
 
 protected:
@@ -127,6 +129,7 @@ protected:
 
 private:
     BounceController m_bounceController;
+    int m_integrator;
 };
 
 }  // namespace pathed

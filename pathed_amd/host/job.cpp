@@ -56,6 +56,9 @@ std::shared_ptr<Integrator> Job::integrator() const
     const std::string name = integratorName();
     if (name == "PathTracer") {
         return std::make_shared<HipPathTracer>(m_bounceController);
+    } else if (name == "VolumePathTracer") {
+        // src/job.cpp:71-72: participating media behind passthrough containers
+        return std::make_shared<HipPathTracer>(m_bounceController, PATHED_INTEGRATOR_VOLUME_PATH_TRACER);
     } else if (name == "DataParallelIntegrator") {
         // the reference's stage-wise integrator needs its external sampler server; its
         // wavefront STRUCTURE is what HipPathTracer implements

@@ -24,6 +24,7 @@ struct LoaderContext {
     FlatScene *scene;
     std::string assetRoot;
     MaterialMap materialLookup;
+    std::map<std::string, int> mediumLookup;   // scene JSON "media" by name -> index into FlatScene::media
 
     std::string resolve(const std::string &filename) const
     {
@@ -226,6 +227,9 @@ int parseMaterial(const Json &json, LoaderContext &context)
         return found->second;
     } else if (type == "mirror") {
         return context.addMaterial(blankMaterial(PATHED_MAT_MIRROR));
+    } else if (type == "passthrough") {
+        // the boundary of a participating medium, scene_parser.cpp:593-594
+        return context.addMaterial(blankMaterial(PATHED_MAT_PASSTHROUGH));
     } else if (type == "glass") {
         PathedMaterial material = blankMaterial(PATHED_MAT_GLASS);
         float ior;
@@ -288,7 +292,7 @@ struct MeshBuffers {
     std::vector<int32_t> faceMaterial;
 };
 
-void appendMesh(FlatScene &scene, const MeshBuffers &mesh)
+void appendMesh(FlatScene &scene, const MeshBuffers &mesh, int medium)
 {
     const uint32_t vertexBase = (uint32_t)(scene.positions.size() / 3);
     const size_t vertexCount = mesh.positions.size() / 3;
@@ -311,6 +315,7 @@ void appendMesh(FlatScene &scene, const MeshBuffers &mesh)
     geom.type = PATHED_GEOM_MESH;
     geom.first = (int32_t)(scene.indices.size() / 3);
     geom.count = (int32_t)(mesh.indices.size() / 3);
+    geom.medium = medium;
     scene.geoms.push_back(geom);
 
     for (uint32_t index : mesh.indices) { scene.indices.push_back(vertexBase + index); }
@@ -768,8 +773,11 @@ void parseModels(const Json &models, LoaderContext &context)
         if (parseBool(model["skip"], false)) { continue; }
         const std::string type = model["type"].isString() ? model["type"].asString() : "";
 
+        // "internal_medium": scene_parser.cpp:324-337, 370-379, 503-514; an unknown name is a null medium there
+        int medium = -1;
         if (model["internal_medium"].isString()) {
-            throw SceneLoadError("Unsupported: participating media are outside the hot-path scope (SURVEY.md §2 #12)");
+            auto found = context.mediumLookup.find(model["internal_medium"].asString());
+            if (found != context.mediumLookup.end()) { medium = found->second; }
         }
 
         if (type == "obj") {
@@ -777,7 +785,7 @@ void parseModels(const Json &models, LoaderContext &context)
             const int material = parseMaterial(model["bsdf"], context);
             const std::string prefix = model["materialPrefix"].isString() ? model["materialPrefix"].asString() : "";
             ObjReader reader(context, transform, prefix, material);
-            appendMesh(scene, reader.parse(context.resolve(model["filename"].asString())));
+            appendMesh(scene, reader.parse(context.resolve(model["filename"].asString())), medium);
         } else if (type == "ply") {
             const Transform transform = parseTransform(model["transform"]);
             int material = parseMaterial(model["bsdf"], context);
@@ -786,7 +794,7 @@ void parseModels(const Json &models, LoaderContext &context)
                 const float green[3] = { 0.f, 1.f, 0.f };
                 material = context.addMaterial(makeLambertian(green, kBlack));
             }
-            appendMesh(scene, parsePly(context.resolve(model["filename"].asString()), transform, material));
+            appendMesh(scene, parsePly(context.resolve(model["filename"].asString()), transform, material), medium);
         } else if (type == "quad") {
             const Transform transform = parseTransform(model["transform"]);
             const int material = requireMaterial(parseMaterial(model["bsdf"], context), "quad");
@@ -797,7 +805,7 @@ void parseModels(const Json &models, LoaderContext &context)
                 else if (axis == "y") { zUp = false; }
                 else { throw SceneLoadError("Unsupported axis: " + axis); }
             }
-            appendMesh(scene, makeQuad(transform, material, zUp));
+            appendMesh(scene, makeQuad(transform, material, zUp), -1);
         } else if (type == "sphere") {
             PathedSphere sphere;
             sphere.material = requireMaterial(parseMaterial(model["bsdf"], context), "sphere");
@@ -810,6 +818,7 @@ void parseModels(const Json &models, LoaderContext &context)
             geom.type = PATHED_GEOM_SPHERE;
             geom.first = (int32_t)scene.spheres.size();
             geom.count = 1;
+            geom.medium = medium;
             scene.geoms.push_back(geom);
             scene.spheres.push_back(sphere);
         } else if (type == "instance" || type == "instanced" || type == "pbrt-curve" || type == "b-spline") {
@@ -858,6 +867,8 @@ PathedSceneDesc FlatScene::desc() const
     for (size_t t = 0; t < textures.size(); t++) { const_cast<FlatScene *>(this)->textures[t].rgb = textureData[t].data(); }
     d.n_textures = (uint32_t)textures.size();
     d.textures = textures.data();
+    d.n_media = (uint32_t)media.size();
+    d.media = media.data();
     return d;
 }
 
@@ -900,9 +911,19 @@ FlatScene loadScene(
         }
     }
 
+    // media: scene_parser.cpp:202-229 (homogeneous only; voxel grids are outside the scope)
     const Json &media = json["media"];
-    if (media.isArray() && media.size() > 0) {
-        throw SceneLoadError("Unsupported: participating media are outside the hot-path scope (SURVEY.md §2 #12)");
+    if (media.isArray()) {
+        for (const Json &mediumJson : media.elements()) {
+            const std::string kind = mediumJson["type"].isString() ? mediumJson["type"].asString() : "";
+            if (kind == "heterogeneous") { throw SceneLoadError("Unsupported: heterogeneous (voxel) media are outside the hot-path scope (SURVEY.md §2)"); }
+            if (kind != "homogeneous") { continue; }   // the reference ignores unknown kinds
+            PathedMedium medium;
+            parseColor(mediumJson["sigma_t"], kBlack, medium.sigma_t);
+            parseColor(mediumJson["sigma_s"], kBlack, medium.sigma_s);
+            context.mediumLookup[mediumJson["name"].asString()] = (int)scene.media.size();
+            scene.media.push_back(medium);
+        }
     }
 
     parseModels(json["models"], context);

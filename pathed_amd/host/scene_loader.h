@@ -34,6 +34,7 @@ struct FlatScene {
     std::vector<PathedSphere> spheres;
     std::vector<PathedGeom> geoms;
     std::vector<PathedMaterial> materials;
+    std::vector<PathedMedium> media;
 
     bool hasEnv = false;
     PathedEnvLight env;

@@ -129,6 +129,12 @@ class HipScene:
         _check(self._lib, self._lib.pathed_hip_set_samples_per_unit(self._handle, int(samples)),
                "pathed_hip_set_samples_per_unit")
 
+    def set_integrator(self, name):
+        """"PathTracer" (default) or "VolumePathTracer" (reference src/job.cpp:65-97)."""
+        code = {"PathTracer": _capi.INTEGRATOR_PATH_TRACER, "DataParallelIntegrator": _capi.INTEGRATOR_PATH_TRACER,
+                "VolumePathTracer": _capi.INTEGRATOR_VOLUME_PATH_TRACER}[name]
+        _check(self._lib, self._lib.pathed_hip_set_integrator(self._handle, code), "pathed_hip_set_integrator")
+
     def set_stats_mode(self, count=False, time_kernels=False, time_sampled=False):
         """time_kernels: HIP events around every launch; time_sampled: around every 8th (cheaper, same averages)."""
         mode = (1 if count else 0) | (2 if time_kernels else 0) | (4 if time_sampled else 0)
@@ -215,7 +221,8 @@ class PathTracer:
 def integrator_from_job(job, **kwargs):
     """reference Job::integrator(), src/job.cpp:65-97 — only the hot-path integrator exists here."""
     name = job["integrator"]
-    if name in ("PathTracer", "DataParallelIntegrator"):
+    if name in ("PathTracer", "DataParallelIntegrator", "VolumePathTracer"):
+        # the caller selects the arithmetic on the scene: HipScene.set_integrator(name)
         return PathTracer(BounceController(job["startBounce"], job["lastBounce"]),
                           spp=job["spp"] if job["spp"] > 0 else 9999999, **kwargs)
     raise PathedError("Unimplemented")

@@ -50,7 +50,7 @@ def main(argv=None):
     spp = job["spp"] if job["spp"] > 0 else 9999999
     seed = int(job.get("seed", 1))
     bounces = BounceController(job["startBounce"], job["lastBounce"])
-    if job["integrator"] not in ("PathTracer", "DataParallelIntegrator"):
+    if job["integrator"] not in ("PathTracer", "DataParallelIntegrator", "VolumePathTracer"):
         raise SystemExit("Unimplemented")  # the reference throws "Unimplemented" (src/job.cpp:96)
     out_dir = job["output_directory"] + "/"
 
@@ -81,6 +81,7 @@ def main(argv=None):
 
     scene = LoadedScene(job["scene"], width, height, asset_root if asset_root is not None else job.get("asset_root"))
     gpu = HipScene(scene.desc, device=local_rank, bvh_builder=job.get("bvh_builder", "sah"))
+    gpu.set_integrator(job["integrator"])
     host = _capi.load_host()
     stream = torch.cuda.current_stream().cuda_stream
 

@@ -48,6 +48,8 @@ def load():
     lib.oracle_env_eval.restype = C.c_int
     lib.oracle_light_count.argtypes = [vp]
     lib.oracle_light_count.restype = C.c_int
+    lib.oracle_set_integrator.argtypes = [vp, C.c_int]
+    lib.oracle_set_integrator.restype = C.c_int
     _lib = lib
     return lib
 
@@ -114,6 +116,11 @@ class OracleScene:
         if n < 0:
             raise RuntimeError("oracle_env_eval(%s) -> %d" % (fn, n))
         return out[:n]
+
+    def set_integrator(self, name):
+        code = {"PathTracer": 0, "VolumePathTracer": 1}[name]
+        if self.lib.oracle_set_integrator(self.handle, code) != 0:
+            raise RuntimeError("oracle_set_integrator")
 
     def light_count(self):
         return self.lib.oracle_light_count(self.handle)

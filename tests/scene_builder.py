@@ -22,6 +22,7 @@ class BuiltScene:
         self.positions, self.normals, self.uvs = [], [], []
         self.indices, self.tri_material = [], []
         self.spheres, self.geoms, self.materials = [], [], []
+        self.media = []
         self.env = None
         self.textures = []
         self._keep = []
@@ -54,28 +55,47 @@ class BuiltScene:
         self.materials.append(m)
         return len(self.materials) - 1
 
-    def mesh(self, vertices, faces, material, normals=None, uvs=None):
+    def medium(self, sigma_t, sigma_s=(0.0, 0.0, 0.0)):
+        """homogeneous medium; returns its index (pass it as `medium=` to mesh / quad / sphere)"""
+        m = _capi.PathedMedium()
+        m.sigma_t[:] = sigma_t
+        m.sigma_s[:] = sigma_s
+        self.media.append(m)
+        return len(self.media) - 1
+
+    def mesh(self, vertices, faces, material, normals=None, uvs=None, medium=-1):
         base = len(self.positions)
         vertices = np.asarray(vertices, dtype=np.float32)
         self.positions.extend(vertices.tolist())
         self.normals.extend((np.zeros_like(vertices) if normals is None else np.asarray(normals, dtype=np.float32)).tolist())
         self.uvs.extend((np.zeros((len(vertices), 2)) if uvs is None else np.asarray(uvs, dtype=np.float32)).tolist())
-        geom = _capi.PathedGeom(_capi.GEOM_MESH, len(self.indices), len(faces))
+        geom = _capi.PathedGeom(_capi.GEOM_MESH, len(self.indices), len(faces), medium)
         for face in faces:
             self.indices.append([base + int(i) for i in face])
             self.tri_material.append(material)
         self.geoms.append(geom)
 
-    def quad(self, corners, material):
-        self.mesh(corners, [(0, 1, 2), (0, 2, 3)], material, uvs=[(0, 0), (1, 0), (1, 1), (0, 1)])
+    def quad(self, corners, material, medium=-1):
+        self.mesh(corners, [(0, 1, 2), (0, 2, 3)], material, uvs=[(0, 0), (1, 0), (1, 1), (0, 1)], medium=medium)
 
-    def sphere(self, center, radius, material):
+    def box(self, lo, hi, material, medium=-1):
+        """axis-aligned closed box, outward normals (counter-clockwise seen from outside)"""
+        x0, y0, z0 = lo
+        x1, y1, z1 = hi
+        v = [(x0, y0, z0), (x1, y0, z0), (x1, y1, z0), (x0, y1, z0), (x0, y0, z1), (x1, y0, z1), (x1, y1, z1), (x0, y1, z1)]
+        quads = [(0, 3, 2, 1), (4, 5, 6, 7), (0, 1, 5, 4), (3, 7, 6, 2), (0, 4, 7, 3), (1, 2, 6, 5)]
+        faces = []
+        for a, b, c, d in quads:
+            faces += [(a, b, c), (a, c, d)]
+        self.mesh(v, faces, material, medium=medium)
+
+    def sphere(self, center, radius, material, medium=-1):
         s = _capi.PathedSphere()
         s.center_world[:] = center
         s.center_sample[:] = center
         s.radius = radius
         s.material = material
-        self.geoms.append(_capi.PathedGeom(_capi.GEOM_SPHERE, len(self.spheres), 1))
+        self.geoms.append(_capi.PathedGeom(_capi.GEOM_SPHERE, len(self.spheres), 1, medium))
         self.spheres.append(s)
 
     def environment(self, rgba, scale=1.0):
@@ -119,4 +139,7 @@ class BuiltScene:
         texture_array = (_capi.PathedTexture * max(1, len(self.textures)))(*self.textures)
         self._keep.append(texture_array)
         d.n_textures, d.textures = len(self.textures), texture_array
+        media_array = (_capi.PathedMedium * max(1, len(self.media)))(*self.media)
+        self._keep.append(media_array)
+        d.n_media, d.media = len(self.media), media_array
         return C.pointer(d)
