@@ -61,6 +61,11 @@ struct DEnv {
     // sample xi is bracketed by two table reads instead of a log2(size)-deep chain of dependent loads
     const int *thetaGuide;     // height + 1
     const int *phiGuide;       // height * (width + 1), row-major
+    // sampling records, one per guide cell (2 x float4): (first candidate lo, last candidate hi, cdf[lo-1], cdf[lo]) (cdf[lo+1],
+    // cdf[lo+2], -, -): ONE 32-byte load resolves a sample that lands on lo .. lo+2 (the usual case) with its pdf;
+    // lo = -1 marks an empty distribution.  Same index and pdf as the searches over cdf / guide, which stay as the fallback.
+    const float4 *thetaRecords;  // 2 * (height + 1)
+    const float4 *phiRecords;    // 2 * height * (width + 1), row-major
     int thetaEmpty;
     float scale;
     float mapToWorld[9];       // 3x3 part, row-major (the reference applies it to directions only)

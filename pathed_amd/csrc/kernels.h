@@ -779,7 +779,11 @@ __device__ inline TriShade loadTriCorners(const DScene &scene, int prim)
 __device__ inline Isect makeIsect(const DScene &scene, V3 o, V3 d, float4 h)
 {
     const float t = h.x, u = h.y, v = h.z;
+#if defined(PATHED_ABLATE) && PATHED_ABLATE == 1
+    const int prim = floatAsInt(h.w) & 1023;   // profiling build: shading records from a cache-resident corner of the table
+#else
     const int prim = floatAsInt(h.w);
+#endif
 
     V3 geometricNormal;
     V3 shadingNormal = v3(0.f, 0.f, 0.f);
@@ -840,6 +844,9 @@ __device__ inline float lightsPDF(const DScene &scene, V3 referencePoint, const 
 // Scene::environmentL, src/scene.cpp:486-492
 __device__ inline Rgb environmentL(const DScene &scene, V3 direction)
 {
+#if defined(PATHED_ABLATE) && PATHED_ABLATE == 3
+    return rgb(0.f);   // profiling build: no environment lookups on misses
+#endif
     if (scene.hasEnv) { return envEmit(scene.env, -direction); }
     return rgb(0.f);
 }
@@ -858,6 +865,9 @@ __device__ inline Rgb sampleLightsTerm(
     const Isect &isect, const DMaterial &material, Rng &random, ShadowRequest *shadow
 ) {
     shadow->push = false;
+#if defined(PATHED_ABLATE) && PATHED_ABLATE == 2
+    return rgb(0.f);   // profiling build: no light sampling, no shadow rays
+#endif
     if (isDelta(material)) { return rgb(0.f); }
     if (scene.nLights == 0) { return rgb(0.f); }
 

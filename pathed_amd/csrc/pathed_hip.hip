@@ -153,6 +153,7 @@ struct PathedScene {
     DeviceBuffer<DLight> lights;
     DeviceBuffer<float> thetaCdf, phiCdf;
     DeviceBuffer<int> phiEmpty, thetaGuide, phiGuide;
+    DeviceBuffer<float4> thetaRecords, phiRecords;
     DeviceBuffer<DMedium> media;
     DeviceBuffer<int> primMedium;
     DeviceBuffer<int> volumeOverflow;   // the volume kernel's traversal-stack spill, per thread
@@ -207,6 +208,7 @@ struct PathedScene {
         spheres.release(); materials.release(); lights.release();
         thetaCdf.release(); phiCdf.release(); phiEmpty.release(); thetaGuide.release(); phiGuide.release();
         media.release(); primMedium.release(); volumeOverflow.release();
+        thetaRecords.release(); phiRecords.release();
         rayO.release(); rayD.release(); hit.release(); mod.release(); thr.release();
         res.release(); pend.release(); acc.release(); shO.release(); shD.release(); chunkBuf.release();
         counters.release(); stats.release();
@@ -860,6 +862,7 @@ int pathed_hip_scene_create_ex(const PathedSceneDesc *desc, const PathedSceneOpt
     std::vector<float4> envRgba;
     std::vector<float> thetaCdf, phiCdf;
     std::vector<int> phiEmpty, thetaGuide, phiGuide;
+    std::vector<float4> thetaRecords, phiRecords;
     if (desc->env) {
         const PathedEnvLight &env = *desc->env;
         const size_t texels = (size_t)env.width * env.height;
@@ -896,6 +899,29 @@ int pathed_hip_scene_create_ex(const PathedSceneDesc *desc, const PathedSceneOpt
         phiGuide.resize((size_t)env.height * ((size_t)env.width + 1));
         for (int row = 0; row < env.height; row++) {
             buildGuide(&phiCdf[(size_t)row * env.width], (size_t)env.width, &phiGuide[(size_t)row * (env.width + 1)]);
+        }
+        // sampling records (device_scene.h): for the guide cell `bucket` the search window of cdfSample is
+        // [guide[bucket - 1], guide[bucket + 2]]; the record carries its start, its end and the CDF around the start
+        auto buildRecords = [](const float *cdf, const int *guide, size_t size, bool empty, float4 *records) {
+            for (size_t bucket = 0; bucket <= size; bucket++) {
+                const size_t below = bucket == 0 ? 0 : bucket - 1;
+                const size_t above = bucket + 2 > size ? size : bucket + 2;
+                const int lo = guide[below], hi = guide[above];
+                auto at = [&](int index) { return cdf[(size_t)(index < 0 ? 0 : (index > (int)size - 1 ? (int)size - 1 : index))]; };
+                int loBits = empty ? -1 : lo;
+                float loAsFloat, hiAsFloat;
+                std::memcpy(&loAsFloat, &loBits, 4);
+                std::memcpy(&hiAsFloat, &hi, 4);
+                records[2 * bucket + 0] = make_float4(loAsFloat, hiAsFloat, lo > 0 ? at(lo - 1) : 0.f, at(lo));
+                records[2 * bucket + 1] = make_float4(at(lo + 1), at(lo + 2), 0.f, 0.f);
+            }
+        };
+        thetaRecords.resize(2 * ((size_t)env.height + 1));
+        buildRecords(thetaCdf.data(), thetaGuide.data(), (size_t)env.height, d.env.thetaEmpty != 0, thetaRecords.data());
+        phiRecords.resize(2 * (size_t)env.height * ((size_t)env.width + 1));
+        for (int row = 0; row < env.height; row++) {
+            buildRecords(&phiCdf[(size_t)row * env.width], &phiGuide[(size_t)row * (env.width + 1)], (size_t)env.width,
+                         phiEmpty[(size_t)row] != 0, &phiRecords[2 * (size_t)row * ((size_t)env.width + 1)]);
         }
         d.env.width = env.width;
         d.env.height = env.height;
@@ -1025,6 +1051,8 @@ int pathed_hip_scene_create_ex(const PathedSceneDesc *desc, const PathedSceneOpt
     if ((status = scene->phiEmpty.upload(phiEmpty)) != hipSuccess) { return fail_cleanup(status, "upload env cdf"); }
     if ((status = scene->thetaGuide.upload(thetaGuide)) != hipSuccess) { return fail_cleanup(status, "upload env cdf"); }
     if ((status = scene->phiGuide.upload(phiGuide)) != hipSuccess) { return fail_cleanup(status, "upload env cdf"); }
+    if ((status = scene->thetaRecords.upload(thetaRecords)) != hipSuccess) { return fail_cleanup(status, "upload env cdf"); }
+    if ((status = scene->phiRecords.upload(phiRecords)) != hipSuccess) { return fail_cleanup(status, "upload env cdf"); }
 
     d.nodes = scene->nodes.ptr;
     d.leafTris = scene->leafTris.ptr;
@@ -1047,6 +1075,8 @@ int pathed_hip_scene_create_ex(const PathedSceneDesc *desc, const PathedSceneOpt
     d.env.phiEmpty = scene->phiEmpty.ptr;
     d.env.thetaGuide = scene->thetaGuide.ptr;
     d.env.phiGuide = scene->phiGuide.ptr;
+    d.env.thetaRecords = scene->thetaRecords.ptr;
+    d.env.phiRecords = scene->phiRecords.ptr;
 
     if (options.pools > 0) { scene->pools = options.pools; }
     if (const char *poolCount = getenv("PATHED_POOLS")) {

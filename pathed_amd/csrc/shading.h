@@ -763,6 +763,30 @@ __device__ inline int cdfSample(const float *cdf, const int *guide, int size, in
     return lo;
 }
 
+// The same sample through the per-cell record (device_scene.h): one dependent load instead of guide -> search -> pdf.
+__device__ inline int cdfSampleRecord(const float4 *records, const float *cdf, int size, float xi, float *pdf)
+{
+    int bucket = (int)(xi * (float)size);
+    bucket = bucket < 0 ? 0 : (bucket > size ? size : bucket);
+    const float4 a = records[2 * bucket + 0];
+    const float4 b = records[2 * bucket + 1];
+    const int lo = floatAsInt(a.x);
+    if (lo < 0) { *pdf = 0.f; return 0; }   // empty distribution
+    if (xi <= a.w) { *pdf = (lo > 0) ? a.w - a.z : a.w; return lo; }
+    if (xi <= b.x) { *pdf = b.x - a.w; return lo + 1; }
+    if (xi <= b.y) { *pdf = b.y - b.x; return lo + 2; }
+    // rare: many entries inside the cell's window (a flat stretch of the CDF)
+    int first = lo + 3, last = floatAsInt(a.y);
+    if (first > last) { first = last; }
+    while (first < last) {
+        const int mid = (first + last) >> 1;
+        if (xi <= cdf[mid]) { last = mid; } else { first = mid + 1; }
+    }
+    if (!(xi <= cdf[first])) { *pdf = 0.f; return size - 1; }
+    *pdf = (first > 0) ? cdf[first] - cdf[first - 1] : cdf[first];
+    return first;
+}
+
 // Distribution::pdf, src/distribution.cpp:55-64
 __device__ inline float cdfPdf(const float *cdf, int empty, int index)
 {
@@ -792,10 +816,10 @@ __device__ inline Rgb envEmit(const DEnv &env, V3 lightWo)
 __device__ inline SurfaceSample envSample(const DEnv &env, V3 point, Rng &random)
 {
     float thetaPDF, phiPDF;
-    const int thetaStep = cdfSample(env.thetaCdf, env.thetaGuide, env.height, env.thetaEmpty, random.next(), &thetaPDF);
-    const int phiStep = cdfSample(
-        env.phiCdf + (size_t)thetaStep * env.width, env.phiGuide + (size_t)thetaStep * (env.width + 1), env.width,
-        env.phiEmpty[thetaStep], random.next(), &phiPDF);
+    const int thetaStep = cdfSampleRecord(env.thetaRecords, env.thetaCdf, env.height, random.next(), &thetaPDF);
+    const int phiStep = cdfSampleRecord(
+        env.phiRecords + (size_t)2 * thetaStep * (env.width + 1), env.phiCdf + (size_t)thetaStep * env.width, env.width,
+        random.next(), &phiPDF);
 
     const float phiCanonical = (phiStep + 0.5f) / env.width;
     const float thetaCanonical = (thetaStep + 0.5f) / env.height;
