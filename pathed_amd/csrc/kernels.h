@@ -41,6 +41,9 @@ static const int kRefillThreshold = PATHED_REFILL;  // refill a wave's idle lane
 #ifndef PATHED_LEAF_THRESHOLD
 #define PATHED_LEAF_THRESHOLD 24
 #endif
+#ifndef PATHED_WARM_LINES
+#define PATHED_WARM_LINES 0   // 1: k_trace touches the next leaf / stack entry one step early (trace.h: warmLine) -- measured 4-6 % SLOWER
+#endif
 static const int kLeafThreshold = PATHED_LEAF_THRESHOLD;  // lanes with a leaf pending that trigger a triangle phase
 
 // counters[] layout (unsigned int)
@@ -380,7 +383,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_T
                 if (active && ray.pendingLeaf != 0) { done = leafStep<COUNT, STACK, kBlock>(geometry, stack, ray, &counters); }
             } else {
                 if (active && ray.pendingLeaf == 0) {
-                    done = (geometry.nNodes == 0) || innerStep<COUNT, STACK, kBlock>(geometry, stack, p.maxStack, ray, &counters);
+                    done = (geometry.nNodes == 0) || innerStep<COUNT, STACK, kBlock, PATHED_WARM_LINES && !LDS_SCENE>(geometry, stack, p.maxStack, ray, &counters);
                 }
             }
             if (COUNT) {

@@ -211,11 +211,22 @@ __device__ inline bool popWork(const LaneStack &stack, LaneRay &ray)
     return false;
 }
 
+// Cache warming for the dependent fetch chain: a 4-byte load whose destination is the lane's dword of the stack's
+// scratch row in LDS (global_load_lds_dword: no VGPR result, nothing ever reads it), so the 128-byte line of a node
+// or the first line of a leaf is on its way to L2 / L1 while the lane still works on something else.
+template <int ROWS, int STRIDE>
+__device__ inline void warmLine(const LaneStack &stack, const float4 *address)
+{
+    int *waveRow = stack.lds + ROWS * STRIDE - (int)(threadIdx.x & 63u);   // wave-uniform: lane 0's scratch dword
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)address,
+                                     (__attribute__((address_space(3))) void *)waveRow, 4, 0, 0);
+}
+
 // Visit ONE inner node (lane must not have a leaf pending): four slab tests, the children that
 // are hit sorted leaves-first then near-to-far, the first becomes the lane's next piece of work,
 // the others are stacked far-to-near.  Returns true when the BVH part of the query is complete.
 // `maxStack` is the tree's bound on stack entries (3 per level).
-template <bool COUNT, int ROWS, int STRIDE>
+template <bool COUNT, int ROWS, int STRIDE, bool WARM = false>
 __device__ inline bool innerStep(
     const TraceGeometry &g, const LaneStack &stack, int maxStack, LaneRay &ray, TraceCounters *counters
 ) {
@@ -284,6 +295,16 @@ __device__ inline bool innerStep(
     }
     if (ref[0] >= 0) { ray.current = ref[0]; }
     else { ray.pendingLeaf = -ref[0] - 1; }
+    if (WARM) {
+        // the leaf this lane will test in the wave's next triangle phase, and the entry it will pop first
+        // (a sphere leaf, count 0, has no triangle record: those lanes touch the node they already hold)
+        const int leaf0 = -ref[0] - 1, leaf1 = -ref[1] - 1;
+        const float4 *nearLeaf = (ref[0] < 0 && (leaf0 & 7) != 0) ? g.tris + 3 * (leaf0 >> 3) : node;
+        const float4 *nextEntry = hits < 2 ? node
+            : (ref[1] >= 0 ? g.nodes + 8 * ref[1] : ((leaf1 & 7) != 0 ? g.tris + 3 * (leaf1 >> 3) : node));
+        warmLine<ROWS, STRIDE>(stack, nearLeaf);
+        warmLine<ROWS, STRIDE>(stack, nextEntry);
+    }
     return false;
 }
 

@@ -109,6 +109,32 @@ def test_volume_kernel_matches_the_oracle_with_media(sigma, env, sphere_light):
 
 
 @pytest.mark.gpu
+def test_reference_cornell_medium_scene_matches_the_oracle():
+    """scenes/cornell-medium.json is the reference's own VolumePathTracer scene (unmodified; its two OBJs are absent
+    upstream and generated by tools/make_assets.py): gas container, glass sphere inside, the Cornell room around it."""
+    import oracle_lib
+    from pathed_amd.integrator import HipScene
+    from pathed_amd.scene import LoadedScene
+    size, spp = 64, 16
+    scene = LoadedScene("scenes/cornell-medium.json", size, size)
+    desc = scene.desc.contents
+    assert desc.n_media == 1 and desc.n_spheres == 1 and desc.geoms[0].medium == 0
+    gpu = HipScene(scene.desc, device=0)
+    gpu.set_integrator("VolumePathTracer")
+    oracle = oracle_lib.OracleScene(scene.desc)
+    oracle.set_integrator("VolumePathTracer")
+    image = gpu.render(1, 0, spp, 0, 10)
+    expected, stats = oracle.render(size, size, 1, 0, spp, 0, 10, threads=os.cpu_count(), chunk=4)
+    rel = float(np.linalg.norm(image - expected) / np.linalg.norm(expected))
+    bad = float((np.abs(image - expected) > 1e-2 * np.maximum(np.abs(expected), 1e-3)).any(axis=2).mean())
+    assert rel <= 1e-2 and bad <= 5e-3, (rel, bad)
+    assert stats["dropped"] == 0 and gpu.stats()["dropped_samples"] == 0 and gpu.stats()["path_kernel"] == 4
+    # the gas glows under the light: the column below it is brighter than the room's far corners seen through the gas
+    mean = image / spp
+    assert mean[size // 2:, size // 2 - 4:size // 2 + 4].mean() > mean[: size // 4, : size // 4].mean()
+
+
+@pytest.mark.gpu
 def test_volume_job_through_the_host_executable(tmp_path):
     """job.json "integrator": "VolumePathTracer" + scene JSON "media" / "internal_medium" / "passthrough" (reference
     src/job.cpp:71-72, src/scene_parser.cpp:202-229, 324-337, 593-594) through the C++ host."""

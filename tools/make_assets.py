@@ -12,6 +12,9 @@ here is SYNTHETIC (labelled so in DESIGN.md); file formats are the reference's o
   assets/dragon.obj -> assets/dragon.ply is NOT used: scenes/dragon.json reads an OBJ, the
       large-BVH stand-in is scenes/dragon-standin.json + assets/dragon-standin.ply (--dragon N)
   assets/20060807_wells6_hd.exr                    procedural sky for scenes/dragon*.json
+  assets/cornell-volume-caustic/{bounds,CornellBox-Frame}.obj   for scenes/cornell-medium.json: the gas container (a box
+                                                   around the glass sphere, below the light) and the Cornell room
+                                                   without its two boxes (cut from scenes/CornellBox-Original.obj)
   test_scenes/1_pixel_test.exr                     1000x500, one texel (col 753,row 239)=1e4,
                                                    as decoded from the reference's file
 """
@@ -157,6 +160,28 @@ def make_env_test():
     write_exr(os.path.join(REPO_ROOT, "test_scenes", "1_pixel_test.exr"), rgba)
 
 
+def make_cornell_medium():
+    """scenes/cornell-medium.json (reference, unmodified) reads two OBJs the reference does not ship."""
+    root = os.path.join(REPO_ROOT, "assets", "cornell-volume-caustic")
+    os.makedirs(root, exist_ok=True)
+    lines = open(os.path.join(REPO_ROOT, "scenes", "CornellBox-Original.obj")).read().split("\n")
+    begin = next(i for i, line in enumerate(lines) if line.startswith("## Object shortBox"))
+    end = next(i for i, line in enumerate(lines) if line.startswith("## Object light"))
+    with open(os.path.join(root, "CornellBox-Frame.obj"), "w") as handle:
+        handle.write("# synthetic stand-in written by tools/make_assets.py: CornellBox-Original.obj without shortBox / tallBox\n")
+        handle.write("\n".join(lines[:begin] + lines[end:]))
+    lo, hi = (-0.9, 0.1, -0.9), (0.9, 1.9, 0.9)
+    corners = [(x, y, z) for x in (lo[0], hi[0]) for y in (lo[1], hi[1]) for z in (lo[2], hi[2])]
+    quads = [(0, 1, 3, 2), (4, 6, 7, 5), (0, 4, 5, 1), (2, 3, 7, 6), (0, 2, 6, 4), (1, 5, 7, 3)]
+    with open(os.path.join(root, "bounds.obj"), "w") as handle:
+        handle.write("# synthetic stand-in written by tools/make_assets.py: the gas container of scenes/cornell-medium.json\n")
+        for corner in corners:
+            handle.write("v %.6f %.6f %.6f\n" % corner)
+        handle.write("g bounds\n")
+        for quad in quads:
+            handle.write("f %d %d %d %d\n" % tuple(index + 1 for index in quad))
+
+
 def icosphere(subdivisions):
     t = (1.0 + math.sqrt(5.0)) / 2.0
     verts = [(-1, t, 0), (1, t, 0), (-1, -t, 0), (1, -t, 0), (0, -1, t), (0, 1, t), (0, -1, -t), (0, 1, -t),
@@ -215,11 +240,12 @@ def main():
     parser.add_argument("--force", action="store_true")
     args = parser.parse_args()
 
-    marker = os.path.join(REPO_ROOT, "assets", ".generated-v1")
+    marker = os.path.join(REPO_ROOT, "assets", ".generated-v2")
     if args.force or not os.path.exists(marker):
         make_mis()
         make_teapot()
         make_env_test()
+        make_cornell_medium()
         write_exr(os.path.join(REPO_ROOT, "assets", "20060807_wells6_hd.exr"), sky(256, 128, sun_dir=(0.3, 0.2, 0.8)))
         with open(marker, "w") as handle:
             handle.write("tools/make_assets.py\n")

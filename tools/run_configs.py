@@ -26,6 +26,8 @@ CONFIGS = [
     ("C3", "scenes/mis-pbrt.json", 1024, 1024, 256, 8, "plates/floor synthetic; plastic+Beckmann, sphere lights"),
     ("C4", "scenes/teapot.json", 1024, 1024, 256, 4, "mesh + env synthetic; glass, checkerboard, env light"),
     ("C5", "scenes/dragon-standin.json", 1920, 1080, 64, 2, "procedural mesh + env synthetic; plastic, env light"),
+    # not a BASELINE configuration: the reference's own participating-media scene under its VolumePathTracer
+    ("VOL", "scenes/cornell-medium.json", 1024, 1024, 64, 4, "container / frame OBJs synthetic; homogeneous gas, glass sphere", "VolumePathTracer"),
 ]
 
 
@@ -42,12 +44,13 @@ def main():
     parser.add_argument("--parity-full", type=int, default=0, metavar="SPP",
                         help="also compare GPU and CPU oracle at the configuration's FULL resolution with this many spp")
     args = parser.parse_args()
-    full_spp = {"C1": 16, "C2": 4096, "C3": 1024, "C4": 2048, "C5": 8192}
+    full_spp = {"C1": 16, "C2": 4096, "C3": 1024, "C4": 2048, "C5": 8192, "VOL": 1024}
     subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_assets.py"), "--dragon", str(args.dragon)], check=True,
                    stdout=subprocess.DEVNULL)
     cores = os.cpu_count()
     rows = []
-    for name, path, w, h, spp, cpu_spp, note in CONFIGS:
+    for name, path, w, h, spp, cpu_spp, note, *integrator in CONFIGS:
+        integrator = integrator[0] if integrator else "PathTracer"
         if args.only and name not in args.only.split(","):
             continue
         if args.full:
@@ -56,6 +59,7 @@ def main():
         t0 = time.perf_counter()
         gpu = HipScene(scene.desc, device=0, bvh_builder=args.builder)
         setup = time.perf_counter() - t0
+        gpu.set_integrator(integrator)
         accum = torch.zeros((h, w, 3), dtype=torch.float32, device="cuda")
         gpu.render_device(1, 0, min(spp, 16), 0, 10, accum.data_ptr())  # warm-up
         accum.zero_()
@@ -82,11 +86,12 @@ def main():
         rays = counted["closest_rays"] + counted["shadow_rays"]
         alg = 48 * counted["closest_rays"] + 36 * counted["shadow_rays"] + 32 * counted["nodes_visited"] + 48 * counted["tris_tested"]
         alg_total = alg * spp / count_spp
-        fused = counted["path_kernel"] == 3   # one kernel carries the whole path: there is no separate trace kernel to rate
+        fused = counted["path_kernel"] in (3, 4)   # one kernel carries the whole path: there is no separate trace kernel to rate
         gbs = alg_total / (timed["trace_ms"] * 1e-3) / 1e9 if timed["trace_ms"] and not fused else 0.0
 
         # CPU oracle rate at the same resolution
         oracle = oracle_lib.OracleScene(scene.desc)
+        oracle.set_integrator(integrator)
         t0 = time.perf_counter()
         oracle.render(w, h, 1, 0, cpu_spp, 0, 10, threads=cores)
         cpu_elapsed = time.perf_counter() - t0
@@ -95,6 +100,8 @@ def main():
         pw, ph = (96, 96) if w == h else (128, 72)
         small = LoadedScene(path, pw, ph)
         g2, o2 = HipScene(small.desc, device=0), oracle_lib.OracleScene(small.desc)
+        g2.set_integrator(integrator)
+        o2.set_integrator(integrator)
         image = g2.render(1, 0, 16, 0, 10)
         expected, _ = o2.render(pw, ph, 1, 0, 16, 0, 10, threads=cores, chunk=4)
         full_parity = None
@@ -109,7 +116,7 @@ def main():
                 "pixels_off_by_more_than_1_percent": round(float((difference > 1e-2 * np.maximum(np.abs(expected_full), 1e-3)).any(axis=2).mean()), 6),
             }
         rows.append({
-            "config": name, "scene": path, "res": "%dx%d" % (w, h), "spp": spp, "note": note,
+            "config": name, "scene": path, "integrator": integrator, "res": "%dx%d" % (w, h), "spp": spp, "note": note,
             "triangles": scene.n_triangles, "scene_create_s": round(setup, 2), "bvh_builder": args.builder,
             "bvh_build_ms": round(timed["bvh_build_ms"], 1), "render_s": round(elapsed, 3),
             "gpu_Msamples_s": round(w * h * spp / elapsed / 1e6, 1),
@@ -117,7 +124,7 @@ def main():
             "trace_Grays_s": round(rays * spp / count_spp / timed["trace_ms"] / 1e6, 2) if timed["trace_ms"] and not fused else None,
             "trace_algorithmic_GBs": round(gbs, 0) if not fused else None, "frac_of_8TBs": round(gbs / 8000.0, 3) if not fused else None,
             "intersector": ["BVH in HBM", "BVH in LDS", "all triangles (scalar loads)"][counted["scene_in_lds"]],
-            "path_kernel": ["", "wavefront: k_trace + k_shade", "wavefront: k_trace + k_shade_staged", "fused: k_path_small"][counted["path_kernel"]],
+            "path_kernel": ["", "wavefront: k_trace + k_shade", "wavefront: k_trace + k_shade_staged", "fused: k_path_small", "volume: k_path_volume"][counted["path_kernel"]],
             "cpu_oracle_Msamples_s": round(w * h * cpu_spp / cpu_elapsed / 1e6, 2), "cpu_cores": cores,
             "relL2_vs_oracle_%dx%d_16spp" % (pw, ph): "%.2e" % relative_l2(image, expected),
             "mean_rgb": [round(float(v), 4) for v in (accum / spp).mean(dim=(0, 1)).tolist()],
