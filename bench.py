@@ -217,7 +217,9 @@ def large_bvh_leg(args, torch, stream):
         subprocess.run([sys.executable, os.path.join(REPO_ROOT, "tools", "make_assets.py"), "--dragon", str(args.large_bvh_subdiv)],
                        check=True, stdout=subprocess.DEVNULL)
     width, height = 1920, 1080
-    count_spp, warm_spp, timed_spp = 16, 32, 256
+    # timed: one full internal pass (1024 spp at this resolution), as every pass of the 8192-spp configuration is --
+    # a shorter call pays the same ~20 ms drain of the last paths over fewer samples (64 spp: -18 %, 256 spp: -7 %)
+    count_spp, warm_spp, timed_spp = 16, 32, 1024
     t0 = time.perf_counter()
     scene = LoadedScene("scenes/dragon-standin.json", width, height)
     gpu = HipScene(scene.desc, device=torch.cuda.current_device(), bvh_builder=args.bvh_builder)
@@ -258,6 +260,27 @@ def large_bvh_leg(args, torch, stream):
         "image_mean_rgb": (accum / float(timed_spp)).mean(dim=(0, 1)).tolist(),
     }
     gpu.close()
+    # The two pools overlap k_trace with the other pool's k_shade, so the per-launch durations above are shares of a
+    # shared chip.  One pool: the launches alternate, HIP events around every launch time each kernel on its own.
+    alone = HipScene(scene.desc, device=torch.cuda.current_device(), bvh_builder=args.bvh_builder, pools=1)
+    alone.render_device(args.seed, 0, warm_spp, 0, args.last_bounce, accum.data_ptr(), stream)
+    alone.set_stats_mode(count=False, time_kernels=True)
+    alone.reset_stats()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    alone.render_device(args.seed, 2000, 256, 0, args.last_bounce, accum.data_ptr(), stream)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    serial = alone.stats()
+    if serial["trace_launches"]:   # one k_shade launch follows every k_trace launch
+        result["one_pool"] = {
+            "note": "PathedSceneOptions.pools = 1: no overlap, every launch timed with HIP events, 256 spp",
+            "msamples_per_s": width * height * 256 / elapsed / 1e6,
+            "k_trace_avg_launch_us": 1e3 * serial["trace_ms"] / serial["trace_launches"],
+            "k_shade_avg_launch_us": 1e3 * serial["shade_ms"] / serial["trace_launches"],
+            "k_trace_ms": serial["trace_ms"], "k_shade_ms": serial["shade_ms"], "launches": serial["trace_launches"],
+        }
+    alone.close()
     return result
 
 

@@ -107,7 +107,7 @@ protected:
     void saveState(const std::vector<float> &sums, int width, int height, int done) const;
     int loadState(std::vector<float> &sums, int width, int height) const;
 
-    int m_sppPerLaunch = 64;
+    int m_sppPerLaunch = 1024;
     bool m_resume = false;
     std::string m_statePath;
     std::string m_logPrefix;

@@ -189,7 +189,7 @@ class PathTracer:
     reference's PDFIntegrator also overrides run()).
     """
 
-    def __init__(self, bounce_controller, spp=1, seed=1, spp_per_launch=64):
+    def __init__(self, bounce_controller, spp=1, seed=1, spp_per_launch=1024):
         self.bounce_controller = bounce_controller
         self.spp = spp
         self.seed = seed

@@ -75,7 +75,7 @@ def main(argv=None):
             dist.destroy_process_group()
         return 1
 
-    spp_per_launch = int(job.get("spp_per_launch", 64))
+    spp_per_launch = int(job.get("spp_per_launch", 1024))
     if spp_per_launch < 1:
         raise SystemExit("spp_per_launch must be >= 1")
 

@@ -28,7 +28,11 @@ def digest():
 def totals(name):
     """{counter: {kernel: [launches, total]}} over the pathed:: kernels of one pass"""
     out = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
-    for path in glob.glob(os.path.join(base, name, "*", "*_counter_collection.csv")):
+    paths = glob.glob(os.path.join(base, name, "*", "*_counter_collection.csv"))
+    if len(paths) > 1:
+        # gpurun MERGES a call's files into gpurun_out/: an earlier collection's file (another pid) may still lie here
+        raise SystemExit("%s: %d counter files in one pass directory -- remove gpurun_out/pmcps_* before collecting again" % (name, len(paths)))
+    for path in paths:
         for row in csv.DictReader(open(path)):
             kernel = row["Kernel_Name"].split("(")[0]
             if "pathed::" not in kernel:
