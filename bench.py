@@ -280,6 +280,10 @@ def large_bvh_leg(args, torch, stream):
             "k_shade_avg_launch_us": 1e3 * serial["shade_ms"] / serial["trace_launches"],
             "k_trace_ms": serial["trace_ms"], "k_shade_ms": serial["shade_ms"], "launches": serial["trace_launches"],
         }
+        own = kernel_rates(counted, width * height * count_spp, serial, width * height * 256)
+        if own:   # the same algorithmic bytes against each kernel's own time
+            result["one_pool"]["k_trace"] = own["trace"]
+            result["one_pool"]["k_shade"] = own["shade"]
     alone.close()
     return result
 

@@ -311,9 +311,10 @@ int pathed_hip_set_integrator(PathedScene *scene, int integrator);
 
 /* Summation granularity.  A pixel's samples are summed in sample order in groups of
  * `samples` (a work unit); the group sums are then added to the pixel in group order.
- * The result is deterministic for a given value.  samples == 1 reproduces the reference's
- * order exactly (radianceLookup += one sample per wave, src/integrator.cpp:42-51) at lower
- * throughput; the default is 4.  Range [1, 128]. */
+ * The result is deterministic for a given value.  The default, samples == 1, reproduces the
+ * reference's order exactly (radianceLookup += one sample per wave, src/integrator.cpp:42-51);
+ * it is also the finest grain of the work queue (a render call drains its last UNITS).
+ * Larger groups write fewer partial sums (16 bytes per unit).  Range [1, 128]. */
 int pathed_hip_set_samples_per_unit(PathedScene *scene, int samples);
 
 /* Test hook onto the intersector that stands in for Embree.

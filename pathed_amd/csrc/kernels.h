@@ -1,12 +1,13 @@
 // The wavefront path-tracing kernels (gfx950).
 //
-// Work decomposition.  A UNIT is `chunk` consecutive samples of one pixel; unit u covers pixel
-// u % nPixels and samples sppBegin + (u / nPixels) * chunk + [0, chunk).  A pool of path SLOTS
-// pulls units dynamically (block-aggregated grab from one of kUnitQueues cursors), so lanes stay
-// busy whatever the per-pixel path length ("path regeneration").  A unit's samples are summed in
-// sample order into a partial sum; the partial is written to chunkBuf[u], and k_resolve adds a
-// pixel's partials to the radiance sum in chunk order.  The result is deterministic and does
-// not depend on scheduling; with chunk == 1 it is exactly the reference's order
+// Work decomposition.  A UNIT is `chunk` consecutive samples of one pixel (default 1): chunk c of
+// pixel x covers the samples sppBegin + c * chunk + [0, chunk); which unit id stands for which (c, x) is
+// THE UNIT ORDER below.  A pool of path SLOTS pulls units dynamically (block-aggregated grab from one of
+// kUnitQueues cursors, moving on to the other queues when its own is empty), so lanes stay busy whatever
+// the per-pixel path length ("path regeneration").  A unit's samples are summed in sample order into a
+// partial sum; the partial is written to chunkBuf[c * nPixels + x], and k_resolve adds a pixel's partials
+// to the radiance sum in chunk order.  The result is deterministic and does not depend on scheduling;
+// with chunk == 1 it is exactly the reference's order
 // (radianceLookup += one sample per wave, src/integrator.cpp:42-51, sample_integrator.cpp:61-63).
 //
 // Per iteration, two launches on one stream:
@@ -34,6 +35,28 @@ static_assert(kBlock == kVolumeBlock, "volume.h indexes the LDS stack rows with 
 static const int kWavesPerBlock = kBlock / 64;
 static const int kMaxLdsMaterials = 96;  // 96 x 96 B = 9 KiB of LDS
 static const int kUnitQueues = 32;       // sharded work-unit cursors
+static const unsigned int kUnitGroup = 256u;   // pixels of a group of the unit order: a 32 x 8 tile where the resolution allows
+
+// n / d for a launch-invariant d (Granlund & Montgomery 1994, figure 4.1; exact for every 32-bit n): the unit order
+// needs three such divisions per unit and hipcc's general 32-bit division is ~25 instructions.
+struct FastDiv {
+    unsigned int magic, shift1, shift2;
+};
+__host__ inline FastDiv makeFastDiv(unsigned int d)
+{
+    int l = 0;
+    while ((1ull << l) < (unsigned long long)d) { l++; }
+    FastDiv f;
+    f.magic = (unsigned int)(((1ull << 32) * ((1ull << l) - (unsigned long long)d)) / (unsigned long long)d + 1ull);
+    f.shift1 = l < 1 ? (unsigned int)l : 1u;
+    f.shift2 = l > 1 ? (unsigned int)(l - 1) : 0u;
+    return f;
+}
+__device__ inline unsigned int fastDivide(unsigned int n, FastDiv d)
+{
+    const unsigned int t = __umulhi(d.magic, n);
+    return (t + ((n - t) >> d.shift1)) >> d.shift2;
+}
 #ifndef PATHED_REFILL
 #define PATHED_REFILL 48
 #endif
@@ -117,7 +140,7 @@ struct PathState {
     float4 *acc;    // partial radiance sum of the unit in flight
     float4 *shO;    // shadow rays, one dense list per iteration: origin.xyz, tfar
     float4 *shD;    //                                             direction.xyz, bits(slot)
-    float4 *chunkBuf;                // nUnits partial sums, index = unit
+    float4 *chunkBuf;                // one partial sum per unit, index = chunk * nPixels + pixel (partialIndex)
 };
 
 struct RenderParams {
@@ -137,9 +160,16 @@ struct RenderParams {
     int nSlots;            // multiple of kBlock
     int nPixels;
     unsigned int nUnits;   // units of THIS pool
-    unsigned int unitBase; // global id of the pool's first unit (pixel / chunk derive from the global id)
+    // unit order (unitPlace): which pixel groups this pool's queues walk
+    int unitOrder;                     // kOrderStripes | kOrderStripesTiled | kOrderTiles
+    unsigned int pool, pools;          // queue q of pool h owns the chunks / pixel groups (q * pools + h) + j * (nQueues * pools), j = 0, 1, ..
+    unsigned int nGroups;              // what the queues share out: chunks per pixel (stripes) or ceil(nPixels / kUnitGroup) (tiles)
+    unsigned int lastGroupPixels;      // tiles: pixels of group nGroups - 1 (1 .. kUnitGroup)
+    unsigned int groupUnits;           // units of one owned item: nPixels (stripes) or kUnitGroup * chunksPerPixel (tiles)
+    FastDiv divStride, divGroupUnits, divBand;   // by unitsPerQueue, by groupUnits, by 8 * image width
+    unsigned int queueUnits[kUnitQueues];        // units each queue of this pool holds
     int nQueues;           // min(kUnitQueues, shade blocks): every queue has a consumer
-    unsigned int unitsPerQueue;
+    unsigned int unitsPerQueue;        // stride of the unit ids: unit = queue * unitsPerQueue + position in the queue
     int unitGrab;          // k_path_small: units a wave reserves per atomic
     int chunk;             // samples per unit
     int chunksPerPixel;
@@ -962,46 +992,123 @@ __device__ inline void startSample(const RenderParams &p, uint32_t pixel, uint32
     *rayD = make_float4(direction.x, direction.y, direction.z, intAsFloat(sampleInUnit << kStSampleShift));
 }
 
-// Block-aggregated grab of work units: returns this lane's unit (or nUnits-or-more = none).
-// One atomic per block on one of kUnitQueues cursors; queue q owns units [q*U_q, (q+1)*U_q).
+// Block-aggregated grab of work units: returns this lane's unit, or 0xFFFFFFFF when every queue is dealt out.
+// One atomic per block and queue tried.  A block starts at its home queue (blockIdx mod queues: the slots of a block then
+// work on one patch of the image, see THE UNIT ORDER) and moves on through the others once that is empty, so no unit
+// is left behind by a block whose own slots have all retired, and no slot idles while any queue still holds work.
 __device__ inline unsigned int grabUnits(const RenderParams &p, bool want, unsigned int *ldsScratch)
 {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const unsigned long long mask = __ballot(want);
-    const unsigned int before = (unsigned int)__popcll(mask & ((1ull << lane) - 1ull));
-    if (lane == 0) { ldsScratch[wave] = (unsigned int)__popcll(mask); }
-    __syncthreads();
-    unsigned int offset = 0, total = 0;
-    #pragma unroll
-    for (int w = 0; w < kWavesPerBlock; w++) {
-        const unsigned int count = ldsScratch[w];
-        if (w < wave) { offset += count; }
-        total += count;
+    const unsigned int queues = (unsigned int)p.nQueues;
+    const unsigned int home = blockIdx.x % queues;
+    unsigned int mine = 0xFFFFFFFFu;
+    for (unsigned int attempt = 0; attempt < queues; attempt++) {
+        const unsigned long long mask = __ballot(want);
+        const unsigned int before = (unsigned int)__popcll(mask & ((1ull << lane) - 1ull));
+        if (lane == 0) { ldsScratch[wave] = (unsigned int)__popcll(mask); }
+        __syncthreads();
+        unsigned int offset = 0, total = 0;
+        #pragma unroll
+        for (int w = 0; w < kWavesPerBlock; w++) {
+            const unsigned int count = ldsScratch[w];
+            if (w < wave) { offset += count; }
+            total += count;
+        }
+        if (total == 0u) { __syncthreads(); break; }   // nobody (left) wants a unit: block-uniform
+        const unsigned int queue = home + attempt < queues ? home + attempt : home + attempt - queues;
+        const unsigned int limit = p.queueUnits[queue];
+        if (threadIdx.x == 0) {
+            unsigned int *cursor = &p.counters[kCtrUnitCursor + queue * kCursorStride];
+            // a queue that is already dealt out costs a load, not an atomic (the drain of a pass asks every queue)
+            const unsigned int seen = __atomic_load_n(cursor, __ATOMIC_RELAXED);
+            ldsScratch[kWavesPerBlock] = seen < limit ? atomicAdd(cursor, total) : 0xFFFFFFFFu;
+        }
+        __syncthreads();
+        const unsigned int base = ldsScratch[kWavesPerBlock];
+        __syncthreads();  // scratch is reused by the next attempt and by the caller
+        if (base >= limit) { continue; }
+        if (want) {
+            const unsigned int k = base + offset + before;
+            if (k < limit) { mine = queue * p.unitsPerQueue + k; want = false; }
+        }
+        if (base + total <= limit) { break; }   // everybody was served
     }
-    const unsigned int queue = blockIdx.x % (unsigned int)p.nQueues;
-    if (threadIdx.x == 0) {
-        ldsScratch[kWavesPerBlock] = total ? atomicAdd(&p.counters[kCtrUnitCursor + queue * kCursorStride], total) : 0u;
+    return mine;
+}
+
+// THE UNIT ORDER.  A unit is (pixel, chunk of the pass's samples); which slot renders it, and when, cannot change a
+// result (every unit's partial sum has its own place and k_resolve adds them in chunk order), so the order is free to
+// serve the memory system and the balance of the queues.  Unit id = queue * unitsPerQueue + position in the queue.
+//   kOrderStripes (default): queue q of pool h owns the CHUNKS (q * pools + h) + j * (queues * pools), j = 0, 1, ..,
+//     each a whole image walked in pixel order: every queue starts every chunk at the first pixel, so all queues sweep
+//     the image in step, a band of it in flight at any time, whatever the number of chunks (the former contiguous
+//     split of a chunk-major numbering did that only when the chunk count was a multiple of the queue count: a pass
+//     of 517 chunks per pixel ran 10 % slower than one of 512).  Queues are equal up to one chunk; grabUnits moves a
+//     block on when its queue is dealt out.
+//   kOrderStripesTiled: the same with the pixels of a chunk walked in 32 x 8 tiles (below) instead of rows.
+//   kOrderTiles: pixel GROUPS of 256 (tiles) dealt round-robin to the queues, a queue hands out all chunks of a group
+//     before it moves on: the slots of a block all work on one patch of the image.  Measured 6-8 % SLOWER on the mesh
+//     scenes than the stripes (tools/chunk_sweep2.py): kept selectable (PATHED_UNIT_ORDER).
+// Tile walk: bands of 8 rows, blocks of 32 columns inside a band, row-major inside a block; ragged last band / block.
+static const int kOrderStripes = 0, kOrderStripesTiled = 1, kOrderTiles = 2;
+
+__device__ inline unsigned int tileWalkPixel(const RenderParams &p, unsigned int index)
+{
+    const unsigned int width = (unsigned int)p.scene.camera.resX, height = (unsigned int)p.scene.camera.resY;
+    const unsigned int band = fastDivide(index, p.divBand);
+    const unsigned int inBand = index - band * 8u * width;
+    const unsigned int rowsLeft = height - 8u * band;
+    const unsigned int rows = rowsLeft < 8u ? rowsLeft : 8u;
+    const unsigned int block = rows == 8u ? inBand >> 8 : inBand / (32u * rows);
+    const unsigned int inBlock = inBand - block * 32u * rows;
+    const unsigned int columnsLeft = width - 32u * block;
+    const unsigned int columns = columnsLeft < 32u ? columnsLeft : 32u;
+    const unsigned int y = columns == 32u ? inBlock >> 5 : inBlock / columns;
+    const unsigned int x = inBlock - y * columns;
+    return (8u * band + y) * width + 32u * block + x;
+}
+
+__device__ inline void unitPlace(const RenderParams &p, unsigned int unit, uint32_t *pixel, uint32_t *chunkIndex)
+{
+    const unsigned int queue = fastDivide(unit, p.divStride);
+    const unsigned int k = unit - queue * p.unitsPerQueue;
+    const unsigned int j = fastDivide(k, p.divGroupUnits);
+    const unsigned int w = k - j * p.groupUnits;
+    const unsigned int owned = queue * p.pools + p.pool + j * (unsigned int)p.nQueues * p.pools;   // j-th chunk / group of the queue
+    if (p.unitOrder != kOrderTiles) {
+        *chunkIndex = owned;                                   // groupUnits = pixels of the image
+        *pixel = p.unitOrder == kOrderStripes ? w : tileWalkPixel(p, w);
+        return;
     }
-    __syncthreads();
-    const unsigned int base = ldsScratch[kWavesPerBlock];
-    __syncthreads();  // scratch is reused by the caller
-    if (!want) { return 0xFFFFFFFFu; }
-    const unsigned int k = base + offset + before;
-    if (k >= p.unitsPerQueue) { return 0xFFFFFFFFu; }
-    const unsigned int unit = queue * p.unitsPerQueue + k;
-    return unit < p.nUnits ? unit : 0xFFFFFFFFu;
+    unsigned int chunk, within;
+    if (owned + 1u < p.nGroups || p.lastGroupPixels == kUnitGroup) {
+        chunk = w >> 8;
+        within = w & (kUnitGroup - 1u);
+    } else {   // the ragged last group
+        chunk = w / p.lastGroupPixels;
+        within = w - chunk * p.lastGroupPixels;
+    }
+    *pixel = tileWalkPixel(p, owned * kUnitGroup + within);
+    *chunkIndex = chunk;
 }
 
 // first sample index of a unit and one-past-last
 __device__ inline void unitSamples(const RenderParams &p, unsigned int unit, uint32_t *pixel, uint32_t *first, uint32_t *end)
 {
-    const unsigned int globalUnit = p.unitBase + unit;
-    const unsigned int chunkIndex = globalUnit / (unsigned int)p.nPixels;
-    *pixel = globalUnit - chunkIndex * (unsigned int)p.nPixels;
+    uint32_t chunkIndex;
+    unitPlace(p, unit, pixel, &chunkIndex);
     *first = p.sppBegin + chunkIndex * (unsigned int)p.chunk;
     const uint32_t last = *first + (unsigned int)p.chunk;
     *end = last < p.sppEnd ? last : p.sppEnd;
+}
+
+// where a unit's partial sum goes: chunk-major, so that k_resolve reads a chunk's pixels coalesced
+__device__ inline size_t partialIndex(const RenderParams &p, unsigned int unit)
+{
+    uint32_t pixel, chunkIndex;
+    unitPlace(p, unit, &pixel, &chunkIndex);
+    return (size_t)chunkIndex * (size_t)p.nPixels + pixel;
 }
 
 __global__ __launch_bounds__(kBlock) void k_init(RenderParams p)
@@ -1039,7 +1146,20 @@ __global__ __launch_bounds__(kBlock) void k_resolve(RenderParams p)
     if (pixel >= p.nPixels) { return; }
     float *out = p.accum + 3 * (size_t)pixel;
     float r = out[0], g = out[1], b = out[2];
-    for (int chunk = 0; chunk < p.chunksPerPixel; chunk++) {
+    // the additions are a dependent chain, the loads are not: eight in flight per lane
+    int chunk = 0;
+    for (; chunk + 8 <= p.chunksPerPixel; chunk += 8) {
+        float4 partial[8];
+        #pragma unroll
+        for (int k = 0; k < 8; k++) { partial[k] = p.state.chunkBuf[(size_t)(chunk + k) * p.nPixels + pixel]; }
+        #pragma unroll
+        for (int k = 0; k < 8; k++) {
+            r += partial[k].x;
+            g += partial[k].y;
+            b += partial[k].z;
+        }
+    }
+    for (; chunk < p.chunksPerPixel; chunk++) {
         const float4 partial = p.state.chunkBuf[(size_t)chunk * p.nPixels + pixel];
         r += partial.x;
         g += partial.y;
@@ -1328,7 +1448,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(RenderParams p)
             nextSample = firstSample + (uint32_t)sampleInUnit;
             p.state.acc[slot] = partial;
         } else {
-            p.state.chunkBuf[unit] = partial;
+            p.state.chunkBuf[partialIndex(p, unit)] = partial;
             p.state.acc[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
             needUnit = true;
         }
@@ -1844,7 +1964,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_S
                 nextSample = firstSample + (uint32_t)sampleInUnit;
                 p.state.acc[slot] = partial;
             } else {
-                p.state.chunkBuf[unit] = partial;
+                p.state.chunkBuf[partialIndex(p, unit)] = partial;
                 p.state.acc[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
                 needUnit = true;
             }
@@ -1940,11 +2060,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_F
                 unsigned int ticket = 0;
                 if (lane == 0) { ticket = atomicAdd(&p.counters[kCtrUnitCursor + queue * kCursorStride], (unsigned int)p.unitGrab); }
                 ticket = (unsigned int)__builtin_amdgcn_readfirstlane((int)ticket);
-                // queue q owns units [q * unitsPerQueue, (q + 1) * unitsPerQueue), clipped to the pool's nUnits
-                unsigned int limit = p.unitsPerQueue;
-                const unsigned long long first = (unsigned long long)queue * p.unitsPerQueue;
-                if (first >= p.nUnits) { limit = 0u; }
-                else if (first + limit > p.nUnits) { limit = (unsigned int)(p.nUnits - first); }
+                const unsigned int limit = p.queueUnits[queue];   // unit ids of queue q: q * unitsPerQueue + [0, limit)
                 if (ticket >= limit) {
                     queue = (queue + 1u) % (unsigned int)p.nQueues;
                     queuesTried++;
@@ -2192,7 +2308,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_F
             if (sample < endSample) {
                 startNext = true;
             } else {
-                p.state.chunkBuf[unit] = partial;
+                p.state.chunkBuf[partialIndex(p, unit)] = partial;
                 partial = make_float4(0.f, 0.f, 0.f, 0.f);
                 needUnit = true;
             }
@@ -2273,10 +2389,7 @@ __global__ __launch_bounds__(kBlock) void k_path_volume(RenderParams p)
                 unsigned int ticket = 0;
                 if (lane == 0) { ticket = atomicAdd(&p.counters[kCtrUnitCursor + queue * kCursorStride], (unsigned int)p.unitGrab); }
                 ticket = (unsigned int)__builtin_amdgcn_readfirstlane((int)ticket);
-                unsigned int limit = p.unitsPerQueue;
-                const unsigned long long first = (unsigned long long)queue * p.unitsPerQueue;
-                if (first >= p.nUnits) { limit = 0u; }
-                else if (first + limit > p.nUnits) { limit = (unsigned int)(p.nUnits - first); }
+                const unsigned int limit = p.queueUnits[queue];
                 if (ticket >= limit) {
                     queue = (queue + 1u) % (unsigned int)p.nQueues;
                     queuesTried++;
@@ -2538,7 +2651,7 @@ __global__ __launch_bounds__(kBlock) void k_path_volume(RenderParams p)
                 }
                 samplesDone++;
             }
-            p.state.chunkBuf[unit] = partial;
+            p.state.chunkBuf[partialIndex(p, unit)] = partial;
         }
     }
     (void)samplesDone;

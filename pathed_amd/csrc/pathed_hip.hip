@@ -161,7 +161,7 @@ struct PathedScene {
     // render state, allocated on first use
     int nSlots = 0;
     size_t chunkCapacity = 0;     // float4 entries of chunkBuf
-    int samplesPerUnit = 4;       // "chunk": samples a slot sums before it publishes a partial
+    int samplesPerUnit = 1;       // "chunk": samples a slot sums before it publishes a partial (1 = the reference's summation order)
     int maxSlots = 1 << 20;
     int pools = 2;                // independent slot pools on separate streams (trace || shade); PATHED_POOLS = 1..kMaxPools
     hipStream_t poolStreams[kMaxPools] = { nullptr, nullptr, nullptr, nullptr };
@@ -366,10 +366,11 @@ int validate(const PathedSceneDesc *desc)
     return PATHED_OK;
 }
 
-// chunks (units per pixel) rendered per internal pass: bounds chunkBuf to 256 float4 per pixel (4.3 GB at
-// 1024^2, 8.5 GB at 1080p; further capped at 2^30 units).  Every pass pays the slot pool's ramp-up and tail
-// once: 256 instead of 64 chunks per pass is worth 2-3 % on long renders (tools/pass_sweep.py).
-const int kMaxChunksPerPass = 256;
+// chunks (units per pixel) rendered per internal pass: bounds chunkBuf to 1 024 float4 per pixel (17 GB at 1024^2, 34 GB
+// at 1080p) and to 2^31 units in all -- a tenth of 288 GB of HBM at most, allocated when a call first needs it.  Every pass pays the slot pool's
+// ramp-up and drain once, so a pass should be long: with one sample per unit (the default) 1 024 units per pixel are
+// the 1 024 spp of one bench step (tools/pass_sweep.py, tools/chunk_sweep2.py).
+const int kMaxChunksPerPass = 1024;
 
 int ensureRenderState(PathedScene *scene, int nSlots, size_t chunkEntries)
 {
@@ -1141,6 +1142,66 @@ void pathed_hip_scene_destroy(PathedScene *scene)
     delete scene;
 }
 
+// The unit order of one pool's launch parameters (kernels.h: THE UNIT ORDER).  The (nQueues x pools) queues share out
+// ITEMS round-robin -- the chunks of the pass (stripes: an item is one whole image of units) or groups of kUnitGroup pixels
+// (tiles: an item is all chunks of the group) -- queue q of pool `pool` owns the items (q * pools + pool) + j * queues.
+// Returns false when the unit ids of the pass do not fit 32 bits.
+static int unitOrderFromEnvironment()
+{
+    static int order = -1;
+    if (order < 0) {
+        order = kOrderStripes;
+        if (const char *text = getenv("PATHED_UNIT_ORDER")) {   // experiments
+            if (!strcmp(text, "tiles")) { order = kOrderTiles; }
+            else if (!strcmp(text, "stripes-tiled")) { order = kOrderStripesTiled; }
+        }
+    }
+    return order;
+}
+
+static bool fillUnitOrder(RenderParams &q, int width, int height, int chunksPerPixel, int pool, int pools, int nQueues)
+{
+    const int order = unitOrderFromEnvironment();
+    const unsigned long long nPixels = (unsigned long long)width * (unsigned long long)height;
+    const unsigned long long allQueues = (unsigned long long)nQueues * (unsigned long long)pools;
+    unsigned long long items, itemUnits, lastItemShortfall = 0;
+    if (order == kOrderTiles) {
+        items = (nPixels + kUnitGroup - 1ull) / kUnitGroup;
+        itemUnits = (unsigned long long)kUnitGroup * (unsigned long long)chunksPerPixel;
+        q.lastGroupPixels = (unsigned int)(nPixels - (items - 1ull) * kUnitGroup);
+        lastItemShortfall = (kUnitGroup - (unsigned long long)q.lastGroupPixels) * (unsigned long long)chunksPerPixel;
+    } else {
+        items = (unsigned long long)chunksPerPixel;
+        itemUnits = nPixels;
+        q.lastGroupPixels = kUnitGroup;
+    }
+    const unsigned long long stride = ((items + allQueues - 1ull) / allQueues) * itemUnits;   // the longest queue
+    if (stride * (unsigned long long)nQueues >= 0xFFFFFFF0ull || nPixels + kUnitGroup >= 0xFFFFFFF0ull) { return false; }
+    q.unitOrder = order;
+    q.pool = (unsigned int)pool;
+    q.pools = (unsigned int)pools;
+    q.nQueues = nQueues;
+    q.nGroups = (unsigned int)items;
+    q.groupUnits = (unsigned int)itemUnits;
+    q.unitsPerQueue = (unsigned int)stride;
+    q.divStride = makeFastDiv((unsigned int)stride);
+    q.divGroupUnits = makeFastDiv((unsigned int)itemUnits);
+    q.divBand = makeFastDiv(8u * (unsigned int)width);
+    unsigned long long total = 0;
+    for (int k = 0; k < kUnitQueues; k++) {
+        unsigned long long units = 0;
+        const unsigned long long first = (unsigned long long)k * (unsigned long long)pools + (unsigned long long)pool;
+        if (k < nQueues && first < items) {
+            units = ((items - 1ull - first) / allQueues + 1ull) * itemUnits;
+            if ((items - 1ull - first) % allQueues == 0ull) { units -= lastItemShortfall; }   // owns the ragged last group
+        }
+        q.queueUnits[k] = (unsigned int)units;
+        total += units;
+    }
+    q.nUnits = (unsigned int)total;
+    return true;
+}
+
 // One internal pass of the fused path kernel (scenes of <= 64 triangles): a single persistent launch
 // renders every unit of the pass; no slot pool, no iteration loop, no polling.
 static int renderPassFused(PathedScene *scene, uint64_t seed, uint32_t begin, uint32_t count,
@@ -1179,15 +1240,15 @@ static int renderPassFused(PathedScene *scene, uint64_t seed, uint32_t begin, ui
     params.stats = scene->stats.ptr;
     params.accum = d_accum;
     params.nPixels = nPixels;
-    params.nUnits = nUnits;
-    params.unitBase = 0;
-    params.nQueues = (int)(waves < (unsigned int)kUnitQueues ? waves : (unsigned int)kUnitQueues);
-    params.unitsPerQueue = (nUnits + (unsigned int)params.nQueues - 1) / (unsigned int)params.nQueues;
+    if (!fillUnitOrder(params, scene->width, scene->height, chunksPerPixel, 0, 1,
+                       (int)(waves < (unsigned int)kUnitQueues ? waves : (unsigned int)kUnitQueues))) {
+        return fail(PATHED_E_INVALID, "too many work units in one pass");
+    }
     {
         // a wave reserves up to one unit per lane at a time; passes too small for that hand out less per atomic,
         // so that the last reservations of a queue do not leave most waves idle
         const unsigned int wavesPerQueue = (waves + (unsigned int)params.nQueues - 1) / (unsigned int)params.nQueues;
-        unsigned int grab = params.unitsPerQueue / (wavesPerQueue * 4u);
+        unsigned int grab = (nUnits / (unsigned int)params.nQueues) / (wavesPerQueue * 4u);
         params.unitGrab = (int)(grab < 1u ? 1u : grab > 64u ? 64u : grab);
     }
     params.chunk = chunk;
@@ -1269,13 +1330,13 @@ static int renderPassVolume(PathedScene *scene, uint64_t seed, uint32_t begin, u
     params.maxStack = scene->maxStack;
     params.accum = d_accum;
     params.nPixels = nPixels;
-    params.nUnits = nUnits;
-    params.unitBase = 0;
-    params.nQueues = (int)(waves < (unsigned int)kUnitQueues ? waves : (unsigned int)kUnitQueues);
-    params.unitsPerQueue = (nUnits + (unsigned int)params.nQueues - 1) / (unsigned int)params.nQueues;
+    if (!fillUnitOrder(params, scene->width, scene->height, chunksPerPixel, 0, 1,
+                       (int)(waves < (unsigned int)kUnitQueues ? waves : (unsigned int)kUnitQueues))) {
+        return fail(PATHED_E_INVALID, "too many work units in one pass");
+    }
     {
         const unsigned int wavesPerQueue = (waves + (unsigned int)params.nQueues - 1) / (unsigned int)params.nQueues;
-        unsigned int grab = params.unitsPerQueue / (wavesPerQueue * 4u);
+        unsigned int grab = (nUnits / (unsigned int)params.nQueues) / (wavesPerQueue * 4u);
         params.unitGrab = (int)(grab < 1u ? 1u : grab > 64u ? 64u : grab);
     }
     params.chunk = chunk;
@@ -1350,8 +1411,6 @@ static int renderPass(PathedScene *scene, uint64_t seed, uint32_t begin, uint32_
     for (int h = 0; h < pools; h++) {
         RenderParams &q = params[h];
         const size_t slotBase = (size_t)h * slotsPerPool;
-        const unsigned int unitBase = (unsigned int)((unsigned long long)nUnits * h / pools);
-        const unsigned int unitEnd = (unsigned int)((unsigned long long)nUnits * (h + 1) / pools);
         q.scene = scene->device;
         q.state.rayO = scene->rayO.ptr + slotBase;
         q.state.rayD = scene->rayD.ptr + slotBase;
@@ -1363,7 +1422,7 @@ static int renderPass(PathedScene *scene, uint64_t seed, uint32_t begin, uint32_
         q.state.acc = scene->acc.ptr + slotBase;
         q.state.shO = scene->shO.ptr + slotBase;
         q.state.shD = scene->shD.ptr + slotBase;
-        q.state.chunkBuf = scene->chunkBuf.ptr + unitBase;
+        q.state.chunkBuf = scene->chunkBuf.ptr;
         q.counters = scene->counters.ptr + (size_t)h * kCtrCount;
         const size_t traceWaves = (size_t)scene->traceGrid * kWavesPerBlock;
         q.suspendLanes = scene->bruteForce ? 0 : scene->suspendLanes;
@@ -1382,10 +1441,9 @@ static int renderPass(PathedScene *scene, uint64_t seed, uint32_t begin, uint32_
         q.accum = d_accum;
         q.nSlots = slotsPerPool;
         q.nPixels = nPixels;
-        q.nUnits = unitEnd - unitBase;
-        q.unitBase = unitBase;
-        q.nQueues = nQueues;
-        q.unitsPerQueue = (q.nUnits + (unsigned int)nQueues - 1) / (unsigned int)nQueues;
+        if (!fillUnitOrder(q, scene->width, scene->height, chunksPerPixel, h, pools, nQueues)) {
+            return fail(PATHED_E_INVALID, "too many work units in one pass");
+        }
         q.chunk = chunk;
         q.chunksPerPixel = chunksPerPixel;
         q.seedLo = (uint32_t)seed;
@@ -1525,7 +1583,7 @@ int pathed_hip_render_device(PathedScene *scene, uint64_t seed,
     int chunksPerPass = kMaxChunksPerPass;
     {
         const unsigned long long pixels = (unsigned long long)scene->width * (unsigned long long)scene->height;
-        const unsigned long long cap = (1ull << 30) / (pixels ? pixels : 1ull);
+        const unsigned long long cap = (1ull << 31) / (pixels ? pixels : 1ull);   // 2^31 partial sums = 34 GB
         if ((unsigned long long)chunksPerPass > cap) { chunksPerPass = cap >= 1ull ? (int)cap : 1; }
     }
     if (const char *text = getenv("PATHED_CHUNKS_PER_PASS")) {   // tuning: fewer, longer passes at the cost of a larger partial-sum buffer

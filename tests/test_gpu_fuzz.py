@@ -104,7 +104,7 @@ def test_random_scene_parity(seed):
             assert np.array_equal(other.trace(rays).view(np.int32), hits.view(np.int32)), builder
             assert np.array_equal(other.render(7, 0, 8, 0, 6), image), builder
 
-    expected, _ = cpu.render(size, size, 7, 0, 8, 0, 6, threads=os.cpu_count(), chunk=4)
+    expected, _ = cpu.render(size, size, 7, 0, 8, 0, 6, threads=os.cpu_count())
     assert np.isfinite(image).all()
     rel = float(np.linalg.norm(image - expected) / max(np.linalg.norm(expected), 1e-30))
     bad = float((np.abs(image - expected) > 1e-2 * np.maximum(np.abs(expected), 1e-3)).any(axis=2).mean())

@@ -52,7 +52,7 @@ def test_pathed_executable_runs_config_1(tmp_path):
     assert b"B\x00\x01\x00\x00\x00" in blob and b"G\x00\x01\x00\x00\x00" in blob and b"R\x00\x01\x00\x00\x00" in blob  # HALF channels
 
     scene = LoadedScene("scenes/cornell.json", 96, 96)
-    expected, _ = oracle_lib.OracleScene(scene.desc).render(96, 96, 1, 0, 16, 0, 10, threads=os.cpu_count(), chunk=4)
+    expected, _ = oracle_lib.OracleScene(scene.desc).render(96, 96, 1, 0, 16, 0, 10, threads=os.cpu_count())
     expected = (expected / 16)[::-1]  # Image::set flips: EXR row 0 is the top scanline
     half = expected.astype(np.float16).astype(np.float32)
     assert np.allclose(image, half, rtol=2e-3, atol=2e-3)

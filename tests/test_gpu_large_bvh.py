@@ -64,7 +64,7 @@ def test_full_size_stand_in_traced_and_rendered_against_the_oracle(large_scene):
     nodes, tris = gpu.export_bvh()
     assert tris.shape[0] == scene.n_triangles - 2 + 2 and nodes.shape[0] == stats["bvh_nodes"]
     image = gpu.render(1, 0, 8, 0, 10)
-    expected, oracle_stats = cpu.render(128, 72, 1, 0, 8, 0, 10, threads=os.cpu_count(), chunk=4)
+    expected, oracle_stats = cpu.render(128, 72, 1, 0, 8, 0, 10, threads=os.cpu_count())
     rel = float(np.linalg.norm(image - expected) / np.linalg.norm(expected))
     bad = float((np.abs(image - expected) > 1e-2 * np.maximum(np.abs(expected), 1e-3)).any(axis=2).mean())
     assert rel <= 2e-3 and bad <= 2e-3, (rel, bad)

@@ -79,7 +79,7 @@ def test_empty_and_ragged_inputs(libs):
     image = gpu.render(3, 0, 0, 0, 10)  # zero samples: nothing is added
     assert not image.any()
     image = gpu.render(3, 5, 3, 0, 10)
-    expected, _ = cpu.render(17, 5, 3, 5, 3, 0, 10, chunk=4)
+    expected, _ = cpu.render(17, 5, 3, 5, 3, 0, 10)
     rel, bad = _image_metrics(image, expected)
     assert rel < 2e-3 and bad <= 0.012  # 1 of 85 pixels
 
@@ -148,7 +148,7 @@ def test_batches_continue_the_sum_bit_exactly(libs):
     _, HipScene, LoadedScene = libs
     scene = LoadedScene("scenes/cornell.json", 64, 64)
     gpu = HipScene(scene.desc, device=0)
-    # samples-per-unit 1: the reference's exact per-sample order, any split is bit-identical
+    # samples-per-unit 1 (the default): the reference's exact per-sample order, any split is bit-identical
     gpu.set_samples_per_unit(1)
     once = torch.zeros((64, 64, 3), dtype=torch.float32, device="cuda")
     gpu.render_device(4, 0, 12, 0, 10, once.data_ptr())
@@ -156,7 +156,7 @@ def test_batches_continue_the_sum_bit_exactly(libs):
     for begin, count in ((0, 5), (5, 1), (6, 6)):
         gpu.render_device(4, begin, count, 0, 10, split.data_ptr())
     assert torch.equal(once, split)
-    # default granularity (4): splits on unit boundaries are bit-identical, and the result is
+    # coarser units (4 samples): splits on unit boundaries are bit-identical, and the result is
     # deterministic although slots pull work dynamically (no float atomics anywhere)
     gpu.set_samples_per_unit(4)
     once = torch.zeros_like(once)
@@ -324,10 +324,10 @@ def test_shade_kernels_are_bit_identical(libs, scene_path, size, spp, last_bounc
         staged = HipScene(scene.desc, device=0, shade_kernel="staged", **options)
         assert np.array_equal(staged.render(7, 3, spp, 0, last_bounce), expected), options
         assert staged.stats()["path_kernel"] == 2
-    # bounce windows and the exact-reference summation order (one sample per unit)
+    # bounce windows and units of several samples (the default is one sample per unit, the reference's summation order)
     staged = HipScene(scene.desc, device=0, shade_kernel="staged")
-    staged.set_samples_per_unit(1)
-    per_slot.set_samples_per_unit(1)
+    staged.set_samples_per_unit(4)
+    per_slot.set_samples_per_unit(4)
     windowed = per_slot.render(2, 0, 3, 1, 2)
     assert np.array_equal(staged.render(2, 0, 3, 1, 2), windowed)
     automatic = HipScene(scene.desc, device=0)
@@ -335,7 +335,7 @@ def test_shade_kernels_are_bit_identical(libs, scene_path, size, spp, last_bounc
         # the default for tiny scenes is the fused kernel
         assert automatic.stats()["path_kernel"] == 3
         assert np.array_equal(automatic.render(7, 3, spp, 0, last_bounce), expected)
-        automatic.set_samples_per_unit(1)
+        automatic.set_samples_per_unit(4)
         assert np.array_equal(automatic.render(2, 0, 3, 1, 2), windowed)
         automatic.set_samples_per_unit(7)
         per_slot.set_samples_per_unit(7)
@@ -442,7 +442,7 @@ def test_large_mesh_intersector_and_render_parity(libs):
     assert (hits_cpu[:, 3].view(np.int32) >= 0).mean() > 0.5
     assert np.array_equal(gpu.trace(rays, any_hit=True), cpu.trace(rays, any_hit=True))
     image = gpu.render(1, 0, 8, 0, 10)
-    expected, _ = cpu.render(96, 54, 1, 0, 8, 0, 10, threads=os.cpu_count(), chunk=4)
+    expected, _ = cpu.render(96, 54, 1, 0, 8, 0, 10, threads=os.cpu_count())
     rel, bad = _image_metrics(image, expected)
     assert rel <= 2e-3 and bad <= 2e-3, (rel, bad)
 
@@ -488,11 +488,11 @@ def test_unbounded_last_bounce_terminates_and_matches(libs):
     built.sphere((0, 0.6, 0), 0.6, built.material(diffuse=(0.7, 0.3, 0.2)))
     desc = built.finish()
     image = HipScene(desc, device=0).render(2, 0, 8, 0, -1)
-    expected, stats = oracle_lib.OracleScene(desc).render(48, 48, 2, 0, 8, 0, -1, chunk=4)
+    expected, stats = oracle_lib.OracleScene(desc).render(48, 48, 2, 0, 8, 0, -1)
     rel, bad = _image_metrics(image, expected)
     assert rel < 2e-3 and bad <= 2e-3
     assert stats["vertices"] > 0.5 * stats["camera_samples"]  # most camera rays hit and bounce
-    shallow, _ = oracle_lib.OracleScene(desc).render(48, 48, 2, 0, 8, 0, 1, chunk=4)
+    shallow, _ = oracle_lib.OracleScene(desc).render(48, 48, 2, 0, 8, 0, 1)
     assert expected.sum() > shallow.sum() * 1.01  # the unbounded render carries indirect light
 
 
@@ -545,7 +545,7 @@ def test_many_spheres_live_in_the_tree_not_in_a_list(libs):
     image = gpu.render(3, 0, 8, 0, 8)
     stats = gpu.stats()
     assert stats["tris_tested"] < 12 * (stats["closest_rays"] + stats["shadow_rays"])   # not 300 sphere tests per ray
-    expected_image, _ = cpu.render(64, 48, 3, 0, 8, 0, 8, threads=os.cpu_count(), chunk=4)
+    expected_image, _ = cpu.render(64, 48, 3, 0, 8, 0, 8, threads=os.cpu_count())
     rel, bad = _image_metrics(image, expected_image)
     assert rel <= 1e-2 and bad <= 5e-3, (rel, bad)              # glass and mirror spheres: a flipped decision changes a path
     # the same tree through the kernel with 8 stack rows and eager parking, and a tree of spheres ONLY (no triangle)
@@ -556,7 +556,7 @@ def test_many_spheres_live_in_the_tree_not_in_a_list(libs):
     assert gpu_only.stats()["scene_in_lds"] in (0, 1) and gpu_only.stats()["bvh_nodes"] > 0     # a small tree may be staged in LDS
     assert np.array_equal(gpu_only.trace(rays).view(np.int32), cpu_only.trace(rays).view(np.int32))
     image_only = gpu_only.render(5, 0, 8, 0, 6)
-    expected_only, _ = cpu_only.render(64, 48, 5, 0, 8, 0, 6, threads=os.cpu_count(), chunk=4)
+    expected_only, _ = cpu_only.render(64, 48, 5, 0, 8, 0, 6, threads=os.cpu_count())
     rel, bad = _image_metrics(image_only, expected_only)
     assert image_only.any() and rel <= 1e-2 and bad <= 5e-3, (rel, bad)
     # sixteen spheres or fewer beside a tiny mesh stay with the all-triangles kernels (Veach's scene has five)

@@ -97,7 +97,7 @@ def test_volume_kernel_matches_the_oracle_with_media(sigma, env, sphere_light):
     oracle = oracle_lib.OracleScene(desc)
     oracle.set_integrator("VolumePathTracer")
     image = gpu.render(4, 0, 16, 0, 8)
-    expected, stats = oracle.render(48, 40, 4, 0, 16, 0, 8, threads=os.cpu_count(), chunk=4)
+    expected, stats = oracle.render(48, 40, 4, 0, 16, 0, 8, threads=os.cpu_count())
     rel = float(np.linalg.norm(image - expected) / np.linalg.norm(expected))
     bad = float((np.abs(image - expected) > 1e-2 * np.maximum(np.abs(expected), 1e-3)).any(axis=2).mean())
     assert rel <= 1e-2 and bad <= 5e-3, (rel, bad)      # a glass sphere inside: a flipped Fresnel decision changes a path
@@ -124,7 +124,7 @@ def test_reference_cornell_medium_scene_matches_the_oracle():
     oracle = oracle_lib.OracleScene(scene.desc)
     oracle.set_integrator("VolumePathTracer")
     image = gpu.render(1, 0, spp, 0, 10)
-    expected, stats = oracle.render(size, size, 1, 0, spp, 0, 10, threads=os.cpu_count(), chunk=4)
+    expected, stats = oracle.render(size, size, 1, 0, spp, 0, 10, threads=os.cpu_count())
     rel = float(np.linalg.norm(image - expected) / np.linalg.norm(expected))
     bad = float((np.abs(image - expected) > 1e-2 * np.maximum(np.abs(expected), 1e-3)).any(axis=2).mean())
     assert rel <= 1e-2 and bad <= 5e-3, (rel, bad)

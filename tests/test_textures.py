@@ -179,7 +179,7 @@ def test_gpu_matches_the_oracle_on_a_textured_scene(tmp_path):
     loaded = LoadedScene(str(path), 64, 64)
     gpu = HipScene(loaded.desc, device=0)
     image = gpu.render(3, 0, 32, 0, 6)
-    expected, _ = oracle_lib.OracleScene(loaded.desc).render(64, 64, 3, 0, 32, 0, 6, threads=os.cpu_count(), chunk=4)
+    expected, _ = oracle_lib.OracleScene(loaded.desc).render(64, 64, 3, 0, 32, 0, 6, threads=os.cpu_count())
     rel = float(np.linalg.norm(image - expected) / np.linalg.norm(expected))
     bad = float((np.abs(image - expected) > 1e-2 * np.maximum(np.abs(expected), 1e-3)).any(axis=2).mean())
     assert rel <= 2e-3 and bad <= 1e-3, (rel, bad)   # SURVEY.md §8d tolerance

@@ -44,7 +44,7 @@ if not args.no_oracle:
     w, h = 160, 90
     small = LoadedScene("scenes/dragon-standin.json", w, h)
     g2, c2 = HipScene(small.desc, device=0), oracle_lib.OracleScene(small.desc)
-    ig = g2.render(1, 0, 8, 0, 10); ic, _ = c2.render(w, h, 1, 0, 8, 0, 10, threads=os.cpu_count(), chunk=4)
+    ig = g2.render(1, 0, 8, 0, 10); ic, _ = c2.render(w, h, 1, 0, 8, 0, 10, threads=os.cpu_count())
     print("render parity %dx%d 8spp relL2 %.3e mean %s" % (w, h, np.linalg.norm(ig - ic) / np.linalg.norm(ic), (ig / 8).reshape(-1, 3).mean(0)))
 
 import torch

@@ -103,12 +103,12 @@ def main():
         g2.set_integrator(integrator)
         o2.set_integrator(integrator)
         image = g2.render(1, 0, 16, 0, 10)
-        expected, _ = o2.render(pw, ph, 1, 0, 16, 0, 10, threads=cores, chunk=4)
+        expected, _ = o2.render(pw, ph, 1, 0, 16, 0, 10, threads=cores)
         full_parity = None
         if args.parity_full > 0:
             n = args.parity_full
             image_full = gpu.render(1, 0, n, 0, 10)
-            expected_full, _ = oracle.render(w, h, 1, 0, n, 0, 10, threads=cores, chunk=4)
+            expected_full, _ = oracle.render(w, h, 1, 0, n, 0, 10, threads=cores)
             difference = np.abs(image_full - expected_full)
             full_parity = {
                 "spp": n, "relL2": "%.2e" % relative_l2(image_full, expected_full),

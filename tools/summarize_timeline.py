@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Reads a rocprofv3 --kernel-trace directory and prints, for the path kernels of the LAST step in it: launches, mean and
 summed duration per kernel, the wall time their union covers, the time two path kernels run at once, and the idle time
-between kernels.  Usage: summarize_timeline.py <dir> [ms_per_step]"""
+between kernels.  Usage: summarize_timeline.py <dir> [ms_per_step [N]]"""
 import csv
 import glob
 import sys
@@ -32,6 +32,12 @@ def main():
         by.setdefault(k, []).append(e - s)
     for k, v in sorted(by.items(), key=lambda kv: -sum(kv[1])):
         print("  %-34s n=%5d mean %8.1f us  sum %8.2f ms" % (k[:34], len(v), sum(v) / len(v) / 1e3, sum(v) / 1e6))
+    if len(sys.argv) > 3:   # series: every Nth launch of the two path kernels, "offset ms: duration us"
+        every = int(sys.argv[3])
+        for kernel in ("k_trace", "k_shade"):
+            launches = [(s, e) for s, e, k in step if k.startswith(kernel)]
+            print("  %s series (offset ms:duration us): %s" % (kernel, " ".join(
+                "%.1f:%.0f" % ((s - t0) / 1e6, (e - s) / 1e3) for s, e in launches[::every])))
     events = []
     for s, e, k in step:
         events.append((s, 1))

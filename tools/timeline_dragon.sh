@@ -16,7 +16,7 @@ for pools in ${POOLS:-2 1}; do
   rocprofv3 --kernel-trace --output-format csv -d $OUT/p$pools -- python3 $ROOT/bench.py $ARGS > $OUT/p$pools.log 2>&1 || { echo "pools $pools failed"; tail -3 $OUT/p$pools.log; }
   grep -o '"value": [0-9.]*' $OUT/p$pools.log | head -1 >> $OUT/summary.txt
   MS=$(grep -o '"ms_per_step": [0-9.]*' $OUT/p$pools.log | head -1 | cut -d' ' -f2)
-  python3 $ROOT/tools/summarize_timeline.py $OUT/p$pools $MS >> $OUT/summary.txt
+  python3 $ROOT/tools/summarize_timeline.py $OUT/p$pools $MS ${SERIES:-} >> $OUT/summary.txt
   echo "pools $pools done"
 done
 cat $OUT/summary.txt
