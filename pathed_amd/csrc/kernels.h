@@ -34,7 +34,10 @@ static const int kBlock = 256;
 static_assert(kBlock == kVolumeBlock, "volume.h indexes the LDS stack rows with the block size");
 static const int kWavesPerBlock = kBlock / 64;
 static const int kMaxLdsMaterials = 96;  // 96 x 96 B = 9 KiB of LDS
-static const int kUnitQueues = 32;       // sharded work-unit cursors
+#ifndef PATHED_UNIT_QUEUES
+#define PATHED_UNIT_QUEUES 32
+#endif
+static const int kUnitQueues = PATHED_UNIT_QUEUES;       // sharded work-unit cursors
 static const unsigned int kUnitGroup = 256u;   // pixels of a group of the unit order: a 32 x 8 tile where the resolution allows
 
 // n / d for a launch-invariant d (Granlund & Montgomery 1994, figure 4.1; exact for every 32-bit n): the unit order

@@ -366,11 +366,13 @@ int validate(const PathedSceneDesc *desc)
     return PATHED_OK;
 }
 
-// chunks (units per pixel) rendered per internal pass: bounds chunkBuf to 1 024 float4 per pixel (17 GB at 1024^2, 34 GB
-// at 1080p) and to 2^31 units in all -- a tenth of 288 GB of HBM at most, allocated when a call first needs it.  Every pass pays the slot pool's
-// ramp-up and drain once, so a pass should be long: with one sample per unit (the default) 1 024 units per pixel are
-// the 1 024 spp of one bench step (tools/pass_sweep.py, tools/chunk_sweep2.py).
-const int kMaxChunksPerPass = 1024;
+// chunks (units per pixel) rendered per internal pass: bounds chunkBuf to 256 float4 per pixel (4.3 GB at 1024^2, 8.5 GB
+// at 1080p; further capped at 2^30 units).  Every pass pays the slot pool's ramp-up and drain once -- with one sample
+// per unit and the queues in step that is a few milliseconds on a BVH scene (256 against 1 024 units per pixel: -0.3 %
+// on Cornell and the 5.2 M-triangle mesh, -2.4 % on the teapot, tools/chunk_sweep2.py) -- and fresh VRAM costs the
+// process about 40 ms per GB the first time (tools/alloc_probe.py): a 17 GB buffer would add 0.7 s to a 2 s job.
+// PATHED_CHUNKS_PER_PASS overrides for experiments.
+const int kMaxChunksPerPass = 256;
 
 int ensureRenderState(PathedScene *scene, int nSlots, size_t chunkEntries)
 {
@@ -1583,7 +1585,7 @@ int pathed_hip_render_device(PathedScene *scene, uint64_t seed,
     int chunksPerPass = kMaxChunksPerPass;
     {
         const unsigned long long pixels = (unsigned long long)scene->width * (unsigned long long)scene->height;
-        const unsigned long long cap = (1ull << 31) / (pixels ? pixels : 1ull);   // 2^31 partial sums = 34 GB
+        const unsigned long long cap = (1ull << 30) / (pixels ? pixels : 1ull);   // 2^30 partial sums = 17 GB
         if ((unsigned long long)chunksPerPass > cap) { chunksPerPass = cap >= 1ull ? (int)cap : 1; }
     }
     if (const char *text = getenv("PATHED_CHUNKS_PER_PASS")) {   // tuning: fewer, longer passes at the cost of a larger partial-sum buffer
