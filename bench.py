@@ -217,8 +217,7 @@ def large_bvh_leg(args, torch, stream):
         subprocess.run([sys.executable, os.path.join(REPO_ROOT, "tools", "make_assets.py"), "--dragon", str(args.large_bvh_subdiv)],
                        check=True, stdout=subprocess.DEVNULL)
     width, height = 1920, 1080
-    # timed: one full internal pass (1024 spp at this resolution), as every pass of the 8192-spp configuration is --
-    # a shorter call pays the same ~20 ms drain of the last paths over fewer samples (64 spp: -18 %, 256 spp: -7 %)
+    # timed: 1024 spp = four internal passes of 256, as the 8192-spp configuration runs them
     # (the warm-up is one full pass too: it sizes the partial-sum buffer, and fresh VRAM costs ~40 ms per GB once)
     count_spp, warm_spp, timed_spp = 16, 256, 1024
     t0 = time.perf_counter()

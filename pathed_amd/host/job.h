@@ -3,8 +3,8 @@
 // output_directory, output_name, showUI, force, width, height); job-file numbers are real
 // JSON numbers.  Optional extra keys with defaults, so reference job files run unchanged:
 //   "seed" (1), "gpu" (0), "asset_root" (directory paths resolve in),
-//   "spp_per_launch" (1024 = one internal pass: every render call drains its last paths, ~20 ms on a BVH scene, so
-//               short calls cost rate -- 64 spp per call: -18 %, 256: -7 %, 1024: -2 %; checkpoints still bound a call),
+//   "spp_per_launch" (1024): samples per render call.  A call drains its last paths before it returns (a few ms on a
+//               BVH scene: 64 spp per call cost 4 %, 256 and more < 1 %); checkpoints still bound a call,
 //   "bvh_builder" ("sah" | "lbvh" | "ploc": include/pathed_hip.h PATHED_BVH_*),
 //   "gpus" (1): a count N -> devices gpu .. gpu+N-1, or an explicit list of device ids (an id may
 //               repeat: several replicas on one GPU); the samples of every batch are split over them,
