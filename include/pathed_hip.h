@@ -261,7 +261,7 @@ typedef struct PathedSceneOptions {
     int32_t suspend_lanes;      /* park a trace wave's tail below this many rays, 1..64; -1 = never (0 = 32) */
     int32_t suspend_patience;   /* ... after this many steps without a new card, >= 1; -1 = none (0 = 24)     */
     int32_t park_min_cards;     /* ... while the pool has this many cards per wave, >= 1; -1 = always (0 = 1)  */
-    int32_t max_slots;          /* path slots (0 = 1 Mi for all-triangles scenes, 4 Mi for BVH scenes)         */
+    int32_t max_slots;          /* path slots (0 = 1 Mi for all-triangles scenes; BVH scenes 8 Mi, fewer for short calls) */
     int32_t intersector;        /* 0 automatic, 1 always walk the BVH (never the all-triangles kernel)         */
     int32_t trace_blocks_per_cu;/* persistent trace blocks per CU (0 = automatic)              */
     int32_t shade_kernel;       /* 0 automatic; 1 wavefront, k_shade (one lane per slot); 2 wavefront, k_shade_staged (dense,

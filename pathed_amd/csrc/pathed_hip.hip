@@ -159,7 +159,8 @@ struct PathedScene {
     DeviceBuffer<int> volumeOverflow;   // the volume kernel's traversal-stack spill, per thread
 
     // render state, allocated on first use
-    int nSlots = 0;
+    int nSlots = 0;               // capacity of the per-slot state buffers
+    bool adaptiveSlots = false;   // BVH scenes without an explicit max_slots: short calls use fewer slots
     size_t chunkCapacity = 0;     // float4 entries of chunkBuf
     int samplesPerUnit = 1;       // "chunk": samples a slot sums before it publishes a partial (1 = the reference's summation order)
     int maxSlots = 1 << 20;
@@ -376,7 +377,7 @@ const int kMaxChunksPerPass = 256;
 
 int ensureRenderState(PathedScene *scene, int nSlots, size_t chunkEntries)
 {
-    if (scene->nSlots != nSlots || !scene->rayO.ptr) {
+    if (scene->nSlots < nSlots || !scene->rayO.ptr) {   // capacity: a call that wants fewer slots uses a prefix
         scene->nSlots = nSlots;
         const size_t n = (size_t)nSlots;
         HIP_TRY(scene->rayO.allocate(n));
@@ -1089,10 +1090,13 @@ int pathed_hip_scene_create_ex(const PathedSceneDesc *desc, const PathedSceneOpt
     configureTrace(scene);
     scene->bruteForce = scene->device.nTris <= kBruteForceMaxTris && scene->device.nSpheres <= kBruteForceMaxSpheres
         && options.intersector != 1 && !getenv("PATHED_NO_BRUTE_FORCE");
-    // BVH scenes: more slots = more rays per persistent wave to refill finished lanes from
-    // (ray cost is heavy-tailed); the all-triangles kernel has uniform cost and prefers the
-    // smaller, Infinity-Cache-resident state
-    scene->maxSlots = scene->bruteForce ? (1 << 20) : (1 << 22);
+    // BVH scenes: more slots = more rays per persistent wave to refill finished lanes from (ray cost is heavy-tailed) and
+    // fewer, longer launches: 8 Mi slots (1.3 GB of path state) against 4 Mi: +3.6 % on the teapot, +6.1 % on the 5.2 M-
+    // triangle mesh at >= 256 spp per call, 16 Mi +1 % / +7.6 %, 32 Mi less again (tools/slots_sweep.py); short calls want
+    // fewer (renderPass: at least 16 units per slot).  The all-triangles wavefront kernel has uniform cost and prefers the
+    // smaller, Infinity-Cache-resident state.
+    scene->maxSlots = scene->bruteForce ? (1 << 20) : (1 << 23);
+    scene->adaptiveSlots = !scene->bruteForce;
     // which kernels carry the radiance loop: scenes of <= 64 triangles default to the fused in-register path
     // kernel, everything else to the wavefront with the per-slot shade kernel (the staged shade kernel is
     // selectable: it issues fewer instructions but overlaps worse with the other pool's trace kernel)
@@ -1129,10 +1133,10 @@ int pathed_hip_scene_create_ex(const PathedSceneDesc *desc, const PathedSceneOpt
             }
         }
     }
-    if (options.max_slots >= kBlock) { scene->maxSlots = options.max_slots; }
+    if (options.max_slots >= kBlock) { scene->maxSlots = options.max_slots; scene->adaptiveSlots = false; }
     if (const char *slots = getenv("PATHED_MAX_SLOTS")) {
         const long value = atol(slots);
-        if (value >= kBlock) { scene->maxSlots = (int)value; }
+        if (value >= kBlock) { scene->maxSlots = (int)value; scene->adaptiveSlots = false; }
     }
     *out = scene;
     return PATHED_OK;
@@ -1389,6 +1393,14 @@ static int renderPass(PathedScene *scene, uint64_t seed, uint32_t begin, uint32_
     if (nUnits64 < 4ull * kBlock * (unsigned long long)pools) { pools = 1; }
 
     unsigned long long wanted = nUnits64 < (unsigned long long)scene->maxSlots ? nUnits64 : (unsigned long long)scene->maxSlots;
+    if (scene->adaptiveSlots) {
+        // a slot should render at least 16 units in a call, or the ramp-up and the drain of the pool outweigh its size
+        // (16 spp at 1024^2: 4 Mi slots 899, 8 Mi 794 Msamples/s on the teapot), but never fewer than 4 Mi
+        const unsigned long long floorSlots = 1ull << 22;
+        unsigned long long byWork = nUnits64 / 16ull;
+        if (byWork < floorSlots) { byWork = floorSlots; }
+        if (wanted > byWork) { wanted = byWork; }
+    }
     // a block of the staged shade kernel owns stageRounds x 256 slots: pools are whole blocks
     const unsigned long long slotQuantum = (unsigned long long)kBlock * (scene->stagedShade ? scene->stageRounds : 1);
     const int slotsPerPool = (int)((wanted / pools + slotQuantum - 1) / slotQuantum * slotQuantum);
