@@ -268,7 +268,9 @@ typedef struct PathedSceneOptions {
                                    state-sorted stages per block); 3 k_path_small (fused: whole paths in registers; scenes of
                                    <= 64 triangles only, their default)                          */
     int32_t stage_slots;        /* slots per block of the staged kernel: 512 or 1024 (0 = automatic)           */
-    int32_t reserved[3];        /* must be 0                                                   */
+    int32_t unit_order;         /* order work units are handed out in (scheduling only, results identical):
+                                 * 0 automatic = 1; 1 chunk stripes, rows; 2 chunk stripes, 32 x 8 tiles; 3 pixel tiles */
+    int32_t reserved[2];        /* must be 0                                                   */
 } PathedSceneOptions;
 int pathed_hip_scene_create_ex(const PathedSceneDesc *desc, const PathedSceneOptions *options, PathedScene **out);
 int pathed_hip_scene_device(const PathedScene *scene);   /* the HIP device the scene lives on, or a negative error */

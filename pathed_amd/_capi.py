@@ -150,7 +150,8 @@ class PathedSceneOptions(C.Structure):
         ("trace_blocks_per_cu", C.c_int32),
         ("shade_kernel", C.c_int32),
         ("stage_slots", C.c_int32),
-        ("reserved", C.c_int32 * 3),
+        ("unit_order", C.c_int32),
+        ("reserved", C.c_int32 * 2),
     ]
 
 

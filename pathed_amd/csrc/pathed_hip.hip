@@ -161,6 +161,7 @@ struct PathedScene {
     // render state, allocated on first use
     int nSlots = 0;               // capacity of the per-slot state buffers
     bool adaptiveSlots = false;   // BVH scenes without an explicit max_slots: short calls use fewer slots
+    int unitOrder = kOrderStripes;   // kernels.h: THE UNIT ORDER
     size_t chunkCapacity = 0;     // float4 entries of chunkBuf
     int samplesPerUnit = 1;       // "chunk": samples a slot sums before it publishes a partial (1 = the reference's summation order)
     int maxSlots = 1 << 20;
@@ -749,6 +750,16 @@ int pathed_hip_scene_device(const PathedScene *scene)
     return scene->deviceId;
 }
 
+static int unitOrderFromEnvironment(int fallback)
+{
+    if (const char *text = getenv("PATHED_UNIT_ORDER")) {   // experiments
+        if (!strcmp(text, "tiles")) { return kOrderTiles; }
+        if (!strcmp(text, "stripes-tiled")) { return kOrderStripesTiled; }
+        if (!strcmp(text, "stripes")) { return kOrderStripes; }
+    }
+    return fallback;
+}
+
 int pathed_hip_scene_create_ex(const PathedSceneDesc *desc, const PathedSceneOptions *optionsIn, PathedScene **out)
 {
     if (!out) { return fail(PATHED_E_INVALID, "out pointer is null"); }
@@ -761,9 +772,10 @@ int pathed_hip_scene_create_ex(const PathedSceneDesc *desc, const PathedSceneOpt
     if (optionsIn) {
         if (optionsIn->struct_size != sizeof(PathedSceneOptions)) { return fail(PATHED_E_INVALID, "PathedSceneOptions.struct_size mismatch"); }
         options = *optionsIn;
-        for (int k = 0; k < 3; k++) {
+        for (int k = 0; k < 2; k++) {
             if (options.reserved[k] != 0) { return fail(PATHED_E_INVALID, "PathedSceneOptions.reserved must be zero"); }
         }
+        if (options.unit_order < 0 || options.unit_order > 3) { return fail(PATHED_E_INVALID, "unit_order must be 0..3"); }
         if (options.bvh_builder < 0 || options.bvh_builder > PATHED_BVH_PLOC_DEVICE + 1) { return fail(PATHED_E_INVALID, "unknown BVH builder"); }
         if (options.pools < 0 || options.pools > kMaxPools) { return fail(PATHED_E_INVALID, "pools must be 0..4"); }
         if (options.stack_rows != 0 && options.stack_rows != 8 && options.stack_rows != 16 && options.stack_rows != 22) {
@@ -1133,6 +1145,7 @@ int pathed_hip_scene_create_ex(const PathedSceneDesc *desc, const PathedSceneOpt
             }
         }
     }
+    scene->unitOrder = unitOrderFromEnvironment(options.unit_order == 2 ? kOrderStripesTiled : options.unit_order == 3 ? kOrderTiles : kOrderStripes);
     if (options.max_slots >= kBlock) { scene->maxSlots = options.max_slots; scene->adaptiveSlots = false; }
     if (const char *slots = getenv("PATHED_MAX_SLOTS")) {
         const long value = atol(slots);
@@ -1152,22 +1165,8 @@ void pathed_hip_scene_destroy(PathedScene *scene)
 // ITEMS round-robin -- the chunks of the pass (stripes: an item is one whole image of units) or groups of kUnitGroup pixels
 // (tiles: an item is all chunks of the group) -- queue q of pool `pool` owns the items (q * pools + pool) + j * queues.
 // Returns false when the unit ids of the pass do not fit 32 bits.
-static int unitOrderFromEnvironment()
+static bool fillUnitOrder(RenderParams &q, int order, int width, int height, int chunksPerPixel, int pool, int pools, int nQueues)
 {
-    static int order = -1;
-    if (order < 0) {
-        order = kOrderStripes;
-        if (const char *text = getenv("PATHED_UNIT_ORDER")) {   // experiments
-            if (!strcmp(text, "tiles")) { order = kOrderTiles; }
-            else if (!strcmp(text, "stripes-tiled")) { order = kOrderStripesTiled; }
-        }
-    }
-    return order;
-}
-
-static bool fillUnitOrder(RenderParams &q, int width, int height, int chunksPerPixel, int pool, int pools, int nQueues)
-{
-    const int order = unitOrderFromEnvironment();
     const unsigned long long nPixels = (unsigned long long)width * (unsigned long long)height;
     const unsigned long long allQueues = (unsigned long long)nQueues * (unsigned long long)pools;
     unsigned long long items, itemUnits, lastItemShortfall = 0;
@@ -1246,7 +1245,7 @@ static int renderPassFused(PathedScene *scene, uint64_t seed, uint32_t begin, ui
     params.stats = scene->stats.ptr;
     params.accum = d_accum;
     params.nPixels = nPixels;
-    if (!fillUnitOrder(params, scene->width, scene->height, chunksPerPixel, 0, 1,
+    if (!fillUnitOrder(params, scene->unitOrder, scene->width, scene->height, chunksPerPixel, 0, 1,
                        (int)(waves < (unsigned int)kUnitQueues ? waves : (unsigned int)kUnitQueues))) {
         return fail(PATHED_E_INVALID, "too many work units in one pass");
     }
@@ -1336,7 +1335,7 @@ static int renderPassVolume(PathedScene *scene, uint64_t seed, uint32_t begin, u
     params.maxStack = scene->maxStack;
     params.accum = d_accum;
     params.nPixels = nPixels;
-    if (!fillUnitOrder(params, scene->width, scene->height, chunksPerPixel, 0, 1,
+    if (!fillUnitOrder(params, scene->unitOrder, scene->width, scene->height, chunksPerPixel, 0, 1,
                        (int)(waves < (unsigned int)kUnitQueues ? waves : (unsigned int)kUnitQueues))) {
         return fail(PATHED_E_INVALID, "too many work units in one pass");
     }
@@ -1455,7 +1454,7 @@ static int renderPass(PathedScene *scene, uint64_t seed, uint32_t begin, uint32_
         q.accum = d_accum;
         q.nSlots = slotsPerPool;
         q.nPixels = nPixels;
-        if (!fillUnitOrder(q, scene->width, scene->height, chunksPerPixel, h, pools, nQueues)) {
+        if (!fillUnitOrder(q, scene->unitOrder, scene->width, scene->height, chunksPerPixel, h, pools, nQueues)) {
             return fail(PATHED_E_INVALID, "too many work units in one pass");
         }
         q.chunk = chunk;

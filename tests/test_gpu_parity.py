@@ -300,6 +300,30 @@ def test_result_does_not_depend_on_scheduling_or_intersector_variant(libs):
         assert np.array_equal(glass_one, glass_several), pools
 
 
+@pytest.mark.parametrize("scene_path,width,height,spp", [
+    ("scenes/cornell.json", 97, 53, 7),          # fused kernel; ragged bands, blocks and last group
+    ("scenes/cornell-glass.json", 70, 41, 5),    # wavefront, two pools
+    ("scenes/teapot.json", 33, 19, 3),           # fewer chunks than queues: most queues are empty, blocks move on
+])
+def test_unit_orders_are_bit_identical(libs, scene_path, width, height, spp):
+    """Which slot renders which (pixel, chunk) unit, and when, is scheduling: chunk stripes (default), stripes walked in
+    32 x 8 tiles, pixel tiles, one or several samples per unit, any pool count -- the same floats (kernels.h: THE UNIT ORDER)."""
+    _, HipScene, LoadedScene = libs
+    scene = LoadedScene(scene_path, width, height)
+    expected = HipScene(scene.desc, device=0).render(3, 1, spp, 0, 8)
+    assert expected.any()
+    for options in ({"unit_order": "stripes-tiled"}, {"unit_order": "tiles"}, {"unit_order": "tiles", "pools": 1},
+                    {"unit_order": "tiles", "shade_kernel": "per-slot", "pools": 3},
+                    {"unit_order": "stripes-tiled", "shade_kernel": "staged"}, {"unit_order": "tiles", "shade_kernel": "staged", "max_slots": 4096}):
+        gpu = HipScene(scene.desc, device=0, **options)
+        assert np.array_equal(gpu.render(3, 1, spp, 0, 8), expected), options
+    coarse = HipScene(scene.desc, device=0)
+    coarse.set_samples_per_unit(3)           # ragged last unit
+    tiled = HipScene(scene.desc, device=0, unit_order="tiles", pools=1)
+    tiled.set_samples_per_unit(3)
+    assert np.array_equal(tiled.render(3, 1, spp, 0, 8), coarse.render(3, 1, spp, 0, 8))
+
+
 @pytest.mark.parametrize("scene_path,size,spp,last_bounce", [
     ("scenes/cornell.json", 96, 12, 10),            # all-triangles kernel, emitter hits, paths that run to lastBounce
     ("scenes/cornell-glass.json", 80, 8, 10),       # BVH walk, glass + Lambertian, parked rays
