@@ -48,10 +48,19 @@ struct DeviceBuffer {
 
     hipError_t allocate(size_t n)
     {
+        const bool report = getenv("PATHED_DEBUG_ALLOC") != nullptr && n * sizeof(T) >= ((size_t)1 << 28);
+        const auto t0 = std::chrono::steady_clock::now();
         release();
+        const auto t1 = std::chrono::steady_clock::now();
         count = n;
         if (n == 0) { return hipSuccess; }
-        return hipMalloc((void **)&ptr, n * sizeof(T));
+        const hipError_t status = hipMalloc((void **)&ptr, n * sizeof(T));
+        if (report) {
+            const auto t2 = std::chrono::steady_clock::now();
+            fprintf(stderr, "[pathed] device buffer of %.2f GB: hipFree of the old one %.3f s, hipMalloc %.3f s\n", (double)(n * sizeof(T)) / 1e9,
+                    std::chrono::duration<double>(t1 - t0).count(), std::chrono::duration<double>(t2 - t1).count());
+        }
+        return status;
     }
 
     hipError_t upload(const std::vector<T> &host)
@@ -371,9 +380,10 @@ int validate(const PathedSceneDesc *desc)
 // chunks (units per pixel) rendered per internal pass: bounds chunkBuf to 256 float4 per pixel (4.3 GB at 1024^2, 8.5 GB
 // at 1080p; further capped at 2^30 units).  Every pass pays the slot pool's ramp-up and drain once -- with one sample
 // per unit and the queues in step that is a few milliseconds on a BVH scene (256 against 1 024 units per pixel: -0.3 %
-// on Cornell and the 5.2 M-triangle mesh, -2.4 % on the teapot, tools/chunk_sweep2.py) -- and fresh VRAM costs the
-// process about 40 ms per GB the first time (tools/alloc_probe.py): a 17 GB buffer would add 0.7 s to a 2 s job.
-// PATHED_CHUNKS_PER_PASS overrides for experiments.
+// on Cornell, -1.8 % on the 5.2 M-triangle mesh, -4 % on the teapot with 8 Mi slots, tools/pass_length_sweep.sh) -- but
+// hipMalloc of a large buffer is not free here: 17 GB take 0.5 s, 1.0 s when another 17 GB were freed just before
+// (PATHED_DEBUG_ALLOC=1 prints it), which would add a quarter to a 2 s job.  PATHED_CHUNKS_PER_PASS overrides for
+// experiments and long-lived processes.
 const int kMaxChunksPerPass = 256;
 
 int ensureRenderState(PathedScene *scene, int nSlots, size_t chunkEntries)
