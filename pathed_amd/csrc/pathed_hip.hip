@@ -517,10 +517,12 @@ void configureTrace(PathedScene *scene)
 
     int blocksPerCu = (int)((160 * 1024) / (scene->traceLdsBytes ? scene->traceLdsBytes : 1));
     if (blocksPerCu > 8) { blocksPerCu = 8; }
-    // measured on MI355X (4-wide tree, 5.2M-triangle mesh / teapot, Msamples/s): with the other
-    // pool's k_shade sharing the CUs 3 blocks per CU are best (1325 / 1452; 4: 1219 / 1298;
-    // 5: 1192 / 1292); a single pool wants all five the LDS allows (1266 / 1316).
-    if (!scene->sceneInLds) { blocksPerCu = scene->pools > 1 ? (blocksPerCu < 3 ? blocksPerCu : 3) : (blocksPerCu < 5 ? blocksPerCu : 5); }
+    // measured on MI355X (4-wide tree; teapot / 5.2 M-triangle mesh / the same mesh filling the frame, Msamples/s, 8 Mi
+    // slots, queues in step): with the other pool's k_shade sharing the CUs TWO blocks per CU are best -- 1 786 / 2 172 /
+    // 1 417 against 1 725 / 2 093 / 1 378 with three (the round-1 optimum, when k_shade was the slower partner by less)
+    // and 1 411 / 1 829 / 1 106 with one: two 96-VGPR trace waves leave a SIMD room for THREE 104-VGPR k_shade waves.
+    // 448 .. 640 blocks are within 2 % (PATHED_TRACE_GRID).  A single pool wants at least four (tools/occupancy_sweep.sh).
+    if (!scene->sceneInLds) { blocksPerCu = scene->pools > 1 ? (blocksPerCu < 2 ? blocksPerCu : 2) : (blocksPerCu < 5 ? blocksPerCu : 5); }
     if (blocksPerCu < 1) { blocksPerCu = 1; }
     if (options.trace_blocks_per_cu >= 1 && options.trace_blocks_per_cu <= 16) { blocksPerCu = options.trace_blocks_per_cu; }
     if (const char *override = getenv("PATHED_TRACE_BLOCKS_PER_CU")) {
@@ -528,6 +530,10 @@ void configureTrace(PathedScene *scene)
         if (value >= 1 && value <= 16) { blocksPerCu = value; }
     }
     scene->traceGrid = scene->computeUnits * blocksPerCu;
+    if (const char *override = getenv("PATHED_TRACE_GRID")) {   // experiments: the persistent grid in blocks, any number
+        const int value = atoi(override);
+        if (value >= 1 && value <= scene->computeUnits * 16) { scene->traceGrid = value; }
+    }
     if (options.park_min_cards != 0) { scene->parkMinCards = options.park_min_cards < 0 ? 0 : (options.park_min_cards > 1024 ? 1024 : options.park_min_cards); }
     if (options.suspend_patience != 0) { scene->suspendPatience = options.suspend_patience < 0 ? 0 : (options.suspend_patience > 4096 ? 4096 : options.suspend_patience); }
     if (options.suspend_lanes != 0) { scene->suspendLanes = options.suspend_lanes < 0 ? 0 : (options.suspend_lanes > 64 ? 64 : options.suspend_lanes); }

@@ -1,6 +1,7 @@
-"""Register budgets the two-pool overlap depends on ("Two slot pools"): three 96-VGPR trace waves and
-two k_shade waves share a SIMD only while k_shade stays at 104 VGPRs or fewer; one register more cost 6-8 % on the
-mesh scenes every time it was tried (profiles/r1s2_ab_*.log).  Compile-only: hipcc reports the usage per kernel."""
+"""Register budgets the two-pool overlap depends on ("Two slot pools"): two 96-VGPR trace waves and
+three k_shade waves (round 1: three and two) share a SIMD only while k_shade stays at 104 VGPRs or fewer; one register
+more cost 6-8 % on the mesh scenes every time it was tried (profiles/r1s2_ab_*.log).  Compile-only: hipcc reports the
+usage per kernel."""
 import os
 import re
 import shutil
