@@ -162,10 +162,27 @@ def cpu_baseline(scene, args):
     oracle.render(args.width, args.height, args.seed, 1, spp, 0, args.last_bounce, threads=cores)
     elapsed = time.perf_counter() - t0
     samples = args.width * args.height * spp
+    # one thread on a 256 x 256 rendering of the same scene: the scalar rate the reference's per-core code is comparable to
+    from pathed_amd.scene import LoadedScene
+    small = LoadedScene(args.scene, 256, 256)
+    small_oracle = oracle_lib.OracleScene(small.desc)
+    t0 = time.perf_counter()
+    small_oracle.render(256, 256, args.seed, 0, 2, 0, args.last_bounce, threads=1)
+    single = time.perf_counter() - t0
+    model = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
     return {
         "value": samples / elapsed / 1e6,
         "unit": "Msamples/s",
         "cores": cores,
+        "cpu_model": model,
+        "single_thread": 256 * 256 * 2 / single / 1e6,
         "kind": "port",
         "sample": "%s %dx%d, %d spp, lastBounce %d, OpenMP over rows, %.1f s" % (
             args.scene, args.width, args.height, spp, args.last_bounce, elapsed),

@@ -527,7 +527,8 @@ __device__ inline f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a
 // u det >= 0, v det >= 0, (det - u - v) det >= 0, t det >= 0, taken as "not (min < 0)" so that -0,
 // underflow and NaN all err on the side of keeping the candidate; phase 2 decides.  Bits are shifted in
 // (cand = 2 cand + bit), so triangle k of a 32-triangle word ends up at bit 31 - (k & 31).
-__device__ __forceinline__ void smallCandidates(const f2 *pairRecords, int nTris, V3 origin, V3 direction, unsigned int *low, unsigned int *high)
+template <typename Records>   // const f2 * (kernarg: scalar loads) or an LDS-qualified pointer (k_path_volume: broadcast ds_read)
+__device__ __forceinline__ void smallCandidates(Records pairRecords, int nTris, V3 origin, V3 direction, unsigned int *low, unsigned int *high)
 {
     const int nPairs = (nTris + 1) / 2;
     unsigned int candidatesLow = 0, candidatesHigh = 0;
@@ -536,7 +537,7 @@ __device__ __forceinline__ void smallCandidates(const f2 *pairRecords, int nTris
     // one pair of triangles: returns (bit of a) * 2 + bit of b
     auto testPair = [&](int pair) -> unsigned int {
         // uniform index into the kernarg segment -> scalar loads, broadcast to the wave
-        const f2 *record = pairRecords + kSmallPairWords * pair;
+        const Records record = pairRecords + kSmallPairWords * pair;
         const f2 v0x = record[0], v0y = record[1], v0z = record[2];
         const f2 e1x = record[3], e1y = record[4], e1z = record[5];
         const f2 e2x = record[6], e2y = record[7], e2z = record[8];
@@ -2338,26 +2339,82 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_F
 }
 
 // ------------------------------------------------------------------------- volume path kernel
+// volumeQuery for scenes of <= kBruteForceMaxTris triangles: the all-triangles intersector (smallCandidates + a resolve
+// loop) with volumeAccept's rule instead of a per-lane walk of a tiny tree.  The pair records sit in LDS (every lane
+// reads the same address: a broadcast) because this is a real function with six call sites, and kernarg scalar loads
+// need the inlined address.  Same hits and events as volumeQuery: acceptance and the two nearest events do not depend
+// on the order primitives are met in; an occlusion query that is decided returns no events anybody reads.
+typedef const __attribute__((address_space(3))) f2 *LdsPairRecords;
+
+template <typename MaterialTable>
+__device__ __noinline__ bool volumeQuerySmall(const VolumeContext<MaterialTable> &c, LdsPairRecords pairRecords, int mode, V3 o, V3 d, float tfar,
+                                              RayHit *hit, VolumeEvents *eventsOut)
+{
+    LaneRay ray;
+    const bool anyHit = mode == kQueryVolumeOccluded;
+    laneRayInit(ray, o, d, PATHED_TNEAR, tfar, anyHit);
+    VolumeEvents events;
+    eventsClear(events);
+    unsigned int low = 0u, high = 0u;
+    smallCandidates(pairRecords, c.geometry.nTris, o, d, &low, &high);
+    bool decided = false;
+    while (__ballot((low | high) != 0u) != 0ull) {
+        if ((low | high) != 0u) {
+            int k;  // triangle k of a word is bit 31 - (k & 31): take the highest set bit first
+            if (low != 0u) { k = __clz((int)low); low &= ~(0x80000000u >> k); }
+            else { k = __clz((int)high); high &= ~(0x80000000u >> k); k += 32; }
+            const float4 t0 = c.geometry.tris[3 * k + 0];
+            const float4 t1 = c.geometry.tris[3 * k + 1];
+            const float4 t2 = c.geometry.tris[3 * k + 2];
+            float t, u, v;
+            if (intersectTriangle(ray.o, ray.d, v3(t0.x, t0.y, t0.z), v3(t1.x, t1.y, t1.z), v3(t2.x, t2.y, t2.z), &t, &u, &v)) {
+                if (volumeAccept(c, mode, ray, events, t, u, v, floatAsInt(t0.w))) { decided = true; low = 0u; high = 0u; }
+            }
+        }
+    }
+    if (!decided) {
+        for (int i = 0; i < c.geometry.nSpheres; i++) {
+            if (volumeSphere(c, mode, ray, events, i)) { break; }
+        }
+    }
+    if (mode == kQueryVolumeClosest) { eventsClip(events, ray.best); }
+    if (eventsOut) { *eventsOut = events; }
+    if (anyHit) { return ray.occluded; }
+    hit->t = ray.best;
+    hit->u = ray.bestU;
+    hit->v = ray.bestV;
+    hit->prim = ray.bestPrim;
+    return ray.bestPrim >= 0;
+}
+
+
 // k_path_volume: SampleIntegrator::samplePixel + VolumePathTracer::L (see volume.h), one path per lane, persistent waves,
 // work units as in k_path_small.  Arithmetic on a path's values follows the reference statement by statement; on a
 // scene without media the result is PathTracer's, bit for bit (the two share their direct-lighting arithmetic; GPU test).
-template <bool LDS_MATERIALS, int STACK>
-__global__ __launch_bounds__(kBlock) void k_path_volume(RenderParams p)
+template <bool LDS_MATERIALS, int STACK, bool SMALL>
+__global__ __launch_bounds__(kBlock) void k_path_volume(RenderParams p, SmallTris smallTris)
 {
     extern __shared__ float4 ldsRaw[];
-    // LDS: [STACK + 1][kBlock] traversal stack rows, then (LDS_MATERIALS) the material table
+    // LDS: [STACK + 1][kBlock] traversal stack rows, then (SMALL) the triangle pair records, then (LDS_MATERIALS) the material table
+    constexpr int kPairQuads = SMALL ? (int)(sizeof(SmallTris) / 16) : 0;
+    if (SMALL) {
+        const int *source = reinterpret_cast<const int *>(smallTris.data);
+        int *target = reinterpret_cast<int *>(ldsRaw + ((STACK + 1) * kBlock) / 4);
+        for (int i = threadIdx.x; i < (int)(sizeof(SmallTris) / 4); i += kBlock) { target[i] = source[i]; }
+    }
+    const LdsPairRecords pairRecords = (LdsPairRecords)(ldsRaw + ((STACK + 1) * kBlock) / 4);
     MaterialAccess<LDS_MATERIALS> materials;
     if (LDS_MATERIALS) {
-        float4 *table = ldsRaw + ((STACK + 1) * kBlock) / 4;
+        float4 *table = ldsRaw + ((STACK + 1) * kBlock) / 4 + kPairQuads;
         const int words = p.scene.nMaterials * (int)(sizeof(DMaterial) / 4);
         const int *source = reinterpret_cast<const int *>(p.scene.materials);
         int *target = reinterpret_cast<int *>(table);
         for (int i = threadIdx.x; i < words; i += kBlock) { target[i] = source[i]; }
-        __syncthreads();
         materials.table = reinterpret_cast<const DMaterial *>(table);
     } else {
         materials.table = p.scene.materials;
     }
+    if (SMALL || LDS_MATERIALS) { __syncthreads(); }
 
     const DScene &scene = p.scene;
     VolumeContext<MaterialAccess<LDS_MATERIALS>> context;
@@ -2412,6 +2469,12 @@ __global__ __launch_bounds__(kBlock) void k_path_volume(RenderParams p)
         return mine;
     };
 
+    // one ray query: the all-triangles intersector (SMALL) or the per-lane walk of the 4-wide tree
+    auto query = [&](int mode, V3 origin, V3 direction, float tfar, RayHit *hit, VolumeEvents *events) -> bool {
+        if constexpr (SMALL) { return volumeQuerySmall(context, pairRecords, mode, origin, direction, tfar, hit, events); }
+        else { return volumeQuery<STACK>(context, mode, origin, direction, tfar, hit, events); }
+    };
+
     // DirectLightingHelper::Ld, src/direct_lighting_helper.cpp:37-187
     auto directLighting = [&](const Isect &isect, int medium, const DMaterial &material, const BSDFSample &bsdfSample, Rng &random) -> Rgb {
         if (material.type == PATHED_MAT_PASSTHROUGH) { return rgb(0.f); }
@@ -2445,7 +2508,7 @@ __global__ __launch_bounds__(kBlock) void k_path_volume(RenderParams p)
                 const float lightDistance = length(lightDirection);
                 VolumeEvents events;
                 RayHit unused;
-                const bool occluded = volumeQuery<STACK>(context, kQueryVolumeOccluded, isect.point, wiWorld, lightDistance - 1e-3f, &unused, &events);
+                const bool occluded = query(kQueryVolumeOccluded, isect.point, wiWorld, lightDistance - 1e-3f, &unused, &events);
                 if (!occluded) {
                     const Rgb transmittance = rayTransmission(context.media, isect.point, wiWorld, events, medium);
                     float pdf;
@@ -2478,7 +2541,7 @@ __global__ __launch_bounds__(kBlock) void k_path_volume(RenderParams p)
         Rgb bsdfTerm = rgb(0.f);
         {
             RayHit bounceHit;
-            const bool found = volumeQuery<STACK>(context, kQueryVolumeClosest, isect.point, bsdfSample.wiWorld, PATHED_TFAR, &bounceHit, nullptr);
+            const bool found = query(kQueryVolumeClosest, isect.point, bsdfSample.wiWorld, PATHED_TFAR, &bounceHit, nullptr);
             if (found) {
                 const Isect bounce = makeIsect(scene, isect.point, bsdfSample.wiWorld,
                                                make_float4(bounceHit.t, bounceHit.u, bounceHit.v, intAsFloat(bounceHit.prim)));
@@ -2538,7 +2601,7 @@ __global__ __launch_bounds__(kBlock) void k_path_volume(RenderParams p)
         const float lightDistance = length(sampleDirection);
         VolumeEvents events;
         RayHit unused;
-        if (volumeQuery<STACK>(context, kQueryVolumeOccluded, samplePoint, wiWorld, lightDistance - 1e-3f, &unused, &events)) { return rgb(0.f); }
+        if (query(kQueryVolumeOccluded, samplePoint, wiWorld, lightDistance - 1e-3f, &unused, &events)) { return rgb(0.f); }
         float pdf;
         if (surfaceSample.solidAngle) {
             pdf = 1.f / invPDF;
@@ -2574,7 +2637,7 @@ __global__ __launch_bounds__(kBlock) void k_path_volume(RenderParams p)
 
         Rgb color = rgb(0.f);
         RayHit hit;
-        if (!volumeQuery<STACK>(context, kQueryRegular, rayOrigin, rayDirection, PATHED_TFAR, &hit, nullptr)) {
+        if (!query(kQueryRegular, rayOrigin, rayDirection, PATHED_TFAR, &hit, nullptr)) {
             return color + environmentL(scene, rayDirection);
         }
         Isect last = makeIsect(scene, rayOrigin, rayDirection, make_float4(hit.t, hit.u, hit.v, intAsFloat(hit.prim)));
@@ -2586,7 +2649,7 @@ __global__ __launch_bounds__(kBlock) void k_path_volume(RenderParams p)
                 // what is seen through the container, src/sample_integrator.cpp:35-51
                 VolumeEvents events;
                 RayHit through;
-                const bool found = volumeQuery<STACK>(context, kQueryVolumeClosest, rayOrigin, rayDirection, PATHED_TFAR, &through, &events);
+                const bool found = query(kQueryVolumeClosest, rayOrigin, rayDirection, PATHED_TFAR, &through, &events);
                 const Rgb transmittance = rayTransmission(context.media, rayOrigin, rayDirection, events, -1);
                 if (found) { color = color + matEmit(materials[primMaterial(context, through.prim)]) * transmittance; }
                 else { color = color + environmentL(scene, rayDirection) * transmittance; }
@@ -2609,7 +2672,7 @@ __global__ __launch_bounds__(kBlock) void k_path_volume(RenderParams p)
                 if (dot(last.normal, bsdfSample.wiWorld) < 0.f) { medium = context.primMedium[last.prim]; }
                 else { medium = -1; }
             }
-            if (!volumeQuery<STACK>(context, kQueryRegular, last.point, bsdfSample.wiWorld, PATHED_TFAR, &hit, nullptr)) { break; }
+            if (!query(kQueryRegular, last.point, bsdfSample.wiWorld, PATHED_TFAR, &hit, nullptr)) { break; }
             const Isect next = makeIsect(scene, last.point, bsdfSample.wiWorld, make_float4(hit.t, hit.u, hit.v, intAsFloat(hit.prim)));
             const float invPDF = 1.f / bsdfSample.pdf;
             const float cosTheta = fabsf(dot(last.shadingNormal, bsdfSample.wiWorld));

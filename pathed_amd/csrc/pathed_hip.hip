@@ -478,19 +478,22 @@ void launchShade(PathedScene *scene, const RenderParams &params, hipStream_t str
     }
 }
 
-template <int STACK>
-void launchVolumeStack(const RenderParams &params, dim3 grid, size_t lds, bool ldsMaterials, hipStream_t stream)
+template <int STACK, bool SMALL>
+void launchVolumeStack(const RenderParams &params, const SmallTris &smallTris, dim3 grid, size_t lds, bool ldsMaterials, hipStream_t stream)
 {
-    if (ldsMaterials) { hipLaunchKernelGGL((k_path_volume<true, STACK>), grid, dim3(kBlock), lds, stream, params); }
-    else { hipLaunchKernelGGL((k_path_volume<false, STACK>), grid, dim3(kBlock), lds, stream, params); }
+    if (ldsMaterials) { hipLaunchKernelGGL((k_path_volume<true, STACK, SMALL>), grid, dim3(kBlock), lds, stream, params, smallTris); }
+    else { hipLaunchKernelGGL((k_path_volume<false, STACK, SMALL>), grid, dim3(kBlock), lds, stream, params, smallTris); }
 }
 
-void launchVolume(int stackRows, const RenderParams &params, dim3 grid, size_t lds, bool ldsMaterials, hipStream_t stream)
+// small: the scene's triangles go through the all-triangles intersector (records staged in LDS), no tree walk
+void launchVolume(int stackRows, bool small, const RenderParams &params, const SmallTris &smallTris, dim3 grid, size_t lds, bool ldsMaterials,
+                  hipStream_t stream)
 {
+    if (small) { launchVolumeStack<8, true>(params, smallTris, grid, lds, ldsMaterials, stream); return; }
     switch (stackRows) {
-    case 8: launchVolumeStack<8>(params, grid, lds, ldsMaterials, stream); break;
-    case 16: launchVolumeStack<16>(params, grid, lds, ldsMaterials, stream); break;
-    default: launchVolumeStack<22>(params, grid, lds, ldsMaterials, stream); break;
+    case 8: launchVolumeStack<8, false>(params, smallTris, grid, lds, ldsMaterials, stream); break;
+    case 16: launchVolumeStack<16, false>(params, smallTris, grid, lds, ldsMaterials, stream); break;
+    default: launchVolumeStack<22, false>(params, smallTris, grid, lds, ldsMaterials, stream); break;
     }
 }
 
@@ -1331,7 +1334,9 @@ static int renderPassVolume(PathedScene *scene, uint64_t seed, uint32_t begin, u
     }
 
     const bool ldsMaterials = scene->device.nMaterials <= kMaxLdsMaterials;
-    const size_t lds = (size_t)(scene->stackRows + 1) * kBlock * sizeof(int) + (ldsMaterials ? (size_t)scene->device.nMaterials * sizeof(DMaterial) : 0);
+    const bool small = scene->bruteForce;   // <= 64 triangles, <= 16 spheres: the all-triangles intersector
+    const size_t lds = (size_t)((small ? 8 : scene->stackRows) + 1) * kBlock * sizeof(int) + (small ? sizeof(SmallTris) : 0)
+        + (ldsMaterials ? (size_t)scene->device.nMaterials * sizeof(DMaterial) : 0);
     unsigned long long blocks = (unsigned long long)scene->computeUnits * 2;   // the kernel's registers keep two blocks per CU resident
     const unsigned long long blocksNeeded = (nUnits64 + (unsigned long long)kBlock - 1) / kBlock;
     if (blocks > blocksNeeded) { blocks = blocksNeeded; }
@@ -1376,7 +1381,7 @@ static int renderPassVolume(PathedScene *scene, uint64_t seed, uint32_t begin, u
         timed = scene->traceEvents.acquire();
         (void)hipEventRecord(scene->traceEvents.start[timed], stream);
     }
-    launchVolume(scene->stackRows, params, grid, lds, ldsMaterials, stream);
+    launchVolume(scene->stackRows, small, params, scene->smallTris, grid, lds, ldsMaterials, stream);
     if (timed >= 0) { (void)hipEventRecord(scene->traceEvents.stop[timed], stream); }
     scene->traceLaunchesAll++;
     const dim3 pixelGrid((unsigned)((nPixels + kBlock - 1) / kBlock));
