@@ -2391,8 +2391,11 @@ __device__ __noinline__ bool volumeQuerySmall(const VolumeContext<MaterialTable>
 // k_path_volume: SampleIntegrator::samplePixel + VolumePathTracer::L (see volume.h), one path per lane, persistent waves,
 // work units as in k_path_small.  Arithmetic on a path's values follows the reference statement by statement; on a
 // scene without media the result is PathTracer's, bit for bit (the two share their direct-lighting arithmetic; GPU test).
+#ifndef PATHED_VOLUME_WAVES
+#define PATHED_VOLUME_WAVES 3   // 168 registers per lane + scratch; measured 2 / 3 / 4 / 5 waves: 476 / 527 / 517 / 401 (Cornell), 426 / 429 / 409 / 323 (cornell-medium), 301 / 368 / 388 / 383 (teapot) Msamples/s; without the attribute the all-triangles variant takes 260 registers and runs ONE wave
+#endif
 template <bool LDS_MATERIALS, int STACK, bool SMALL>
-__global__ __launch_bounds__(kBlock) void k_path_volume(RenderParams p, SmallTris smallTris)
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_VOLUME_WAVES, PATHED_VOLUME_WAVES))) void k_path_volume(RenderParams p, SmallTris smallTris)
 {
     extern __shared__ float4 ldsRaw[];
     // LDS: [STACK + 1][kBlock] traversal stack rows, then (SMALL) the triangle pair records, then (LDS_MATERIALS) the material table

@@ -1337,7 +1337,7 @@ static int renderPassVolume(PathedScene *scene, uint64_t seed, uint32_t begin, u
     const bool small = scene->bruteForce;   // <= 64 triangles, <= 16 spheres: the all-triangles intersector
     const size_t lds = (size_t)((small ? 8 : scene->stackRows) + 1) * kBlock * sizeof(int) + (small ? sizeof(SmallTris) : 0)
         + (ldsMaterials ? (size_t)scene->device.nMaterials * sizeof(DMaterial) : 0);
-    unsigned long long blocks = (unsigned long long)scene->computeUnits * 2;   // the kernel's registers keep two blocks per CU resident
+    unsigned long long blocks = (unsigned long long)scene->computeUnits * PATHED_VOLUME_WAVES;   // what the kernel's register budget keeps resident
     const unsigned long long blocksNeeded = (nUnits64 + (unsigned long long)kBlock - 1) / kBlock;
     if (blocks > blocksNeeded) { blocks = blocksNeeded; }
     if (blocks < 1) { blocks = 1; }
