@@ -527,8 +527,7 @@ __device__ inline f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a
 // u det >= 0, v det >= 0, (det - u - v) det >= 0, t det >= 0, taken as "not (min < 0)" so that -0,
 // underflow and NaN all err on the side of keeping the candidate; phase 2 decides.  Bits are shifted in
 // (cand = 2 cand + bit), so triangle k of a 32-triangle word ends up at bit 31 - (k & 31).
-template <typename Records>   // const f2 * (kernarg: scalar loads) or an LDS-qualified pointer (k_path_volume: broadcast ds_read)
-__device__ __forceinline__ void smallCandidates(Records pairRecords, int nTris, V3 origin, V3 direction, unsigned int *low, unsigned int *high)
+__device__ __forceinline__ void smallCandidates(const f2 *pairRecords, int nTris, V3 origin, V3 direction, unsigned int *low, unsigned int *high)
 {
     const int nPairs = (nTris + 1) / 2;
     unsigned int candidatesLow = 0, candidatesHigh = 0;
@@ -537,7 +536,7 @@ __device__ __forceinline__ void smallCandidates(Records pairRecords, int nTris, 
     // one pair of triangles: returns (bit of a) * 2 + bit of b
     auto testPair = [&](int pair) -> unsigned int {
         // uniform index into the kernarg segment -> scalar loads, broadcast to the wave
-        const Records record = pairRecords + kSmallPairWords * pair;
+        const f2 *record = pairRecords + kSmallPairWords * pair;
         const f2 v0x = record[0], v0y = record[1], v0z = record[2];
         const f2 e1x = record[3], e1y = record[4], e1z = record[5];
         const f2 e2x = record[6], e2y = record[7], e2z = record[8];
@@ -2339,16 +2338,14 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_F
 }
 
 // ------------------------------------------------------------------------- volume path kernel
-// volumeQuery for scenes of <= kBruteForceMaxTris triangles: the all-triangles intersector (smallCandidates + a resolve
-// loop) with volumeAccept's rule instead of a per-lane walk of a tiny tree.  The pair records sit in LDS (every lane
-// reads the same address: a broadcast) because this is a real function with six call sites, and kernarg scalar loads
-// need the inlined address.  Same hits and events as volumeQuery: acceptance and the two nearest events do not depend
-// on the order primitives are met in; an occlusion query that is decided returns no events anybody reads.
-typedef const __attribute__((address_space(3))) f2 *LdsPairRecords;
-
+// volumeQuery for scenes of <= kBruteForceMaxTris triangles: the all-triangles intersector (smallCandidates on the
+// kernarg pair records + a resolve loop) with volumeAccept's rule instead of a per-lane walk of a tiny tree.  Inlined at
+// its six call sites: as a real function it cost 40-60 % (call frames in scratch, records through LDS instead of scalar
+// loads).  Same hits and events as volumeQuery: acceptance and the two nearest events do not depend on the order
+// primitives are met in; an occlusion query that is decided returns no events anybody reads.
 template <typename MaterialTable>
-__device__ __noinline__ bool volumeQuerySmall(const VolumeContext<MaterialTable> &c, LdsPairRecords pairRecords, int mode, V3 o, V3 d, float tfar,
-                                              RayHit *hit, VolumeEvents *eventsOut)
+__device__ __forceinline__ bool volumeQuerySmall(const VolumeContext<MaterialTable> &c, const f2 *pairRecords, int mode, V3 o, V3 d, float tfar,
+                                                 RayHit *hit, VolumeEvents *eventsOut)
 {
     LaneRay ray;
     const bool anyHit = mode == kQueryVolumeOccluded;
@@ -2392,23 +2389,16 @@ __device__ __noinline__ bool volumeQuerySmall(const VolumeContext<MaterialTable>
 // work units as in k_path_small.  Arithmetic on a path's values follows the reference statement by statement; on a
 // scene without media the result is PathTracer's, bit for bit (the two share their direct-lighting arithmetic; GPU test).
 #ifndef PATHED_VOLUME_WAVES
-#define PATHED_VOLUME_WAVES 3   // 168 registers per lane + scratch; measured 2 / 3 / 4 / 5 waves: 476 / 527 / 517 / 401 (Cornell), 426 / 429 / 409 / 323 (cornell-medium), 301 / 368 / 388 / 383 (teapot) Msamples/s; without the attribute the all-triangles variant takes 260 registers and runs ONE wave
+#define PATHED_VOLUME_WAVES 4   // 128 registers per lane + scratch; 3 / 4 / 5 waves: 787 / 845 / 799 (Cornell), 732 / 787 / 707 (cornell-medium), 368 / 388 / 382 (teapot) Msamples/s; uncapped the kernel takes 220-260 registers and runs one or two waves
 #endif
 template <bool LDS_MATERIALS, int STACK, bool SMALL>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_VOLUME_WAVES, PATHED_VOLUME_WAVES))) void k_path_volume(RenderParams p, SmallTris smallTris)
 {
     extern __shared__ float4 ldsRaw[];
-    // LDS: [STACK + 1][kBlock] traversal stack rows, then (SMALL) the triangle pair records, then (LDS_MATERIALS) the material table
-    constexpr int kPairQuads = SMALL ? (int)(sizeof(SmallTris) / 16) : 0;
-    if (SMALL) {
-        const int *source = reinterpret_cast<const int *>(smallTris.data);
-        int *target = reinterpret_cast<int *>(ldsRaw + ((STACK + 1) * kBlock) / 4);
-        for (int i = threadIdx.x; i < (int)(sizeof(SmallTris) / 4); i += kBlock) { target[i] = source[i]; }
-    }
-    const LdsPairRecords pairRecords = (LdsPairRecords)(ldsRaw + ((STACK + 1) * kBlock) / 4);
+    // LDS: [STACK + 1][kBlock] traversal stack rows, then (LDS_MATERIALS) the material table
     MaterialAccess<LDS_MATERIALS> materials;
     if (LDS_MATERIALS) {
-        float4 *table = ldsRaw + ((STACK + 1) * kBlock) / 4 + kPairQuads;
+        float4 *table = ldsRaw + ((STACK + 1) * kBlock) / 4;
         const int words = p.scene.nMaterials * (int)(sizeof(DMaterial) / 4);
         const int *source = reinterpret_cast<const int *>(p.scene.materials);
         int *target = reinterpret_cast<int *>(table);
@@ -2417,7 +2407,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_V
     } else {
         materials.table = p.scene.materials;
     }
-    if (SMALL || LDS_MATERIALS) { __syncthreads(); }
+    if (LDS_MATERIALS) { __syncthreads(); }
 
     const DScene &scene = p.scene;
     VolumeContext<MaterialAccess<LDS_MATERIALS>> context;
@@ -2474,7 +2464,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_V
 
     // one ray query: the all-triangles intersector (SMALL) or the per-lane walk of the 4-wide tree
     auto query = [&](int mode, V3 origin, V3 direction, float tfar, RayHit *hit, VolumeEvents *events) -> bool {
-        if constexpr (SMALL) { return volumeQuerySmall(context, pairRecords, mode, origin, direction, tfar, hit, events); }
+        if constexpr (SMALL) { return volumeQuerySmall(context, (const f2 *)smallTris.data, mode, origin, direction, tfar, hit, events); }
         else { return volumeQuery<STACK>(context, mode, origin, direction, tfar, hit, events); }
     };
 

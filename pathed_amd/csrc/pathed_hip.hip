@@ -485,7 +485,7 @@ void launchVolumeStack(const RenderParams &params, const SmallTris &smallTris, d
     else { hipLaunchKernelGGL((k_path_volume<false, STACK, SMALL>), grid, dim3(kBlock), lds, stream, params, smallTris); }
 }
 
-// small: the scene's triangles go through the all-triangles intersector (records staged in LDS), no tree walk
+// small: the scene's triangles go through the all-triangles intersector (kernarg pair records), no tree walk
 void launchVolume(int stackRows, bool small, const RenderParams &params, const SmallTris &smallTris, dim3 grid, size_t lds, bool ldsMaterials,
                   hipStream_t stream)
 {
@@ -1335,7 +1335,7 @@ static int renderPassVolume(PathedScene *scene, uint64_t seed, uint32_t begin, u
 
     const bool ldsMaterials = scene->device.nMaterials <= kMaxLdsMaterials;
     const bool small = scene->bruteForce;   // <= 64 triangles, <= 16 spheres: the all-triangles intersector
-    const size_t lds = (size_t)((small ? 8 : scene->stackRows) + 1) * kBlock * sizeof(int) + (small ? sizeof(SmallTris) : 0)
+    const size_t lds = (size_t)((small ? 8 : scene->stackRows) + 1) * kBlock * sizeof(int)
         + (ldsMaterials ? (size_t)scene->device.nMaterials * sizeof(DMaterial) : 0);
     unsigned long long blocks = (unsigned long long)scene->computeUnits * PATHED_VOLUME_WAVES;   // what the kernel's register budget keeps resident
     const unsigned long long blocksNeeded = (nUnits64 + (unsigned long long)kBlock - 1) / kBlock;

@@ -113,7 +113,7 @@ __device__ inline bool volumeSphere(const VolumeContext<MaterialTable> &c, int m
 static const int kVolumeBlock = 256;   // threads per block of the volume kernel = the LDS stack's row stride (kernels.h: kBlock)
 
 template <int ROWS, typename MaterialTable>
-__device__ __noinline__ bool volumeQuery(const VolumeContext<MaterialTable> &c, int mode, V3 o, V3 d, float tfar,
+__device__ __forceinline__ bool volumeQuery(const VolumeContext<MaterialTable> &c, int mode, V3 o, V3 d, float tfar,
                                          RayHit *hit, VolumeEvents *eventsOut)
 {
     LaneRay ray;
