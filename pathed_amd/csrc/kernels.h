@@ -1194,8 +1194,13 @@ struct MaterialAccess {
     __device__ inline const DMaterial &operator[](int index) const { return table[index]; }
 };
 
+#ifdef PATHED_SHADE_WAVES   // experiments: cap k_shade's registers for this many waves per SIMD
+#define PATHED_SHADE_ATTRIBUTE __attribute__((amdgpu_waves_per_eu(PATHED_SHADE_WAVES, PATHED_SHADE_WAVES)))
+#else
+#define PATHED_SHADE_ATTRIBUTE
+#endif
 template <bool LDS_MATERIALS>
-__global__ __launch_bounds__(kBlock) void k_shade(RenderParams p)
+__global__ __launch_bounds__(kBlock) PATHED_SHADE_ATTRIBUTE void k_shade(RenderParams p)
 {
     __shared__ DMaterial ldsMaterials[LDS_MATERIALS ? kMaxLdsMaterials : 1];
     __shared__ unsigned int scratch[kWavesPerBlock + 1];
