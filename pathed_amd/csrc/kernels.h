@@ -2473,8 +2473,16 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_V
         else { return volumeQuery<STACK>(context, mode, origin, direction, tfar, hit, events); }
     };
 
+    // The reference traces the ray (vertex, BSDF sample) twice: directSampleBSDF asks for the nearest NON-container surface
+    // (testVolumetricIntersect) and the path's next segment for the nearest surface of any kind (testIntersect).  One
+    // traversal answers both: the volumetric query also records the nearest container it skipped (VolumeEvents).
+    RayHit segmentHit;
+    segmentHit.t = 0.f; segmentHit.u = 0.f; segmentHit.v = 0.f; segmentHit.prim = -1;
+    bool segmentFound = false, segmentKnown = false;
+
     // DirectLightingHelper::Ld, src/direct_lighting_helper.cpp:37-187
     auto directLighting = [&](const Isect &isect, int medium, const DMaterial &material, const BSDFSample &bsdfSample, Rng &random) -> Rgb {
+        segmentKnown = false;
         if (material.type == PATHED_MAT_PASSTHROUGH) { return rgb(0.f); }
         if (!isBlack(matEmit(material))) { return rgb(0.f); }
         Rgb result = rgb(0.f);
@@ -2539,7 +2547,20 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_V
         Rgb bsdfTerm = rgb(0.f);
         {
             RayHit bounceHit;
-            const bool found = query(kQueryVolumeClosest, isect.point, bsdfSample.wiWorld, PATHED_TFAR, &bounceHit, nullptr);
+            VolumeEvents skipped;
+            const bool found = query(kQueryVolumeClosest, isect.point, bsdfSample.wiWorld, PATHED_TFAR, &bounceHit, &skipped);
+            segmentHit = bounceHit;
+            segmentFound = found;
+            if (skipped.containerPrim >= 0) {
+                const bool nearer = !found || skipped.containerT < bounceHit.t
+                    || (skipped.containerT == bounceHit.t && skipped.containerPrim < bounceHit.prim);
+                if (nearer) {
+                    segmentHit.t = skipped.containerT; segmentHit.u = skipped.containerU; segmentHit.v = skipped.containerV;
+                    segmentHit.prim = skipped.containerPrim;
+                    segmentFound = true;
+                }
+            }
+            segmentKnown = true;
             if (found) {
                 const Isect bounce = makeIsect(scene, isect.point, bsdfSample.wiWorld,
                                                make_float4(bounceHit.t, bounceHit.u, bounceHit.v, intAsFloat(bounceHit.prim)));
@@ -2622,6 +2643,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_V
 
     // one camera sample: SampleIntegrator::samplePixel, src/sample_integrator.cpp:10-78
     auto samplePixel = [&](uint32_t pixel, uint32_t sample) -> Rgb {
+        segmentKnown = false;
         Rng random;
         makeKey(seed, pixel, sample, &random.k0, &random.k1);
         random.dimension = 0;
@@ -2670,7 +2692,13 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_V
                 if (dot(last.normal, bsdfSample.wiWorld) < 0.f) { medium = context.primMedium[last.prim]; }
                 else { medium = -1; }
             }
-            if (!query(kQueryRegular, last.point, bsdfSample.wiWorld, PATHED_TFAR, &hit, nullptr)) { break; }
+            if (segmentKnown) {
+                segmentKnown = false;
+                if (!segmentFound) { break; }
+                hit = segmentHit;
+            } else if (!query(kQueryRegular, last.point, bsdfSample.wiWorld, PATHED_TFAR, &hit, nullptr)) {
+                break;
+            }
             const Isect next = makeIsect(scene, last.point, bsdfSample.wiWorld, make_float4(hit.t, hit.u, hit.v, intAsFloat(hit.prim)));
             const float invPDF = 1.f / bsdfSample.pdf;
             const float cosTheta = fabsf(dot(last.shadingNormal, bsdfSample.wiWorld));

@@ -30,9 +30,17 @@ struct VolumeEvents {
     float t0, t1;
     int m0, m1;
     int count;   // 0, 1 or 2
+    // the nearest CONTAINER surface a volumetric closest-hit query skipped: with it the same traversal also answers the
+    // regular query on that ray (Scene::testIntersect sees containers), which the path's next segment asks for
+    float containerT, containerU, containerV;
+    int containerPrim;   // -1: none
 };
 
-__device__ inline void eventsClear(VolumeEvents &e) { e.t0 = 0.f; e.t1 = 0.f; e.m0 = -1; e.m1 = -1; e.count = 0; }
+__device__ inline void eventsClear(VolumeEvents &e)
+{
+    e.t0 = 0.f; e.t1 = 0.f; e.m0 = -1; e.m1 = -1; e.count = 0;
+    e.containerT = 0.f; e.containerU = 0.f; e.containerV = 0.f; e.containerPrim = -1;
+}
 
 __device__ inline void eventsAdd(VolumeEvents &e, float t, int medium)
 {
@@ -87,6 +95,13 @@ __device__ inline bool volumeAccept(const VolumeContext<MaterialTable> &c, int m
     if (!(t > ray.tnear)) { return false; }
     if (mode != kQueryRegular && containerPrim(c, prim)) {
         if (mode == kQueryVolumeClosest || t <= ray.tfar) { eventsAdd(events, t, c.primMedium[prim]); }
+        if (mode == kQueryVolumeClosest) {
+            // the regular query's acceptance rule, over the containers only
+            const bool closer = (events.containerPrim < 0)
+                ? (t <= ray.tfar)
+                : (t < events.containerT || (t == events.containerT && prim < events.containerPrim));
+            if (closer) { events.containerT = t; events.containerU = u; events.containerV = v; events.containerPrim = prim; }
+        }
         return false;
     }
     if (ray.anyHit) {
