@@ -213,7 +213,8 @@ typedef struct PathedStats {
     uint32_t trace_launches_all;   /* trace launches since reset_stats, timed or not (trace_launches counts the timed ones) */
     uint32_t path_kernel;          /* 1 wavefront with the per-slot shade kernel, 2 wavefront with the staged shade kernel,
                                       3 fused path kernel (tiny scenes: one persistent launch per pass, timed as trace_ms),
-                                      4 volume path kernel (PATHED_INTEGRATOR_VOLUME_PATH_TRACER)                        */
+                                      4 volume path kernel (PATHED_INTEGRATOR_VOLUME_PATH_TRACER),
+                                      5 wavefront with the split shade stage (k_vertex + k_regen over the trace kernel's lists) */
     uint32_t reserved0;
 } PathedStats;
 
@@ -266,7 +267,8 @@ typedef struct PathedSceneOptions {
     int32_t trace_blocks_per_cu;/* persistent trace blocks per CU (0 = automatic)              */
     int32_t shade_kernel;       /* 0 automatic; 1 wavefront, k_shade (one lane per slot); 2 wavefront, k_shade_staged (dense,
                                    state-sorted stages per block); 3 k_path_small (fused: whole paths in registers; scenes of
-                                   <= 64 triangles only, their default)                          */
+                                   <= 64 triangles only, their default); 4 wavefront, k_vertex + k_regen over the hit / miss
+                                   lists the trace kernel writes (BVH scenes only) */
     int32_t stage_slots;        /* slots per block of the staged kernel: 512 or 1024 (0 = automatic)           */
     int32_t unit_order;         /* order work units are handed out in (scheduling only, results identical):
                                  * 0 automatic = 1; 1 chunk stripes, rows; 2 chunk stripes, 32 x 8 tiles; 3 pixel tiles */

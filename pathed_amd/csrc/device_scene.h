@@ -30,6 +30,7 @@ static_assert(sizeof(DMaterial) == 96, "DMaterial is staged in LDS as 24 words")
 //   q0 = (p0, material)  q1 = (p1, uv0.u)  q2 = (p2, uv0.v)
 //   q3 = (n0, uv1.u)     q4 = (n1, uv1.v)  q5 = (n2, uv2.u)  q6 = (uv2.v, -, -, -)  q7 = pad
 static const int kTriShadeQuads = 8;
+static const int kMaxPlainRanges = 8;
 
 struct DSphere {
     float centerWorld[3];
@@ -86,6 +87,11 @@ struct DScene {
 
     // shading
     const float4 *triShade;    // kTriShadeQuads x float4 per original primitive
+    const float4 *triCompact;  // one float4 per original primitive: (geometric normal, material); valid for the primitives of the plain ranges
+    // primitive-id ranges [begin, end) made of triangles without vertex normals and uvs ("plain": shaded from triCompact
+    // alone).  Whole meshes, merged when adjacent; a scene with more ranges than fit keeps the first kMaxPlainRanges.
+    int plainBegin[8], plainEnd[8];
+    int nPlainRanges;
     const DMaterial *materials;
     int nMaterials;
     const DLight *lights;

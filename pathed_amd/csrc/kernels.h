@@ -81,7 +81,20 @@ static const int kCtrUnitCursor = kCursorStride;                                
 static const int kTraceShards = 32;
 static const int kCtrTraceCursor = kCtrUnitCursor + kUnitQueues * kCursorStride;  // + shard * kCursorStride: next card (rewound by k_shade)
 static const int kCtrShadowCount = kCtrTraceCursor + kTraceShards * kCursorStride;  // + parity * kCursorStride: length of the shadow-ray list
-static const int kCtrCount = kCtrShadowCount + 2 * kCursorStride;
+// The split shade stage (k_vertex + k_regen) works from lists the PRODUCER of a result writes: k_trace appends the slot of
+// every finished closest-hit ray to the HIT list or the MISS list, k_vertex appends the slots whose sample ended at the
+// vertex to the miss list as well (flagged kEntryColorReady).  A list is made of 64-entry blocks; a wave collects entries
+// in LDS and writes one block at a time, its number drawn from one of kListShards cursors (block = ticket * shards +
+// shard, the shard advancing with every block so the cursors stay level): one atomic per 64 entries, no line shared.
+static const int kListShards = 32;
+static const int kListHit = 0, kListMiss = 1;
+static const int kCtrListCount = kCtrShadowCount + 2 * kCursorStride;                   // + ((list * 2 + parity) * kListShards + shard) * kCursorStride
+static const int kCtrDeferred = kCtrListCount + 2 * 2 * kListShards * kCursorStride;    // + (list * 2 + parity) * kCursorStride: slots waiting for a parked shadow ray
+static const int kCtrCount = kCtrDeferred + 2 * 2 * kCursorStride;
+static const unsigned int kEntryInvalid = 0xFFFFFFFFu;      // padding of a partly filled list block
+static const unsigned int kEntryColorReady = 0x40000000u;   // miss-list entry written by k_vertex: the sample's colour is in res.rgb
+static const unsigned int kEntrySlotBits = 0x3FFFFFFFu;
+static const unsigned int kListPending = 0x80000000u;       // k_trace, bit of a lane's `target`: the finished ray's slot has yet to join its list
 #ifndef PATHED_CARD_ROUNDS
 #define PATHED_CARD_ROUNDS 2
 #endif
@@ -144,6 +157,10 @@ struct PathState {
     float4 *shO;    // shadow rays, one dense list per iteration: origin.xyz, tfar
     float4 *shD;    //                                             direction.xyz, bits(slot)
     float4 *chunkBuf;                // one partial sum per unit, index = chunk * nPixels + pixel (partialIndex)
+    // split shade stage: the hit / miss lists (64-entry blocks, kListShards x listCap of them each) and, per list and
+    // parity, the dense list of slots whose shading waits for a parked shadow ray
+    unsigned int *lists[2];
+    unsigned int *deferred[2][2];
 };
 
 struct RenderParams {
@@ -159,6 +176,7 @@ struct RenderParams {
     int suspendPatience;              // ... and the wave has run this many steps since its last card
     int parkMinCardsPerWave;          // ... and the pool still has this many cards' worth of live slots per wave
     int parity;                       // iteration & 1: k_shade(n) fills shadow list n & 1, k_trace(n) consumes list (n - 1) & 1
+    unsigned int listCap;             // split shade stage: list blocks per shard (a list holds kListShards * listCap blocks)
     float *accum;          // 3*W*H radiance sums, index 3*(row*W+col)+c
     int nSlots;            // multiple of kBlock
     int nPixels;
@@ -194,6 +212,120 @@ __device__ inline bool checkCounts(int startBounce, int lastBounce, int bounce)
     return !checkDone(lastBounce, bounce);
 }
 
+// ------------------------------------------------------------------------- slot lists (split shade stage)
+
+__device__ inline unsigned int laneRank(unsigned long long mask)   // set bits of `mask` below this lane
+{
+    return __builtin_amdgcn_mbcnt_hi((unsigned int)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)mask, 0u));
+}
+
+// One wave's end of a slot list: entries collect in `buffer` (128 words of LDS owned by the wave) and leave 64 at a time
+// as one block.  All of a writer's state is ONE wave-uniform count: the trace kernel lives at its register limit, and every
+// value the list code keeps alive across the traversal loop is a spill reload inside it (measured: +45 % on the kernel
+// with two writers of five words each, against +3 % with a count each).  The cursor a block's number is drawn from is picked
+// from the shader clock: nothing to carry along, and the shards stay level to a few per cent, which is all the consumers
+// need (they walk max-over-shards blocks per shard).
+struct ListWriter {
+    unsigned int *buffer;
+    unsigned int count;        // entries waiting in the buffer, < 64 between calls
+};
+
+__device__ inline void listWriterInit(ListWriter &w, unsigned int *buffer)
+{
+    w.buffer = buffer;
+    w.count = 0u;
+}
+
+// Writes the first min(count, 64) buffered entries as one block (padded with kEntryInvalid).  The list has room for every
+// slot once plus one partly filled block per writing wave and every shard takes its share of that (listCap has slack), so a
+// shard with room is found at once; the loop is bounded anyway.
+__device__ inline void listFlush(ListWriter &w, const RenderParams &p, int list)
+{
+    const unsigned int lane = threadIdx.x & 63u;
+    unsigned int *cursors = p.counters + kCtrListCount + (list * 2 + p.parity) * kListShards * kCursorStride;
+    __builtin_amdgcn_wave_barrier();
+    unsigned int shard = ((unsigned int)__builtin_amdgcn_s_memtime() >> 5) % (unsigned int)kListShards;
+    unsigned int ticket = 0u, shardUsed = 0u;
+    bool placed = false;
+    for (int attempt = 0; attempt < 2 * kListShards && !placed; attempt++) {
+        if (lane == 0u) { ticket = atomicAdd(&cursors[shard * kCursorStride], 1u); }
+        ticket = (unsigned int)__builtin_amdgcn_readfirstlane((int)ticket);
+        shardUsed = shard;
+        shard = (shard + 1u) % (unsigned int)kListShards;
+        placed = ticket < p.listCap;
+    }
+    const unsigned int head = lane < w.count ? w.buffer[lane] : kEntryInvalid;
+    const unsigned int rest = w.buffer[64u + lane];
+    if (placed) { p.state.lists[list][((size_t)ticket * kListShards + shardUsed) * 64u + lane] = head; }
+    __builtin_amdgcn_wave_barrier();
+    w.buffer[lane] = rest;
+    __builtin_amdgcn_wave_barrier();
+    w.count = w.count > 64u ? w.count - 64u : 0u;
+}
+
+// Call from wave-uniform control flow; `value` of the lanes with `want` joins the list.
+__device__ inline void listAppend(ListWriter &w, const RenderParams &p, int list, bool want, unsigned int value)
+{
+    const unsigned long long mask = __ballot(want);
+    if (mask == 0ull) { return; }
+    if (want) { w.buffer[w.count + laneRank(mask)] = value; }
+    w.count = (unsigned int)__builtin_amdgcn_readfirstlane((int)(w.count + (unsigned int)__popcll(mask)));
+    if (w.count >= 64u) { listFlush(w, p, list); }
+}
+
+// A list as its consumer sees it: item i of the first `blocks * 64` is entry i of the block list (invalid beyond a shard's
+// count), the items after that are the deferred slots.  Block-uniform; `shardCounts` is kListShards + 1 words of LDS.
+struct ListReader {
+    const unsigned int *list;
+    const unsigned int *deferred;
+    unsigned int *shardCounts;
+    unsigned int blocks;          // kListShards * (most blocks any shard holds)
+    unsigned int deferredCount;
+    unsigned int items;           // blocks * 64 + deferredCount
+};
+
+__device__ inline void listReaderInit(ListReader &r, unsigned int *shardCounts, const RenderParams &p, int list, int parity)
+{
+    r.list = p.state.lists[list];
+    r.deferred = p.state.deferred[list][parity];
+    r.shardCounts = shardCounts;
+    if (threadIdx.x == 0) { shardCounts[kListShards] = 0u; }
+    __syncthreads();
+    if (threadIdx.x < kListShards) {
+        const unsigned int written = p.counters[kCtrListCount + ((list * 2 + parity) * kListShards + threadIdx.x) * kCursorStride];
+        const unsigned int count = written < p.listCap ? written : p.listCap;
+        shardCounts[threadIdx.x] = count;
+        atomicMax(&shardCounts[kListShards], count);
+    }
+    __syncthreads();
+    r.blocks = shardCounts[kListShards] * (unsigned int)kListShards;
+    r.deferredCount = p.counters[kCtrDeferred + (list * 2 + parity) * kCursorStride];
+    r.items = r.blocks * 64u + r.deferredCount;
+}
+
+__device__ inline unsigned int listEntry(const ListReader &r, unsigned int item)
+{
+    if (item < r.blocks * 64u) {
+        const unsigned int block = item >> 6;
+        const unsigned int shard = block % (unsigned int)kListShards, ticket = block / (unsigned int)kListShards;
+        return ticket < r.shardCounts[shard] ? r.list[item] : kEntryInvalid;
+    }
+    return item < r.items ? r.deferred[item - r.blocks * 64u] : kEntryInvalid;
+}
+
+// A slot whose shading has to wait for its parked shadow ray joins the list the next iteration's kernel reads.
+__device__ inline void deferSlot(const RenderParams &p, int list, bool defer, unsigned int slot)
+{
+    const unsigned long long mask = __ballot(defer);
+    if (mask == 0ull) { return; }
+    unsigned int base = 0u;
+    if ((threadIdx.x & 63u) == (unsigned int)(__ffsll((long long)mask) - 1)) {
+        base = atomicAdd(&p.counters[kCtrDeferred + (list * 2 + (p.parity ^ 1)) * kCursorStride], (unsigned int)__popcll(mask));
+    }
+    base = (unsigned int)__shfl((int)base, __ffsll((long long)mask) - 1, 64);
+    if (defer) { p.state.deferred[list][p.parity ^ 1][base + laneRank(mask)] = slot; }
+}
+
 // ------------------------------------------------------------------------- trace
 
 // amdgpu_waves_per_eu(5, 5) caps the kernel at 96 VGPRs: the trace waves resident on a SIMD
@@ -202,13 +334,19 @@ __device__ inline bool checkCounts(int startBounce, int lastBounce, int bounce)
 #ifndef PATHED_TRACE_WAVES
 #define PATHED_TRACE_WAVES 5
 #endif
+#ifndef PATHED_EXP_LISTS_ONLY
+#define PATHED_EXP_LISTS_ONLY 0   // experiment builds: 1 = the trace kernel writes its lists, the per-slot k_shade shades (and ignores them)
+#endif
 
-template <int STACK, bool LDS_SCENE, bool COUNT>
+// LISTS: the split shade stage follows.  The slot of every closest-hit ray that finishes joins the hit list or the miss
+// list (see kCtrListCount); a miss writes no hit record; a closest-hit ray that is parked puts its slot on hold itself
+// (no shade kernel visits a slot that is on no list).
+template <int STACK, bool LDS_SCENE, bool COUNT, bool LISTS>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_TRACE_WAVES, PATHED_TRACE_WAVES))) void k_trace(RenderParams p)
 {
     extern __shared__ float4 ldsRaw[];
     // LDS: [STACK + 1][kBlock] traversal stack rows (the last one is scratch), then 2 x kBlock
-    // float4 of ray staging, then (LDS_SCENE) the tree
+    // float4 of ray staging, then (LISTS) 2 x 128 words per wave of list entries, then (LDS_SCENE) the tree
     LaneStack stack;
     stack.lds = reinterpret_cast<int *>(ldsRaw) + threadIdx.x;
     stack.overflowStride = (size_t)gridDim.x * kBlock;
@@ -225,9 +363,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_T
     float4 *stageO = ldsRaw + ((STACK + 1) * kBlock) / 4 + (threadIdx.x >> 6) * kCard;  // this wave's kCard entries
     float4 *stageD = stageO + kBlock * kCardRounds;
 
+    constexpr int kListQuads = LISTS ? kWavesPerBlock * 2 * 128 / 4 : 0;   // float4 units
     if (LDS_SCENE) {
         // small scenes: the whole BVH + leaf triangles are staged in LDS once per block
-        float4 *ldsNodes = ldsRaw + ((STACK + 1) * kBlock) / 4 + 2 * kBlock * kCardRounds;
+        float4 *ldsNodes = ldsRaw + ((STACK + 1) * kBlock) / 4 + 2 * kBlock * kCardRounds + kListQuads;
         float4 *ldsTris = ldsNodes + 8 * p.scene.nNodes;
         for (int i = threadIdx.x; i < 8 * p.scene.nNodes; i += kBlock) { ldsNodes[i] = p.scene.nodes[i]; }
         for (int i = threadIdx.x; i < 3 * p.scene.nTris; i += kBlock) { ldsTris[i] = p.scene.leafTris[i]; }
@@ -238,6 +377,25 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_T
 
     const int lane = threadIdx.x & 63;
     const unsigned int waveId = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+
+    ListWriter hitWriter, missWriter;
+    listWriterInit(hitWriter, nullptr);
+    listWriterInit(missWriter, nullptr);
+    if (LISTS) {
+        unsigned int *listBuffers = reinterpret_cast<unsigned int *>(ldsRaw + ((STACK + 1) * kBlock) / 4 + 2 * kBlock * kCardRounds)
+            + (threadIdx.x >> 6) * 256;
+        listWriterInit(hitWriter, listBuffers);
+        listWriterInit(missWriter, listBuffers + 128);
+        // the cursors of the other parity are the next trace launch's (and the deferred lists of that parity the ones the
+        // shade stage after THIS launch appends to): nobody uses them while this launch runs
+        if (blockIdx.x == 0) {
+            for (int i = threadIdx.x; i < 2 * kListShards; i += kBlock) {
+                const int list = i / kListShards, shard = i % kListShards;
+                p.counters[kCtrListCount + ((list * 2 + (p.parity ^ 1)) * kListShards + shard) * kCursorStride] = 0u;
+            }
+            if (threadIdx.x < 2) { p.counters[kCtrDeferred + (threadIdx.x * 2 + (p.parity ^ 1)) * kCursorStride] = 0u; }
+        }
+    }
 
     // Ray pool of this launch: item i < nSlots is the closest-hit ray of slot i; item
     // nSlots + j is entry j of the shadow-ray list the previous k_shade compacted.
@@ -360,6 +518,15 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_T
     while (true) {
         unsigned long long stamp = 0;
         if (COUNT) { stamp = __builtin_amdgcn_s_memtime(); }
+        if (LISTS) {
+            // the closest-hit rays that finished in the last burst: their lanes are idle and still hold slot and result
+            const bool finished = (target & kListPending) != 0u;
+            if (__ballot(finished) != 0ull) {
+                target &= ~kListPending;
+                listAppend(hitWriter, p, kListHit, finished && ray.bestPrim >= 0, target);
+                listAppend(missWriter, p, kListMiss, finished && ray.bestPrim < 0, target);
+            }
+        }
         while (true) {
             const unsigned long long idleMask = __ballot(!active);
             if (idleMask == 0ull) { break; }
@@ -428,7 +595,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_T
                 if (ray.anyHit) {
                     if (ray.occluded) { p.state.pend[target] = make_float4(0.f, 0.f, 0.f, 0.f); }
                     else if (restored) { reinterpret_cast<int *>(p.state.pend + target)[3] = 0; }
-                } else {
+                } else if (!LISTS || PATHED_EXP_LISTS_ONLY || ray.bestPrim >= 0) {
                     p.state.hit[target] = make_float4(ray.best, ray.bestU, ray.bestV, intAsFloat(ray.bestPrim));
                 }
                 if (COUNT) {
@@ -436,6 +603,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_T
                     maxBoxes = delta > maxBoxes ? delta : maxBoxes;
                 }
                 active = false;
+                // the slot joins its list when the burst is over (kListPending): no list code inside this loop
+                if (LISTS && !ray.anyHit) { target |= kListPending; }
             }
             const unsigned long long activeMask = __ballot(active);
             if (activeMask == 0ull) { break; }
@@ -460,6 +629,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_T
                     save[17 * 64] = COUNT ? (int)(counters.boxes - rayBoxesStart) : 0;
                     for (int k = 0; k < ray.sp; k++) { save[(kSaveWords + k) * 64] = stackRead<STACK, kBlock>(stack, k); }
                     if (ray.anyHit) { reinterpret_cast<int *>(p.state.pend + target)[3] = kShadowSuspended; }
+                    else if (LISTS) { reinterpret_cast<int *>(p.state.rayD + target)[3] |= kStHold; }
                     else { reinterpret_cast<int *>(p.state.hit + target)[3] = kPrimSuspended; }
                     active = false;
                 }
@@ -470,6 +640,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_T
         }
     }
     if (p.suspendLanes > 0 && lane == 0) { p.suspendMask[waveId] = parkedMask; }
+    if (LISTS) {
+        if (hitWriter.count != 0u) { listFlush(hitWriter, p, kListHit); }
+        if (missWriter.count != 0u) { listFlush(missWriter, p, kListMiss); }
+    }
 
     if (COUNT) {
         atomicAdd(&p.stats[kStatBoxes], (unsigned long long)counters.boxes);
@@ -811,6 +985,9 @@ __device__ inline TriShade loadTriCorners(const DScene &scene, int prim)
     return tri;
 }
 
+// Ng = (v1-v0) x (v2-v0), normalised: ONE definition, used where a hit is shaded and where the 16-byte records are built
+__device__ inline V3 triangleNormal(V3 p0, V3 p1, V3 p2) { return normalized(xcross(p1 - p0, p2 - p0)); }
+
 // Scene::testIntersect's record construction, reference src/scene.cpp:121-218
 __device__ inline Isect makeIsect(const DScene &scene, V3 o, V3 d, float4 h)
 {
@@ -827,19 +1004,30 @@ __device__ inline Isect makeIsect(const DScene &scene, V3 o, V3 d, float4 h)
     int material;
 
     if (prim < scene.nTris) {
-        const float4 *q = scene.triShade + (size_t)kTriShadeQuads * prim;
-        const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4], q5 = q[5], q6 = q[6];
-        const V3 p0 = v3(q0.x, q0.y, q0.z), p1 = v3(q1.x, q1.y, q1.z), p2 = v3(q2.x, q2.y, q2.z);
-        const float w = 1.f - u - v;
-        // rtcInterpolate0 with weights (1-u-v, u, v): uv slot 0, normal slot 1
-        uvU = fmaf(w, q1.w, fmaf(u, q3.w, v * q5.w));
-        uvV = fmaf(w, q2.w, fmaf(u, q4.w, v * q6.x));
-        shadingNormal = v3(
-            fmaf(w, q3.x, fmaf(u, q4.x, v * q5.x)),
-            fmaf(w, q3.y, fmaf(u, q4.y, v * q5.y)),
-            fmaf(w, q3.z, fmaf(u, q4.z, v * q5.z)));
-        geometricNormal = normalized(xcross(p1 - p0, p2 - p0));  // Ng = (v1-v0) x (v2-v0)
-        material = floatAsInt(q0.w);
+        // A triangle without vertex normals and uvs (all exactly zero: the interpolated shading normal has length 0 and
+        // the geometric normal takes its place, uv = 0) is shaded from a 16-byte record.  Which primitives are plain is a
+        // few id ranges in the kernel arguments (scalar compares), so either load is issued at once.
+        bool plain = false;
+        for (int r = 0; r < scene.nPlainRanges; r++) { plain = plain || (prim >= scene.plainBegin[r] && prim < scene.plainEnd[r]); }
+        if (plain) {
+            const float4 compact = scene.triCompact[prim];
+            material = floatAsInt(compact.w);
+            geometricNormal = v3(compact.x, compact.y, compact.z);
+        } else {
+            const float4 *q = scene.triShade + (size_t)kTriShadeQuads * prim;
+            const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4], q5 = q[5], q6 = q[6];
+            const V3 p0 = v3(q0.x, q0.y, q0.z), p1 = v3(q1.x, q1.y, q1.z), p2 = v3(q2.x, q2.y, q2.z);
+            const float w = 1.f - u - v;
+            // rtcInterpolate0 with weights (1-u-v, u, v): uv slot 0, normal slot 1
+            uvU = fmaf(w, q1.w, fmaf(u, q3.w, v * q5.w));
+            uvV = fmaf(w, q2.w, fmaf(u, q4.w, v * q6.x));
+            shadingNormal = v3(
+                fmaf(w, q3.x, fmaf(u, q4.x, v * q5.x)),
+                fmaf(w, q3.y, fmaf(u, q4.y, v * q5.y)),
+                fmaf(w, q3.z, fmaf(u, q4.z, v * q5.z)));
+            geometricNormal = triangleNormal(p0, p1, p2);
+            material = floatAsInt(q0.w);
+        }
     } else {
         const DSphere sphere = scene.spheres[prim - scene.nTris];
         const V3 point = o + d * t;
@@ -1194,6 +1382,13 @@ struct MaterialAccess {
     __device__ inline const DMaterial &operator[](int index) const { return table[index]; }
 };
 
+#ifndef PATHED_SHADE_TRIM
+// 1: a slot that regenerates skips the reset of mod / thr / pend (its camera ray's vertex reads none of them) and, with one
+// sample per unit, the `acc` stream: 80 bytes less per regenerated slot -- and SLOWER (teapot 1 731 against 1 762, the mesh
+// filling the frame 1 362 against 1 380 Msamples/s, same box, profiles/r3_ab_shade_trim.log): a store that half the lanes
+// of a wave skip writes partial cache lines, which cost more than the full 1 KiB lines they replace.
+#define PATHED_SHADE_TRIM 0
+#endif
 #ifdef PATHED_SHADE_WAVES   // experiments: cap k_shade's registers for this many waves per SIMD
 #define PATHED_SHADE_ATTRIBUTE __attribute__((amdgpu_waves_per_eu(PATHED_SHADE_WAVES, PATHED_SHADE_WAVES)))
 #else
@@ -1433,8 +1628,11 @@ __global__ __launch_bounds__(kBlock) PATHED_SHADE_ATTRIBUTE void k_shade(RenderP
     uint32_t nextPixel = 0, nextSample = 0;
     SHADE_REGION(7, active && finished);
     if (active && finished) {
-        // radianceLookup += color, src/sample_integrator.cpp:61-63; non-finite samples dropped
-        float4 partial = p.state.acc[slot];
+        // radianceLookup += color, src/sample_integrator.cpp:61-63; non-finite samples dropped.  With one sample per
+        // unit (the default) the unit's partial sum is 0 + colour: the `acc` stream is not touched at all.
+        const bool singleSample = PATHED_SHADE_TRIM && p.chunk == 1;
+        float4 partial = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!singleSample) { partial = p.state.acc[slot]; }
         const bool finite = isfinite(color.r) && isfinite(color.g) && isfinite(color.b);
         if (finite) {
             partial.x += color.r;
@@ -1457,7 +1655,7 @@ __global__ __launch_bounds__(kBlock) PATHED_SHADE_ATTRIBUTE void k_shade(RenderP
             p.state.acc[slot] = partial;
         } else {
             p.state.chunkBuf[partialIndex(p, unit)] = partial;
-            p.state.acc[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!singleSample) { p.state.acc[slot] = make_float4(0.f, 0.f, 0.f, 0.f); }
             needUnit = true;
         }
     }
@@ -1485,10 +1683,15 @@ __global__ __launch_bounds__(kBlock) PATHED_SHADE_ATTRIBUTE void k_shade(RenderP
     if (active) {
         p.state.rayO[slot] = outRayO;
         p.state.rayD[slot] = outRayD;
-        p.state.mod[slot] = outMod;
-        p.state.thr[slot] = outThr;
         p.state.res[slot] = make_float4(result.r, result.g, result.b, intAsFloat((int)unit));
-        p.state.pend[slot] = outPend;
+        // a slot that starts a camera ray (or retires) keeps its stale mod / thr / pend: the camera ray's vertex reads
+        // none of them (rayBounce == 0, no eligible bit) and writes all three for the rays that follow -- 48 bytes less
+        // per regenerated slot on streams that bound this kernel
+        if (!finished || !PATHED_SHADE_TRIM) {
+            p.state.mod[slot] = outMod;
+            p.state.thr[slot] = outThr;
+            p.state.pend[slot] = outPend;
+        }
     }
 
     // ---- shadow-ray list: wave ballot + prefix popcount + LDS block scan, then ONE atomic per
@@ -2002,6 +2205,396 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_S
             p.state.thr[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
             p.state.res[slot] = make_float4(0.f, 0.f, 0.f, intAsFloat((int)unit));
             p.state.pend[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        retiredTotal += (unsigned int)__popcll(__ballot(retired));
+    }
+    // slots that ran out of units (only at the tail of a render call)
+    if (lane == 0 && retiredTotal != 0u) { atomicSub(&p.counters[kCtrRemaining], retiredTotal); }
+}
+
+// ------------------------------------------------------------------------- split shade stage
+// k_vertex + k_regen: k_shade's per-slot arithmetic as two DENSE kernels over the lists the trace kernel wrote
+// (the reference's stage-wise arrays, src/data_parallel_integrator.cpp:307-371: intersections -> direct light -> bounce,
+// each over everything that needs it).  Nothing is classified or sorted here: k_trace knows hit from miss when a ray
+// finishes and appends the slot to the list of the kernel that has to see it.
+//   k_vertex  one lane per HIT: intersection record, the previous vertex's BSDF-sampling MIS term (emitter hit),
+//             throughput, BSDF sample, light sample, next ray + shadow ray.  No regeneration code, full waves.  A sample
+//             that ends at the vertex leaves its colour in `res` and joins the miss list (kEntryColorReady).
+//   k_regen   one lane per MISS or ended sample: environment term of the miss, colour -> the unit's partial sum, next
+//             sample or next unit, camera ray.  Few registers, no material table in LDS.
+// Both are persistent (a block walks groups of 256 list items), so the prologue is paid once per block.  A slot is shaded
+// from its own state with k_shade's operations in k_shade's order: images are bit-identical (GPU test).
+// A slot whose closest-hit ray is in but whose shadow ray is parked in a trace wave cannot be shaded yet: it is put on
+// hold and handed to the next iteration through the deferred list of its kernel.
+#ifndef PATHED_VERTEX_WAVES
+#define PATHED_VERTEX_WAVES 4
+#endif
+#ifndef PATHED_REGEN_WAVES
+#define PATHED_REGEN_WAVES 6
+#endif
+
+template <bool LDS_MATERIALS>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_VERTEX_WAVES, PATHED_VERTEX_WAVES))) void k_vertex(RenderParams p)
+{
+    extern __shared__ float4 ldsDynamic[];           // LDS_MATERIALS: the material table, nMaterials x 96 B
+    __shared__ unsigned int scratch[kWavesPerBlock + 1];
+    __shared__ unsigned int shardCounts[kListShards + 1];
+    __shared__ unsigned int endedBuffers[kWavesPerBlock * 128];
+
+    MaterialAccess<LDS_MATERIALS> materials;
+    if (LDS_MATERIALS) {
+        const int words = p.scene.nMaterials * (int)(sizeof(DMaterial) / 4);
+        const int *source = reinterpret_cast<const int *>(p.scene.materials);
+        int *target = reinterpret_cast<int *>(ldsDynamic);
+        for (int i = threadIdx.x; i < words; i += kBlock) { target[i] = source[i]; }
+        materials.table = reinterpret_cast<const DMaterial *>(ldsDynamic);
+    } else {
+        materials.table = p.scene.materials;
+    }
+    ListReader hits;
+    listReaderInit(hits, shardCounts, p, kListHit, p.parity);   // its barriers also publish the material table
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const DScene &scene = p.scene;
+    ListWriter endedWriter;   // samples that end at a vertex: on to k_regen through the miss list
+    listWriterInit(endedWriter, endedBuffers + wave * 128);
+
+    const unsigned int groups = (hits.items + kBlock - 1u) / kBlock;
+    for (unsigned int group = blockIdx.x; group < groups; group += gridDim.x) {
+        const unsigned int entry = listEntry(hits, group * kBlock + threadIdx.x);
+        bool have = entry != kEntryInvalid;
+        const int slot = (int)(entry & kEntrySlotBits);
+        ShadowRequest shadow;
+        shadow.push = false;
+        shadow.origin = v3(0.f, 0.f, 0.f);
+        shadow.direction = v3(0.f, 0.f, 0.f);
+        shadow.tfar = 0.f;
+        bool ended = false;       // the sample ended at this vertex
+        bool defer = false;       // the slot's shadow ray is parked
+        if (have) {
+            float4 rd = p.state.rayD[slot];
+            const float4 h = p.state.hit[slot];
+            const float4 ro = p.state.rayO[slot];
+            const float4 resIn = p.state.res[slot];
+            pinLoaded(rd);
+            pinLoaded(h);
+            pinLoaded(ro);
+            pinLoaded(resIn);
+            const int stIn = floatAsInt(rd.w);
+            const int st = stIn & ~kStHold;
+            float4 pendIn = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (st & kStEligible) {
+                pendIn = p.state.pend[slot];
+                if (p.suspendLanes > 0 && floatAsInt(pendIn.w) == kShadowSuspended) {
+                    if (!(stIn & kStHold)) { reinterpret_cast<int *>(p.state.rayD + slot)[3] = stIn | kStHold; }
+                    defer = true;
+                    have = false;
+                }
+            }
+            if (have) {
+                rd.w = intAsFloat(st);
+                const V3 o = v3(ro.x, ro.y, ro.z);
+                const V3 d = v3(rd.x, rd.y, rd.z);
+                const int rayBounce = st & kStBounceMask;  // vertex that spawned this ray, 0 = camera
+                const int sampleInUnit = (st >> kStSampleShift) & kStSampleMask;
+                const unsigned int unit = (unsigned int)floatAsInt(resIn.w);
+                int firstEmitMaterial = floatAsInt(ro.w);
+
+                uint32_t pixel, firstSample, endSample;
+                unitSamples(p, unit, &pixel, &firstSample, &endSample);
+                const uint32_t sample = firstSample + (uint32_t)sampleInUnit;
+
+                Rgb result = rgb(resIn.x, resIn.y, resIn.z);
+                Rgb modulation = rgb(1.f);
+                Rgb color = rgb(0.f);
+                bool haveVertex = false;
+                const int vertex = rayBounce + 1;
+                const Isect isect = makeIsect(scene, o, d, h);
+
+                if (rayBounce == 0) {
+                    // SampleIntegrator::samplePixel, src/sample_integrator.cpp:18-59
+                    firstEmitMaterial = -1;
+                    if (checkCounts(p.startBounce, p.lastBounce, 0)) {
+                        const Rgb emit = matEmit(materials[isect.material]);
+                        const bool backside = dot(isect.normal, isect.wo) < 0.f;
+                        if (!isBlack(emit) && !backside) { firstEmitMaterial = isect.material; }
+                    }
+                    result = rgb(0.f);
+                    haveVertex = true;
+                } else {
+                    // the ray left vertex `rayBounce` along its BSDF sample
+                    const float4 modIn = p.state.mod[slot];
+                    const float4 thrIn = p.state.thr[slot];
+                    modulation = rgb(modIn.x, modIn.y, modIn.z);
+                    const float bsdfPdf = modIn.w;
+                    const Rgb throughput = rgb(thrIn.x, thrIn.y, thrIn.z);
+                    const float cosTheta = thrIn.w;
+
+                    if (st & kStEligible) {
+                        // PathTracer::directSampleBSDF, src/path_tracer.cpp:167-216 (the hit branch)
+                        Rgb bsdfTerm = rgb(0.f);
+                        const Rgb emit = matEmit(materials[isect.material]);
+                        if (!isBlack(emit) && dot(isect.wo, isect.shadingNormal) >= 0.f) {
+                            const float lightPDF = lightsPDF(scene, o, isect);
+                            const float brdfWeight = (st & kStDelta)
+                                ? 1.f
+                                : (1 * bsdfPdf) / (1 * bsdfPdf + 1 * lightPDF);
+                            bsdfTerm = emit * brdfWeight * throughput * cosTheta / bsdfPdf;
+                        }
+                        const Rgb Ld = rgb(pendIn.x, pendIn.y, pendIn.z) + bsdfTerm;
+                        if (rayBounce == 1) { result = Ld; }
+                        else { result = result + Ld * modulation; }
+                    }
+
+                    // PathTracer::L loop body, src/path_tracer.cpp:41-58
+                    if (!(st & kStContinue)) {
+                        ended = true;
+                    } else {
+                        const float invPDF = 1.f / bsdfPdf;
+                        modulation = modulation * (throughput * cosTheta * invPDF);
+                        if (isBlack(modulation)) { ended = true; }
+                        else { haveVertex = true; }
+                    }
+                    if (ended) {
+                        Rgb first = rgb(0.f);
+                        if (firstEmitMaterial >= 0) { first = first + matEmit(materials[firstEmitMaterial]); }
+                        color = first + result;
+                    }
+                }
+
+                float4 outMod = make_float4(modulation.r, modulation.g, modulation.b, 1.f);
+                float4 outRayO = ro, outRayD = rd;
+                float4 outThr = make_float4(0.f, 0.f, 0.f, 0.f);
+                float4 outPend = make_float4(0.f, 0.f, 0.f, 0.f);
+
+                if (haveVertex) {
+                    // PathTracer::L: sample the BSDF, then direct(), src/path_tracer.cpp:30-36, 60-73
+                    const DMaterial &material = materials[isect.material];
+
+                    Rng random;
+                    makeKey(((uint64_t)p.seedHi << 32) | p.seedLo, pixel, sample, &random.k0, &random.k1);
+                    random.dimension = vertexBase(vertex);
+                    const BSDFSample bsdfSample = materialSample(material, isect, random);
+
+                    const bool counts = checkCounts(p.startBounce, p.lastBounce, vertex);
+                    const bool emissive = !isBlack(matEmit(material));
+                    const bool wantDirect = counts && !emissive;  // direct() returns 0 on emitters (:86-90)
+                    const bool wantContinue = !checkDone(p.lastBounce, vertex + 1);
+
+                    Rgb lightTerm = rgb(0.f);
+                    if (wantDirect) {
+                        random.dimension = vertexBase(vertex) + 3;
+                        lightTerm = sampleLightsTerm(scene, materials, isect, material, random, &shadow);
+                    }
+
+                    // see k_shade: a vertex with nothing pending whose BSDF sample has exactly black throughput ends the sample
+                    const bool deadEnd = isBlack(bsdfSample.throughput) && bsdfSample.pdf > 0.f && bsdfSample.pdf < 3e38f
+                        && !shadow.push && isBlack(lightTerm);
+                    if ((!wantDirect && !wantContinue) || deadEnd) {
+                        ended = true;
+                        Rgb first = rgb(0.f);
+                        if (firstEmitMaterial >= 0) { first = first + matEmit(materials[firstEmitMaterial]); }
+                        color = first + result;
+                        shadow.push = false;
+                    } else {
+                        int nextState = vertex | (sampleInUnit << kStSampleShift);
+                        if (wantDirect) { nextState |= kStEligible; }
+                        if (isDelta(material)) { nextState |= kStDelta; }
+                        if (wantContinue) { nextState |= kStContinue; }
+                        outRayO = make_float4(isect.point.x, isect.point.y, isect.point.z, intAsFloat(firstEmitMaterial));
+                        outRayD = make_float4(bsdfSample.wiWorld.x, bsdfSample.wiWorld.y, bsdfSample.wiWorld.z, intAsFloat(nextState));
+                        outMod.w = bsdfSample.pdf;
+                        outThr = make_float4(
+                            bsdfSample.throughput.r, bsdfSample.throughput.g, bsdfSample.throughput.b,
+                            fabsf(dot(isect.shadingNormal, bsdfSample.wiWorld)));
+                        outPend = make_float4(lightTerm.r, lightTerm.g, lightTerm.b, 0.f);
+                    }
+                }
+
+                if (ended) {
+                    // k_regen adds the colour to the unit's partial sum and restarts the slot
+                    p.state.res[slot] = make_float4(color.r, color.g, color.b, intAsFloat((int)unit));
+                } else {
+                    p.state.rayO[slot] = outRayO;
+                    p.state.rayD[slot] = outRayD;
+                    p.state.mod[slot] = outMod;
+                    p.state.thr[slot] = outThr;
+                    p.state.res[slot] = make_float4(result.r, result.g, result.b, intAsFloat((int)unit));
+                    p.state.pend[slot] = outPend;
+                }
+            }
+        }
+
+        deferSlot(p, kListHit, defer, (unsigned int)slot);
+        listAppend(endedWriter, p, kListMiss, ended, (unsigned int)slot | kEntryColorReady);
+
+        // shadow-ray list: wave ballot + prefix popcount + LDS block scan, then ONE atomic per block and group
+        {
+            const unsigned long long mask = __ballot(shadow.push);
+            const unsigned int before = (unsigned int)__popcll(mask & ((1ull << lane) - 1ull));
+            if (lane == 0) { scratch[wave] = (unsigned int)__popcll(mask); }
+            __syncthreads();
+            unsigned int offset = 0, total = 0;
+            #pragma unroll
+            for (int w = 0; w < kWavesPerBlock; w++) {
+                const unsigned int count = scratch[w];
+                if (w < wave) { offset += count; }
+                total += count;
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                scratch[kWavesPerBlock] = total ? atomicAdd(&p.counters[kCtrShadowCount + p.parity * kCursorStride], total) : 0u;
+            }
+            __syncthreads();
+            if (shadow.push) {
+                const unsigned int at = scratch[kWavesPerBlock] + offset + before;
+                p.state.shO[at] = make_float4(shadow.origin.x, shadow.origin.y, shadow.origin.z, shadow.tfar);
+                p.state.shD[at] = make_float4(shadow.direction.x, shadow.direction.y, shadow.direction.z, intAsFloat(slot));
+            }
+            __syncthreads();   // scratch is reused by the next group
+        }
+    }
+    if (endedWriter.count != 0u) { listFlush(endedWriter, p, kListMiss); }
+}
+
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_REGEN_WAVES, PATHED_REGEN_WAVES))) void k_regen(RenderParams p)
+{
+    __shared__ unsigned int scratch[kWavesPerBlock + 1];
+    __shared__ unsigned int shardCounts[kListShards + 1];
+
+    // rewind the card cursors for the pool's next trace launch (same stream: it starts after us)
+    if (blockIdx.x == 0 && threadIdx.x < kTraceShards) { p.counters[kCtrTraceCursor + threadIdx.x * kCursorStride] = 0u; }
+    // ... and empty the shadow list the NEXT k_vertex will fill (the trace launch that read it is over)
+    if (blockIdx.x == 0 && threadIdx.x == kTraceShards) { p.counters[kCtrShadowCount + (p.parity ^ 1) * kCursorStride] = 0u; }
+
+    ListReader misses;
+    listReaderInit(misses, shardCounts, p, kListMiss, p.parity);
+
+    const int lane = threadIdx.x & 63;
+    const DScene &scene = p.scene;
+    const DMaterial *materials = p.scene.materials;   // only the emission of a directly visible emitter is read here
+
+    unsigned int retiredTotal = 0;
+    const unsigned int groups = (misses.items + kBlock - 1u) / kBlock;
+    for (unsigned int group = blockIdx.x; group < groups; group += gridDim.x) {
+        const unsigned int entry = listEntry(misses, group * kBlock + threadIdx.x);
+        bool have = entry != kEntryInvalid;
+        const int slot = (int)(entry & kEntrySlotBits);
+        const bool colorReady = (entry & kEntryColorReady) != 0u;
+        bool needUnit = false, startNext = false, defer = false;
+        uint32_t nextPixel = 0, nextSample = 0;
+        int sampleInUnit = 0;
+        unsigned int unit = 0xFFFFFFFFu;
+        float4 outRayO = make_float4(0.f, 0.f, 0.f, 0.f), outRayD = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (have) {
+            const float4 rd = p.state.rayD[slot];
+            const float4 resIn = p.state.res[slot];
+            const int stIn = floatAsInt(rd.w);
+            const int st = stIn & ~kStHold;
+            outRayD = rd;
+            unit = (unsigned int)floatAsInt(resIn.w);
+            sampleInUnit = (st >> kStSampleShift) & kStSampleMask;
+            Rgb color = rgb(resIn.x, resIn.y, resIn.z);
+            if (!colorReady) {
+                const V3 d = v3(rd.x, rd.y, rd.z);
+                const int rayBounce = st & kStBounceMask;
+                if (rayBounce == 0) {
+                    // SampleIntegrator::samplePixel: the camera ray missed, src/sample_integrator.cpp:18-31
+                    color = rgb(0.f) + environmentL(scene, d);
+                } else {
+                    Rgb result = rgb(resIn.x, resIn.y, resIn.z);
+                    if (st & kStEligible) {
+                        const float4 pendIn = p.state.pend[slot];
+                        if (p.suspendLanes > 0 && floatAsInt(pendIn.w) == kShadowSuspended) {
+                            if (!(stIn & kStHold)) { reinterpret_cast<int *>(p.state.rayD + slot)[3] = stIn | kStHold; }
+                            defer = true;
+                            have = false;
+                        } else {
+                            const float4 modIn = p.state.mod[slot];
+                            const float4 thrIn = p.state.thr[slot];
+                            const Rgb modulation = rgb(modIn.x, modIn.y, modIn.z);
+                            const float bsdfPdf = modIn.w;
+                            const Rgb throughput = rgb(thrIn.x, thrIn.y, thrIn.z);
+                            const float cosTheta = thrIn.w;
+                            // PathTracer::directSampleBSDF, src/path_tracer.cpp:167-216 (the miss branch)
+                            Rgb bsdfTerm = rgb(0.f);
+                            const Rgb environmentLight = environmentL(scene, d);
+                            if (!isBlack(environmentLight)) {
+                                // Scene::environmentPDF, src/scene.cpp:494-502
+                                const float lightPDF = envEmitPDF(scene.env, d) / scene.nLights;
+                                const float brdfWeight = (st & kStDelta)
+                                    ? 1.f
+                                    : (1 * bsdfPdf) / (1 * bsdfPdf + 1 * lightPDF);
+                                bsdfTerm = environmentLight * brdfWeight * throughput * cosTheta / bsdfPdf;
+                            }
+                            const Rgb Ld = rgb(pendIn.x, pendIn.y, pendIn.z) + bsdfTerm;
+                            if (rayBounce == 1) { result = Ld; }
+                            else { result = result + Ld * modulation; }
+                        }
+                    }
+                    if (have) {
+                        const int firstEmitMaterial = floatAsInt(p.state.rayO[slot].w);
+                        Rgb first = rgb(0.f);
+                        if (firstEmitMaterial >= 0) { first = first + matEmit(materials[firstEmitMaterial]); }
+                        color = first + result;
+                    }
+                }
+            }
+
+            if (have) {
+                // radianceLookup += color, src/sample_integrator.cpp:61-63; non-finite samples dropped.  With one sample
+                // per unit (the default) the unit's partial sum is 0 + colour: the `acc` stream is not touched at all.
+                const bool singleSample = p.chunk == 1;
+                float4 partial = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (!singleSample) { partial = p.state.acc[slot]; }
+                const bool finite = isfinite(color.r) && isfinite(color.g) && isfinite(color.b);
+                if (finite) {
+                    partial.x += color.r;
+                    partial.y += color.g;
+                    partial.z += color.b;
+                } else {
+                    atomicAdd(&p.stats[kStatDropped], 1ull);
+                }
+                uint32_t pixel, firstSample, endSample;
+                unitSamples(p, unit, &pixel, &firstSample, &endSample);
+                sampleInUnit++;
+                if (firstSample + (uint32_t)sampleInUnit < endSample) {
+                    startNext = true;
+                    nextPixel = pixel;
+                    nextSample = firstSample + (uint32_t)sampleInUnit;
+                    p.state.acc[slot] = partial;
+                } else {
+                    p.state.chunkBuf[partialIndex(p, unit)] = partial;
+                    if (!singleSample) { p.state.acc[slot] = make_float4(0.f, 0.f, 0.f, 0.f); }
+                    needUnit = true;
+                }
+            }
+        }
+        deferSlot(p, kListMiss, defer, (unsigned int)slot);
+
+        // block-aggregated grab of the next units (wave ballot + LDS scan, one atomic per block and group)
+        const unsigned int newUnit = grabUnits(p, needUnit, scratch);
+        bool retired = false;
+        if (needUnit) {
+            unit = newUnit;
+            if (newUnit != 0xFFFFFFFFu) {
+                uint32_t endSample;
+                unitSamples(p, newUnit, &nextPixel, &nextSample, &endSample);
+                sampleInUnit = 0;
+                startNext = true;
+            } else {
+                outRayD.w = intAsFloat(kStDone);
+                retired = true;
+            }
+        }
+        if (startNext) { startSample(p, nextPixel, nextSample, sampleInUnit, &outRayO, &outRayD); }
+        if (have) {
+            // mod / thr / pend are not reset: a camera ray's vertex reads none of them (k_vertex: rayBounce == 0, no
+            // eligible bit) and writes all three for the rays that follow
+            p.state.rayO[slot] = outRayO;
+            p.state.rayD[slot] = outRayD;
+            p.state.res[slot] = make_float4(0.f, 0.f, 0.f, intAsFloat((int)unit));
         }
         retiredTotal += (unsigned int)__popcll(__ballot(retired));
     }
@@ -2755,7 +3348,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_V
 // and uploading 128 bytes per triangle from one host thread.
 __global__ __launch_bounds__(kBlock) void k_build_tri_shade(
     const float *positions, const float *normals, const float *uvs, const uint32_t *indices, const int *triMaterial,
-    uint32_t nTriangles, float4 *triShade)
+    uint32_t nTriangles, float4 *triShade, float4 *triCompact)
 {
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= nTriangles) { return; }
@@ -2772,6 +3365,9 @@ __global__ __launch_bounds__(kBlock) void k_build_tri_shade(
     q[5] = make_float4(n2[0], n2[1], n2[2], t2[0]);
     q[6] = make_float4(t2[1], 0.f, 0.f, 0.f);
     q[7] = make_float4(0.f, 0.f, 0.f, 0.f);
+    // the 16-byte record (makeIsect): geometric normal + material, read for the triangles of the scene's plain ranges
+    const V3 normal = triangleNormal(v3(p0[0], p0[1], p0[2]), v3(p1[0], p1[1], p1[2]), v3(p2[0], p2[1], p2[2]));
+    triCompact[i] = make_float4(normal.x, normal.y, normal.z, intAsFloat(triMaterial[i]));
 }
 
 // ------------------------------------------------------------------------- bandwidth probe

@@ -156,7 +156,7 @@ struct PathedScene {
     int bvhBuilder = PATHED_BVH_SAH_HOST;
     double bvhBuildMs = 0.0;
 
-    DeviceBuffer<float4> nodes, leafTris, triShade, envRgba, texels;
+    DeviceBuffer<float4> nodes, leafTris, triShade, triCompact, envRgba, texels;
     DeviceBuffer<DSphere> spheres;
     DeviceBuffer<DMaterial> materials;
     DeviceBuffer<DLight> lights;
@@ -191,6 +191,10 @@ struct PathedScene {
     bool spheresInTree = false;   // the host builder put the spheres into leaves (else they are tested one by one after the traversal)
     bool fusedPath = false;   // tiny scenes: k_path_small, whole paths in registers, no wavefront buffers
     bool stagedShade = true;  // k_shade_staged (dense, state-sorted stages inside a block) or k_shade (one lane per slot)
+    bool splitShade = false;  // k_vertex + k_regen over the hit / miss lists the trace kernel writes (kernels.h: split shade stage)
+    int vertexGrid = 0, regenGrid = 0;   // their persistent grids, blocks
+    unsigned int listCap = 0;            // list blocks per shard
+    DeviceBuffer<unsigned int> slotLists, deferredLists;
     int stageRounds = 2;      // staged kernel: a block owns stageRounds x 256 slots
 
     int stackRows = 8;    // LDS rows of the per-lane traversal stack (8 / 16 / 22)
@@ -215,7 +219,7 @@ struct PathedScene {
 
     ~PathedScene()
     {
-        nodes.release(); leafTris.release(); triShade.release(); envRgba.release(); texels.release();
+        nodes.release(); leafTris.release(); triShade.release(); triCompact.release(); envRgba.release(); texels.release();
         spheres.release(); materials.release(); lights.release();
         thetaCdf.release(); phiCdf.release(); phiEmpty.release(); thetaGuide.release(); phiGuide.release();
         media.release(); primMedium.release(); volumeOverflow.release();
@@ -224,6 +228,7 @@ struct PathedScene {
         res.release(); pend.release(); acc.release(); shO.release(); shD.release(); chunkBuf.release();
         counters.release(); stats.release();
         suspendMask.release(); suspendData.release(); stackOverflow.release();
+        slotLists.release(); deferredLists.release();
         if (hostRemaining) { (void)hipHostFree(hostRemaining); }
         for (int h = 0; h < kMaxPools; h++) {
             if (poolStreams[h]) { (void)hipStreamDestroy(poolStreams[h]); }
@@ -406,6 +411,19 @@ int ensureRenderState(PathedScene *scene, int nSlots, size_t chunkEntries)
         HIP_TRY(scene->chunkBuf.allocate(chunkEntries));
         scene->chunkCapacity = chunkEntries;
     }
+    if (scene->splitShade) {
+        // per pool and list: every slot once, plus one partly filled block per wave that writes (trace and k_vertex
+        // waves); sized for the slot capacity, so a call that uses fewer slots fits as well
+        const size_t writerWaves = (size_t)(scene->traceGrid + scene->vertexGrid) * kWavesPerBlock;
+        const size_t blocks = (size_t)scene->nSlots / 64 + writerWaves;
+        // a block's shard is picked from the shader clock: an eighth of slack keeps a shard from ever running full
+        const unsigned int cap = (unsigned int)((blocks + kListShards - 1) / kListShards) * 9u / 8u + 8u;
+        if (cap > scene->listCap || !scene->slotLists.ptr) {
+            scene->listCap = cap;
+            HIP_TRY(scene->slotLists.allocate((size_t)kMaxPools * 2 * (size_t)cap * kListShards * 64));
+            HIP_TRY(scene->deferredLists.allocate((size_t)kMaxPools * 4 * (size_t)scene->nSlots));
+        }
+    }
     if (!scene->counters.ptr) { HIP_TRY(scene->counters.allocate(kMaxPools * kCtrCount)); }
     if (!scene->suspendMask.ptr && !scene->bruteForce) {
         const size_t waves = (size_t)scene->traceGrid * kWavesPerBlock;
@@ -429,12 +447,22 @@ void launchTraceStack(PathedScene *scene, const RenderParams &params, hipStream_
 {
     const dim3 grid((unsigned)scene->traceGrid), block(kBlock);
     const size_t lds = scene->traceLdsBytes;
+    if (scene->splitShade) {
+        if (scene->sceneInLds) {
+            if (scene->countMode) { hipLaunchKernelGGL((k_trace<STACK, true, true, true>), grid, block, lds, stream, params); }
+            else { hipLaunchKernelGGL((k_trace<STACK, true, false, true>), grid, block, lds, stream, params); }
+        } else {
+            if (scene->countMode) { hipLaunchKernelGGL((k_trace<STACK, false, true, true>), grid, block, lds, stream, params); }
+            else { hipLaunchKernelGGL((k_trace<STACK, false, false, true>), grid, block, lds, stream, params); }
+        }
+        return;
+    }
     if (scene->sceneInLds) {
-        if (scene->countMode) { hipLaunchKernelGGL((k_trace<STACK, true, true>), grid, block, lds, stream, params); }
-        else { hipLaunchKernelGGL((k_trace<STACK, true, false>), grid, block, lds, stream, params); }
+        if (scene->countMode) { hipLaunchKernelGGL((k_trace<STACK, true, true, false>), grid, block, lds, stream, params); }
+        else { hipLaunchKernelGGL((k_trace<STACK, true, false, false>), grid, block, lds, stream, params); }
     } else {
-        if (scene->countMode) { hipLaunchKernelGGL((k_trace<STACK, false, true>), grid, block, lds, stream, params); }
-        else { hipLaunchKernelGGL((k_trace<STACK, false, false>), grid, block, lds, stream, params); }
+        if (scene->countMode) { hipLaunchKernelGGL((k_trace<STACK, false, true, false>), grid, block, lds, stream, params); }
+        else { hipLaunchKernelGGL((k_trace<STACK, false, false, false>), grid, block, lds, stream, params); }
     }
 }
 
@@ -457,6 +485,17 @@ void launchTrace(PathedScene *scene, const RenderParams &params, hipStream_t str
 
 void launchShade(PathedScene *scene, const RenderParams &params, hipStream_t stream)
 {
+    if (scene->splitShade && !PATHED_EXP_LISTS_ONLY) {
+        const bool ldsMaterials = scene->device.nMaterials <= kMaxLdsMaterials;
+        const size_t lds = ldsMaterials ? (size_t)scene->device.nMaterials * sizeof(DMaterial) : 0;
+        const int slotBlocks = params.nSlots / kBlock;
+        const dim3 vertexGrid((unsigned)(scene->vertexGrid < slotBlocks ? scene->vertexGrid : slotBlocks));
+        const dim3 regenGrid((unsigned)(scene->regenGrid < slotBlocks ? scene->regenGrid : slotBlocks));
+        if (ldsMaterials) { hipLaunchKernelGGL((k_vertex<true>), vertexGrid, dim3(kBlock), lds, stream, params); }
+        else { hipLaunchKernelGGL((k_vertex<false>), vertexGrid, dim3(kBlock), lds, stream, params); }
+        hipLaunchKernelGGL(k_regen, regenGrid, dim3(kBlock), 0, stream, params);
+        return;
+    }
     if (scene->stagedShade) {
         const dim3 grid((unsigned)(params.nSlots / (kBlock * scene->stageRounds))), block(kBlock);
         const bool ldsMaterials = scene->device.nMaterials <= kMaxLdsMaterials;
@@ -512,7 +551,8 @@ void configureTrace(PathedScene *scene)
     }
 
     // per-thread traversal stacks + the waves' ray staging rows (2 float4 per thread)
-    const size_t stackBytes = (size_t)(scene->stackRows + 1) * kBlock * sizeof(int) + (size_t)2 * kBlock * kCardRounds * sizeof(float4);
+    const size_t stackBytes = (size_t)(scene->stackRows + 1) * kBlock * sizeof(int) + (size_t)2 * kBlock * kCardRounds * sizeof(float4)
+        + (scene->splitShade ? (size_t)kWavesPerBlock * 2 * 128 * sizeof(unsigned int) : 0);
     const size_t sceneBytes = (size_t)scene->device.nNodes * 128 + (size_t)scene->device.nTris * 48;
     // stage the BVH in LDS when it is small enough to leave >= 4 blocks per CU
     scene->sceneInLds = scene->device.nNodes > 0 && (stackBytes + sceneBytes) <= 36 * 1024;
@@ -801,7 +841,7 @@ int pathed_hip_scene_create_ex(const PathedSceneDesc *desc, const PathedSceneOpt
             return fail(PATHED_E_INVALID, "stack_rows must be 0, 8, 16 or 22");
         }
         if (options.max_slots < 0 || (options.max_slots != 0 && options.max_slots < kBlock)) { return fail(PATHED_E_INVALID, "max_slots must be 0 or >= 256"); }
-        if (options.shade_kernel < 0 || options.shade_kernel > 3) { return fail(PATHED_E_INVALID, "shade_kernel must be 0..3"); }
+        if (options.shade_kernel < 0 || options.shade_kernel > 4) { return fail(PATHED_E_INVALID, "shade_kernel must be 0..4"); }
         if (options.stage_slots != 0 && options.stage_slots != 512 && options.stage_slots != 1024) { return fail(PATHED_E_INVALID, "stage_slots must be 0, 512 or 1024"); }
     }
     int deviceId = options.device;
@@ -1003,6 +1043,7 @@ int pathed_hip_scene_create_ex(const PathedSceneDesc *desc, const PathedSceneOpt
         if (status == hipSuccess) { status = deviceIndices.allocate(3 * nt); }
         if (status == hipSuccess) { status = deviceTriMaterial.allocate(nt); }
         if (status == hipSuccess) { status = scene->triShade.allocate((size_t)kTriShadeQuads * nt); }
+        if (status == hipSuccess) { status = scene->triCompact.allocate(nt); }
         if (status == hipSuccess) { status = hipMemcpy(devicePositions.ptr, desc->positions, 3 * nv * sizeof(float), hipMemcpyHostToDevice); }
         if (status == hipSuccess) { status = hipMemcpy(deviceNormals.ptr, desc->normals, 3 * nv * sizeof(float), hipMemcpyHostToDevice); }
         if (status == hipSuccess) { status = hipMemcpy(deviceUvs.ptr, desc->uvs, 2 * nv * sizeof(float), hipMemcpyHostToDevice); }
@@ -1011,7 +1052,7 @@ int pathed_hip_scene_create_ex(const PathedSceneDesc *desc, const PathedSceneOpt
         if (status == hipSuccess) {
             hipLaunchKernelGGL(k_build_tri_shade, dim3((unsigned)((nt + kBlock - 1) / kBlock)), dim3(kBlock), 0, nullptr,
                                devicePositions.ptr, deviceNormals.ptr, deviceUvs.ptr, deviceIndices.ptr, deviceTriMaterial.ptr,
-                               (uint32_t)nt, scene->triShade.ptr);
+                               (uint32_t)nt, scene->triShade.ptr, scene->triCompact.ptr);
             status = hipGetLastError();
         }
         if (status != hipSuccess) { releaseSoup(); return fail_cleanup(status, "upload triangle soup"); }
@@ -1097,6 +1138,31 @@ int pathed_hip_scene_create_ex(const PathedSceneDesc *desc, const PathedSceneOpt
     d.nSpheres = (int)desc->n_spheres;
     d.nLinearSpheres = scene->spheresInTree ? 0 : (int)desc->n_spheres;
     d.triShade = scene->triShade.ptr;
+    d.triCompact = scene->triCompact.ptr;
+    {
+        // plain ranges (device_scene.h): meshes all of whose vertices carry zero normals and zero uvs, e.g. an OBJ without
+        // vn / vt or a PLY of positions
+        d.nPlainRanges = 0;
+        for (uint32_t g = 0; g < desc->n_geoms; g++) {
+            const PathedGeom &geom = desc->geoms[g];
+            if (geom.type != PATHED_GEOM_MESH || geom.count <= 0) { continue; }
+            bool plain = true;
+            for (int i = 0; i < geom.count && plain; i++) {
+                for (int k = 0; k < 3 && plain; k++) {
+                    const size_t v = desc->indices[3 * (size_t)(geom.first + i) + k];
+                    plain = desc->normals[3 * v] == 0.f && desc->normals[3 * v + 1] == 0.f && desc->normals[3 * v + 2] == 0.f
+                        && desc->uvs[2 * v] == 0.f && desc->uvs[2 * v + 1] == 0.f;
+                }
+            }
+            if (!plain) { continue; }
+            if (d.nPlainRanges > 0 && d.plainEnd[d.nPlainRanges - 1] == geom.first) { d.plainEnd[d.nPlainRanges - 1] = geom.first + geom.count; }
+            else if (d.nPlainRanges < kMaxPlainRanges) {
+                d.plainBegin[d.nPlainRanges] = geom.first;
+                d.plainEnd[d.nPlainRanges] = geom.first + geom.count;
+                d.nPlainRanges++;
+            }
+        }
+    }
     d.materials = scene->materials.ptr;
     d.nMaterials = (int)desc->n_materials;
     d.lights = scene->lights.ptr;
@@ -1118,7 +1184,6 @@ int pathed_hip_scene_create_ex(const PathedSceneDesc *desc, const PathedSceneOpt
         const int value = atoi(poolCount);
         scene->pools = value < 1 ? 1 : value > kMaxPools ? kMaxPools : value;
     }
-    configureTrace(scene);
     scene->bruteForce = scene->device.nTris <= kBruteForceMaxTris && scene->device.nSpheres <= kBruteForceMaxSpheres
         && options.intersector != 1 && !getenv("PATHED_NO_BRUTE_FORCE");
     // BVH scenes: more slots = more rays per persistent wave to refill finished lanes from (ray cost is heavy-tailed) and
@@ -1129,18 +1194,31 @@ int pathed_hip_scene_create_ex(const PathedSceneDesc *desc, const PathedSceneOpt
     scene->maxSlots = scene->bruteForce ? (1 << 20) : (1 << 23);
     scene->adaptiveSlots = !scene->bruteForce;
     // which kernels carry the radiance loop: scenes of <= 64 triangles default to the fused in-register path
-    // kernel, everything else to the wavefront with the per-slot shade kernel (the staged shade kernel is
-    // selectable: it issues fewer instructions but overlaps worse with the other pool's trace kernel)
+    // kernel, everything else to the wavefront with the per-slot shade kernel; the staged shade kernel and the split
+    // shade stage (k_vertex + k_regen over lists the trace kernel writes) are selectable: both issue fewer
+    // instructions on fuller waves and both lose to the coalesced per-slot kernel (DESIGN.md has the measurements)
     int shadeKernel = options.shade_kernel;
-    if (const char *text = getenv("PATHED_SHADE_KERNEL")) {   // experiments: "per-slot" | "staged" | "fused"
+    if (const char *text = getenv("PATHED_SHADE_KERNEL")) {   // experiments: "per-slot" | "staged" | "fused" | "split"
         if (!strcmp(text, "per-slot")) { shadeKernel = 1; }
         else if (!strcmp(text, "staged")) { shadeKernel = 2; }
         else if (!strcmp(text, "fused")) { shadeKernel = 3; }
+        else if (!strcmp(text, "split")) { shadeKernel = 4; }
     }
     if (shadeKernel == 3 && !scene->bruteForce) {
         delete scene;
         return fail(PATHED_E_INVALID, "the fused path kernel serves scenes of at most 64 triangles that take the all-triangles intersector");
     }
+    if (shadeKernel == 4 && scene->bruteForce) {
+        delete scene;
+        return fail(PATHED_E_INVALID, "the split shade stage follows the BVH trace kernel: scenes of at most 64 triangles take the fused, per-slot or staged kernels");
+    }
+    scene->splitShade = shadeKernel == 4;
+    configureTrace(scene);
+    // persistent grids of the split stage: k_vertex at PATHED_VERTEX_WAVES blocks per CU, k_regen at PATHED_REGEN_WAVES
+    scene->vertexGrid = scene->computeUnits * PATHED_VERTEX_WAVES;
+    scene->regenGrid = scene->computeUnits * PATHED_REGEN_WAVES;
+    if (const char *text = getenv("PATHED_VERTEX_GRID")) { const int value = atoi(text); if (value >= 1 && value <= 65536) { scene->vertexGrid = value; } }
+    if (const char *text = getenv("PATHED_REGEN_GRID")) { const int value = atoi(text); if (value >= 1 && value <= 65536) { scene->regenGrid = value; } }
     scene->fusedPath = scene->bruteForce && (shadeKernel == 0 || shadeKernel == 3);
     scene->stagedShade = shadeKernel == 2;
     // more slots per block = fuller last waves of the dense stages, fewer blocks to fill the chip with:
@@ -1457,6 +1535,16 @@ static int renderPass(PathedScene *scene, uint64_t seed, uint32_t begin, uint32_
         q.state.shO = scene->shO.ptr + slotBase;
         q.state.shD = scene->shD.ptr + slotBase;
         q.state.chunkBuf = scene->chunkBuf.ptr;
+        if (scene->splitShade) {
+            const size_t listEntries = (size_t)scene->listCap * kListShards * 64;
+            for (int list = 0; list < 2; list++) {
+                q.state.lists[list] = scene->slotLists.ptr + ((size_t)h * 2 + list) * listEntries;
+                for (int parity = 0; parity < 2; parity++) {
+                    q.state.deferred[list][parity] = scene->deferredLists.ptr + (((size_t)h * 2 + list) * 2 + parity) * (size_t)scene->nSlots;
+                }
+            }
+            q.listCap = scene->listCap;
+        }
         q.counters = scene->counters.ptr + (size_t)h * kCtrCount;
         const size_t traceWaves = (size_t)scene->traceGrid * kWavesPerBlock;
         q.suspendLanes = scene->bruteForce ? 0 : scene->suspendLanes;
@@ -1782,7 +1870,7 @@ int pathed_hip_get_stats(PathedScene *scene, PathedStats *out)
     out->bvh_build_ms = scene->bvhBuildMs;
     out->bvh_builder = (uint32_t)scene->bvhBuilder;
     out->trace_launches_all = (uint32_t)scene->traceLaunchesAll;
-    out->path_kernel = scene->integrator == PATHED_INTEGRATOR_VOLUME_PATH_TRACER ? 4u : scene->fusedPath ? 3u : (scene->stagedShade ? 2u : 1u);
+    out->path_kernel = scene->integrator == PATHED_INTEGRATOR_VOLUME_PATH_TRACER ? 4u : scene->fusedPath ? 3u : scene->splitShade ? 5u : (scene->stagedShade ? 2u : 1u);
     if (getenv("PATHED_SHADE_PROFILE")) {   // counters exist in -DPATHED_SHADE_PROFILE builds only
         static const char *regions[11] = { "all waves", "active slots", "makeIsect (hit)", "camera-ray vertex", "finish previous MIS term",
                                            "new vertex: BSDF sample", "light sampling", "sample finished", "startSample (regeneration)", "shadow ray pushed",

@@ -333,8 +333,9 @@ def test_unit_orders_are_bit_identical(libs, scene_path, width, height, spp):
     ("test_scenes/environment_map_sampling.json", 64, 8, 4),
 ])
 def test_shade_kernels_are_bit_identical(libs, scene_path, size, spp, last_bounce):
-    """Three organisations of the same arithmetic.  k_shade: one lane per slot.  k_shade_staged: classify ->
-    key-sorted dense vertex stage -> dense regeneration stage, per block of 512 or 1024 slots.  k_path_small
+    """Four organisations of the same arithmetic.  k_shade: one lane per slot.  k_shade_staged: classify ->
+    key-sorted dense vertex stage -> dense regeneration stage, per block of 512 or 1024 slots.  k_vertex + k_regen (BVH
+    scenes): dense kernels over the hit / miss lists the trace kernel writes.  k_path_small
     (scenes of <= 64 triangles): whole paths in registers, one persistent launch.  Each performs k_shade's
     operations in k_shade's order for every path and the unit decomposition fixes the summation order: the
     radiance sums are the same floats, whatever the block size, pool count or summation granularity."""
@@ -364,9 +365,26 @@ def test_shade_kernels_are_bit_identical(libs, scene_path, size, spp, last_bounc
         automatic.set_samples_per_unit(7)
         per_slot.set_samples_per_unit(7)
         assert np.array_equal(automatic.render(9, 5, 23, 0, last_bounce), per_slot.render(9, 5, 23, 0, last_bounce))   # ragged last unit
+        from pathed_amd.integrator import PathedError
+        with pytest.raises(PathedError):
+            HipScene(scene.desc, device=0, shade_kernel="split")   # the split stage follows the BVH trace kernel
     else:
         from pathed_amd.integrator import PathedError
+        # the default for BVH scenes is the per-slot kernel; the split shade stage (k_vertex + k_regen over the trace
+        # kernel's hit / miss lists) is selectable
         assert automatic.stats()["path_kernel"] == 1
+        split = HipScene(scene.desc, device=0, shade_kernel="split")
+        assert np.array_equal(split.render(7, 3, spp, 0, last_bounce), expected)
+        split.set_samples_per_unit(4)
+        assert np.array_equal(split.render(2, 0, 3, 1, 2), windowed)
+        # any pool count, few slots (many iterations), rays parked eagerly (slots wait for a parked shadow ray on the
+        # deferred lists), a tiny persistent grid of the trace kernel (long lists per wave)
+        for options in ({"pools": 1}, {"pools": 3, "max_slots": 4096}, {"pools": 1, "max_slots": 1024},
+                        {"suspend_lanes": 64, "suspend_patience": 1, "park_min_cards": -1, "trace_blocks_per_cu": 1},
+                        {"suspend_lanes": -1}, {"stack_rows": 8, "unit_order": "tiles"}):
+            split = HipScene(scene.desc, device=0, shade_kernel="split", **options)
+            assert np.array_equal(split.render(7, 3, spp, 0, last_bounce), expected), options
+            assert split.stats()["path_kernel"] == 5
         with pytest.raises(PathedError):
             HipScene(scene.desc, device=0, shade_kernel="fused")
 

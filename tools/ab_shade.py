@@ -20,6 +20,7 @@ parser.add_argument("--scenes", default="cornell,teapot,dragon")
 parser.add_argument("--variants", default="per-slot,staged:1024,fused")
 parser.add_argument("--spp", type=int, default=0)
 parser.add_argument("--pools", type=int, default=0)
+parser.add_argument("--opt", action="append", default=[], help="extra scene option name=integer, e.g. suspend_lanes=-1")
 args = parser.parse_args()
 
 for name in args.scenes.split(","):
@@ -39,6 +40,9 @@ for name in args.scenes.split(","):
             options["stage_slots"] = int(slots)
         if pools or args.pools:
             options["pools"] = int(pools or args.pools)
+        for extra in args.opt:
+            key, _, value = extra.partition("=")
+            options[key] = int(value)
         try:
             gpu = HipScene(scene.desc, device=0, **options)
         except Exception as error:

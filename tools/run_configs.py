@@ -124,7 +124,7 @@ def main():
             "trace_Grays_s": round(rays * spp / count_spp / timed["trace_ms"] / 1e6, 2) if timed["trace_ms"] and not fused else None,
             "trace_algorithmic_GBs": round(gbs, 0) if not fused else None, "frac_of_8TBs": round(gbs / 8000.0, 3) if not fused else None,
             "intersector": ["BVH in HBM", "BVH in LDS", "all triangles (scalar loads)"][counted["scene_in_lds"]],
-            "path_kernel": ["", "wavefront: k_trace + k_shade", "wavefront: k_trace + k_shade_staged", "fused: k_path_small", "volume: k_path_volume"][counted["path_kernel"]],
+            "path_kernel": ["", "wavefront: k_trace + k_shade", "wavefront: k_trace + k_shade_staged", "fused: k_path_small", "volume: k_path_volume", "wavefront: k_trace + k_vertex + k_regen"][counted["path_kernel"]],
             "cpu_oracle_Msamples_s": round(w * h * cpu_spp / cpu_elapsed / 1e6, 2), "cpu_cores": cores,
             "relL2_vs_oracle_%dx%d_16spp" % (pw, ph): "%.2e" % relative_l2(image, expected),
             "mean_rgb": [round(float(v), 4) for v in (accum / spp).mean(dim=(0, 1)).tolist()],
