@@ -54,10 +54,12 @@ def parse_args():
                         help="collective backend: nccl (= RCCL over xGMI); gloo stages the reduce through host memory (rehearsals)")
     parser.add_argument("--share-gpu", action="store_true",
                         help="rehearsal on a one-GPU box: every rank renders on device 0 (use with --backend gloo: RCCL refuses two ranks on one device)")
+    parser.add_argument("--dist-single", action="store_true",
+                        help="run the single-GPU bench as a ONE-rank process group: init, barrier, reduce and all_gather of the N > 1 path execute (RCCL rehearsal on a one-GPU box)")
     parser.add_argument("--no-cpu-baseline", action="store_true")
     parser.add_argument("--no-large-bvh", action="store_true",
                         help="skip the second, BVH-traversal-bound workload (scenes/dragon-standin.json) behind roofline.large_bvh")
-    parser.add_argument("--large-bvh-subdiv", type=int, default=9, help="icosphere subdivisions of the stand-in mesh: 9 = 5.2 M triangles")
+    parser.add_argument("--large-bvh-subdiv", type=int, default=9, help="icosphere subdivisions of the stand-in mesh: 9 = 5.2 M, 10 = 21 M triangles")
     parser.add_argument("--time-every-launch", action="store_true",
                         help="HIP events around every trace / shade launch instead of every 8th")
     parser.add_argument("--no-kernel-timing", action="store_true",
@@ -67,12 +69,34 @@ def parse_args():
 
 # --------------------------------------------------------------------------- launcher (no GPU call)
 
+def visible_gpus():
+    """GPUs this process may use, counted WITHOUT a HIP call or torch: the KFD topology lists every node, the ones
+    with SIMDs are GPUs; HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES narrow the set."""
+    for name in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        value = os.environ.get(name)
+        if value is not None:
+            return len([item for item in value.split(",") if item.strip() != ""])
+    count = 0
+    nodes = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        for node in os.listdir(nodes):
+            try:
+                with open(os.path.join(nodes, node, "properties")) as handle:
+                    fields = dict(line.split()[:2] for line in handle if len(line.split()) >= 2)
+                if int(fields.get("simd_count", "0")) > 0:
+                    count += 1
+            except (OSError, ValueError):
+                continue
+    except OSError:
+        return None   # no KFD here: let the ranks find out
+    return count or None   # a sysfs view without GPU nodes (a restricted container) says nothing either
+
+
 def launch_ranks(args):
-    """`python bench.py --gpus N` without a launcher: start the N ranks as child processes.  The parent makes
-    no HIP call (counting devices does not initialise the GPU on this image) and never re-executes itself."""
-    import torch
-    visible = torch.cuda.device_count()
-    if visible < args.gpus and not args.share_gpu:
+    """`python bench.py --gpus N` without a launcher: start the N ranks as child processes.  The parent imports
+    neither torch nor HIP (devices are counted from sysfs) and never re-executes itself."""
+    visible = visible_gpus()
+    if visible is not None and visible < args.gpus and not args.share_gpu:
         raise SystemExit("bench.py --gpus %d: this machine shows %d GPU(s)" % (args.gpus, visible))
     with socket.socket() as probe:
         probe.bind(("127.0.0.1", 0))
@@ -216,23 +240,19 @@ def kernel_rates(counted, counted_samples, timed, timed_samples):
     }
 
 
+def ensure_large_bvh_mesh(args):
+    """The stand-in mesh is generated on the box (the 100 MB file does not travel with the snapshot) -- by a child
+    process, so this runs BEFORE this process makes its first GPU call."""
+    subprocess.run([sys.executable, os.path.join(REPO_ROOT, "tools", "make_assets.py"), "--dragon", str(args.large_bvh_subdiv)],
+                   check=True, stdout=subprocess.DEVNULL)   # a no-op when the file already has that many faces
+
+
 def large_bvh_leg(args, torch, stream):
     """The workload the north-star roofline target is about: BVH traversal over a tree that does not fit the
     256 MB Infinity Cache (scenes/dragon-standin.json, procedural mesh, 1920x1080), timed in this very run."""
     from pathed_amd.integrator import HipScene
     from pathed_amd.scene import LoadedScene
 
-    mesh = os.path.join(REPO_ROOT, "assets", "dragon-standin.ply")
-    wanted = 20 * 4 ** args.large_bvh_subdiv
-    have = 0
-    if os.path.exists(mesh):
-        with open(mesh, "rb") as handle:
-            for line in handle.read(400).split(b"\n"):
-                if line.startswith(b"element face"):
-                    have = int(line.split()[2])
-    if have != wanted:   # generated on the box: the 100 MB file does not travel with the snapshot
-        subprocess.run([sys.executable, os.path.join(REPO_ROOT, "tools", "make_assets.py"), "--dragon", str(args.large_bvh_subdiv)],
-                       check=True, stdout=subprocess.DEVNULL)
     width, height = 1920, 1080
     # timed: 1024 spp = four internal passes of 256, as the 8192-spp configuration runs them
     # (the warm-up is one full pass too: it sizes the partial-sum buffer, and fresh VRAM costs ~40 ms per GB once)
@@ -311,10 +331,19 @@ def run_rank(args):
     import torch
     import torch.distributed as dist
 
+    if args.dist_single and "WORLD_SIZE" not in os.environ:
+        with socket.socket() as probe:
+            probe.bind(("127.0.0.1", 0))
+            port = probe.getsockname()[1]
+        os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", LOCAL_WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = 0 if args.share_gpu else int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world_size > 1
+    distributed = world_size > 1 or args.dist_single
+    wants_large_bvh = (world_size == 1 and not args.no_large_bvh and not args.no_kernel_timing and args.scene == "scenes/cornell.json")
+    if wants_large_bvh and rank == 0:
+        ensure_large_bvh_mesh(args)   # a child process: before anything here touches the GPU
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -483,7 +512,7 @@ def run_rank(args):
                     "achieved": rates[dominant]["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": rates[dominant]["frac"],
                     "traffic": traffic, "hbm": hbm,
                 }
-            if roofline is not None and world_size == 1 and not args.no_large_bvh and args.scene == "scenes/cornell.json":
+            if roofline is not None and wants_large_bvh:
                 roofline["large_bvh"] = large_bvh_leg(args, torch, stream)
 
         baseline = None
@@ -514,7 +543,9 @@ def run_rank(args):
                 "spp_per_step": spp,
                 "total_samples": total_samples,
                 "parallelism": ("the samples of every step split over %d GPU(s)" if strong else "a full step on each of %d GPU(s)") % world_size
-                               + ", one RCCL reduce of 3*W*H fp32 sums to rank 0 inside the timed region",
+                               + (", one %s of 3*W*H fp32 sums to rank 0 inside the timed region" % (
+                                   "reduce staged through host memory (gloo)" if staged else "RCCL reduce") if distributed else ", no exchange"),
+                "collective": None if not distributed else "%s, world size %d" % ("gloo (host-staged)" if staged else "nccl (RCCL)", world_size),
             },
             "per_rank_s": {"render": [row[0] for row in per_rank], "reduce": [row[1] for row in per_rank], "total": [row[2] for row in per_rank]},
             "roofline": roofline,

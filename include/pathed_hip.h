@@ -33,8 +33,10 @@
 extern "C" {
 #endif
 
-#define PATHED_ABI_VERSION 3   /* 2: image-texture albedo (PathedTexture, PathedMaterial.texture)
-                                * 3: participating media (PathedMedium, PathedGeom.medium, PATHED_MAT_PASSTHROUGH) */
+#define PATHED_ABI_VERSION 4   /* 2: image-texture albedo (PathedTexture, PathedMaterial.texture)
+                                * 3: participating media (PathedMedium, PathedGeom.medium, PATHED_MAT_PASSTHROUGH)
+                                * 4: the process-global pathed_hip_set_bvh_builder is gone (PathedSceneOptions.bvh_builder);
+                                *    PathedSceneOptions.build_threads; pathed_hip_comm_* (RCCL reduce of the radiance sums) */
 /* Additions that leave PathedSceneDesc unchanged (no version bump): PathedSceneOptions /
  * pathed_hip_scene_create_ex (per-scene device and tuning), pathed_hip_measure_valu,
  * pathed_hip_accum_add / pathed_hip_accum_copy_peer (multi-GPU fan-in of the radiance sums). */
@@ -224,8 +226,8 @@ typedef struct PathedStats {
  * Replaces the reference's rtcNewDevice / rtcNewScene (app/main.cpp:46-52). */
 int pathed_hip_init(int device_id);
 
-/* Which builder stands in for rtcCommitScene (reference src/scene.cpp:39) in the scene_create
- * calls that follow (process-wide; the environment variable PATHED_BVH_BUILDER=sah|lbvh|ploc overrides):
+/* Which builder stands in for rtcCommitScene (reference src/scene.cpp:39): PathedSceneOptions.bvh_builder
+ * (the environment variable PATHED_BVH_BUILDER=sah|lbvh|ploc overrides, for experiments):
  *   PATHED_BVH_SAH_HOST     binned-SAH tree built on the host cores (default: cheapest to traverse)
  *   PATHED_BVH_LBVH_DEVICE  Morton-code linear BVH built on the GPU in milliseconds;
  *                           same node format, so hits and images are bit-identical, traversal costs more.
@@ -235,7 +237,6 @@ int pathed_hip_init(int device_id);
 #define PATHED_BVH_SAH_HOST    0
 #define PATHED_BVH_LBVH_DEVICE 1
 #define PATHED_BVH_PLOC_DEVICE 2
-int pathed_hip_set_bvh_builder(int builder);
 
 /* Flatten + upload once: leaf-ordered 48-B triangles, flattened 4-wide BVH (128-B nodes),
  * spheres, material table, light table, env map + CDFs, camera.
@@ -256,7 +257,7 @@ void pathed_hip_scene_destroy(PathedScene *scene);
 typedef struct PathedSceneOptions {
     uint32_t struct_size;       /* sizeof(PathedSceneOptions)                                  */
     int32_t device;             /* HIP device id, or PATHED_DEVICE_CURRENT                     */
-    int32_t bvh_builder;        /* PATHED_BVH_* + 1 (0 = the process default of set_bvh_builder) */
+    int32_t bvh_builder;        /* PATHED_BVH_* + 1 (0 = PATHED_BVH_SAH_HOST)                  */
     int32_t stack_rows;         /* LDS rows of the traversal stack: 8, 16 or 22 (0 = by tree depth); deeper entries spill to HBM */
     int32_t pools;              /* independent slot pools, 1..4 (0 = 2)                        */
     int32_t suspend_lanes;      /* park a trace wave's tail below this many rays, 1..64; -1 = never (0 = 32) */
@@ -272,7 +273,8 @@ typedef struct PathedSceneOptions {
     int32_t stage_slots;        /* slots per block of the staged kernel: 512 or 1024 (0 = automatic)           */
     int32_t unit_order;         /* order work units are handed out in (scheduling only, results identical):
                                  * 0 automatic = 1; 1 chunk stripes, rows; 2 chunk stripes, 32 x 8 tiles; 3 pixel tiles */
-    int32_t reserved[2];        /* must be 0                                                   */
+    int32_t build_threads;      /* host threads of the SAH builder (0 = all cores; the tree does not depend on it) */
+    int32_t reserved[1];        /* must be 0                                                   */
 } PathedSceneOptions;
 int pathed_hip_scene_create_ex(const PathedSceneDesc *desc, const PathedSceneOptions *options, PathedScene **out);
 int pathed_hip_scene_device(const PathedScene *scene);   /* the HIP device the scene lives on, or a negative error */
@@ -386,8 +388,20 @@ int pathed_hip_accum_free(PathedScene *scene, float *buffer);
 int pathed_hip_accum_download(PathedScene *scene, const float *buffer, size_t count, float *host);
 int pathed_hip_accum_upload(PathedScene *scene, float *buffer, size_t count, const float *host);
 
+/* The same exchange step as ONE collective: ncclReduce(sum, fp32, count, root = replica 0) over RCCL / xGMI
+ * (the reference adds its waves in src/integrator.cpp:42-51).  A communicator spans the
+ * devices of one process's replicas (ncclCommInitAll); librccl is loaded when the first communicator is made,
+ * so a single-GPU host never pays for it.  Devices must be distinct (RCCL refuses two ranks on one device:
+ * replicas that share a GPU use the peer-copy calls above); n_devices = 1 is a valid communicator.
+ *   pathed_hip_comm_reduce  send[r] holds `count` floats on device_ids[r]; their sum lands in recv_root on
+ *                           device_ids[0] (may equal send[0]: in place); blocking. */
+typedef struct PathedComm PathedComm;
+int pathed_hip_comm_init(int n_devices, const int *device_ids, PathedComm **out);
+int pathed_hip_comm_reduce(PathedComm *comm, const float *const *send, float *recv_root, size_t count);
+void pathed_hip_comm_destroy(PathedComm *comm);
+
 const char *pathed_hip_last_error(void);
-const char *pathed_hip_version(void);
+const char *pathed_hip_version(void);   /* "pathed_hip <version> (gfx950, abi <PATHED_ABI_VERSION>)" */
 
 #ifdef __cplusplus
 }

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 REPO_ROOT = os.path.dirname(_HERE)
 LIB_DIR = os.path.join(_HERE, "lib")
 
-PATHED_ABI_VERSION = 3
+PATHED_ABI_VERSION = 4
 
 MAT_LAMBERTIAN, MAT_OREN_NAYAR, MAT_MICROFACET, MAT_PLASTIC, MAT_GLASS, MAT_MIRROR, MAT_PASSTHROUGH = range(7)
 INTEGRATOR_PATH_TRACER, INTEGRATOR_VOLUME_PATH_TRACER = 0, 1
@@ -151,7 +151,8 @@ class PathedSceneOptions(C.Structure):
         ("shade_kernel", C.c_int32),
         ("stage_slots", C.c_int32),
         ("unit_order", C.c_int32),
-        ("reserved", C.c_int32 * 2),
+        ("build_threads", C.c_int32),
+        ("reserved", C.c_int32 * 1),
     ]
 
 
@@ -160,7 +161,6 @@ DEVICE_CURRENT = -1
 # every symbol include/pathed_hip.h declares; tests check that the library exports all
 HIP_SYMBOLS = [
     "pathed_hip_init",
-    "pathed_hip_set_bvh_builder",
     "pathed_hip_scene_create",
     "pathed_hip_scene_create_ex",
     "pathed_hip_scene_device",
@@ -183,6 +183,9 @@ HIP_SYMBOLS = [
     "pathed_hip_accum_free",
     "pathed_hip_accum_download",
     "pathed_hip_accum_upload",
+    "pathed_hip_comm_init",
+    "pathed_hip_comm_reduce",
+    "pathed_hip_comm_destroy",
     "pathed_hip_last_error",
     "pathed_hip_version",
 ]
@@ -218,8 +221,6 @@ def load_hip():
     vp = C.c_void_p
     lib.pathed_hip_init.argtypes = [C.c_int]
     lib.pathed_hip_init.restype = C.c_int
-    lib.pathed_hip_set_bvh_builder.argtypes = [C.c_int]
-    lib.pathed_hip_set_bvh_builder.restype = C.c_int
     lib.pathed_hip_scene_create.argtypes = [C.POINTER(PathedSceneDesc), C.POINTER(vp)]
     lib.pathed_hip_scene_create.restype = C.c_int
     lib.pathed_hip_scene_create_ex.argtypes = [C.POINTER(PathedSceneDesc), C.POINTER(PathedSceneOptions), C.POINTER(vp)]
@@ -243,6 +244,12 @@ def load_hip():
     lib.pathed_hip_accum_download.restype = C.c_int
     lib.pathed_hip_accum_upload.argtypes = [vp, vp, C.c_size_t, fp]
     lib.pathed_hip_accum_upload.restype = C.c_int
+    lib.pathed_hip_comm_init.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(vp)]
+    lib.pathed_hip_comm_init.restype = C.c_int
+    lib.pathed_hip_comm_reduce.argtypes = [vp, C.POINTER(vp), vp, C.c_size_t]
+    lib.pathed_hip_comm_reduce.restype = C.c_int
+    lib.pathed_hip_comm_destroy.argtypes = [vp]
+    lib.pathed_hip_comm_destroy.restype = None
     lib.pathed_hip_scene_destroy.argtypes = [vp]
     lib.pathed_hip_scene_destroy.restype = None
     lib.pathed_hip_render.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.POINTER(C.c_float)]

@@ -215,8 +215,9 @@ inline void putInt(float *slot, int value) { std::memcpy(slot, &value, 4); }
 
 // positions: 3 floats per vertex; indices: 3 per triangle; spheres: (centre.xyz, radius) each, may be null.
 // Sphere s becomes the leaf reference -(((s + 1) << 3) | 0) - 1: count 0 marks it, trace.h tests it.
+// `buildThreads` > 0 fixes the number of host threads (PathedSceneOptions.build_threads); the tree does not depend on it
 inline FlatBvh buildBvh(const float *positions, const uint32_t *indices, uint32_t triangleCount,
-                        const float *spheres = nullptr, uint32_t sphereCount = 0)
+                        const float *spheres = nullptr, uint32_t sphereCount = 0, int buildThreads = 0)
 {
     using namespace bvh_detail;
     FlatBvh out;
@@ -257,10 +258,7 @@ inline FlatBvh buildBvh(const float *positions, const uint32_t *indices, uint32_
     int maxDepth = 0;
     // large meshes: the top of the tree here, its subtrees on the host's other cores
     unsigned int hostThreads = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
-    if (const char *text = getenv("PATHED_BUILD_THREADS")) {
-        const int parsed = atoi(text);
-        if (parsed >= 1 && parsed <= 256) { hostThreads = (unsigned int)parsed; }
-    }
+    if (buildThreads >= 1) { hostThreads = (unsigned int)buildThreads; }
     if (primCount >= 200000 && hostThreads > 1) { builder.deferThreshold = primCount / 256; }
     const int root = builder.build(0, primCount, 0, &maxDepth);
     if (!builder.deferred.empty()) {

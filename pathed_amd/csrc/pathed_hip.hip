@@ -9,10 +9,13 @@
 
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -22,7 +25,6 @@ namespace {
 
 thread_local std::string g_error;
 int g_device = -1;
-int g_bvhBuilder = PATHED_BVH_SAH_HOST;   // pathed_hip_set_bvh_builder / PATHED_BVH_BUILDER
 
 int fail(int code, const std::string &message)
 {
@@ -374,6 +376,15 @@ int validate(const PathedSceneDesc *desc)
         if (desc->env->width <= 0 || desc->env->height <= 0 || !desc->env->rgba) { return fail(PATHED_E_INVALID, "environment map missing"); }
     }
     if (desc->n_media && !desc->media) { return fail(PATHED_E_INVALID, "media array missing"); }
+    for (uint32_t i = 0; i < desc->n_media; i++) {
+        // HomogeneousMedium asserts sigma_t.r == g == b (reference src/homogeneous_medium.cpp): distances are sampled with
+        // one channel and attenuated with all three, so unequal channels would render a biased image silently
+        const float *t = desc->media[i].sigma_t, *sc = desc->media[i].sigma_s;
+        if (!(t[0] == t[1] && t[1] == t[2])) { return fail(PATHED_E_INVALID, "homogeneous medium: the three sigma_t channels must be equal"); }
+        for (int k = 0; k < 3; k++) {
+            if (!(t[k] >= 0.f && t[k] < 3e38f && sc[k] >= 0.f && sc[k] < 3e38f)) { return fail(PATHED_E_INVALID, "homogeneous medium: sigma_t and sigma_s must be finite and not negative"); }
+        }
+    }
     for (uint32_t i = 0; i < desc->n_geoms; i++) {
         if (desc->geoms[i].medium < -1 || (desc->geoms[i].medium >= 0 && (uint32_t)desc->geoms[i].medium >= desc->n_media)) {
             return fail(PATHED_E_INVALID, "geom medium index out of range");
@@ -600,7 +611,9 @@ extern "C" {
 
 const char *pathed_hip_last_error(void) { return g_error.c_str(); }
 
-const char *pathed_hip_version(void) { return "pathed_hip 0.2.0 (gfx950, abi 2)"; }
+#define PATHED_STRINGIFY2(x) #x
+#define PATHED_STRINGIFY(x) PATHED_STRINGIFY2(x)
+const char *pathed_hip_version(void) { return "pathed_hip 0.3.0 (gfx950, abi " PATHED_STRINGIFY(PATHED_ABI_VERSION) ")"; }
 
 int pathed_hip_init(int device_id)
 {
@@ -789,13 +802,124 @@ int pathed_hip_accum_add(PathedScene *dst_scene, float *dst, const float *src, s
     return PATHED_OK;
 }
 
-int pathed_hip_set_bvh_builder(int builder)
+// ---- RCCL reduce of the per-device radiance sums (include/pathed_hip.h: multi-GPU fan-in) ----
+// librccl is opened on first use: its types are restated here so that neither this library nor a single-GPU
+// host links against it (rccl.h: ncclFloat32 = 7, ncclSum = 0, ncclSuccess = 0).
+namespace {
+struct RcclApi {
+    void *library = nullptr;
+    int (*commInitAll)(void **, int, const int *) = nullptr;
+    int (*commDestroy)(void *) = nullptr;
+    int (*reduce)(const void *, void *, size_t, int, int, int, void *, hipStream_t) = nullptr;
+    int (*groupStart)() = nullptr;
+    int (*groupEnd)() = nullptr;
+    const char *(*errorString)(int) = nullptr;
+};
+RcclApi g_rccl;
+std::mutex g_rcclMutex;
+
+bool loadRccl(std::string *why)
 {
-    if (builder != PATHED_BVH_SAH_HOST && builder != PATHED_BVH_LBVH_DEVICE && builder != PATHED_BVH_PLOC_DEVICE) {
-        return fail(PATHED_E_INVALID, "unknown BVH builder");
+    std::lock_guard<std::mutex> guard(g_rcclMutex);
+    if (g_rccl.library) { return true; }
+    void *library = nullptr;
+    for (const char *name : { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" }) {
+        library = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        if (library) { break; }
     }
-    g_bvhBuilder = builder;
+    if (!library) { *why = std::string("cannot load librccl: ") + dlerror(); return false; }
+    RcclApi api;
+    api.library = library;
+    api.commInitAll = reinterpret_cast<int (*)(void **, int, const int *)>(dlsym(library, "ncclCommInitAll"));
+    api.commDestroy = reinterpret_cast<int (*)(void *)>(dlsym(library, "ncclCommDestroy"));
+    api.reduce = reinterpret_cast<int (*)(const void *, void *, size_t, int, int, int, void *, hipStream_t)>(dlsym(library, "ncclReduce"));
+    api.groupStart = reinterpret_cast<int (*)()>(dlsym(library, "ncclGroupStart"));
+    api.groupEnd = reinterpret_cast<int (*)()>(dlsym(library, "ncclGroupEnd"));
+    api.errorString = reinterpret_cast<const char *(*)(int)>(dlsym(library, "ncclGetErrorString"));
+    if (!api.commInitAll || !api.commDestroy || !api.reduce || !api.groupStart || !api.groupEnd || !api.errorString) {
+        *why = "librccl lacks one of ncclCommInitAll / ncclCommDestroy / ncclReduce / ncclGroupStart / ncclGroupEnd / ncclGetErrorString";
+        dlclose(library);
+        return false;
+    }
+    g_rccl = api;
+    return true;
+}
+}  // namespace
+
+struct PathedComm {
+    std::vector<int> devices;
+    std::vector<void *> comms;          // ncclComm_t per device
+    std::vector<hipStream_t> streams;   // one per device
+};
+
+int pathed_hip_comm_init(int n_devices, const int *device_ids, PathedComm **out)
+{
+    if (!out) { return fail(PATHED_E_INVALID, "out pointer is null"); }
+    *out = nullptr;
+    if (n_devices < 1 || !device_ids) { return fail(PATHED_E_INVALID, "a communicator needs at least one device"); }
+    int visible = 0;
+    HIP_TRY(hipGetDeviceCount(&visible));
+    for (int i = 0; i < n_devices; i++) {
+        if (device_ids[i] < 0 || device_ids[i] >= visible) { return fail(PATHED_E_INVALID, "device id out of range"); }
+        for (int k = 0; k < i; k++) {
+            if (device_ids[k] == device_ids[i]) { return fail(PATHED_E_UNSUPPORTED, "RCCL takes one rank per device: replicas that share a GPU use pathed_hip_accum_copy_peer"); }
+        }
+    }
+    std::string why;
+    if (!loadRccl(&why)) { return fail(PATHED_E_UNSUPPORTED, why); }
+    PathedComm *comm = new PathedComm();
+    comm->devices.assign(device_ids, device_ids + n_devices);
+    comm->comms.assign((size_t)n_devices, nullptr);
+    comm->streams.assign((size_t)n_devices, nullptr);
+    const int status = g_rccl.commInitAll(comm->comms.data(), n_devices, device_ids);
+    if (status != 0) {
+        const std::string message = std::string("ncclCommInitAll: ") + g_rccl.errorString(status);
+        delete comm;
+        return fail(PATHED_E_DEVICE, message);
+    }
+    for (int i = 0; i < n_devices; i++) {
+        hipError_t error = hipSetDevice(device_ids[i]);
+        if (error == hipSuccess) { error = hipStreamCreateWithFlags(&comm->streams[(size_t)i], hipStreamNonBlocking); }
+        if (error != hipSuccess) {
+            const std::string message = std::string("communicator stream: ") + hipGetErrorString(error);
+            pathed_hip_comm_destroy(comm);
+            return fail(PATHED_E_DEVICE, message);
+        }
+    }
+    *out = comm;
     return PATHED_OK;
+}
+
+int pathed_hip_comm_reduce(PathedComm *comm, const float *const *send, float *recv_root, size_t count)
+{
+    if (!comm || !send || !recv_root) { return fail(PATHED_E_INVALID, "null communicator or buffer"); }
+    const size_t n = comm->devices.size();
+    for (size_t r = 0; r < n; r++) { if (!send[r]) { return fail(PATHED_E_INVALID, "null send buffer"); } }
+    // whatever the caller queued on the devices' null streams (its renders are blocking) is done; the collective runs on
+    // the communicator's own streams
+    int status = g_rccl.groupStart();
+    for (size_t r = 0; r < n && status == 0; r++) {
+        status = g_rccl.reduce(send[r], r == 0 ? recv_root : nullptr, count, /* ncclFloat32 */ 7, /* ncclSum */ 0, /* root */ 0,
+                               comm->comms[r], comm->streams[r]);
+    }
+    const int ended = g_rccl.groupEnd();
+    if (status == 0) { status = ended; }
+    if (status != 0) { return fail(PATHED_E_DEVICE, std::string("ncclReduce: ") + g_rccl.errorString(status)); }
+    for (size_t r = 0; r < n; r++) {
+        HIP_TRY(hipSetDevice(comm->devices[r]));
+        HIP_TRY(hipStreamSynchronize(comm->streams[r]));
+    }
+    return PATHED_OK;
+}
+
+void pathed_hip_comm_destroy(PathedComm *comm)
+{
+    if (!comm) { return; }
+    for (size_t r = 0; r < comm->devices.size(); r++) {
+        if (comm->streams[r]) { (void)hipSetDevice(comm->devices[r]); (void)hipStreamDestroy(comm->streams[r]); }
+        if (comm->comms[r] && g_rccl.commDestroy) { (void)g_rccl.commDestroy(comm->comms[r]); }
+    }
+    delete comm;
 }
 
 int pathed_hip_scene_create(const PathedSceneDesc *desc, PathedScene **out)
@@ -831,9 +955,8 @@ int pathed_hip_scene_create_ex(const PathedSceneDesc *desc, const PathedSceneOpt
     if (optionsIn) {
         if (optionsIn->struct_size != sizeof(PathedSceneOptions)) { return fail(PATHED_E_INVALID, "PathedSceneOptions.struct_size mismatch"); }
         options = *optionsIn;
-        for (int k = 0; k < 2; k++) {
-            if (options.reserved[k] != 0) { return fail(PATHED_E_INVALID, "PathedSceneOptions.reserved must be zero"); }
-        }
+        if (options.reserved[0] != 0) { return fail(PATHED_E_INVALID, "PathedSceneOptions.reserved must be zero"); }
+        if (options.build_threads < 0 || options.build_threads > 4096) { return fail(PATHED_E_INVALID, "build_threads must be 0..4096"); }
         if (options.unit_order < 0 || options.unit_order > 3) { return fail(PATHED_E_INVALID, "unit_order must be 0..3"); }
         if (options.bvh_builder < 0 || options.bvh_builder > PATHED_BVH_PLOC_DEVICE + 1) { return fail(PATHED_E_INVALID, "unknown BVH builder"); }
         if (options.pools < 0 || options.pools > kMaxPools) { return fail(PATHED_E_INVALID, "pools must be 0..4"); }
@@ -1017,7 +1140,7 @@ int pathed_hip_scene_create_ex(const PathedSceneDesc *desc, const PathedSceneOpt
     };
 
     hipError_t status;
-    int builder = options.bvh_builder > 0 ? options.bvh_builder - 1 : g_bvhBuilder;
+    int builder = options.bvh_builder > 0 ? options.bvh_builder - 1 : PATHED_BVH_SAH_HOST;
     if (const char *text = getenv("PATHED_BVH_BUILDER")) {
         if (!strcmp(text, "lbvh")) { builder = PATHED_BVH_LBVH_DEVICE; }
         else if (!strcmp(text, "ploc")) { builder = PATHED_BVH_PLOC_DEVICE; }
@@ -1087,7 +1210,8 @@ int pathed_hip_scene_create_ex(const PathedSceneDesc *desc, const PathedSceneOpt
             }
         }
         scene->spheresInTree = !sphereBounds.empty();
-        scene->bvh = buildBvh(desc->positions, desc->indices, desc->n_triangles, sphereBounds.data(), (uint32_t)(sphereBounds.size() / 4));
+        scene->bvh = buildBvh(desc->positions, desc->indices, desc->n_triangles, sphereBounds.data(), (uint32_t)(sphereBounds.size() / 4),
+                              scene->options.build_threads);
         scene->bvhBuildMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - buildStart).count();
         std::vector<float4> nodes(scene->bvh.nodes.size() / 4), tris(scene->bvh.leafTris.size() / 4);
         std::memcpy(nodes.data(), scene->bvh.nodes.data(), scene->bvh.nodes.size() * sizeof(float));
@@ -1111,10 +1235,13 @@ int pathed_hip_scene_create_ex(const PathedSceneDesc *desc, const PathedSceneOpt
         std::vector<int> primMedium((size_t)desc->n_triangles + desc->n_spheres, -1);
         for (uint32_t g = 0; g < desc->n_geoms; g++) {
             const PathedGeom &geom = desc->geoms[g];
+            // (a medium with sigma_t = 0 stays a medium: its surface is still a container the volumetric queries skip; its
+            // distance sample -log(1 - xi) / 0 is +inf, "no event", as in the reference)
+            const int medium = geom.medium;
             if (geom.type == PATHED_GEOM_MESH) {
-                for (int i = 0; i < geom.count; i++) { primMedium[(size_t)(geom.first + i)] = geom.medium; }
+                for (int i = 0; i < geom.count; i++) { primMedium[(size_t)(geom.first + i)] = medium; }
             } else {
-                primMedium[(size_t)desc->n_triangles + (size_t)geom.first] = geom.medium;
+                primMedium[(size_t)desc->n_triangles + (size_t)geom.first] = medium;
             }
         }
         for (uint32_t i = 0; i < desc->n_materials; i++) { scene->hasContainers = scene->hasContainers || desc->materials[i].type == PATHED_MAT_PASSTHROUGH; }

@@ -129,6 +129,12 @@ int runJob(const std::string &jobPath, const std::string &assetRootOverride)
         std::shared_ptr<Integrator> integrator = job.integrator();
         integrator->configure(job.spp(), job.seed(), job.sppPerLaunch(), job.outputDirectory());
         integrator->setStateFile(job.outputDirectory() + "auto.state", job.resume());
+        integrator->setStateIdentity(job.scene() + "|" + job.integratorName());
+        const std::string reduce = job.reduceMethod();
+        if (reduce != "rccl" && reduce != "peer-copy") { throw std::runtime_error("job: \"reduce\" must be \"rccl\" or \"peer-copy\""); }
+        integrator->setUseRccl(reduce == "rccl");
+        const std::string metricsLevel = job.metricsLevel();
+        if (metricsLevel != "full" && metricsLevel != "basic") { throw std::runtime_error("job: \"metrics\" must be \"full\" or \"basic\""); }
 
         // the reference renders on a dedicated thread while the UI owns the main thread
         // (app/main.cpp:98); kept so `quit` and the Image lock behave the same
@@ -152,6 +158,25 @@ int runJob(const std::string &jobPath, const std::string &assetRootOverride)
             std::memset(&stats, 0, sizeof stats);
             pathed_hip_get_stats(scene.handle(), &stats);
             const double samples = (double)m.width * m.height * (double)(m.lastSample - m.firstSample);
+            // what the reference prints per render (RTCManager::printStats, src/rtc_manager.cpp:94-115) and per wave
+            // (src/integrator.cpp:97-102), as rates: a one-sample counting pass over sample index `spp` into a scratch
+            // buffer (the COUNT kernel variants never run inside the timed loop)
+            PathedStats counted;
+            std::memset(&counted, 0, sizeof counted);
+            bool haveCounts = false;
+            if (metricsLevel == "full" && samples > 0.0) {
+                float *scratch = nullptr;
+                const size_t floats = (size_t)3 * m.width * m.height;
+                if (pathed_hip_accum_alloc(scene.handle(), floats, &scratch) == PATHED_OK) {
+                    pathed_hip_set_stats_mode(scene.handle(), 1);
+                    pathed_hip_reset_stats(scene.handle());
+                    haveCounts = pathed_hip_render_device(scene.handle(), job.seed(), (uint32_t)m.lastSample, 1, job.startBounce(), job.lastBounce(),
+                                                          scratch, nullptr, 1) == PATHED_OK
+                        && pathed_hip_get_stats(scene.handle(), &counted) == PATHED_OK;
+                    pathed_hip_set_stats_mode(scene.handle(), 0);
+                    pathed_hip_accum_free(scene.handle(), scratch);
+                }
+            }
             std::ofstream out(job.outputDirectory() + "metrics.json");
             out << std::setprecision(9);
             out << "{\n";
@@ -166,7 +191,20 @@ int runJob(const std::string &jobPath, const std::string &assetRootOverride)
                 << ", \"bvh_bytes\": " << stats.bvh_bytes << ", \"bvh_nodes\": " << stats.bvh_nodes << ",\n";
             out << "  \"render_seconds\": " << m.loopSeconds << ",\n";
             out << "  \"msamples_per_second\": " << (m.loopSeconds > 0.0 ? samples / m.loopSeconds / 1e6 : 0.0) << ",\n";
-            out << "  \"reduce_seconds\": " << m.reduceSeconds << ", \"reduces\": " << m.reduces << ",\n";
+            out << "  \"reduce_seconds\": " << m.reduceSeconds << ", \"reduces\": " << m.reduces << ", \"reduce_method\": \"" << m.reduceMethod << "\",\n";
+            if (haveCounts && counted.camera_samples > 0) {
+                // per ray 32 B + S_hit (16 closest / 4 any-hit) + 32 B per child box + 48 B per triangle tested
+                const double perSample = 1.0 / (double)counted.camera_samples;
+                const double rays = (double)(counted.closest_rays + counted.shadow_rays) * perSample;
+                const double bytes = (48.0 * counted.closest_rays + 36.0 * counted.shadow_rays + 32.0 * counted.nodes_visited + 48.0 * counted.tris_tested) * perSample;
+                const double rate = m.loopSeconds > 0.0 ? samples / m.loopSeconds : 0.0;
+                out << "  \"rays_per_sample\": " << rays << ", \"mrays_per_second\": " << rays * rate / 1e6 << ",\n";
+                out << "  \"boxes_per_ray\": " << (rays > 0.0 ? counted.nodes_visited * perSample / rays : 0.0)
+                    << ", \"triangles_per_ray\": " << (rays > 0.0 ? counted.tris_tested * perSample / rays : 0.0) << ",\n";
+                out << "  \"trace_algorithmic_bytes_per_sample\": " << bytes << ", \"trace_algorithmic_gbs\": " << bytes * rate / 1e9
+                    << ", \"hbm_roofline_fraction\": " << bytes * rate / 8.0e12 << ",\n";
+                out << "  \"counter_bytes_per_sample\": null,\n";   // measured HBM bytes need a rocprofv3 --pmc pass (tools/pmc_per_sample.sh)
+            }
             out << "  \"replica_seconds\": [";
             for (size_t i = 0; i < m.replicaSeconds.size(); i++) { out << (i ? ", " : "") << m.replicaSeconds[i]; }
             out << "],\n";

@@ -1,11 +1,13 @@
 #include "integrator.h"
 
 #include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
 #include <iomanip>
 #include <iostream>
+#include <mutex>
 #include <sstream>
 #include <stdexcept>
 #include <thread>
@@ -19,35 +21,97 @@ std::string hipError(const char *what)
     return std::string(what) + ": " + pathed_hip_last_error();
 }
 
-// run `work(replica)` for every replica, each on its own host thread (one worker per device);
-// the first failure is rethrown on the caller's thread
-template <typename Work>
-void forEachReplica(size_t replicas, Work work)
-{
-    if (replicas == 1) { work((size_t)0); return; }
-    std::vector<std::string> failures(replicas);
-    std::vector<std::thread> workers;
-    for (size_t r = 0; r < replicas; r++) {
-        workers.emplace_back([&, r]() {
-            try { work(r); } catch (const std::exception &error) { failures[r] = error.what(); if (failures[r].empty()) { failures[r] = "unknown error"; } }
-        });
+// One host thread per replica (= per device), alive for the whole render: `run(work)` hands work(replica) to every
+// worker and returns when all are through; the first failure is rethrown on the caller's thread.  (Round 2 created and
+// joined the threads for every batch: at the 1-, 1-, 2-, 4-sample batches of the first checkpoints that was most of
+// the batch.)
+class ReplicaWorkers {
+public:
+    explicit ReplicaWorkers(size_t replicas) : m_failures(replicas)
+    {
+        for (size_t r = 1; r < replicas; r++) { m_threads.emplace_back([this, r]() { serve(r); }); }
     }
-    for (std::thread &worker : workers) { worker.join(); }
-    for (const std::string &failure : failures) {
-        if (!failure.empty()) { throw std::runtime_error(failure); }
+    ~ReplicaWorkers()
+    {
+        {
+            std::lock_guard<std::mutex> guard(m_mutex);
+            m_stop = true;
+            m_generation++;
+        }
+        m_wake.notify_all();
+        for (std::thread &thread : m_threads) { thread.join(); }
     }
-}
+    void run(const std::function<void(size_t)> &work)
+    {
+        const size_t replicas = m_failures.size();
+        for (std::string &failure : m_failures) { failure.clear(); }
+        if (replicas > 1) {
+            std::lock_guard<std::mutex> guard(m_mutex);
+            m_work = &work;
+            m_pending = replicas - 1;
+            m_generation++;
+        }
+        m_wake.notify_all();
+        attempt(work, 0);   // replica 0 on the caller's thread
+        if (replicas > 1) {
+            std::unique_lock<std::mutex> lock(m_mutex);
+            m_done.wait(lock, [this]() { return m_pending == 0; });
+            m_work = nullptr;
+        }
+        for (const std::string &failure : m_failures) {
+            if (!failure.empty()) { throw std::runtime_error(failure); }
+        }
+    }
+
+private:
+    void attempt(const std::function<void(size_t)> &work, size_t replica)
+    {
+        try { work(replica); }
+        catch (const std::exception &error) { m_failures[replica] = error.what(); if (m_failures[replica].empty()) { m_failures[replica] = "unknown error"; } }
+        catch (...) { m_failures[replica] = "unknown error"; }
+    }
+    void serve(size_t replica)
+    {
+        unsigned long long seen = 0;
+        while (true) {
+            const std::function<void(size_t)> *work = nullptr;
+            {
+                std::unique_lock<std::mutex> lock(m_mutex);
+                m_wake.wait(lock, [&]() { return m_generation != seen; });
+                seen = m_generation;
+                if (m_stop) { return; }
+                work = m_work;
+            }
+            if (work) { attempt(*work, replica); }
+            {
+                std::lock_guard<std::mutex> guard(m_mutex);
+                if (m_pending > 0) { m_pending--; }
+            }
+            m_done.notify_one();
+        }
+    }
+
+    std::vector<std::thread> m_threads;
+    std::vector<std::string> m_failures;
+    std::mutex m_mutex;
+    std::condition_variable m_wake, m_done;
+    const std::function<void(size_t)> *m_work = nullptr;
+    size_t m_pending = 0;
+    unsigned long long m_generation = 0;
+    bool m_stop = false;
+};
 
 // The sidecar a resumed job continues from: the fp32 radiance SUMS and how many samples they hold.
 // Because the random stream is a pure function of (seed, pixel, sample, dimension), "the next
 // sample" needs no generator state: a resumed run is the straight run, bit for bit, as long as the
 // interruption fell on a batch boundary (it always does: the file is written after a batch).
 struct StateHeader {
-    char magic[8];            // "PATHEDS1"
+    char magic[8];            // "PATHEDS2"
     int32_t width, height;
     int32_t done;             // samples per pixel already in the sums
     int32_t startBounce, lastBounce;
     uint64_t seed;
+    uint64_t jobDigest;       // what else the sums depend on: scene file, integrator, samples per unit (Integrator::setStateIdentity)
 };
 
 }  // namespace
@@ -71,7 +135,8 @@ void Scene::upload(int bvhBuilderPlusOne)
     const PathedSceneDesc desc = m_flat.desc();
     try {
         // every device builds / uploads its own replica, in parallel
-        forEachReplica(m_devices.size(), [&](size_t r) {
+        ReplicaWorkers workers(m_devices.size());
+        workers.run([&](size_t r) {
             PathedSceneOptions options;
             std::memset(&options, 0, sizeof options);
             options.struct_size = sizeof options;
@@ -127,27 +192,42 @@ void Integrator::run(
     printf("Pre-process complete (0.0s elapsed)\n");
 
     std::vector<float *> deviceSums(replicas, nullptr);
-    float *staging = nullptr;   // on replica 0's device: a peer's sums on their way into the total
+    float *staging = nullptr;   // on replica 0's device: a peer's sums on their way into the total (peer-copy fan-in only)
     float *total = nullptr;     // on replica 0's device: sum over replicas (G > 1 only)
+    PathedComm *comm = nullptr; // RCCL communicator over the replicas' devices (distinct devices only)
     struct Cleanup {
         Scene &scene;
         std::vector<float *> &sums;
         float *&staging;
         float *&total;
+        PathedComm *&comm;
         ~Cleanup()
         {
+            pathed_hip_comm_destroy(comm);
             for (size_t r = 0; r < sums.size(); r++) { if (sums[r]) { pathed_hip_accum_free(scene.handle(r), sums[r]); } }
             if (staging) { pathed_hip_accum_free(scene.handle(0), staging); }
             if (total) { pathed_hip_accum_free(scene.handle(0), total); }
         }
-    } cleanup{ scene, deviceSums, staging, total };
+    } cleanup{ scene, deviceSums, staging, total, comm };
     for (size_t r = 0; r < replicas; r++) {
         if (pathed_hip_accum_alloc(scene.handle(r), floats, &deviceSums[r]) != PATHED_OK) { throw std::runtime_error(hipError("pathed_hip_accum_alloc")); }
     }
+    m_metrics = RenderMetrics();
     if (replicas > 1) {
-        if (pathed_hip_accum_alloc(scene.handle(0), floats, &staging) != PATHED_OK) { throw std::runtime_error(hipError("pathed_hip_accum_alloc")); }
         if (pathed_hip_accum_alloc(scene.handle(0), floats, &total) != PATHED_OK) { throw std::runtime_error(hipError("pathed_hip_accum_alloc")); }
+        // the path's one exchange step as ONE collective (RCCL reduce over xGMI); replicas that share a
+        // device, or a machine without librccl, fall back to peer copies + adds on replica 0
+        if (m_useRccl && pathed_hip_comm_init((int)replicas, scene.devices().data(), &comm) != PATHED_OK) {
+            comm = nullptr;
+            m_metrics.reduceFallback = pathed_hip_last_error();
+            std::cout << "[" << m_logPrefix << "] RCCL reduce unavailable (" << m_metrics.reduceFallback << "): using peer copies" << std::endl;
+        }
+        if (!comm) {
+            if (pathed_hip_accum_alloc(scene.handle(0), floats, &staging) != PATHED_OK) { throw std::runtime_error(hipError("pathed_hip_accum_alloc")); }
+        }
     }
+    m_metrics.reduceMethod = replicas == 1 ? "none" : comm ? "rccl" : "peer-copy";
+    ReplicaWorkers workers(replicas);
 
     std::vector<float> radianceLookup(floats, 0.f);
     int done = 0;
@@ -160,9 +240,20 @@ void Integrator::run(
             }
             std::cout << "[" << m_logPrefix << "] resuming at sample " << done << "/" << primarySamples << std::endl;
         }
+        if (done >= primarySamples) {
+            // nothing left to render: the image is the one the state file holds
+            std::lock_guard<std::mutex> guard(image.getLock());
+            image.setSpp(done);
+            for (int row = 0; row < height; row++) {
+                for (int col = 0; col < width; col++) {
+                    const size_t index = (size_t)3 * ((size_t)row * width + col);
+                    image.set(row, col, radianceLookup[index + 0] / done, radianceLookup[index + 1] / done, radianceLookup[index + 2] / done);
+                }
+            }
+            std::cout << "[" << m_logPrefix << "] the state file already holds " << done << " samples: nothing to render" << std::endl;
+        }
     }
 
-    m_metrics = RenderMetrics();
     m_metrics.replicas = (int)replicas;
     m_metrics.firstSample = done;
     m_metrics.replicaSeconds.assign(replicas, 0.0);
@@ -178,7 +269,7 @@ void Integrator::run(
         count = std::min(count, nextPower - done);
 
         const auto begin = std::chrono::steady_clock::now();
-        forEachReplica(replicas, [&](size_t r) {
+        workers.run([&](size_t r) {
             unsigned first = 0, mine = 0;
             strongRange((unsigned)r, (unsigned)replicas, (unsigned)done, (unsigned)count, &first, &mine);
             if (mine == 0) { return; }
@@ -201,8 +292,12 @@ void Integrator::run(
         if (checkpoint || done == primarySamples || stopping) {
             const auto reduceBegin = std::chrono::steady_clock::now();
             const float *source = deviceSums[0];
-            if (replicas > 1) {
-                // the path's one exchange step: per-device sums -> replica 0, over xGMI
+            if (replicas > 1 && comm) {
+                std::vector<const float *> send(deviceSums.begin(), deviceSums.end());
+                if (pathed_hip_comm_reduce(comm, send.data(), total, floats) != PATHED_OK) { throw std::runtime_error(hipError("pathed_hip_comm_reduce")); }
+                source = total;
+            } else if (replicas > 1) {
+                // per-device sums -> replica 0 one by one (hipMemcpyPeer over xGMI + add)
                 if (pathed_hip_accum_copy_peer(scene.handle(0), total, scene.handle(0), deviceSums[0], floats) != PATHED_OK) { throw std::runtime_error(hipError("pathed_hip_accum_copy_peer")); }
                 for (size_t r = 1; r < replicas; r++) {
                     if (pathed_hip_accum_copy_peer(scene.handle(0), staging, scene.handle(r), deviceSums[r], floats) != PATHED_OK) { throw std::runtime_error(hipError("pathed_hip_accum_copy_peer")); }
@@ -244,18 +339,26 @@ void Integrator::run(
     m_metrics.height = height;
 }
 
+void Integrator::setStateIdentity(const std::string &identity)
+{
+    unsigned long long hash = 1469598103934665603ull;   // FNV-1a
+    for (unsigned char c : identity) { hash = (hash ^ c) * 1099511628211ull; }
+    m_stateDigest = hash;
+}
+
 void Integrator::saveState(const std::vector<float> &sums, int width, int height, int done) const
 {
     if (m_statePath.empty()) { return; }
     StateHeader header;
     std::memset(&header, 0, sizeof header);
-    std::memcpy(header.magic, "PATHEDS1", 8);
+    std::memcpy(header.magic, "PATHEDS2", 8);
     header.width = width;
     header.height = height;
     header.done = done;
     header.startBounce = stateStartBounce();
     header.lastBounce = stateLastBounce();
     header.seed = m_seed;
+    header.jobDigest = m_stateDigest;
     // write beside, then rename: an interrupted write never leaves a truncated state behind
     const std::string scratch = m_statePath + ".tmp";
     {
@@ -274,11 +377,12 @@ int Integrator::loadState(std::vector<float> &sums, int width, int height) const
     if (!in) { return 0; }   // nothing to resume from: start at sample 0
     StateHeader header;
     in.read(reinterpret_cast<char *>(&header), sizeof header);
-    if (!in || std::memcmp(header.magic, "PATHEDS1", 8) != 0) { throw std::runtime_error("resume: " + m_statePath + " is not a pathed state file"); }
+    if (!in || std::memcmp(header.magic, "PATHEDS2", 8) != 0) { throw std::runtime_error("resume: " + m_statePath + " is not a pathed state file (of this version)"); }
     if (header.width != width || header.height != height) { throw std::runtime_error("resume: state file has another resolution"); }
     if (header.seed != m_seed || header.startBounce != stateStartBounce() || header.lastBounce != stateLastBounce()) {
         throw std::runtime_error("resume: state file was rendered with another seed or bounce window");
     }
+    if (header.jobDigest != m_stateDigest) { throw std::runtime_error("resume: state file was rendered from another scene, integrator or job configuration"); }
     if (header.done < 0 || header.done > m_spp) { throw std::runtime_error("resume: state file holds more samples than the job asks for"); }
     in.read(reinterpret_cast<char *>(sums.data()), (std::streamsize)(sums.size() * sizeof(float)));
     if (!in) { throw std::runtime_error("resume: state file is truncated"); }

@@ -32,6 +32,8 @@ struct RenderMetrics {
     double loopSeconds = 0.0;              // the render loop, checkpoints included
     double reduceSeconds = 0.0;            // fan-in of the per-device sums + download
     int reduces = 0;
+    std::string reduceMethod = "none";     // "rccl" (pathed_hip_comm_reduce), "peer-copy" (hipMemcpyPeer + add) or "none" (one replica)
+    std::string reduceFallback;            // why RCCL was not used, when it was asked for and is not
     std::vector<double> replicaSeconds;    // time each replica spent inside sampleImage
 };
 
@@ -92,6 +94,11 @@ public:
     // <outdir>/auto.state: fp32 radiance sums + sample count, rewritten whenever an image is published.
     // With resume the run continues from it (a missing file means "start at 0").
     void setStateFile(const std::string &path, bool resume) { m_statePath = path; m_resume = resume; }
+    // everything besides resolution, seed and bounce window that the sums depend on (scene file, integrator name,
+    // samples per unit): a state file of another identity is refused
+    void setStateIdentity(const std::string &identity);
+    // job key "reduce": "rccl" (default; falls back to peer copies when RCCL cannot be used) or "peer-copy"
+    void setUseRccl(bool use) { m_useRccl = use; }
     const RenderMetrics &metrics() const { return m_metrics; }
 
 protected:
@@ -109,6 +116,8 @@ protected:
 
     int m_sppPerLaunch = 1024;
     bool m_resume = false;
+    bool m_useRccl = true;
+    unsigned long long m_stateDigest = 0;
     std::string m_statePath;
     std::string m_logPrefix;
     RenderMetrics m_metrics;

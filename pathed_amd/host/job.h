@@ -65,6 +65,11 @@ public:
     int gpu() const { return m_json["gpu"].isNumber() ? m_json["gpu"].asInt() : 0; }
     std::string assetRoot() const { return m_json["asset_root"].isString() ? m_json["asset_root"].asString() : ""; }
     std::string bvhBuilder() const { return m_json["bvh_builder"].isString() ? m_json["bvh_builder"].asString() : "sah"; }
+    // fan-in of several devices' sums: "rccl" (one ncclReduce; falls back to peer copies where RCCL cannot be used) | "peer-copy"
+    std::string reduceMethod() const { return m_json["reduce"].isString() ? m_json["reduce"].asString() : "rccl"; }
+    // metrics.json: "full" (default) adds rays per sample, Mrays/s, algorithmic bytes and the roofline fraction from a
+    // one-sample counting pass after the render; "basic" leaves them out
+    std::string metricsLevel() const { return m_json["metrics"].isString() ? m_json["metrics"].asString() : "full"; }
 
     // string -> class factory, src/job.cpp:65-97; only the hot-path integrators exist here
     std::shared_ptr<Integrator> integrator() const;

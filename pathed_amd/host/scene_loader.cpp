@@ -921,6 +921,7 @@ FlatScene loadScene(
             PathedMedium medium;
             parseColor(mediumJson["sigma_t"], kBlack, medium.sigma_t);
             parseColor(mediumJson["sigma_s"], kBlack, medium.sigma_s);
+            if (!mediumJson["name"].isString()) { throw SceneLoadError("media: a medium needs a string \"name\""); }
             context.mediumLookup[mediumJson["name"].asString()] = (int)scene.media.size();
             scene.media.push_back(medium);
         }

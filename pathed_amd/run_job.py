@@ -53,6 +53,12 @@ def main(argv=None):
     if job["integrator"] not in ("PathTracer", "DataParallelIntegrator", "VolumePathTracer"):
         raise SystemExit("Unimplemented")  # the reference throws "Unimplemented" (src/job.cpp:96)
     out_dir = job["output_directory"] + "/"
+    # keys of the C++ host this runner does not implement are refused, not ignored: a job file must not behave
+    # differently between the two runners (here the GPUs are the ranks of torch.distributed.run, and there is no auto.state)
+    if job.get("resume", False):
+        raise SystemExit("pathed_amd.run_job: \"resume\" is a key of the C++ host (pathed <job.json>); this runner keeps no auto.state")
+    if "gpus" in job:
+        raise SystemExit("pathed_amd.run_job: \"gpus\" is a key of the C++ host; start this runner under torch.distributed.run, one rank per GPU")
 
     # rank 0 decides whether the job may run (output directory rules, src/job.cpp:33-63) and tells the
     # others BEFORE anyone builds a scene or enters a collective: every rank leaves with the same code
@@ -102,7 +108,7 @@ def main(argv=None):
             gpu.render_device(seed, begin, mine, bounces.start_bounce, bounces.last_bounce, accum.data_ptr(), stream)
         done += count
         checkpoint = (done & (done - 1)) == 0
-        if checkpoint or done == spp:
+        if checkpoint:   # images are written at the power-of-two sample counts only (src/integrator.cpp:87-92)
             total.copy_(accum)
             parallel.reduce_to_root(total, root=0)
         torch.cuda.synchronize()

@@ -15,3 +15,15 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def repo_root():
     return REPO_ROOT
+
+
+@pytest.fixture(scope="session", autouse=True)
+def generated_assets(request):
+    """GPU runs: the sized variants of the procedural stand-in mesh (assets/dragon-standin-<n>.ply/.json) are generated
+    HERE, by a child process, before any test of the session makes this process's first GPU call."""
+    expression = request.config.getoption("-m") or ""
+    if "gpu" in expression and "not gpu" not in expression:
+        import subprocess
+        subprocess.run([sys.executable, os.path.join(REPO_ROOT, "tools", "make_assets.py"), "--dragon-variants", "6,7,9"],
+                       check=True, stdout=subprocess.DEVNULL)
+    yield

@@ -47,8 +47,14 @@ def test_struct_sizes_match_the_header():
 
 
 def test_version_string():
+    # the string carries the header's ABI number: a host that checks it cannot accept a library of another struct layout
     lib = _capi.load_hip()
-    assert b"gfx950" in lib.pathed_hip_version()
+    lib.pathed_hip_version.restype = C.c_char_p
+    version = lib.pathed_hip_version()
+    header = open(os.path.join(_capi.REPO_ROOT, "include", "pathed_hip.h")).read()
+    abi = int(re.search(r"#define PATHED_ABI_VERSION (\d+)", header).group(1))
+    assert b"gfx950" in version and ("abi %d)" % abi).encode() in version
+    assert abi == _capi.PATHED_ABI_VERSION
 
 
 def test_no_gpu_means_a_loud_error_not_a_fallback():

@@ -112,11 +112,11 @@ def test_bvh_builder_job_key_changes_the_build_not_the_image(tmp_path):
 
 
 def _read_state(path):
-    """<outdir>/auto.state: 40-byte header (magic, w, h, done, startBounce, lastBounce, seed) + fp32 sums."""
+    """<outdir>/auto.state: 48-byte header (magic, w, h, done, startBounce, lastBounce, pad, seed, job digest) + fp32 sums."""
     blob = open(path, "rb").read()
-    assert blob[:8] == b"PATHEDS1"
+    assert blob[:8] == b"PATHEDS2"
     width, height, done, start, last = np.frombuffer(blob, dtype="<i4", count=5, offset=8)
-    sums = np.frombuffer(blob, dtype="<f4", offset=40).reshape(height, width, 3)
+    sums = np.frombuffer(blob, dtype="<f4", offset=48).reshape(height, width, 3)
     return int(done), sums
 
 
@@ -156,6 +156,10 @@ def test_gpus_job_key_fans_the_samples_out_and_sums_them_back(tmp_path):
         metrics = json.load(open(os.path.join(out_dir, "metrics.json")))
         assert metrics["devices"] == gpus and len(metrics["replica_seconds"]) == len(gpus)
         assert metrics["last_sample"] == 16 and metrics["msamples_per_second"] > 0 and metrics["reduces"] == 5
+        # two replicas on ONE device: RCCL takes one rank per device, the host says so and sums through peer copies
+        assert metrics["reduce_method"] == "peer-copy" and "RCCL reduce unavailable" in result.stdout
+        # what the reference prints per render (src/rtc_manager.cpp:94-115): rays, as rates
+        assert metrics["rays_per_sample"] > 2 and metrics["mrays_per_second"] > 0 and 0 < metrics["hbm_roofline_fraction"] < 1
     # a device this box does not have is an error, not a crash
     _, result = _run_job(tmp_path, "absent", dict(job, gpus=[0, 63]))
     assert result.returncode != 0 and "device" in (result.stdout + result.stderr)
@@ -183,5 +187,55 @@ def test_resumed_job_continues_bit_identically(tmp_path):
     assert open(os.path.join(second_dir, "auto-00016spp.exr"), "rb").read() == open(os.path.join(straight_dir, "auto-00016spp.exr"), "rb").read()
     _, result = _run_job(tmp_path, "resumed", dict(job, spp=32, resume=True, seed=5))
     assert result.returncode != 0 and "seed" in (result.stdout + result.stderr)
+    # another scene of the same resolution, or another integrator, is not what the sums hold
+    _, result = _run_job(tmp_path, "resumed", dict(job, spp=32, resume=True, scene="scenes/cornell-glossy.json"))
+    assert result.returncode != 0 and "another scene" in (result.stdout + result.stderr)
+    # a state file that already holds every sample: nothing is rendered, the image is the state's
+    before = open(os.path.join(second_dir, "auto.exr"), "rb").read()
+    _, result = _run_job(tmp_path, "resumed", dict(job, spp=16, resume=True))
+    assert result.returncode == 0 and "nothing to render" in result.stdout
+    assert open(os.path.join(second_dir, "auto.exr"), "rb").read() == before
     _, result = _run_job(tmp_path, "bad-launch", dict(job, spp_per_launch=0))
     assert result.returncode != 0 and "spp_per_launch" in (result.stdout + result.stderr)
+
+
+def test_rccl_reduce_through_the_c_abi():
+    """pathed_hip_comm_*: librccl loaded on demand, ncclCommInitAll over the devices of one process, ONE ncclReduce
+    (sum, fp32, root = device_ids[0]) -- here with the one device of this box, so RCCL itself has executed on hardware
+    before the 8-GPU node does it (reference src/integrator.cpp:42-51).  Two ranks on one device are
+    refused with a message (the host then falls back to peer copies)."""
+    import torch
+    from pathed_amd import _capi
+    lib = _capi.load_hip()
+    devices = (C.c_int * 1)(0)
+    comm = C.c_void_p()
+    assert lib.pathed_hip_comm_init(1, devices, C.byref(comm)) == 0, lib.pathed_hip_last_error()
+    send = torch.arange(3 * 64 * 48, dtype=torch.float32, device="cuda") * 0.25
+    total = torch.zeros_like(send)
+    torch.cuda.synchronize()
+    pointers = (C.c_void_p * 1)(send.data_ptr())
+    assert lib.pathed_hip_comm_reduce(comm, pointers, total.data_ptr(), send.numel()) == 0, lib.pathed_hip_last_error()
+    assert torch.equal(total, send)
+    # in place on the root
+    assert lib.pathed_hip_comm_reduce(comm, pointers, send.data_ptr(), send.numel()) == 0, lib.pathed_hip_last_error()
+    assert torch.equal(total, send)
+    lib.pathed_hip_comm_destroy(comm)
+    twice = (C.c_int * 2)(0, 0)
+    assert lib.pathed_hip_comm_init(2, twice, C.byref(comm)) == -4 and b"one rank per device" in lib.pathed_hip_last_error()
+    absent = (C.c_int * 1)(63)
+    assert lib.pathed_hip_comm_init(1, absent, C.byref(comm)) == -1
+
+
+def test_bench_runs_as_a_one_rank_rccl_process_group():
+    """bench.py --dist-single: the N > 1 code path of the benchmark -- init_process_group("nccl"), the barrier, the
+    reduce to rank 0 inside the timed region, the all_gather of the per-rank times -- executed with world size 1, so
+    the driver's 8-GPU scaling run is not the first time RCCL and that path run."""
+    import sys
+    from pathed_amd import _capi
+    command = [sys.executable, os.path.join(_capi.REPO_ROOT, "bench.py"), "--dist-single", "--steps", "2", "--warmup", "1",
+               "--spp-per-step", "8", "--width", "96", "--height", "64", "--no-cpu-baseline", "--no-large-bvh"]
+    result = subprocess.run(command, capture_output=True, text=True, timeout=600)
+    assert result.returncode == 0, result.stdout + result.stderr
+    line = json.loads(result.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["value"] > 0 and line["config"]["collective"] == "nccl (RCCL), world size 1"
+    assert len(line["per_rank_s"]["reduce"]) == 1 and 0.05 < line["image_mean_rgb"][0] < 0.4

@@ -136,9 +136,7 @@ def test_device_build_on_a_large_mesh(libs, builder, builder_code):
     """The stand-in dragon at ~330 K triangles: valid tree, hits and image identical to the SAH
     tree's, and the counting kernel says what the cheaper build costs in traversal work."""
     _, HipScene, LoadedScene = libs
-    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_assets.py"), "--dragon", "7"], check=True,
-                   stdout=subprocess.DEVNULL)
-    scene = LoadedScene("scenes/dragon-standin.json", 96, 54)
+    scene = LoadedScene("assets/dragon-standin-7.json", 96, 54)   # generated by tests/conftest.py before the first GPU call
     assert scene.n_triangles >= 200000
     sah = HipScene(scene.desc, device=0)
     lbvh = HipScene(scene.desc, device=0, bvh_builder=builder)

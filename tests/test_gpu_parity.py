@@ -463,9 +463,7 @@ def test_large_mesh_intersector_and_render_parity(libs):
     import sys
     oracle_lib, HipScene, LoadedScene = libs
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    subprocess.run([sys.executable, os.path.join(root, "tools", "make_assets.py"), "--dragon", "6"], check=True,
-                   stdout=subprocess.DEVNULL)
-    scene = LoadedScene("scenes/dragon-standin.json", 96, 54)
+    scene = LoadedScene("assets/dragon-standin-6.json", 96, 54)   # generated by tests/conftest.py before the first GPU call
     assert scene.n_triangles > 80000
     gpu, cpu = HipScene(scene.desc, device=0), oracle_lib.OracleScene(scene.desc)
     stats = gpu.stats()
@@ -496,22 +494,11 @@ def test_threaded_bvh_build_gives_the_sequential_tree(libs):
     import sys
     _, HipScene, LoadedScene = libs
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    subprocess.run([sys.executable, os.path.join(root, "tools", "make_assets.py"), "--dragon", "7"], check=True,
-                   stdout=subprocess.DEVNULL)
-    scene = LoadedScene("scenes/dragon-standin.json", 64, 36)
+    scene = LoadedScene("assets/dragon-standin-7.json", 64, 36)   # generated by tests/conftest.py before the first GPU call
     assert scene.n_triangles >= 200000
-    saved = os.environ.get("PATHED_BUILD_THREADS")
-    try:
-        os.environ["PATHED_BUILD_THREADS"] = "1"
-        nodes_one, tris_one = HipScene(scene.desc, device=0).export_bvh()
-        os.environ["PATHED_BUILD_THREADS"] = "8"
-        threaded = HipScene(scene.desc, device=0)
-        nodes_many, tris_many = threaded.export_bvh()
-    finally:
-        if saved is None:
-            os.environ.pop("PATHED_BUILD_THREADS", None)
-        else:
-            os.environ["PATHED_BUILD_THREADS"] = saved
+    nodes_one, tris_one = HipScene(scene.desc, device=0, build_threads=1).export_bvh()
+    threaded = HipScene(scene.desc, device=0, build_threads=8)
+    nodes_many, tris_many = threaded.export_bvh()
     assert np.array_equal(nodes_one.view(np.int32), nodes_many.view(np.int32))
     assert np.array_equal(tris_one.view(np.int32), tris_many.view(np.int32))
     assert threaded.render(1, 0, 2, 0, 4).any()

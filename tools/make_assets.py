@@ -234,9 +234,37 @@ def make_dragon(subdivisions, path=None):
     return len(f)
 
 
+def ply_faces(path):
+    """Face count a PLY header declares, 0 when the file is missing."""
+    if not os.path.exists(path):
+        return 0
+    with open(path, "rb") as handle:
+        for line in handle.read(400).split(b"\n"):
+            if line.startswith(b"element face"):
+                return int(line.split()[2])
+    return 0
+
+
+def make_dragon_variant(subdivisions):
+    """assets/dragon-standin-<n>.ply + assets/dragon-standin-<n>.json (scenes/dragon-standin.json pointed at it): sized
+    variants of the stand-in with names of their own, so that tests which want different sizes do not regenerate one file
+    in turn -- and can all be generated before a test process makes its first GPU call."""
+    import json
+    mesh = os.path.join(REPO_ROOT, "assets", "dragon-standin-%d.ply" % subdivisions)
+    if ply_faces(mesh) != 20 * 4 ** subdivisions:
+        make_dragon(subdivisions, mesh)
+    scene = json.load(open(os.path.join(REPO_ROOT, "scenes", "dragon-standin.json")))
+    for model in scene["models"]:
+        if model.get("type") == "ply":
+            model["filename"] = "assets/dragon-standin-%d.ply" % subdivisions
+    with open(os.path.join(REPO_ROOT, "assets", "dragon-standin-%d.json" % subdivisions), "w") as handle:
+        json.dump(scene, handle, indent=2)
+
+
 def main():
     parser = argparse.ArgumentParser()
     parser.add_argument("--dragon", type=int, default=-1, help="icosphere subdivisions of the large-BVH stand-in (off by default)")
+    parser.add_argument("--dragon-variants", default="", help="comma-separated subdivision levels: writes assets/dragon-standin-<n>.ply / .json each")
     parser.add_argument("--force", action="store_true")
     args = parser.parse_args()
 
@@ -251,8 +279,11 @@ def main():
             handle.write("tools/make_assets.py\n")
         print("assets written under assets/ and test_scenes/")
     if args.dragon >= 0:
-        count = make_dragon(args.dragon)
-        print("dragon stand-in: %d triangles" % count)
+        if ply_faces(os.path.join(REPO_ROOT, "assets", "dragon-standin.ply")) != 20 * 4 ** args.dragon or args.force:
+            make_dragon(args.dragon)
+        print("dragon stand-in: %d triangles" % (20 * 4 ** args.dragon))
+    for level in [int(item) for item in args.dragon_variants.split(",") if item.strip()]:
+        make_dragon_variant(level)
 
 
 if __name__ == "__main__":

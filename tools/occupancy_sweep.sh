@@ -1,4 +1,5 @@
-ROOT=${GRAFT_REPO_ROOT}
+#!/bin/bash
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 python3 $ROOT/tools/make_assets.py --dragon 9 > /dev/null
 for cfg in "2 3" "2 4" "1 3" "1 4" "1 5" "1 6"; do
   set -- $cfg

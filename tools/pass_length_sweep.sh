@@ -1,4 +1,5 @@
-ROOT=${GRAFT_REPO_ROOT}
+#!/bin/bash
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 python3 $ROOT/tools/make_assets.py --dragon 9 > /dev/null
 for c in 256 512 1024 128 256; do
   export PATHED_CHUNKS_PER_PASS=$c

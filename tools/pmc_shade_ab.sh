@@ -10,7 +10,6 @@ for variant in ${VARIANTS:-per-slot staged}; do
   export PATHED_SHADE_KERNEL=$variant
   for pass in "p1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU" \
               "p2 SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_SMEM SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS"; do
-    set -- $pass_args
     name=${pass%% *}; counters=${pass#* }
     rocprofv3 --pmc $counters --kernel-trace --output-format csv -d $OUT/$variant-$name -- python3 $ROOT/bench.py --steps 1 --warmup 0 --spp-per-step ${SPP:-64} --no-cpu-baseline --no-kernel-timing --no-large-bvh $BENCH_ARGS > $OUT/$variant-$name.log 2>&1 || { echo "$variant $name failed"; tail -3 $OUT/$variant-$name.log; }
   done
