@@ -59,7 +59,7 @@ def parse_args():
     parser.add_argument("--no-cpu-baseline", action="store_true")
     parser.add_argument("--no-large-bvh", action="store_true",
                         help="skip the second, BVH-traversal-bound workload (scenes/dragon-standin.json) behind roofline.large_bvh")
-    parser.add_argument("--large-bvh-subdiv", type=int, default=9, help="icosphere subdivisions of the stand-in mesh: 9 = 5.2 M, 10 = 21 M triangles")
+    parser.add_argument("--large-bvh-subdiv", type=int, default=10, help="icosphere subdivisions of the stand-in mesh: 9 = 5.2 M, 10 = 21 M triangles")
     parser.add_argument("--time-every-launch", action="store_true",
                         help="HIP events around every trace / shade launch instead of every 8th")
     parser.add_argument("--no-kernel-timing", action="store_true",
@@ -249,7 +249,12 @@ def ensure_large_bvh_mesh(args):
 
 def large_bvh_leg(args, torch, stream):
     """The workload the north-star roofline target is about: BVH traversal over a tree that does not fit the
-    256 MB Infinity Cache (scenes/dragon-standin.json, procedural mesh, 1920x1080), timed in this very run."""
+    256 MB Infinity Cache (scenes/dragon-standin.json: procedural mesh, 21 M triangles by default, 1920x1080), timed in
+    this very run.  Two rows over ONE upload of the scene: the reference's camera (scenes/dragon.json:2-11; most camera
+    rays miss the mesh and die on the environment) and a close-up that fills the frame with it
+    (scenes/dragon-standin-close.json's camera, set with pathed_hip_scene_set_camera)."""
+    import copy
+    import ctypes
     from pathed_amd.integrator import HipScene
     from pathed_amd.scene import LoadedScene
 
@@ -259,46 +264,74 @@ def large_bvh_leg(args, torch, stream):
     count_spp, warm_spp, timed_spp = 16, 256, 1024
     t0 = time.perf_counter()
     scene = LoadedScene("scenes/dragon-standin.json", width, height)
+    loaded_s = time.perf_counter() - t0
     gpu = HipScene(scene.desc, device=torch.cuda.current_device(), bvh_builder=args.bvh_builder)
     setup_s = time.perf_counter() - t0
     accum = torch.zeros((height, width, 3), dtype=torch.float32, device="cuda")
-    gpu.render_device(args.seed, 0, warm_spp, 0, args.last_bounce, accum.data_ptr(), stream)
-    gpu.set_stats_mode(count=True)
-    gpu.reset_stats()
-    gpu.render_device(args.seed, 1000, count_spp, 0, args.last_bounce, accum.data_ptr(), stream)
-    torch.cuda.synchronize()
-    counted = gpu.stats()
-    gpu.set_stats_mode(count=False, time_sampled=True)
-    gpu.reset_stats()
-    accum.zero_()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    gpu.render_device(args.seed, 2000, timed_spp, 0, args.last_bounce, accum.data_ptr(), stream)
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    timed = gpu.stats()
-    rates = kernel_rates(counted, width * height * count_spp, timed, width * height * timed_spp)
     pmc = pmc_per_sample("large_bvh")
-    traffic = None
-    if pmc and rates:
-        traffic = {name: pmc["hbm_bytes_per_sample"][name] * width * height * timed_spp / rates["launches"]
-                   for name in ("trace", "shade") if name in pmc.get("hbm_bytes_per_sample", {})}
+
+    def row(label, seed_offset):
+        gpu.set_stats_mode(count=False)
+        gpu.render_device(args.seed, seed_offset, warm_spp, 0, args.last_bounce, accum.data_ptr(), stream)
+        gpu.set_stats_mode(count=True)
+        gpu.reset_stats()
+        gpu.render_device(args.seed, seed_offset + 1000, count_spp, 0, args.last_bounce, accum.data_ptr(), stream)
+        torch.cuda.synchronize()
+        counted = gpu.stats()
+        gpu.set_stats_mode(count=False, time_sampled=True)
+        gpu.reset_stats()
+        accum.zero_()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        gpu.render_device(args.seed, seed_offset + 2000, timed_spp, 0, args.last_bounce, accum.data_ptr(), stream)
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        timed = gpu.stats()
+        rates = kernel_rates(counted, width * height * count_spp, timed, width * height * timed_spp)
+        traffic = None
+        if pmc and rates and label == "reference camera":
+            traffic = {name: pmc["hbm_bytes_per_sample"][name] * width * height * timed_spp / rates["launches"]
+                       for name in ("trace", "shade") if name in pmc.get("hbm_bytes_per_sample", {})}
+        return counted, timed, {
+            "camera": label,
+            "msamples_per_s": width * height * timed_spp / elapsed / 1e6,
+            # the pipeline figures FIRST: k_trace of one pool shares the chip with k_shade of the other
+            "k_trace": rates["trace"] if rates else None,
+            "k_shade": rates["shade"] if rates else None,
+            "rays_per_sample": rates["rays_per_sample"] if rates else None,
+            "vertices_per_sample": rates["vertices_per_sample"] if rates else None,
+            "mrays_per_s": (rates["rays_per_sample"] * width * height * timed_spp / elapsed / 1e6) if rates else None,
+            "traffic": traffic,
+            "image_mean_rgb": (accum / float(timed_spp)).mean(dim=(0, 1)).tolist(),
+        }
+
+    counted, timed, reference_row = row("reference camera", 0)
+    close_camera = copy.copy(scene.desc.contents.camera)
+    close_camera.origin = (ctypes.c_float * 3)(117.4, -127.3, 143.7)   # scenes/dragon-standin-close.json
+    close_camera.target = (ctypes.c_float * 3)(0.0, 0.0, 25.0)
+    gpu.set_camera(close_camera)
+    _, _, close_row = row("close-up: the mesh fills the frame", 100000)
+    gpu.set_camera(scene.desc.contents.camera)
+
     result = {
-        "workload": "scenes/dragon-standin.json %dx%d, %d spp timed (%d spp counted), bounces 0..%d; %s" % (
+        "workload": "scenes/dragon-standin.json %dx%d, %d spp timed per row (%d spp counted), bounces 0..%d; %s" % (
             width, height, timed_spp, count_spp, args.last_bounce, scene_description(scene, timed)),
         "bvh_bytes": timed["bvh_bytes"], "bvh_builder": args.bvh_builder, "bvh_build_ms": timed["bvh_build_ms"],
-        "setup_s": setup_s, "msamples_per_s": width * height * timed_spp / elapsed / 1e6,
+        "scene_load_s": loaded_s, "setup_s": setup_s,
         "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "k_trace": rates["trace"] if rates else None,
-        "k_shade": rates["shade"] if rates else None,
-        "rays_per_sample": rates["rays_per_sample"] if rates else None,
-        "traffic": traffic,
+        "note": "k_trace / k_shade: algorithmic bytes per launch (SURVEY.md 8d) / HIP-event time of the launch AS THE PIPELINE RUNS "
+                "(two pools: a trace launch shares the chip with the other pool's shade launch); one_pool below is a diagnostic",
+        # headline row = the reference's camera; the same keys as round 2 so the lines stay comparable
+        "msamples_per_s": reference_row["msamples_per_s"],
+        "k_trace": reference_row["k_trace"], "k_shade": reference_row["k_shade"],
+        "rays_per_sample": reference_row["rays_per_sample"],
+        "traffic": reference_row["traffic"],
         "traffic_source": None if not pmc else {"file": "profiles/pmc_per_sample.json", "stale": pmc["stale"]},
-        "image_mean_rgb": (accum / float(timed_spp)).mean(dim=(0, 1)).tolist(),
+        "image_mean_rgb": reference_row["image_mean_rgb"],
+        "rows": [reference_row, close_row],
     }
     gpu.close()
-    # The two pools overlap k_trace with the other pool's k_shade, so the per-launch durations above are shares of a
-    # shared chip.  One pool: the launches alternate, HIP events around every launch time each kernel on its own.
+    # Diagnostic: one pool -- the launches alternate, HIP events around every launch time each kernel on its own
     alone = HipScene(scene.desc, device=torch.cuda.current_device(), bvh_builder=args.bvh_builder, pools=1)
     alone.render_device(args.seed, 0, warm_spp, 0, args.last_bounce, accum.data_ptr(), stream)
     alone.set_stats_mode(count=False, time_kernels=True)
@@ -311,7 +344,7 @@ def large_bvh_leg(args, torch, stream):
     serial = alone.stats()
     if serial["trace_launches"]:   # one k_shade launch follows every k_trace launch
         result["one_pool"] = {
-            "note": "PathedSceneOptions.pools = 1: no overlap, every launch timed with HIP events, 256 spp",
+            "note": "diagnostic, PathedSceneOptions.pools = 1: no overlap, every launch timed with HIP events, 256 spp, reference camera",
             "msamples_per_s": width * height * 256 / elapsed / 1e6,
             "k_trace_avg_launch_us": 1e3 * serial["trace_ms"] / serial["trace_launches"],
             "k_shade_avg_launch_us": 1e3 * serial["shade_ms"] / serial["trace_launches"],
@@ -480,9 +513,14 @@ def run_rank(args):
                 # reaches on THIS box with independent v_fma_f32 on VGPR operands (pathed_hip_measure_valu_modes);
                 # numerator: SQ_INSTS_VALU per camera sample from the committed PMC pass x the samples of the timed
                 # region / the kernels' own time, measured live with HIP events (fused kernel: every launch).
-                from pathed_amd.integrator import VALU_MODES, measure_valu_modes
+                from pathed_amd.integrator import VALU_MODES, measure_valu_clocks, measure_valu_modes
                 probes = {waves: measure_valu_modes(waves, repeats=5) for waves in (1, 4, 8)}
-                peak = max(row[2] for row in probes.values())
+                # the same instruction with the probe's own clocks, 2 / 4 / 8 waves per SIMD x 8 / 16 independent chains:
+                # cycles per instruction at the frequency the chip really ran at (it drops to ~2.2 GHz under this load)
+                clock_probe = {"%d waves, %d chains" % (waves, chains): measure_valu_clocks(waves, chains, repeats=5)
+                               for waves in (2, 4, 8) for chains in (8, 16)}
+                peak = max(max(row[2] for row in probes.values()), max(entry["rate"] for entry in clock_probe.values()))
+                peak_guide = 1228.8e9   # MI355X_MICROARCH.md constants table: v_fma_f32 wave64 2 cycles, 1024 SIMDs, 2.4 GHz
                 issued = pmc["valu_wave_instructions_per_sample"] * my_samples if pmc else None
                 kernel_s = (timed["trace_ms"] * 1e-3) if fused and timed["trace_ms"] > 0 else rendered
                 roofline = {
@@ -493,13 +531,19 @@ def run_rank(args):
                     "peak": peak / 1e9,
                     "unit": "G wave-instr/s",
                     "frac": (issued / kernel_s / peak) if issued else None,
+                    "peak_guide": peak_guide / 1e9,
+                    "frac_of_guide": (issued / kernel_s / peak_guide) if issued else None,
                     "traffic": traffic,
                     "kernel_seconds": kernel_s, "launches": launches,
                     "rays_per_sample": (counted["closest_rays"] + counted["shadow_rays"]) / float(counted_samples),
-                    "peak_note": "best of the occupancies probed on this box, v_fma_f32 on three VGPR operands, independent chains; "
-                                 "G wave-instr/s by instruction mix and waves per SIMD below",
+                    "peak_note": "peak = best rate any probe reaches on this box (v_fma_f32, three VGPR operands, 8 or 16 independent chains, "
+                                 "1..8 waves per SIMD); peak_guide = the guide's 2 cycles per instruction at 2.4 GHz",
                     "peak_probe": {"modes": list(VALU_MODES),
-                                   "waves_per_simd": {str(waves): [rate / 1e9 for rate in row] for waves, row in probes.items()}},
+                                   "waves_per_simd": {str(waves): [rate / 1e9 for rate in row] for waves, row in probes.items()},
+                                   "with_clocks": {key: {"g_instr_per_s": entry["rate"] / 1e9, "shader_clock_mhz": entry["shader_clock_mhz"],
+                                                         "cycles_per_instruction": entry["cycles_per_instruction_events"]}
+                                                   for key, entry in clock_probe.items()},
+                                   "note": "cycles_per_instruction = SIMDs x measured shader clock / rate; the guide's 2 cycles at 2.4 GHz is peak_guide"},
                     "instructions_source": None if not pmc else {
                         "file": "profiles/pmc_per_sample.json", "valu_wave_instructions_per_sample": pmc["valu_wave_instructions_per_sample"],
                         "stale": pmc["stale"]},

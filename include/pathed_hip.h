@@ -278,6 +278,9 @@ typedef struct PathedSceneOptions {
 } PathedSceneOptions;
 int pathed_hip_scene_create_ex(const PathedSceneDesc *desc, const PathedSceneOptions *options, PathedScene **out);
 int pathed_hip_scene_device(const PathedScene *scene);   /* the HIP device the scene lives on, or a negative error */
+/* Another view of the same scene: replaces the camera (reference Camera, src/camera.cpp:13-30) without rebuilding or
+ * re-uploading anything; the resolution must stay (the caller's radiance sums are per pixel). */
+int pathed_hip_scene_set_camera(PathedScene *scene, const PathedCamera *camera);
 
 /* ---- the hot path -------------------------------------------------------- */
 
@@ -371,6 +374,22 @@ int pathed_hip_measure_valu(int waves_per_simd, int repeats, double *fma_rate, d
  * 0 v_fma_f32 with one VGPR source (scalar multiplier / addend: no register-bank conflicts), 1 six of those + v_rcp_f32 +
  * v_sqrt_f32, 2 v_fma_f32 with three VGPR sources, 3 v_pk_fma_f32 (two FMAs per lane), 4 v_mul_lo_u32. */
 int pathed_hip_measure_valu_modes(int waves_per_simd, int repeats, double *rates, int n_modes);
+
+/* The probe with its own clocks: `chains` (8 or 16) independent v_fma_f32 chains per lane on three VGPR operands; every
+ * wave reads the shader clock (s_memtime) and the constant-rate wall clock (s_memrealtime) around its loop, so the issue
+ * rate comes out in CYCLES PER INSTRUCTION at the frequency the chip actually ran at under this load, beside the rate
+ * in instructions per second from HIP events.  (The guide's constants table has v_fma_f32 at 2 cycles per wave64
+ * instruction: 1 228.8 G wave-instr/s at 2.4 GHz on 1 024 SIMDs.) */
+typedef struct PathedValuClocks {
+    double rate;                          /* wave-instructions / s, HIP events over `repeats` launches              */
+    double shader_clock_mhz;              /* s_memtime ticks / s_memrealtime ticks x wall_clock_mhz                   */
+    double wall_clock_mhz;                /* hipDeviceAttributeWallClockRate                                         */
+    double peak_clock_mhz;                /* hipDeviceAttributeClockRate (what the device advertises)                */
+    double wave_ticks_per_instruction;    /* shader-clock ticks one wave needs per instruction it issues             */
+    double cycles_per_instruction;        /* ... divided by the waves that share its SIMD: the SIMD's issue interval */
+    double cycles_per_instruction_events; /* SIMDs x shader clock / rate: the same from the event time               */
+} PathedValuClocks;
+int pathed_hip_measure_valu_clocks(int waves_per_simd, int chains, int repeats, PathedValuClocks *out);
 
 /* ---- multi-GPU fan-in ------------------------------------------------------ */
 /* The path's one exchange step: per-GPU radiance sums -> one buffer (the reference's

@@ -156,6 +156,12 @@ class PathedSceneOptions(C.Structure):
     ]
 
 
+class PathedValuClocks(C.Structure):
+    _fields_ = [(name, C.c_double) for name in (
+        "rate", "shader_clock_mhz", "wall_clock_mhz", "peak_clock_mhz", "wave_ticks_per_instruction",
+        "cycles_per_instruction", "cycles_per_instruction_events")]
+
+
 DEVICE_CURRENT = -1
 
 # every symbol include/pathed_hip.h declares; tests check that the library exports all
@@ -164,6 +170,7 @@ HIP_SYMBOLS = [
     "pathed_hip_scene_create",
     "pathed_hip_scene_create_ex",
     "pathed_hip_scene_device",
+    "pathed_hip_scene_set_camera",
     "pathed_hip_scene_destroy",
     "pathed_hip_render",
     "pathed_hip_render_device",
@@ -177,6 +184,7 @@ HIP_SYMBOLS = [
     "pathed_hip_measure_bandwidth",
     "pathed_hip_measure_valu",
     "pathed_hip_measure_valu_modes",
+    "pathed_hip_measure_valu_clocks",
     "pathed_hip_accum_copy_peer",
     "pathed_hip_accum_add",
     "pathed_hip_accum_alloc",
@@ -227,10 +235,14 @@ def load_hip():
     lib.pathed_hip_scene_create_ex.restype = C.c_int
     lib.pathed_hip_scene_device.argtypes = [vp]
     lib.pathed_hip_scene_device.restype = C.c_int
+    lib.pathed_hip_scene_set_camera.argtypes = [vp, C.POINTER(PathedCamera)]
+    lib.pathed_hip_scene_set_camera.restype = C.c_int
     lib.pathed_hip_measure_valu.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.pathed_hip_measure_valu.restype = C.c_int
     lib.pathed_hip_measure_valu_modes.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_double), C.c_int]
     lib.pathed_hip_measure_valu_modes.restype = C.c_int
+    lib.pathed_hip_measure_valu_clocks.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(PathedValuClocks)]
+    lib.pathed_hip_measure_valu_clocks.restype = C.c_int
     fp = C.POINTER(C.c_float)
     lib.pathed_hip_accum_copy_peer.argtypes = [vp, vp, vp, vp, C.c_size_t]
     lib.pathed_hip_accum_copy_peer.restype = C.c_int

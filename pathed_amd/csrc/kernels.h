@@ -3451,6 +3451,55 @@ __global__ __launch_bounds__(kBlock) void k_valu_probe(int iterations, float see
     if (total == 12345.678f) { *sink = total; }   // keeps the chains alive
 }
 
+// The same probe with its own clocks (pathed_hip_measure_valu_clocks): CHAINS independent v_fma_f32 chains per lane on
+// three VGPR operands, and every wave reads the shader clock (s_memtime) and the constant-rate wall clock (s_memrealtime)
+// around its loop.  cycles per instruction = shader-clock ticks / instructions issued, per wave, whatever frequency the
+// chip ran at under this load; ticks / wall ticks x the wall-clock rate is that frequency.
+template <int CHAINS>
+__global__ __launch_bounds__(kBlock) void k_valu_clock_probe(int iterations, float seed, float *sink, unsigned long long *clocks)
+{
+    static_assert(CHAINS == 8 || CHAINS == 16, "8 or 16 chains");
+    float a[16];
+    #pragma unroll
+    for (int k = 0; k < 16; k++) { a[k] = seed + threadIdx.x + k; }
+    const float m = 0.999f, c = 0.001f;
+    const unsigned long long shaderStart = __builtin_amdgcn_s_memtime();
+    const unsigned long long wallStart = __builtin_amdgcn_s_memrealtime();
+    for (int i = 0; i < iterations; i++) {
+        #pragma unroll
+        for (int k = 0; k < kValuProbeUnroll / 16; k++) {
+            if (CHAINS == 16) {
+                asm volatile(
+                    "v_fma_f32 %0, %0, %16, %17\n v_fma_f32 %1, %1, %16, %17\n v_fma_f32 %2, %2, %16, %17\n v_fma_f32 %3, %3, %16, %17\n"
+                    "v_fma_f32 %4, %4, %16, %17\n v_fma_f32 %5, %5, %16, %17\n v_fma_f32 %6, %6, %16, %17\n v_fma_f32 %7, %7, %16, %17\n"
+                    "v_fma_f32 %8, %8, %16, %17\n v_fma_f32 %9, %9, %16, %17\n v_fma_f32 %10, %10, %16, %17\n v_fma_f32 %11, %11, %16, %17\n"
+                    "v_fma_f32 %12, %12, %16, %17\n v_fma_f32 %13, %13, %16, %17\n v_fma_f32 %14, %14, %16, %17\n v_fma_f32 %15, %15, %16, %17\n"
+                    : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]),
+                      "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15])
+                    : "v"(m), "v"(c));
+            } else {
+                asm volatile(
+                    "v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %1, %1, %8, %9\n v_fma_f32 %2, %2, %8, %9\n v_fma_f32 %3, %3, %8, %9\n"
+                    "v_fma_f32 %4, %4, %8, %9\n v_fma_f32 %5, %5, %8, %9\n v_fma_f32 %6, %6, %8, %9\n v_fma_f32 %7, %7, %8, %9\n"
+                    "v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %1, %1, %8, %9\n v_fma_f32 %2, %2, %8, %9\n v_fma_f32 %3, %3, %8, %9\n"
+                    "v_fma_f32 %4, %4, %8, %9\n v_fma_f32 %5, %5, %8, %9\n v_fma_f32 %6, %6, %8, %9\n v_fma_f32 %7, %7, %8, %9\n"
+                    : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]) : "v"(m), "v"(c));
+            }
+        }
+    }
+    const unsigned long long shaderTicks = __builtin_amdgcn_s_memtime() - shaderStart;
+    const unsigned long long wallTicks = __builtin_amdgcn_s_memrealtime() - wallStart;
+    if ((threadIdx.x & 63) == 0) {
+        const size_t wave = (size_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+        clocks[2 * wave + 0] = shaderTicks;
+        clocks[2 * wave + 1] = wallTicks;
+    }
+    float total = 0.f;
+    #pragma unroll
+    for (int k = 0; k < 16; k++) { total += a[k]; }
+    if (total == 12345.678f) { *sink = total; }   // keeps the chains alive
+}
+
 // dst[i] += src[i]: the fan-in of per-GPU radiance sums inside one process (pathed_hip_accum_add)
 __global__ __launch_bounds__(kBlock) void k_accum_add(float *dst, const float *src, size_t count)
 {

@@ -741,6 +741,74 @@ int pathed_hip_measure_valu_modes(int waves_per_simd, int repeats, double *rates
     return PATHED_OK;
 }
 
+int pathed_hip_measure_valu_clocks(int waves_per_simd, int chains, int repeats, PathedValuClocks *out)
+{
+    if (!out || repeats < 1 || repeats > 1000) { return fail(PATHED_E_INVALID, "bad argument"); }
+    if (waves_per_simd < 1 || waves_per_simd > 8) { return fail(PATHED_E_INVALID, "waves_per_simd must be 1..8"); }
+    if (chains != 8 && chains != 16) { return fail(PATHED_E_INVALID, "chains must be 8 or 16"); }
+    if (g_device < 0) {
+        const int code = pathed_hip_init(0);
+        if (code != PATHED_OK) { return code; }
+    }
+    std::memset(out, 0, sizeof *out);
+    int device = 0;
+    HIP_TRY(hipGetDevice(&device));
+    hipDeviceProp_t properties;
+    int units = 256;
+    if (hipGetDeviceProperties(&properties, device) == hipSuccess && properties.multiProcessorCount > 0) { units = properties.multiProcessorCount; }
+    int wallKhz = 0;
+    if (hipDeviceGetAttribute(&wallKhz, hipDeviceAttributeWallClockRate, device) != hipSuccess || wallKhz <= 0) { wallKhz = 100000; }   // 100 MHz on CDNA
+    int peakKhz = 0;
+    (void)hipDeviceGetAttribute(&peakKhz, hipDeviceAttributeClockRate, device);
+    const dim3 grid((unsigned)(units * waves_per_simd)), block(kBlock);
+    const size_t waves = (size_t)grid.x * kWavesPerBlock;
+    const int iterations = 8192;   // 393 216 instructions per wave and launch
+    float *sink = nullptr;
+    unsigned long long *clocks = nullptr;
+    hipEvent_t start = nullptr, stop = nullptr;
+    hipError_t status = hipMalloc((void **)&sink, sizeof(float));
+    if (status == hipSuccess) { status = hipMalloc((void **)&clocks, 2 * waves * sizeof(unsigned long long)); }
+    if (status == hipSuccess) { status = hipEventCreate(&start); }
+    if (status == hipSuccess) { status = hipEventCreate(&stop); }
+    auto launch = [&]() {
+        if (chains == 16) { hipLaunchKernelGGL((k_valu_clock_probe<16>), grid, block, 0, nullptr, iterations, 1.f, sink, clocks); }
+        else { hipLaunchKernelGGL((k_valu_clock_probe<8>), grid, block, 0, nullptr, iterations, 1.f, sink, clocks); }
+    };
+    float ms = 0.f;
+    if (status == hipSuccess) {
+        launch();   // warm-up
+        (void)hipEventRecord(start, nullptr);
+        for (int r = 0; r < repeats; r++) { launch(); }
+        (void)hipEventRecord(stop, nullptr);
+        status = hipEventSynchronize(stop);
+    }
+    if (status == hipSuccess) { status = hipEventElapsedTime(&ms, start, stop); }
+    std::vector<unsigned long long> host(2 * waves);
+    if (status == hipSuccess) { status = hipMemcpy(host.data(), clocks, host.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost); }
+    if (status == hipSuccess && ms > 0.f) {
+        const double perWave = (double)iterations * kValuProbeUnroll;   // instructions of the last launch's waves
+        double shaderTicks = 0.0, wallTicks = 0.0;
+        for (size_t w = 0; w < waves; w++) { shaderTicks += (double)host[2 * w]; wallTicks += (double)host[2 * w + 1]; }
+        out->rate = (double)waves * perWave * repeats / (ms * 1e-3);
+        out->wall_clock_mhz = wallKhz / 1e3;
+        out->peak_clock_mhz = peakKhz / 1e3;
+        out->shader_clock_mhz = wallTicks > 0.0 ? shaderTicks / wallTicks * out->wall_clock_mhz : 0.0;
+        // a wave issues its instructions while waves_per_simd - 1 others share its SIMD: the SIMD's cycles per instruction
+        // are the wave's ticks per instruction divided by the waves that share it
+        out->wave_ticks_per_instruction = shaderTicks / ((double)waves * perWave);
+        out->cycles_per_instruction = out->wave_ticks_per_instruction / waves_per_simd;
+        // ... and from the event time alone, against the frequency measured in the same launches
+        const double simds = (double)units * 4.0;
+        out->cycles_per_instruction_events = out->shader_clock_mhz > 0.0 ? simds * out->shader_clock_mhz * 1e6 / out->rate : 0.0;
+    }
+    if (sink) { (void)hipFree(sink); }
+    if (clocks) { (void)hipFree(clocks); }
+    if (start) { (void)hipEventDestroy(start); }
+    if (stop) { (void)hipEventDestroy(stop); }
+    if (status != hipSuccess) { return fail(PATHED_E_DEVICE, std::string("VALU clock probe: ") + hipGetErrorString(status)); }
+    return PATHED_OK;
+}
+
 int pathed_hip_accum_alloc(PathedScene *scene, size_t count, float **out)
 {
     if (!scene || !out || count == 0) { return fail(PATHED_E_INVALID, "bad argument"); }
@@ -1855,6 +1923,16 @@ int pathed_hip_render_device(PathedScene *scene, uint64_t seed,
         scene->traceEvents.harvestAll();
         scene->shadeEvents.harvestAll();
     }
+    return PATHED_OK;
+}
+
+int pathed_hip_scene_set_camera(PathedScene *scene, const PathedCamera *camera)
+{
+    if (!scene || !camera) { return fail(PATHED_E_INVALID, "null scene or camera"); }
+    if (camera->width != scene->width || camera->height != scene->height) {
+        return fail(PATHED_E_INVALID, "the new camera must keep the scene's resolution (the radiance sums are per pixel)");
+    }
+    buildCamera(*camera, &scene->device.camera);
     return PATHED_OK;
 }
 

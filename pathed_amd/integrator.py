@@ -53,6 +53,15 @@ def measure_valu_modes(waves_per_simd=4, repeats=5):
     return list(rates)
 
 
+def measure_valu_clocks(waves_per_simd=4, chains=8, repeats=5):
+    """v_fma_f32 issue rate with the probe's own clocks (pathed_hip_measure_valu_clocks): a dict with the rate, the shader
+    clock the chip ran at, and cycles per instruction."""
+    lib = _capi.load_hip()
+    out = _capi.PathedValuClocks()
+    _check(lib, lib.pathed_hip_measure_valu_clocks(int(waves_per_simd), int(chains), int(repeats), C.byref(out)), "pathed_hip_measure_valu_clocks")
+    return {name: getattr(out, name) for name, _ in _capi.PathedValuClocks._fields_}
+
+
 class HipScene:
     """A scene uploaded to one GPU (PathedScene handle).
 
@@ -130,6 +139,10 @@ class HipScene:
         """Summation granularity (see include/pathed_hip.h); 1 = the reference's exact order."""
         _check(self._lib, self._lib.pathed_hip_set_samples_per_unit(self._handle, int(samples)),
                "pathed_hip_set_samples_per_unit")
+
+    def set_camera(self, camera):
+        """Another view of the same scene (pathed_hip_scene_set_camera): `camera` is a _capi.PathedCamera of the scene's resolution."""
+        _check(self._lib, self._lib.pathed_hip_scene_set_camera(self._handle, C.byref(camera)), "pathed_hip_scene_set_camera")
 
     def set_integrator(self, name):
         """"PathTracer" (default) or "VolumePathTracer" (reference src/job.cpp:65-97)."""
