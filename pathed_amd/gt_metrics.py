@@ -125,3 +125,32 @@ def compare(render, gt, max_spp, block=16):
         "mean_rgb": ours.mean(axis=(0, 1)).tolist(), "gt_mean_rgb": gt.mean(axis=(0, 1)).tolist(),
         "energy_ratio": float(ours.sum() / gt.sum()),
     }
+
+
+# ---- scenes/veach-ajar against the Tungsten render the reference ships (tests/golden/veach_ajar_tungsten_blocks.npz) ----
+
+def veach_ajar_blocks(radiance, block=16):
+    """Block means of a (H, W, 3) image whose row 0 is the BOTTOM scanline (the C ABI's convention), top row first like the EXR."""
+    import numpy as np
+    image = np.asarray(radiance, dtype=np.float64)[::-1]
+    h, w = image.shape[:2]
+    return image[:h - h % block, :w - w % block].reshape(h // block, block, w // block, block, 3).mean(axis=(1, 3))
+
+
+def veach_ajar_compare(ours, theirs, mask):
+    """Sanity-level comparison of two block-mean images outside `mask` (True = ignore): a third-party renderer, other
+    sampler, other texture filtering -- energy and block structure, not per-pixel values."""
+    import numpy as np
+    keep = ~np.asarray(mask, dtype=bool)
+    a = np.asarray(ours, dtype=np.float64)[keep].sum(axis=1)
+    b = np.asarray(theirs, dtype=np.float64)[keep].sum(axis=1)
+    relative = np.abs(a - b) / np.maximum(b, 1e-3)
+    log_ratio = np.log((a + 1e-4) / (b + 1e-4))
+    return {
+        "blocks_compared": int(keep.sum()),
+        "energy_ratio": float(a.sum() / b.sum()),
+        "median_relative_difference": float(np.median(relative)),
+        "p90_relative_difference": float(np.percentile(relative, 90)),
+        "log_ratio_correlation": float(np.corrcoef(np.log(a + 1e-4), np.log(b + 1e-4))[0, 1]),
+        "median_log_ratio": float(np.median(log_ratio)),
+    }
