@@ -85,6 +85,7 @@ def test_a_wrong_bounce_count_is_caught_by_the_block_means():
         assert np.percentile(relative, 50) > 1e-2, last_bounce
 
 
+@pytest.mark.gpu
 def test_veach_ajar_against_the_tungsten_render_the_reference_ships():
     """A second reference-held image: scenes/veach-ajar.json (reference scenes/veach-ajar.json:13-27; 16 of its 18
     OBJs are in the reference's repository, three JPEG textures through Texture::lookup, src/texture.cpp:33-49, a checkerboard,
