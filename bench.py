@@ -292,6 +292,13 @@ def large_bvh_leg(args, torch, stream):
         if pmc and rates and label == "reference camera":
             traffic = {name: pmc["hbm_bytes_per_sample"][name] * width * height * timed_spp / rates["launches"]
                        for name in ("trace", "shade") if name in pmc.get("hbm_bytes_per_sample", {})}
+            # the same kernels against the bytes the COUNTERS saw cross the fabric (2 x FETCH_SIZE + WRITE_SIZE, committed
+            # PMC passes): what is left of the algorithmic figure once L1 / L2 / Infinity Cache have served the top of the tree
+            for name in traffic:
+                kernel = rates[name]
+                kernel["counter_bytes_per_launch"] = traffic[name]
+                kernel["counter_achieved"] = traffic[name] / (kernel["avg_launch_us"] * 1e-6) / 1e9
+                kernel["counter_frac"] = kernel["counter_achieved"] / HBM_PEAK_GBS
         return counted, timed, {
             "camera": label,
             "msamples_per_s": width * height * timed_spp / elapsed / 1e6,

@@ -13,7 +13,7 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r2"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r3"
 base = os.path.join(ROOT, "gpurun_out", "pmcps_" + tag)
 
 
@@ -44,7 +44,15 @@ def totals(name):
 
 
 def kernel_class(kernel):
-    return "trace" if "k_trace" in kernel else "path" if "k_path" in kernel else "shade"
+    """trace / path (fused) / shade (shade kernels + k_init + k_resolve: the render loop's own traffic) / setup (scene_create's
+    kernels -- shading records, device BVH builders -- which run once per scene and are not part of a camera sample)"""
+    if "k_trace" in kernel:
+        return "trace"
+    if "k_path" in kernel:
+        return "path"
+    if "k_build_tri_shade" in kernel or "k_lbvh" in kernel or "k_ploc" in kernel:
+        return "setup"
+    return "shade"
 
 
 def workload(prefix, samples, with_valu):
@@ -72,14 +80,16 @@ def workload(prefix, samples, with_valu):
     for kernel, (launches, total) in write.items():
         classes[kernel_class(kernel)] += total * 1024.0
         per_kernel[kernel]["WRITE_SIZE_KiB_per_launch"] = total / launches
-    entry["hbm_bytes_per_sample"] = {name: value / samples for name, value in sorted(classes.items())}
+    entry["hbm_bytes_per_sample"] = {name: value / samples for name, value in sorted(classes.items()) if name != "setup"}
+    entry["setup_hbm_bytes"] = classes.get("setup", 0.0)
     entry["kernels"] = {kernel: dict(sorted(values.items())) for kernel, values in sorted(per_kernel.items())}
     return entry
 
 
 summary = {
     "note": "rocprofv3 --pmc passes of tools/pmc_per_sample.sh, one counter group per pass, over exactly the timed path's kernels; "
-            "HBM bytes = 2 x FETCH_SIZE + WRITE_SIZE (gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md)",
+            "HBM bytes = 2 x FETCH_SIZE + WRITE_SIZE (gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md); large_bvh is ONE 64-spp call "
+            "(ramp-up and drain of the slot pool included: 61 % of the slot visits carry a ray, a long render does better)",
     "tag": tag,
     "cornell_1024": workload("cornell", 1024 * 1024 * 256, True),
     "large_bvh": workload("dragon", 1920 * 1080 * 64, False),
