@@ -439,6 +439,14 @@ def run_rank(args):
 
     for index in range(args.warmup):
         step(index)
+    if distributed:
+        # warm the collective itself: RCCL sets up the channels of an operation on its first use, which would otherwise
+        # land inside the timed region (the reduce there is 12.6 MB: a fraction of a millisecond once the links are up)
+        if staged:
+            dist.reduce(accum.cpu(), dst=0, op=dist.ReduceOp.SUM)
+        else:
+            dist.reduce(accum.clone(), dst=0, op=dist.ReduceOp.SUM)
+        torch.cuda.synchronize()
     accum.zero_()
 
     # HIP-event pairs around every 8th launch of each pool: timing every launch keeps a pool's kernels from
