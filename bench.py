@@ -247,7 +247,7 @@ def ensure_large_bvh_mesh(args):
                    check=True, stdout=subprocess.DEVNULL)   # a no-op when the file already has that many faces
 
 
-def large_bvh_leg(args, torch, stream):
+def large_bvh_leg(args, torch, stream, measured_copy_gbs=None):
     """The workload the north-star roofline target is about: BVH traversal over a tree that does not fit the
     256 MB Infinity Cache (scenes/dragon-standin.json: procedural mesh, 21 M triangles by default, 1920x1080), timed in
     this very run.  Two rows over ONE upload of the scene: the reference's camera (scenes/dragon.json:2-11; most camera
@@ -299,8 +299,20 @@ def large_bvh_leg(args, torch, stream):
                 kernel["counter_bytes_per_launch"] = traffic[name]
                 kernel["counter_achieved"] = traffic[name] / (kernel["avg_launch_us"] * 1e-6) / 1e9
                 kernel["counter_frac"] = kernel["counter_achieved"] / HBM_PEAK_GBS
+        pipeline = None
+        if pmc and label == "reference camera" and "hbm_bytes_per_sample" in pmc:
+            # the whole pipeline against the memory system: every byte the counters saw cross the fabric per camera sample
+            # (trace + shade-side kernels) x the rate of this row
+            per_sample = sum(pmc["hbm_bytes_per_sample"].values())
+            achieved = per_sample * width * height * timed_spp / elapsed / 1e9
+            pipeline = {"counter_bytes_per_sample": per_sample, "achieved": achieved, "unit": "GB/s", "frac_of_peak": achieved / HBM_PEAK_GBS,
+                        "frac_of_measured_copy": (achieved / measured_copy_gbs) if measured_copy_gbs else None,
+                        "measured_copy": measured_copy_gbs,
+                        "note": "2 x FETCH_SIZE + WRITE_SIZE of the committed PMC passes (one 64-spp call) x this row's Msamples/s; "
+                                "measured_copy = what a plain read + write stream reaches on this box (pathed_hip_measure_bandwidth)"}
         return counted, timed, {
             "camera": label,
+            "pipeline_hbm": pipeline,
             "msamples_per_s": width * height * timed_spp / elapsed / 1e6,
             # the pipeline figures FIRST: k_trace of one pool shares the chip with k_shade of the other
             "k_trace": rates["trace"] if rates else None,
@@ -572,7 +584,7 @@ def run_rank(args):
                     "traffic": traffic, "hbm": hbm,
                 }
             if roofline is not None and wants_large_bvh:
-                roofline["large_bvh"] = large_bvh_leg(args, torch, stream)
+                roofline["large_bvh"] = large_bvh_leg(args, torch, stream, measured_copy)
 
         baseline = None
         # the CPU oracle is timed on rank 0 of the single-GPU run only
