@@ -591,3 +591,45 @@ def test_many_spheres_live_in_the_tree_not_in_a_list(libs):
     # sixteen spheres or fewer beside a tiny mesh stay with the all-triangles kernels (Veach's scene has five)
     few = _sphere_field(12).finish()
     assert HipScene(few, device=0).stats()["scene_in_lds"] == 2
+
+
+def test_set_camera_is_a_fresh_scene_with_that_camera(libs):
+    """pathed_hip_scene_set_camera: another view of an uploaded scene, nothing rebuilt -- the same floats as a scene created
+    with that camera; another resolution is refused (the caller's sums are per pixel)."""
+    import copy
+    import ctypes
+    from pathed_amd import _capi
+    from pathed_amd.integrator import PathedError
+    _, HipScene, LoadedScene = libs
+    for path, size in (("scenes/cornell.json", 40), ("scenes/cornell-glass.json", 36)):   # fused kernel / wavefront
+        first = LoadedScene(path, size, size)
+        gpu = HipScene(first.desc, device=0)
+        before = gpu.render(3, 0, 4, 0, 6)
+        moved = copy.copy(first.desc.contents.camera)
+        moved.origin = (ctypes.c_float * 3)(0.4, 1.3, 5.5)
+        moved.target = (ctypes.c_float * 3)(-0.1, 0.8, 0.0)
+        gpu.set_camera(moved)
+        other = _capi.PathedSceneDesc()          # a shallow copy of the description (its arrays stay the loader's)
+        ctypes.memmove(ctypes.byref(other), first.desc, ctypes.sizeof(other))
+        other.camera = moved
+        fresh = HipScene(ctypes.pointer(other), device=0)
+        image = gpu.render(3, 0, 4, 0, 6)
+        assert np.array_equal(image, fresh.render(3, 0, 4, 0, 6)) and not np.array_equal(image, before)
+        gpu.set_camera(first.desc.contents.camera)
+        assert np.array_equal(gpu.render(3, 0, 4, 0, 6), before)
+        wrong = copy.copy(moved)
+        wrong.width = size + 1
+        with pytest.raises(PathedError):
+            gpu.set_camera(wrong)
+
+
+def test_valu_clock_probe_reports_consistent_clocks():
+    """pathed_hip_measure_valu_clocks: the rate from HIP events and the cycles per instruction from the waves' own clocks
+    describe the same run; bad arguments are PATHED_E_INVALID."""
+    from pathed_amd.integrator import PathedError, measure_valu_clocks
+    probe = measure_valu_clocks(waves_per_simd=2, chains=8, repeats=2)
+    assert 1e11 < probe["rate"] < 2e12 and 500.0 < probe["shader_clock_mhz"] < 4000.0 and probe["wall_clock_mhz"] > 1.0
+    assert 1.5 < probe["cycles_per_instruction_events"] < 8.0 and 1.0 < probe["wave_ticks_per_instruction"] < 40.0
+    for bad in (dict(waves_per_simd=0), dict(chains=12), dict(repeats=0)):
+        with pytest.raises(PathedError):
+            measure_valu_clocks(**dict(dict(waves_per_simd=2, chains=8, repeats=2), **bad))
