@@ -274,7 +274,8 @@ typedef struct PathedSceneOptions {
     int32_t unit_order;         /* order work units are handed out in (scheduling only, results identical):
                                  * 0 automatic = 1; 1 chunk stripes, rows; 2 chunk stripes, 32 x 8 tiles; 3 pixel tiles */
     int32_t build_threads;      /* host threads of the SAH builder (0 = all cores; the tree does not depend on it) */
-    int32_t reserved[1];        /* must be 0                                                   */
+    int32_t generic_kernels;    /* 1: never pick a scene-specialised kernel instantiation (k_shade<.., ENV_ONLY> for scenes whose
+                                   one light is the environment and whose materials do not emit): A/B runs and tests */
 } PathedSceneOptions;
 int pathed_hip_scene_create_ex(const PathedSceneDesc *desc, const PathedSceneOptions *options, PathedScene **out);
 int pathed_hip_scene_device(const PathedScene *scene);   /* the HIP device the scene lives on, or a negative error */

@@ -152,7 +152,7 @@ class PathedSceneOptions(C.Structure):
         ("stage_slots", C.c_int32),
         ("unit_order", C.c_int32),
         ("build_threads", C.c_int32),
-        ("reserved", C.c_int32 * 1),
+        ("generic_kernels", C.c_int32),
     ]
 
 

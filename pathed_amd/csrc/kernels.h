@@ -989,6 +989,7 @@ __device__ inline TriShade loadTriCorners(const DScene &scene, int prim)
 __device__ inline V3 triangleNormal(V3 p0, V3 p1, V3 p2) { return normalized(xcross(p1 - p0, p2 - p0)); }
 
 // Scene::testIntersect's record construction, reference src/scene.cpp:121-218
+template <typename TRAITS = TraitsAll>
 __device__ inline Isect makeIsect(const DScene &scene, V3 o, V3 d, float4 h)
 {
     const float t = h.x, u = h.y, v = h.z;
@@ -1003,7 +1004,7 @@ __device__ inline Isect makeIsect(const DScene &scene, V3 o, V3 d, float4 h)
     float uvU = 0.f, uvV = 0.f;
     int material;
 
-    if (prim < scene.nTris) {
+    if (!TRAITS::spheres || prim < scene.nTris) {
         // A triangle without vertex normals and uvs (all exactly zero: the interpolated shading normal has length 0 and
         // the geometric normal takes its place, uv = 0) is shaded from a 16-byte record.  Which primitives are plain is a
         // few id ranges in the kernel arguments (scalar compares), so either load is issued at once.
@@ -1051,10 +1052,11 @@ __device__ inline Isect makeIsect(const DScene &scene, V3 o, V3 d, float4 h)
 }
 
 // Scene::lightsPDF, src/scene.cpp:469-484
+template <typename TRAITS = TraitsAll>
 __device__ inline float lightsPDF(const DScene &scene, V3 referencePoint, const Isect &lightIsect)
 {
     float measurePDF;
-    if (lightIsect.prim < scene.nTris) {
+    if (!TRAITS::spheres || lightIsect.prim < scene.nTris) {
         const TriShade tri = loadTriCorners(scene, lightIsect.prim);
         measurePDF = trianglePdfSolidAngle(tri.p0, tri.p1, tri.p2, lightIsect.point, referencePoint);
     } else {
@@ -1066,8 +1068,10 @@ __device__ inline float lightsPDF(const DScene &scene, V3 referencePoint, const 
 }
 
 // Scene::environmentL, src/scene.cpp:486-492
+template <typename TRAITS = TraitsAll>
 __device__ inline Rgb environmentL(const DScene &scene, V3 direction)
 {
+    if (!TRAITS::env) { return rgb(0.f); }
 #if defined(PATHED_ABLATE) && PATHED_ABLATE == 3
     return rgb(0.f);   // profiling build: no environment lookups on misses
 #endif
@@ -1083,7 +1087,10 @@ struct ShadowRequest {
 
 // PathTracer::directSampleLights, src/path_tracer.cpp:113-165, up to (not including) the
 // occlusion query: returns the contribution assuming visibility and the shadow ray to test.
-template <typename MaterialTable>
+// ENV_ONLY: the scene's one light is the environment and no material emits (the env-lit mesh scenes): the light choice is
+// index 0 (its random number is still consumed), the triangle / sphere sampling code and the emitter look-ups are compiled out.
+// With one light every `* lightCount`, `/ nLights` is a multiplication or division by 1: the same floats.
+template <bool ENV_ONLY = false, typename TRAITS = TraitsAll, typename MaterialTable>
 __device__ inline Rgb sampleLightsTerm(
     const DScene &scene, const MaterialTable &materials,
     const Isect &isect, const DMaterial &material, Rng &random, ShadowRequest *shadow
@@ -1092,28 +1099,42 @@ __device__ inline Rgb sampleLightsTerm(
 #if defined(PATHED_ABLATE) && PATHED_ABLATE == 2
     return rgb(0.f);   // profiling build: no light sampling, no shadow rays
 #endif
-    if (isDelta(material)) { return rgb(0.f); }
+    if (isDeltaT<TRAITS>(material)) { return rgb(0.f); }
     if (scene.nLights == 0) { return rgb(0.f); }
 
     // Scene::sampleDirectLights, src/scene.cpp:446-467
-    const int lightCount = scene.nLights;
-    int lightIndex = (int)floorf(random.next() * lightCount);
-    lightIndex = imin(lightIndex, lightCount - 1);
-    const DLight light = scene.lights[lightIndex];
+    const int lightCount = ENV_ONLY ? 1 : scene.nLights;
+    DLight light;
+    light.kind = 2;
+    light.index = 0;
+    if (ENV_ONLY) {
+        random.dimension++;   // the light choice: floor(u * 1) = 0
+    } else {
+        int lightIndex = (int)floorf(random.next() * lightCount);
+        lightIndex = imin(lightIndex, lightCount - 1);
+        light = scene.lights[lightIndex];
+    }
 
     SurfaceSample surfaceSample;
     int lightMaterial = 0;
-    if (light.kind == 0) {
+    if (ENV_ONLY) {
+        surfaceSample = envSample(scene.env, isect.point, random);
+    } else if (TRAITS::triangleLights && (light.kind == 0 || (!TRAITS::spheres && !TRAITS::env))) {
         const TriShade tri = loadTriCorners(scene, light.index);
         surfaceSample = triangleSample(tri.p0, tri.p1, tri.p2, random);
         lightMaterial = tri.material;
-    } else if (light.kind == 1) {
+    } else if (TRAITS::spheres && (light.kind == 1 || !TRAITS::env)) {
         const DSphere sphere = scene.spheres[light.index];
         surfaceSample = sphereSample(
             v3(sphere.centerSample[0], sphere.centerSample[1], sphere.centerSample[2]), sphere.radius, isect.point, random);
         lightMaterial = sphere.material;
-    } else {
+    } else if (TRAITS::env) {
         surfaceSample = envSample(scene.env, isect.point, random);
+    } else {   // not reached: a light of a kind the instantiation's scene set does not contain
+        surfaceSample.point = isect.point;
+        surfaceSample.normal = v3(0.f, 0.f, 0.f);
+        surfaceSample.invPDF = 1.f;
+        surfaceSample.solidAngle = 1;
     }
     const float lightChoicePDF = 1.f / lightCount;
     const float invPDF = surfaceSample.invPDF * (1.f / lightChoicePDF);
@@ -1137,7 +1158,7 @@ __device__ inline Rgb sampleLightsTerm(
     }
 
     float brdfPDF;
-    const Rgb f = materialF(material, isect, wiWorld, &brdfPDF);
+    const Rgb f = materialF<TRAITS>(material, isect, wiWorld, &brdfPDF);
     const float lightWeight = (1 * pdf) / (1 * pdf + 1 * brdfPDF);  // include/mis.h:4-7
 
     // The reference asks for the occlusion first and evaluates emitted * weight * f * cos / pdf afterwards.
@@ -1149,7 +1170,7 @@ __device__ inline Rgb sampleLightsTerm(
 
     const V3 lightWo = -normalized(lightDirection);
     Rgb emitted;
-    if (light.kind == 2) { emitted = envEmit(scene.env, lightWo); }
+    if (ENV_ONLY || (TRAITS::env && light.kind == 2)) { emitted = envEmit(scene.env, lightWo); }
     else { emitted = matEmit(materials[lightMaterial]); }
 
     // Scene::testOcclusion's interval, src/scene.cpp:366-367
@@ -1394,7 +1415,7 @@ struct MaterialAccess {
 #else
 #define PATHED_SHADE_ATTRIBUTE
 #endif
-template <bool LDS_MATERIALS>
+template <bool LDS_MATERIALS, bool ENV_ONLY, typename TRAITS = TraitsAll>
 __global__ __launch_bounds__(kBlock) PATHED_SHADE_ATTRIBUTE void k_shade(RenderParams p)
 {
     __shared__ DMaterial ldsMaterials[LDS_MATERIALS ? kMaxLdsMaterials : 1];
@@ -1417,6 +1438,8 @@ __global__ __launch_bounds__(kBlock) PATHED_SHADE_ATTRIBUTE void k_shade(RenderP
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const DScene &scene = p.scene;
+    // ENV_ONLY scenes have no emissive material: every emission look-up below is black at compile time
+    auto emission = [&](int material) -> Rgb { return ENV_ONLY ? rgb(0.f) : matEmit(materials[material]); };
 
     // rewind the card cursors for the pool's next trace launch (same stream: it starts after us)
     if (blockIdx.x == 0 && threadIdx.x < kTraceShards) { p.counters[kCtrTraceCursor + threadIdx.x * kCursorStride] = 0u; }
@@ -1497,19 +1520,19 @@ __global__ __launch_bounds__(kBlock) PATHED_SHADE_ATTRIBUTE void k_shade(RenderP
         // the lanes of a wave sit at different path depths, and code inlined in both branches is
         // executed twice by every mixed wave
         SHADE_REGION(2, !miss);   // makeIsect
-        if (!miss) { isect = makeIsect(scene, o, d, h); }
+        if (!miss) { isect = makeIsect<TRAITS>(scene, o, d, h); }
         SHADE_REGION(3, rayBounce == 0);
         SHADE_REGION(4, rayBounce != 0 && (st & kStEligible) != 0);   // finishes the previous vertex's MIS term
 
         if (rayBounce == 0) {
             // SampleIntegrator::samplePixel, src/sample_integrator.cpp:18-59
             if (miss) {
-                color = rgb(0.f) + environmentL(scene, d);
+                color = rgb(0.f) + environmentL<TRAITS>(scene, d);
                 finished = true;
             } else {
                 firstEmitMaterial = -1;
                 if (checkCounts(p.startBounce, p.lastBounce, 0)) {
-                    const Rgb emit = matEmit(materials[isect.material]);
+                    const Rgb emit = emission(isect.material);
                     const bool backside = dot(isect.normal, isect.wo) < 0.f;
                     if (!isBlack(emit) && !backside) { firstEmitMaterial = isect.material; }
                 }
@@ -1529,19 +1552,19 @@ __global__ __launch_bounds__(kBlock) PATHED_SHADE_ATTRIBUTE void k_shade(RenderP
                 // PathTracer::directSampleBSDF, src/path_tracer.cpp:167-216
                 Rgb bsdfTerm = rgb(0.f);
                 if (!miss) {
-                    const Rgb emit = matEmit(materials[isect.material]);
+                    const Rgb emit = emission(isect.material);
                     if (!isBlack(emit) && dot(isect.wo, isect.shadingNormal) >= 0.f) {
-                        const float lightPDF = lightsPDF(scene, o, isect);
+                        const float lightPDF = lightsPDF<TRAITS>(scene, o, isect);
                         const float brdfWeight = (st & kStDelta)
                             ? 1.f
                             : (1 * bsdfPdf) / (1 * bsdfPdf + 1 * lightPDF);
                         bsdfTerm = emit * brdfWeight * throughput * cosTheta / bsdfPdf;
                     }
                 } else {
-                    const Rgb environmentLight = environmentL(scene, d);
+                    const Rgb environmentLight = environmentL<TRAITS>(scene, d);
                     if (!isBlack(environmentLight)) {
                         // Scene::environmentPDF, src/scene.cpp:494-502
-                        const float lightPDF = envEmitPDF(scene.env, d) / scene.nLights;
+                        const float lightPDF = envEmitPDF(scene.env, d) / (ENV_ONLY ? 1 : scene.nLights);
                         const float brdfWeight = (st & kStDelta)
                             ? 1.f
                             : (1 * bsdfPdf) / (1 * bsdfPdf + 1 * lightPDF);
@@ -1564,7 +1587,7 @@ __global__ __launch_bounds__(kBlock) PATHED_SHADE_ATTRIBUTE void k_shade(RenderP
             }
             if (finished) {
                 Rgb first = rgb(0.f);
-                if (firstEmitMaterial >= 0) { first = first + matEmit(materials[firstEmitMaterial]); }
+                if (firstEmitMaterial >= 0) { first = first + emission(firstEmitMaterial); }
                 color = first + result;
             }
         }
@@ -1579,10 +1602,10 @@ __global__ __launch_bounds__(kBlock) PATHED_SHADE_ATTRIBUTE void k_shade(RenderP
             Rng random;
             makeKey(((uint64_t)p.seedHi << 32) | p.seedLo, pixel, sample, &random.k0, &random.k1);
             random.dimension = vertexBase(vertex);
-            const BSDFSample bsdfSample = materialSample(material, isect, random);
+            const BSDFSample bsdfSample = materialSample<TRAITS>(material, isect, random);
 
             const bool counts = checkCounts(p.startBounce, p.lastBounce, vertex);
-            const bool emissive = !isBlack(matEmit(material));
+            const bool emissive = !ENV_ONLY && !isBlack(matEmit(material));
             const bool wantDirect = counts && !emissive;  // direct() returns 0 on emitters (:86-90)
             const bool wantContinue = !checkDone(p.lastBounce, vertex + 1);
 
@@ -1591,7 +1614,7 @@ __global__ __launch_bounds__(kBlock) PATHED_SHADE_ATTRIBUTE void k_shade(RenderP
             SHADE_REGION(10, isBlack(bsdfSample.throughput));   // the continuation ray cannot contribute
             if (wantDirect) {
                 random.dimension = vertexBase(vertex) + 3;
-                lightTerm = sampleLightsTerm(scene, materials, isect, material, random, &shadow);
+                lightTerm = sampleLightsTerm<ENV_ONLY, TRAITS>(scene, materials, isect, material, random, &shadow);
             }
 
             // A vertex with nothing pending (no light term, no shadow ray) whose BSDF sample has exactly black
@@ -1603,13 +1626,13 @@ __global__ __launch_bounds__(kBlock) PATHED_SHADE_ATTRIBUTE void k_shade(RenderP
             if ((!wantDirect && !wantContinue) || deadEnd) {
                 finished = true;
                 Rgb first = rgb(0.f);
-                if (firstEmitMaterial >= 0) { first = first + matEmit(materials[firstEmitMaterial]); }
+                if (firstEmitMaterial >= 0) { first = first + emission(firstEmitMaterial); }
                 color = first + result;
                 shadow.push = false;
             } else {
                 int nextState = vertex | (sampleInUnit << kStSampleShift);
                 if (wantDirect) { nextState |= kStEligible; }
-                if (isDelta(material)) { nextState |= kStDelta; }
+                if (isDeltaT<TRAITS>(material)) { nextState |= kStDelta; }
                 if (wantContinue) { nextState |= kStContinue; }
                 outRayO = make_float4(isect.point.x, isect.point.y, isect.point.z, intAsFloat(firstEmitMaterial));
                 outRayD = make_float4(bsdfSample.wiWorld.x, bsdfSample.wiWorld.y, bsdfSample.wiWorld.z, intAsFloat(nextState));
@@ -2618,7 +2641,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_R
 #ifndef PATHED_FUSED_WAVES
 #define PATHED_FUSED_WAVES 4
 #endif
-template <bool LDS_MATERIALS, bool COUNT>
+// TRAITS: the compile-time set of material / light / albedo kinds the scene may contain (shading.h: SceneTraits)
+template <bool LDS_MATERIALS, bool COUNT, typename TRAITS>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_FUSED_WAVES, PATHED_FUSED_WAVES))) void k_path_small(RenderParams p, SmallTris smallTris)
 {
     extern __shared__ float4 ldsDynamic[];           // LDS_MATERIALS: the material table, nMaterials x 96 B
@@ -2780,12 +2804,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_F
             bool haveVertex = false;
             Isect isect;
             const int vertex = rayBounce + 1;
-            if (!miss) { isect = makeIsect(scene, o, d, h); }
+            if (!miss) { isect = makeIsect<TRAITS>(scene, o, d, h); }
 
             if (rayBounce == 0) {
                 // SampleIntegrator::samplePixel, src/sample_integrator.cpp:18-59
                 if (miss) {
-                    color = rgb(0.f) + environmentL(scene, d);
+                    color = rgb(0.f) + environmentL<TRAITS>(scene, d);
                     finished = true;
                 } else {
                     firstEmitMaterial = -1;
@@ -2805,15 +2829,15 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_F
                     if (!miss) {
                         const Rgb emit = matEmit(materials[isect.material]);
                         if (!isBlack(emit) && dot(isect.wo, isect.shadingNormal) >= 0.f) {
-                            const float lightPDF = lightsPDF(scene, o, isect);
+                            const float lightPDF = lightsPDF<TRAITS>(scene, o, isect);
                             const float brdfWeight = (st & kStDelta)
                                 ? 1.f
                                 : (1 * bsdfPdf) / (1 * bsdfPdf + 1 * lightPDF);
                             bsdfTerm = emit * brdfWeight * throughput * cosTheta / bsdfPdf;
                         }
                     } else {
-                        const Rgb environmentLight = environmentL(scene, d);
-                        if (!isBlack(environmentLight)) {
+                        const Rgb environmentLight = environmentL<TRAITS>(scene, d);
+                        if (TRAITS::env && !isBlack(environmentLight)) {
                             // Scene::environmentPDF, src/scene.cpp:494-502
                             const float lightPDF = envEmitPDF(scene.env, d) / scene.nLights;
                             const float brdfWeight = (st & kStDelta)
@@ -2848,7 +2872,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_F
                 const DMaterial &material = materials[isect.material];
 
                 random.dimension = vertexBase(vertex);
-                const BSDFSample bsdfSample = materialSample(material, isect, random);
+                const BSDFSample bsdfSample = materialSample<TRAITS>(material, isect, random);
 
                 const bool counts = checkCounts(p.startBounce, p.lastBounce, vertex);
                 const bool emissive = !isBlack(matEmit(material));
@@ -2858,7 +2882,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_F
                 Rgb lightTerm = rgb(0.f);
                 if (wantDirect) {
                     random.dimension = vertexBase(vertex) + 3;
-                    lightTerm = sampleLightsTerm(scene, materials, isect, material, random, &shadow);
+                    lightTerm = sampleLightsTerm<false, TRAITS>(scene, materials, isect, material, random, &shadow);
                 }
 
                 // see k_shade: a vertex with nothing pending whose BSDF sample has exactly black throughput ends the sample
@@ -2873,7 +2897,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_F
                 } else {
                     int nextState = vertex;
                     if (wantDirect) { nextState |= kStEligible; }
-                    if (isDelta(material)) { nextState |= kStDelta; }
+                    if (isDeltaT<TRAITS>(material)) { nextState |= kStDelta; }
                     if (wantContinue) { nextState |= kStContinue; }
                     st = nextState;
                     o = isect.point;

@@ -193,6 +193,9 @@ struct PathedScene {
     bool spheresInTree = false;   // the host builder put the spheres into leaves (else they are tested one by one after the traversal)
     bool fusedPath = false;   // tiny scenes: k_path_small, whole paths in registers, no wavefront buffers
     bool stagedShade = true;  // k_shade_staged (dense, state-sorted stages inside a block) or k_shade (one lane per slot)
+    bool lambertianTriangles = false;   // constant-albedo Lambertian surfaces, triangle lights, no spheres, no environment: k_path_small<.., TraitsLambertianTriangles>
+    bool lambertianPlasticSpheres = false;   // the Veach scene's set (shading.h)
+    bool envOnly = false;     // the one light is the environment and no material emits: k_shade<.., ENV_ONLY> (kernels.h)
     bool splitShade = false;  // k_vertex + k_regen over the hit / miss lists the trace kernel writes (kernels.h: split shade stage)
     int vertexGrid = 0, regenGrid = 0;   // their persistent grids, blocks
     unsigned int listCap = 0;            // list blocks per shard
@@ -522,9 +525,14 @@ void launchShade(PathedScene *scene, const RenderParams &params, hipStream_t str
     }
     const dim3 grid((unsigned)(params.nSlots / kBlock)), block(kBlock);
     if (scene->device.nMaterials <= kMaxLdsMaterials) {
-        hipLaunchKernelGGL((k_shade<true>), grid, block, 0, stream, params);
+        // (k_shade narrowed further to {Lambertian, plastic, environment} -- 88 VGPRs against 92 -- shortens the shade launches of
+        // the 5.2 M-triangle mesh by 13 % and LENGTHENS the other pool's trace launches by 23 %: -4.8 % overall, not adopted,
+        // profiles/r3_ab_scene_traits.log)
+        if (scene->envOnly) { hipLaunchKernelGGL((k_shade<true, true>), grid, block, 0, stream, params); }
+        else { hipLaunchKernelGGL((k_shade<true, false>), grid, block, 0, stream, params); }
     } else {
-        hipLaunchKernelGGL((k_shade<false>), grid, block, 0, stream, params);
+        if (scene->envOnly) { hipLaunchKernelGGL((k_shade<false, true>), grid, block, 0, stream, params); }
+        else { hipLaunchKernelGGL((k_shade<false, false>), grid, block, 0, stream, params); }
     }
 }
 
@@ -1023,7 +1031,7 @@ int pathed_hip_scene_create_ex(const PathedSceneDesc *desc, const PathedSceneOpt
     if (optionsIn) {
         if (optionsIn->struct_size != sizeof(PathedSceneOptions)) { return fail(PATHED_E_INVALID, "PathedSceneOptions.struct_size mismatch"); }
         options = *optionsIn;
-        if (options.reserved[0] != 0) { return fail(PATHED_E_INVALID, "PathedSceneOptions.reserved must be zero"); }
+        if (options.generic_kernels != 0 && options.generic_kernels != 1) { return fail(PATHED_E_INVALID, "generic_kernels must be 0 or 1"); }
         if (options.build_threads < 0 || options.build_threads > 4096) { return fail(PATHED_E_INVALID, "build_threads must be 0..4096"); }
         if (options.unit_order < 0 || options.unit_order > 3) { return fail(PATHED_E_INVALID, "unit_order must be 0..3"); }
         if (options.bvh_builder < 0 || options.bvh_builder > PATHED_BVH_PLOC_DEVICE + 1) { return fail(PATHED_E_INVALID, "unknown BVH builder"); }
@@ -1362,6 +1370,25 @@ int pathed_hip_scene_create_ex(const PathedSceneDesc *desc, const PathedSceneOpt
     d.nMaterials = (int)desc->n_materials;
     d.lights = scene->lights.ptr;
     d.nLights = (int)lights.size();
+    {
+        bool emissive = false;
+        for (const DMaterial &material : materials) { emissive = emissive || emits(material); }
+        scene->envOnly = desc->env != nullptr && lights.size() == 1 && !emissive && options.generic_kernels == 0 && !getenv("PATHED_NO_ENV_ONLY");
+        bool plainLambertian = desc->env == nullptr && desc->n_spheres == 0;
+        for (uint32_t i = 0; i < desc->n_materials; i++) {
+            plainLambertian = plainLambertian && desc->materials[i].type == PATHED_MAT_LAMBERTIAN && desc->materials[i].albedo_type == PATHED_ALBEDO_CONSTANT;
+        }
+        const bool narrow = options.generic_kernels == 0 && !getenv("PATHED_NO_SCENE_TRAITS");
+        scene->lambertianTriangles = plainLambertian && narrow;
+        bool lambertianPlastic = true;
+        for (uint32_t i = 0; i < desc->n_materials; i++) {
+            lambertianPlastic = lambertianPlastic && (desc->materials[i].type == PATHED_MAT_LAMBERTIAN || desc->materials[i].type == PATHED_MAT_PLASTIC)
+                && desc->materials[i].albedo_type == PATHED_ALBEDO_CONSTANT;
+        }
+        bool triangleLights = false;
+        for (const DLight &light : lights) { triangleLights = triangleLights || light.kind == 0; }
+        scene->lambertianPlasticSpheres = lambertianPlastic && desc->env == nullptr && !triangleLights && narrow;
+    }
     d.media = scene->media.ptr;
     d.primMedium = scene->primMedium.ptr;
     d.nMedia = (int)desc->n_media;
@@ -1566,12 +1593,24 @@ static int renderPassFused(PathedScene *scene, uint64_t seed, uint32_t begin, ui
         timed = scene->traceEvents.acquire();
         (void)hipEventRecord(scene->traceEvents.start[timed], stream);
     }
-    if (ldsMaterials) {
-        if (scene->countMode) { hipLaunchKernelGGL((k_path_small<true, true>), grid, block, lds, stream, params, scene->smallTris); }
-        else { hipLaunchKernelGGL((k_path_small<true, false>), grid, block, lds, stream, params, scene->smallTris); }
+    // the narrowest instantiation whose compile-time scene set contains this scene's (shading.h: SceneTraits)
+    if (scene->lambertianTriangles) {
+        if (ldsMaterials) {
+            if (scene->countMode) { hipLaunchKernelGGL((k_path_small<true, true, TraitsLambertianTriangles>), grid, block, lds, stream, params, scene->smallTris); }
+            else { hipLaunchKernelGGL((k_path_small<true, false, TraitsLambertianTriangles>), grid, block, lds, stream, params, scene->smallTris); }
+        } else {
+            if (scene->countMode) { hipLaunchKernelGGL((k_path_small<false, true, TraitsLambertianTriangles>), grid, block, lds, stream, params, scene->smallTris); }
+            else { hipLaunchKernelGGL((k_path_small<false, false, TraitsLambertianTriangles>), grid, block, lds, stream, params, scene->smallTris); }
+        }
+    } else if (scene->lambertianPlasticSpheres && ldsMaterials) {
+        if (scene->countMode) { hipLaunchKernelGGL((k_path_small<true, true, TraitsLambertianPlasticSpheres>), grid, block, lds, stream, params, scene->smallTris); }
+        else { hipLaunchKernelGGL((k_path_small<true, false, TraitsLambertianPlasticSpheres>), grid, block, lds, stream, params, scene->smallTris); }
+    } else if (ldsMaterials) {
+        if (scene->countMode) { hipLaunchKernelGGL((k_path_small<true, true, TraitsAll>), grid, block, lds, stream, params, scene->smallTris); }
+        else { hipLaunchKernelGGL((k_path_small<true, false, TraitsAll>), grid, block, lds, stream, params, scene->smallTris); }
     } else {
-        if (scene->countMode) { hipLaunchKernelGGL((k_path_small<false, true>), grid, block, lds, stream, params, scene->smallTris); }
-        else { hipLaunchKernelGGL((k_path_small<false, false>), grid, block, lds, stream, params, scene->smallTris); }
+        if (scene->countMode) { hipLaunchKernelGGL((k_path_small<false, true, TraitsAll>), grid, block, lds, stream, params, scene->smallTris); }
+        else { hipLaunchKernelGGL((k_path_small<false, false, TraitsAll>), grid, block, lds, stream, params, scene->smallTris); }
     }
     if (timed >= 0) { (void)hipEventRecord(scene->traceEvents.stop[timed], stream); }
     scene->traceLaunchesAll++;

@@ -12,6 +12,27 @@
 
 namespace pathed {
 
+// What a scene can contain, as a compile-time set.  The kernels are written against every material, light and albedo
+// kind the path supports; a kernel instantiated with a NARROWER set compiles the rest out, which is not about the
+// instructions skipped (a uniform branch skips them anyway) but about the registers the compiler reserves for code that
+// never runs: the fused path kernel lives at 128 VGPRs with spills.  The launch picks the narrowest instantiation whose set
+// contains the scene's (pathed_hip.hip: sceneTraits).  Results cannot differ: absent kinds are absent.
+template <unsigned MATERIALS, bool ENV, bool TRIANGLE_LIGHTS, bool SPHERES, bool VARYING_ALBEDO>
+struct SceneTraits {
+    static constexpr unsigned materials = MATERIALS;       // bit t: material type t (PATHED_MAT_*) may occur
+    static constexpr bool env = ENV;                        // an environment light
+    static constexpr bool triangleLights = TRIANGLE_LIGHTS; // emissive triangles
+    static constexpr bool spheres = SPHERES;                // sphere primitives (as geometry or as lights)
+    static constexpr bool varyingAlbedo = VARYING_ALBEDO;   // checkerboard / image-texture albedo
+    static constexpr bool has(int type) { return ((MATERIALS >> type) & 1u) != 0u; }
+};
+typedef SceneTraits<0x7Fu, true, true, true, true> TraitsAll;
+// Cornell-box-like scenes: constant-albedo Lambertian surfaces, triangle lights, nothing else
+typedef SceneTraits<1u << 0, false, true, false, false> TraitsLambertianTriangles;
+// the Veach MIS scene: Lambertian + plastic surfaces (constant albedo) lit by emissive spheres
+typedef SceneTraits<(1u << 0) | (1u << 3), false, false, true, false> TraitsLambertianPlasticSpheres;
+
+
 #define PATHED_INV_PI 0.3183098861837907f   /* include/util.h:10 */
 #define PATHED_PI 3.14159265358979323846f   /* M_PI narrowed to fp32 */
 #define PATHED_TWO_PI 6.283185307179586f    /* include/util.h:11 */
@@ -287,6 +308,7 @@ __device__ inline Rgb textureLookup(const DMaterial &m, const Isect &isect)
 }
 
 // src/lambertian.cpp:16-40
+template <bool VARYING_ALBEDO = true>
 __device__ inline Rgb lambertianF(const DMaterial &m, const Isect &isect, V3 wiWorld, float *pdf)
 {
     if (dot(isect.wo, isect.shadingNormal) < 0.f) { *pdf = 0.f; return rgb(0.f); }
@@ -295,12 +317,13 @@ __device__ inline Rgb lambertianF(const DMaterial &m, const Isect &isect, V3 wiW
     const V3 wi = normalized(toLocal(isect.frame, wiWorld));
     *pdf = cosineHemispherePdf(wi);
 
-    if (m.albedoType == PATHED_ALBEDO_CHECKERBOARD) { return checkerboardLookup(m, isect) / PATHED_PI; }
-    if (m.albedoType == PATHED_ALBEDO_TEXTURE) { return textureLookup(m, isect) / PATHED_PI; }
+    if (VARYING_ALBEDO && m.albedoType == PATHED_ALBEDO_CHECKERBOARD) { return checkerboardLookup(m, isect) / PATHED_PI; }
+    if (VARYING_ALBEDO && m.albedoType == PATHED_ALBEDO_TEXTURE) { return textureLookup(m, isect) / PATHED_PI; }
     return matDiffuse(m) / PATHED_PI;
 }
 
 // src/lambertian.cpp:42-58
+template <bool VARYING_ALBEDO = true>
 __device__ inline BSDFSample lambertianSample(const DMaterial &m, const Isect &isect, Rng &random)
 {
     const V3 localSample = cosineSampleHemisphere(random);
@@ -309,7 +332,7 @@ __device__ inline BSDFSample lambertianSample(const DMaterial &m, const Isect &i
     sample.wiWorld = worldSample;
     sample.pdf = cosineHemispherePdf(localSample);
     float ignored;
-    sample.throughput = lambertianF(m, isect, worldSample, &ignored);
+    sample.throughput = lambertianF<VARYING_ALBEDO>(m, isect, worldSample, &ignored);
     return sample;
 }
 
@@ -583,27 +606,44 @@ __device__ inline BSDFSample mirrorSample(const Isect &isect)
     return sample;
 }
 
+template <typename TRAITS = TraitsAll>
 __device__ inline Rgb materialF(const DMaterial &m, const Isect &isect, V3 wiWorld, float *pdf)
 {
     switch (m.type) {
-    case PATHED_MAT_LAMBERTIAN: return lambertianF(m, isect, wiWorld, pdf);
-    case PATHED_MAT_OREN_NAYAR: return orenNayarF(m, isect, wiWorld, pdf);
-    case PATHED_MAT_MICROFACET: return microfacetF(m, isect, wiWorld, pdf);
-    case PATHED_MAT_PLASTIC: return plasticF(m, isect, wiWorld, pdf);
-    default: *pdf = 0.f; return rgb(0.f);  // src/glass.cpp:20-28, src/mirror.cpp:11-19
+    case PATHED_MAT_LAMBERTIAN: if (TRAITS::has(PATHED_MAT_LAMBERTIAN)) { return lambertianF<TRAITS::varyingAlbedo>(m, isect, wiWorld, pdf); } break;
+    case PATHED_MAT_OREN_NAYAR: if (TRAITS::has(PATHED_MAT_OREN_NAYAR)) { return orenNayarF(m, isect, wiWorld, pdf); } break;
+    case PATHED_MAT_MICROFACET: if (TRAITS::has(PATHED_MAT_MICROFACET)) { return microfacetF(m, isect, wiWorld, pdf); } break;
+    case PATHED_MAT_PLASTIC: if (TRAITS::has(PATHED_MAT_PLASTIC)) { return plasticF(m, isect, wiWorld, pdf); } break;
+    default: break;
     }
+    *pdf = 0.f;
+    return rgb(0.f);  // src/glass.cpp:20-28, src/mirror.cpp:11-19
 }
 
+template <typename TRAITS = TraitsAll>
 __device__ inline BSDFSample materialSample(const DMaterial &m, const Isect &isect, Rng &random)
 {
     switch (m.type) {
-    case PATHED_MAT_LAMBERTIAN: return lambertianSample(m, isect, random);
-    case PATHED_MAT_OREN_NAYAR: return orenNayarSample(m, isect, random);
-    case PATHED_MAT_MICROFACET: return microfacetSample(m, isect, random);
-    case PATHED_MAT_PLASTIC: return plasticSample(m, isect, random);
-    case PATHED_MAT_GLASS: return glassSample(m, isect, random);
-    default: return mirrorSample(isect);
+    case PATHED_MAT_LAMBERTIAN: if (TRAITS::has(PATHED_MAT_LAMBERTIAN)) { return lambertianSample<TRAITS::varyingAlbedo>(m, isect, random); } break;
+    case PATHED_MAT_OREN_NAYAR: if (TRAITS::has(PATHED_MAT_OREN_NAYAR)) { return orenNayarSample(m, isect, random); } break;
+    case PATHED_MAT_MICROFACET: if (TRAITS::has(PATHED_MAT_MICROFACET)) { return microfacetSample(m, isect, random); } break;
+    case PATHED_MAT_PLASTIC: if (TRAITS::has(PATHED_MAT_PLASTIC)) { return plasticSample(m, isect, random); } break;
+    case PATHED_MAT_GLASS: if (TRAITS::has(PATHED_MAT_GLASS)) { return glassSample(m, isect, random); } break;
+    default: break;
     }
+    // a mirror -- or, in a narrowed instantiation, a material type the scene does not contain (never reached)
+    if (TRAITS::has(PATHED_MAT_MIRROR)) { return mirrorSample(isect); }
+    BSDFSample none;
+    none.wiWorld = isect.wo;
+    none.pdf = 1.f;
+    none.throughput = rgb(0.f);
+    return none;
+}
+
+template <typename TRAITS = TraitsAll>
+__device__ inline bool isDeltaT(const DMaterial &m)
+{
+    return (TRAITS::has(PATHED_MAT_GLASS) && m.type == PATHED_MAT_GLASS) || (TRAITS::has(PATHED_MAT_MIRROR) && m.type == PATHED_MAT_MIRROR);
 }
 
 // ------------------------------------------------------------------------- shapes

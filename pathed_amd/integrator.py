@@ -66,7 +66,7 @@ class HipScene:
     """A scene uploaded to one GPU (PathedScene handle).
 
     Keyword options map onto PathedSceneOptions (include/pathed_hip.h): stack_rows, pools,
-    suspend_lanes, suspend_patience, park_min_cards, max_slots, build_threads, intersector ("auto" | "bvh"),
+    suspend_lanes, suspend_patience, park_min_cards, max_slots, build_threads, generic_kernels, intersector ("auto" | "bvh"),
     trace_blocks_per_cu, shade_kernel ("auto" | "per-slot" | "staged" | "fused" | "split"), stage_slots,
     unit_order ("auto" | "stripes" | "stripes-tiled" | "tiles").  `device=None` keeps the device of an earlier pathed_hip_init.
     """
@@ -83,7 +83,7 @@ class HipScene:
         packed.intersector = {"auto": 0, "bvh": 1}[intersector]
         packed.shade_kernel = {"auto": 0, "per-slot": 1, "staged": 2, "fused": 3, "split": 4}[options.pop("shade_kernel", "auto")]
         packed.unit_order = {"auto": 0, "stripes": 1, "stripes-tiled": 2, "tiles": 3}[options.pop("unit_order", "auto")]
-        for name in ("stack_rows", "pools", "suspend_lanes", "suspend_patience", "park_min_cards", "max_slots", "trace_blocks_per_cu", "stage_slots", "build_threads"):
+        for name in ("stack_rows", "pools", "suspend_lanes", "suspend_patience", "park_min_cards", "max_slots", "trace_blocks_per_cu", "stage_slots", "build_threads", "generic_kernels"):
             if name in options:
                 setattr(packed, name, int(options.pop(name)))
         if options:

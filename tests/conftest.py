@@ -21,8 +21,8 @@ def repo_root():
 def generated_assets(request):
     """GPU runs: the sized variants of the procedural stand-in mesh (assets/dragon-standin-<n>.ply/.json) are generated
     HERE, by a child process, before any test of the session makes this process's first GPU call."""
-    expression = request.config.getoption("-m") or ""
-    if "gpu" in expression and "not gpu" not in expression:
+    # whenever a GPU test is among the selected ones (with -m gpu, -k ..., or a file name on the command line)
+    if any(item.get_closest_marker("gpu") is not None for item in request.session.items):
         import subprocess
         subprocess.run([sys.executable, os.path.join(REPO_ROOT, "tools", "make_assets.py"), "--dragon-variants", "6,7,9"],
                        check=True, stdout=subprocess.DEVNULL)

@@ -360,6 +360,10 @@ def test_shade_kernels_are_bit_identical(libs, scene_path, size, spp, last_bounc
         # the default for tiny scenes is the fused kernel
         assert automatic.stats()["path_kernel"] == 3
         assert np.array_equal(automatic.render(7, 3, spp, 0, last_bounce), expected)
+        # ... in the instantiation narrowed to the scene's material / light kinds (shading.h: SceneTraits) where there is one
+        # (Cornell, the Veach scene), and in the generic one
+        generic = HipScene(scene.desc, device=0, shade_kernel="fused", generic_kernels=1)
+        assert np.array_equal(generic.render(7, 3, spp, 0, last_bounce), expected)
         automatic.set_samples_per_unit(4)
         assert np.array_equal(automatic.render(2, 0, 3, 1, 2), windowed)
         automatic.set_samples_per_unit(7)
@@ -373,6 +377,10 @@ def test_shade_kernels_are_bit_identical(libs, scene_path, size, spp, last_bounc
         # the default for BVH scenes is the per-slot kernel; the split shade stage (k_vertex + k_regen over the trace
         # kernel's hit / miss lists) is selectable
         assert automatic.stats()["path_kernel"] == 1
+        # scenes lit by the environment alone take k_shade<.., ENV_ONLY> (emitter look-ups and the triangle / sphere light
+        # code compiled out): the same floats as the generic instantiation
+        generic = HipScene(scene.desc, device=0, shade_kernel="per-slot", generic_kernels=1)
+        assert np.array_equal(generic.render(7, 3, spp, 0, last_bounce), expected)
         split = HipScene(scene.desc, device=0, shade_kernel="split")
         assert np.array_equal(split.render(7, 3, spp, 0, last_bounce), expected)
         split.set_samples_per_unit(4)

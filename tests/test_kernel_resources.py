@@ -33,8 +33,8 @@ def test_vgpr_budgets_of_the_hot_kernels(tmp_path):
             value = re.search(key + r": (\d+)", line)
             if value and name:
                 usage[name][key.split(" ")[0]] = int(value.group(1))
-    shade = [v for k, v in usage.items() if "k_shadeILb1" in k]
-    assert shade and shade[0]["VGPRs"] <= 104 and shade[0]["ScratchSize"] == 0, shade
+    shade = [v for k, v in usage.items() if "k_shadeILb1" in k]      # generic and ENV_ONLY instantiations
+    assert len(shade) == 2 and all(v["VGPRs"] <= 104 and v["ScratchSize"] == 0 for v in shade), shade
     traces = [v for k, v in usage.items() if re.search(r"k_traceILi\d+ELb[01]ELb0ELb[01]", k)]   # the non-counting variants (plain + list-writing)
     assert len(traces) == 12 and all(v["VGPRs"] <= 96 for v in traces), traces
     # the list-writing variant must not spill more than a few dwords beyond the plain one: every value its list code kept
@@ -48,7 +48,11 @@ def test_vgpr_budgets_of_the_hot_kernels(tmp_path):
     assert small and small[0]["VGPRs"] <= 64 and small[0]["ScratchSize"] == 0, small
     # the fused path kernel lives at four waves per SIMD (128 VGPRs; three waves without spills measured 7 % slower):
     # what it spills stays within a couple of dozen dwords
-    fused = [v for k, v in usage.items() if "k_path_smallILb1ELb0" in k]
-    assert fused and fused[0]["VGPRs"] <= 128 and fused[0]["ScratchSize"] <= 96 and fused[0]["Occupancy"] == 4, fused
+    fused = {k: v for k, v in usage.items() if "k_path_smallILb1ELb0" in k}
+    assert len(fused) == 3 and all(v["VGPRs"] <= 128 and v["ScratchSize"] <= 96 and v["Occupancy"] == 4 for v in fused.values()), fused
+    # the instantiation narrowed to Cornell-like scenes (Lambertian, triangle lights: shading.h SceneTraits) is what the
+    # headline runs on: the code it does not contain is what used to spill (92 bytes of scratch in the generic one)
+    narrow = [v for k, v in fused.items() if "SceneTraitsILj1E" in k]
+    assert len(narrow) == 1 and narrow[0]["ScratchSize"] <= 16, fused
     staged = [v for k, v in usage.items() if "k_shade_stagedILb1" in k]
     assert len(staged) == 2 and all(v["VGPRs"] <= 128 and v["ScratchSize"] == 0 for v in staged), staged
