@@ -341,7 +341,8 @@ __device__ inline void deferSlot(const RenderParams &p, int list, bool defer, un
 // LISTS: the split shade stage follows.  The slot of every closest-hit ray that finishes joins the hit list or the miss
 // list (see kCtrListCount); a miss writes no hit record; a closest-hit ray that is parked puts its slot on hold itself
 // (no shade kernel visits a slot that is on no list).
-template <int STACK, bool LDS_SCENE, bool COUNT, bool LISTS>
+// SPHERES = false: scenes without sphere primitives (the mesh configurations): no sphere code in the kernel
+template <int STACK, bool LDS_SCENE, bool COUNT, bool LISTS, bool SPHERES = true>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_TRACE_WAVES, PATHED_TRACE_WAVES))) void k_trace(RenderParams p)
 {
     extern __shared__ float4 ldsRaw[];
@@ -580,7 +581,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_T
             bool done = false;
             if (COUNT) { stamp = __builtin_amdgcn_s_memtime(); }
             if (trianglePhase) {
-                if (active && ray.pendingLeaf != 0) { done = leafStep<COUNT, STACK, kBlock>(geometry, stack, ray, &counters); }
+                if (active && ray.pendingLeaf != 0) { done = leafStep<COUNT, STACK, kBlock, SPHERES>(geometry, stack, ray, &counters); }
             } else {
                 if (active && ray.pendingLeaf == 0) {
                     done = (geometry.nNodes == 0) || innerStep<COUNT, STACK, kBlock, PATHED_WARM_LINES && !LDS_SCENE>(geometry, stack, p.maxStack, ray, &counters);
@@ -591,7 +592,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_T
                 if (trianglePhase) { leafCycles += elapsed; } else { innerCycles += elapsed; innerSteps++; }
             }
             if (done) {
-                finishRay(geometry, ray);
+                finishRay<SPHERES>(geometry, ray);
                 if (ray.anyHit) {
                     if (ray.occluded) { p.state.pend[target] = make_float4(0.f, 0.f, 0.f, 0.f); }
                     else if (restored) { reinterpret_cast<int *>(p.state.pend + target)[3] = 0; }

@@ -471,6 +471,11 @@ void launchTraceStack(PathedScene *scene, const RenderParams &params, hipStream_
         }
         return;
     }
+    if (!scene->sceneInLds && scene->device.nSpheres == 0 && !scene->options.generic_kernels && !getenv("PATHED_NO_SCENE_TRAITS")) {
+        if (scene->countMode) { hipLaunchKernelGGL((k_trace<STACK, false, true, false, false>), grid, block, lds, stream, params); }
+        else { hipLaunchKernelGGL((k_trace<STACK, false, false, false, false>), grid, block, lds, stream, params); }
+        return;
+    }
     if (scene->sceneInLds) {
         if (scene->countMode) { hipLaunchKernelGGL((k_trace<STACK, true, true, false>), grid, block, lds, stream, params); }
         else { hipLaunchKernelGGL((k_trace<STACK, true, false, false>), grid, block, lds, stream, params); }

@@ -331,13 +331,14 @@ __device__ inline bool testSphere(const TraceGeometry &g, LaneRay &ray, int inde
 // Test the lane's pending leaf (<= 7 triangles, or ONE sphere: count 0, first = sphere index + 1 -- reference
 // src/sphere.cpp:16-48 hands its spheres to Embree's tree the same way), then pop the next piece of work.
 // Returns true when the query is complete.
-template <bool COUNT, int ROWS, int STRIDE>
+// SPHERES = false: the scene has no sphere primitives, their code (and the registers it wants) is compiled out
+template <bool COUNT, int ROWS, int STRIDE, bool SPHERES = true>
 __device__ inline bool leafStep(const TraceGeometry &g, const LaneStack &stack, LaneRay &ray, TraceCounters *counters)
 {
     const int first = ray.pendingLeaf >> 3;
     const int count = ray.pendingLeaf & 7;
     ray.pendingLeaf = 0;
-    if (count == 0) {
+    if (SPHERES && count == 0) {
         if (COUNT) { counters->tris++; }   // one primitive test
         if (testSphere(g, ray, first - 1)) { return true; }
         return popWork<ROWS, STRIDE>(stack, ray);
@@ -366,8 +367,10 @@ __device__ inline bool leafStep(const TraceGeometry &g, const LaneStack &stack, 
 
 // After the BVH: the spheres that are not in the tree (g.nSpheres of them: all of a tiny scene's, none when the host
 // builder put them into leaves) are tested one by one, then the result is final.
+template <bool SPHERES = true>
 __device__ inline void finishRay(const TraceGeometry &g, LaneRay &ray)
 {
+    if (!SPHERES) { return; }
     if (ray.anyHit && ray.occluded) { return; }
     for (int i = 0; i < g.nSpheres; i++) {
         if (testSphere(g, ray, i)) { return; }
