@@ -3014,7 +3014,7 @@ __device__ __forceinline__ bool volumeQuerySmall(const VolumeContext<MaterialTab
 #ifndef PATHED_VOLUME_WAVES
 #define PATHED_VOLUME_WAVES 4   // 128 registers per lane + scratch; 3 / 4 / 5 waves: 787 / 845 / 799 (Cornell), 732 / 787 / 707 (cornell-medium), 368 / 388 / 382 (teapot) Msamples/s; uncapped the kernel takes 220-260 registers and runs one or two waves
 #endif
-template <bool LDS_MATERIALS, int STACK, bool SMALL>
+template <bool LDS_MATERIALS, int STACK, bool SMALL, typename TRAITS = TraitsAll>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_VOLUME_WAVES, PATHED_VOLUME_WAVES))) void k_path_volume(RenderParams p, SmallTris smallTris)
 {
     extern __shared__ float4 ldsRaw[];
@@ -3113,16 +3113,18 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_V
             const DLight light = scene.lights[lightIndex];
             SurfaceSample surfaceSample;
             int lightMaterial = 0;
-            if (light.kind == 0) {
+            if (TRAITS::triangleLights && light.kind == 0) {
                 const TriShade tri = loadTriCorners(scene, light.index);
                 surfaceSample = triangleSample(tri.p0, tri.p1, tri.p2, random);
                 lightMaterial = tri.material;
-            } else if (light.kind == 1) {
+            } else if (TRAITS::spheres && light.kind == 1) {
                 const DSphere sphere = scene.spheres[light.index];
                 surfaceSample = sphereSample(v3(sphere.centerSample[0], sphere.centerSample[1], sphere.centerSample[2]), sphere.radius, isect.point, random);
                 lightMaterial = sphere.material;
-            } else {
+            } else if (TRAITS::env) {
                 surfaceSample = envSample(scene.env, isect.point, random);
+            } else {   // not reached: a light of a kind the instantiation's scene set does not contain
+                surfaceSample.point = isect.point; surfaceSample.normal = v3(0.f, 0.f, 0.f); surfaceSample.invPDF = 1.f; surfaceSample.solidAngle = 1;
             }
             const float lightChoicePDF = 1.f / lightCount;
             const float invPDF = surfaceSample.invPDF * (1.f / lightChoicePDF);
@@ -3145,11 +3147,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_V
                         pdf = (1.f / invPDF) * distance2 / projectedArea;
                     }
                     float brdfPDF;
-                    const Rgb f = materialF(material, isect, wiWorld, &brdfPDF);
+                    const Rgb f = materialF<TRAITS>(material, isect, wiWorld, &brdfPDF);
                     const float lightWeight = (1 * pdf) / (1 * pdf + 1 * brdfPDF);
                     const V3 lightWo = -normalized(lightDirection);
                     Rgb emitted;
-                    if (light.kind == 2) { emitted = envEmit(scene.env, lightWo); }
+                    if (TRAITS::env && light.kind == 2) { emitted = envEmit(scene.env, lightWo); }
                     else { emitted = matEmit(materials[lightMaterial]); }
                     lightContribution = emitted
                         * transmittance
@@ -3180,16 +3182,16 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_V
             }
             segmentKnown = true;
             if (found) {
-                const Isect bounce = makeIsect(scene, isect.point, bsdfSample.wiWorld,
+                const Isect bounce = makeIsect<TRAITS>(scene, isect.point, bsdfSample.wiWorld,
                                                make_float4(bounceHit.t, bounceHit.u, bounceHit.v, intAsFloat(bounceHit.prim)));
                 const Rgb emit = matEmit(materials[bounce.material]);
                 if (!isBlack(emit) && dot(bounce.wo, bounce.shadingNormal) >= 0.f) {
-                    const float lightPDF = lightsPDF(scene, isect.point, bounce);
+                    const float lightPDF = lightsPDF<TRAITS>(scene, isect.point, bounce);
                     const float brdfWeight = volumeIsDelta(material) ? 1.f : (1 * bsdfSample.pdf) / (1 * bsdfSample.pdf + 1 * lightPDF);
                     bsdfTerm = emit * brdfWeight * bsdfSample.throughput * fabsf(dot(isect.shadingNormal, bsdfSample.wiWorld)) / bsdfSample.pdf;
                 }
             } else {
-                const Rgb environmentLight = environmentL(scene, bsdfSample.wiWorld);
+                const Rgb environmentLight = environmentL<TRAITS>(scene, bsdfSample.wiWorld);
                 if (!isBlack(environmentLight)) {
                     const float lightPDF = envEmitPDF(scene.env, bsdfSample.wiWorld) / scene.nLights;
                     const float brdfWeight = volumeIsDelta(material) ? 1.f : (1 * bsdfSample.pdf) / (1 * bsdfSample.pdf + 1 * lightPDF);
@@ -3219,16 +3221,18 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_V
         const DLight light = scene.lights[lightIndex];
         SurfaceSample surfaceSample;
         int lightMaterial = 0;
-        if (light.kind == 0) {
+        if (TRAITS::triangleLights && light.kind == 0) {
             const TriShade tri = loadTriCorners(scene, light.index);
             surfaceSample = triangleSample(tri.p0, tri.p1, tri.p2, random);
             lightMaterial = tri.material;
-        } else if (light.kind == 1) {
+        } else if (TRAITS::spheres && light.kind == 1) {
             const DSphere sphere = scene.spheres[light.index];
             surfaceSample = sphereSample(v3(sphere.centerSample[0], sphere.centerSample[1], sphere.centerSample[2]), sphere.radius, samplePoint, random);
             lightMaterial = sphere.material;
-        } else {
+        } else if (TRAITS::env) {
             surfaceSample = envSample(scene.env, samplePoint, random);
+        } else {   // not reached
+            surfaceSample.point = samplePoint; surfaceSample.normal = v3(0.f, 0.f, 0.f); surfaceSample.invPDF = 1.f; surfaceSample.solidAngle = 1;
         }
         const float lightChoicePDF = 1.f / lightCount;
         const float invPDF = surfaceSample.invPDF * (1.f / lightChoicePDF);
@@ -3253,7 +3257,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_V
         if (events.count == 1) { shadowTransmittance = mediumTransmittance(context.media[medium], samplePoint, samplePoint + wiWorld * events.t0); }
         else if (events.count >= 2) { shadowTransmittance = mediumTransmittance(context.media[medium], samplePoint + wiWorld * events.t0, samplePoint + wiWorld * events.t1); }
         Rgb emitted;
-        if (light.kind == 2) { emitted = envEmit(scene.env, lightWo); }
+        if (TRAITS::env && light.kind == 2) { emitted = envEmit(scene.env, lightWo); }
         else { emitted = matEmit(materials[lightMaterial]); }
         const float fourPi = (float)(4.f * 3.14159265358979323846);   // `4.f * M_PI` is a double, Color::operator/ takes a float
         return emitted * shadowTransmittance * 1.f / fourPi / pdf;
@@ -3276,9 +3280,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_V
         Rgb color = rgb(0.f);
         RayHit hit;
         if (!query(kQueryRegular, rayOrigin, rayDirection, PATHED_TFAR, &hit, nullptr)) {
-            return color + environmentL(scene, rayDirection);
+            return color + environmentL<TRAITS>(scene, rayDirection);
         }
-        Isect last = makeIsect(scene, rayOrigin, rayDirection, make_float4(hit.t, hit.u, hit.v, intAsFloat(hit.prim)));
+        Isect last = makeIsect<TRAITS>(scene, rayOrigin, rayDirection, make_float4(hit.t, hit.u, hit.v, intAsFloat(hit.prim)));
         if (checkCounts(p.startBounce, p.lastBounce, 0)) {
             const DMaterial &first = materials[last.material];
             const bool backside = dot(last.normal, last.wo) < 0.f;
@@ -3290,14 +3294,14 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_V
                 const bool found = query(kQueryVolumeClosest, rayOrigin, rayDirection, PATHED_TFAR, &through, &events);
                 const Rgb transmittance = rayTransmission(context.media, rayOrigin, rayDirection, events, -1);
                 if (found) { color = color + matEmit(materials[primMaterial(context, through.prim)]) * transmittance; }
-                else { color = color + environmentL(scene, rayDirection) * transmittance; }
+                else { color = color + environmentL<TRAITS>(scene, rayDirection) * transmittance; }
             }
         }
 
         // ---- VolumePathTracer::L, src/volume_path_tracer.cpp:14-99
         int medium = -1;
         random.dimension = vertexBase(1);
-        BSDFSample bsdfSample = volumeMaterialSample(materials[last.material], last, random);
+        BSDFSample bsdfSample = volumeMaterialSample<TRAITS>(materials[last.material], last, random);
         Rgb result = rgb(0.f);
         if (checkCounts(p.startBounce, p.lastBounce, 1)) {
             random.dimension = vertexBase(1) + 3;
@@ -3317,7 +3321,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_V
             } else if (!query(kQueryRegular, last.point, bsdfSample.wiWorld, PATHED_TFAR, &hit, nullptr)) {
                 break;
             }
-            const Isect next = makeIsect(scene, last.point, bsdfSample.wiWorld, make_float4(hit.t, hit.u, hit.v, intAsFloat(hit.prim)));
+            const Isect next = makeIsect<TRAITS>(scene, last.point, bsdfSample.wiWorld, make_float4(hit.t, hit.u, hit.v, intAsFloat(hit.prim)));
             const float invPDF = 1.f / bsdfSample.pdf;
             const float cosTheta = fabsf(dot(last.shadingNormal, bsdfSample.wiWorld));
             modulation = modulation * (bsdfSample.throughput * cosTheta * invPDF);
@@ -3330,7 +3334,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_V
             if (isBlack(modulation)) { break; }
 
             random.dimension = vertexBase(bounce);
-            bsdfSample = volumeMaterialSample(materials[next.material], next, random);
+            bsdfSample = volumeMaterialSample<TRAITS>(materials[next.material], next, random);
             last = next;
             if (checkCounts(p.startBounce, p.lastBounce, bounce)) {
                 random.dimension = vertexBase(bounce) + 3;

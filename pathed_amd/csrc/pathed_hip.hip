@@ -195,6 +195,7 @@ struct PathedScene {
     bool stagedShade = true;  // k_shade_staged (dense, state-sorted stages inside a block) or k_shade (one lane per slot)
     bool lambertianTriangles = false;   // constant-albedo Lambertian surfaces, triangle lights, no spheres, no environment: k_path_small<.., TraitsLambertianTriangles>
     bool lambertianPlasticSpheres = false;   // the Veach scene's set (shading.h)
+    bool lambertianGlassContainer = false;   // the reference's volume scene's set
     bool envOnly = false;     // the one light is the environment and no material emits: k_shade<.., ENV_ONLY> (kernels.h)
     bool splitShade = false;  // k_vertex + k_regen over the hit / miss lists the trace kernel writes (kernels.h: split shade stage)
     int vertexGrid = 0, regenGrid = 0;   // their persistent grids, blocks
@@ -549,9 +550,13 @@ void launchVolumeStack(const RenderParams &params, const SmallTris &smallTris, d
 }
 
 // small: the scene's triangles go through the all-triangles intersector (kernarg pair records), no tree walk
-void launchVolume(int stackRows, bool small, const RenderParams &params, const SmallTris &smallTris, dim3 grid, size_t lds, bool ldsMaterials,
+void launchVolume(int stackRows, bool small, bool narrowed, const RenderParams &params, const SmallTris &smallTris, dim3 grid, size_t lds, bool ldsMaterials,
                   hipStream_t stream)
 {
+    if (small && narrowed && ldsMaterials) {   // the reference's own volume scene kinds (shading.h: TraitsLambertianGlassContainer)
+        hipLaunchKernelGGL((k_path_volume<true, 8, true, TraitsLambertianGlassContainer>), grid, dim3(kBlock), lds, stream, params, smallTris);
+        return;
+    }
     if (small) { launchVolumeStack<8, true>(params, smallTris, grid, lds, ldsMaterials, stream); return; }
     switch (stackRows) {
     case 8: launchVolumeStack<8, false>(params, smallTris, grid, lds, ldsMaterials, stream); break;
@@ -1393,6 +1398,13 @@ int pathed_hip_scene_create_ex(const PathedSceneDesc *desc, const PathedSceneOpt
         bool triangleLights = false;
         for (const DLight &light : lights) { triangleLights = triangleLights || light.kind == 0; }
         scene->lambertianPlasticSpheres = lambertianPlastic && desc->env == nullptr && !triangleLights && narrow;
+        bool glassContainer = desc->env == nullptr;
+        for (uint32_t i = 0; i < desc->n_materials; i++) {
+            const int type = desc->materials[i].type;
+            glassContainer = glassContainer && (type == PATHED_MAT_LAMBERTIAN || type == PATHED_MAT_GLASS || type == PATHED_MAT_PASSTHROUGH)
+                && desc->materials[i].albedo_type == PATHED_ALBEDO_CONSTANT;
+        }
+        scene->lambertianGlassContainer = glassContainer && narrow;
     }
     d.media = scene->media.ptr;
     d.primMedium = scene->primMedium.ptr;
@@ -1698,7 +1710,7 @@ static int renderPassVolume(PathedScene *scene, uint64_t seed, uint32_t begin, u
         timed = scene->traceEvents.acquire();
         (void)hipEventRecord(scene->traceEvents.start[timed], stream);
     }
-    launchVolume(scene->stackRows, small, params, scene->smallTris, grid, lds, ldsMaterials, stream);
+    launchVolume(scene->stackRows, small, scene->lambertianGlassContainer, params, scene->smallTris, grid, lds, ldsMaterials, stream);
     if (timed >= 0) { (void)hipEventRecord(scene->traceEvents.stop[timed], stream); }
     scene->traceLaunchesAll++;
     const dim3 pixelGrid((unsigned)((nPixels + kBlock - 1) / kBlock));

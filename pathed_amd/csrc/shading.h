@@ -31,6 +31,8 @@ typedef SceneTraits<0x7Fu, true, true, true, true> TraitsAll;
 typedef SceneTraits<1u << 0, false, true, false, false> TraitsLambertianTriangles;
 // the Veach MIS scene: Lambertian + plastic surfaces (constant albedo) lit by emissive spheres
 typedef SceneTraits<(1u << 0) | (1u << 3), false, false, true, false> TraitsLambertianPlasticSpheres;
+// the reference's VolumePathTracer scene (scenes/cornell-medium.json): Lambertian walls, a glass sphere, a passthrough container, triangle lights
+typedef SceneTraits<(1u << 0) | (1u << 4) | (1u << 6), false, true, true, false> TraitsLambertianGlassContainer;
 
 
 #define PATHED_INV_PI 0.3183098861837907f   /* include/util.h:10 */

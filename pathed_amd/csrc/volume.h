@@ -210,10 +210,11 @@ __device__ inline BSDFSample passthroughSample(const Isect &isect)
 
 __device__ inline bool volumeIsDelta(const DMaterial &m) { return m.type == PATHED_MAT_PASSTHROUGH || isDelta(m); }
 
+template <typename TRAITS = TraitsAll>
 __device__ inline BSDFSample volumeMaterialSample(const DMaterial &m, const Isect &isect, Rng &random)
 {
     if (m.type == PATHED_MAT_PASSTHROUGH) { return passthroughSample(isect); }
-    return materialSample(m, isect, random);
+    return materialSample<TRAITS>(m, isect, random);
 }
 
 // dimensions of the medium's distance sample (+0) and light sample (+1..3) on the segment that ends at `vertex`
