@@ -276,6 +276,9 @@ typedef struct PathedSceneOptions {
     int32_t build_threads;      /* host threads of the SAH builder (0 = all cores; the tree does not depend on it) */
     int32_t generic_kernels;    /* 1: never pick a scene-specialised kernel instantiation (k_shade<.., ENV_ONLY> for scenes whose
                                    one light is the environment and whose materials do not emit): A/B runs and tests */
+    int32_t node_format;        /* the tree the trace kernel walks: 0 automatic; 1 128-byte nodes (four float boxes); 2 compressed
+                                   64-byte nodes (the boxes on an 8-bit grid over their union, rounded outward: same hits) --
+                                   sphere-free scenes whose tree stays in HBM, per-slot pipeline; an error elsewhere */
 } PathedSceneOptions;
 int pathed_hip_scene_create_ex(const PathedSceneDesc *desc, const PathedSceneOptions *options, PathedScene **out);
 int pathed_hip_scene_device(const PathedScene *scene);   /* the HIP device the scene lives on, or a negative error */
@@ -355,6 +358,12 @@ int pathed_hip_reset_stats(PathedScene *scene);
 int pathed_hip_scene_export_bvh(PathedScene *scene,
                                 float *nodes, size_t *n_nodes,
                                 float *tris, size_t *n_tris);
+/* The compressed form of the same nodes (PathedSceneOptions.node_format 2), same indices and refs: 16 words per node,
+ *   (origin.xyz, scale.x) (scale.y, scale.z, qlo.x, qlo.y) (qlo.z, qhi.x, qhi.y, qhi.z) (ref[4])
+ * origin / scale are floats, every q word holds the four children's 8-bit grid indices (child c in bits 8c .. 8c+7):
+ * child c spans [origin + qlo * scale, origin + qhi * scale] per axis and CONTAINS its float box.
+ * *n_nodes comes back 0 for a scene that does not carry the compressed form.  Pass NULL to query the size. */
+int pathed_hip_scene_export_compressed_nodes(PathedScene *scene, uint32_t *nodes, size_t *n_nodes);
 
 /* Measurement aid: what a plain streaming kernel reaches on THIS device, as a
  * second denominator beside the 8 TB/s HBM3E spec figure.  Allocates two probe buffers of `bytes`

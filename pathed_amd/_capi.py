@@ -153,6 +153,7 @@ class PathedSceneOptions(C.Structure):
         ("unit_order", C.c_int32),
         ("build_threads", C.c_int32),
         ("generic_kernels", C.c_int32),
+        ("node_format", C.c_int32),
     ]
 
 
@@ -181,6 +182,7 @@ HIP_SYMBOLS = [
     "pathed_hip_get_stats",
     "pathed_hip_reset_stats",
     "pathed_hip_scene_export_bvh",
+    "pathed_hip_scene_export_compressed_nodes",
     "pathed_hip_measure_bandwidth",
     "pathed_hip_measure_valu",
     "pathed_hip_measure_valu_modes",
@@ -284,6 +286,8 @@ def load_hip():
         vp, C.POINTER(C.c_float), C.POINTER(C.c_size_t), C.POINTER(C.c_float), C.POINTER(C.c_size_t)
     ]
     lib.pathed_hip_scene_export_bvh.restype = C.c_int
+    lib.pathed_hip_scene_export_compressed_nodes.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_size_t)]
+    lib.pathed_hip_scene_export_compressed_nodes.restype = C.c_int
     lib.pathed_hip_measure_bandwidth.argtypes = [C.c_size_t, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.pathed_hip_measure_bandwidth.restype = C.c_int
     lib.pathed_hip_last_error.argtypes = []

@@ -77,7 +77,8 @@ struct DScene {
     DCamera camera;
 
     // intersector
-    const float4 *nodes;       // 4 x float4 per inner node
+    const float4 *nodes;       // 8 x float4 per inner node (trace.h: layout)
+    const float4 *nodesQ;      // 4 x float4 per inner node, same indices: the compressed form (trace.h), or null
     const float4 *leafTris;    // 3 x float4 per leaf-ordered triangle: (v0, prim) (e1, -) (e2, -)
     int nNodes;
     int nTris;

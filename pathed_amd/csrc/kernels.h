@@ -342,7 +342,8 @@ __device__ inline void deferSlot(const RenderParams &p, int list, bool defer, un
 // list (see kCtrListCount); a miss writes no hit record; a closest-hit ray that is parked puts its slot on hold itself
 // (no shade kernel visits a slot that is on no list).
 // SPHERES = false: scenes without sphere primitives (the mesh configurations): no sphere code in the kernel
-template <int STACK, bool LDS_SCENE, bool COUNT, bool LISTS, bool SPHERES = true>
+// QUANT: the tree is walked in its compressed form (trace.h: nodeQ, 64 bytes per node)
+template <int STACK, bool LDS_SCENE, bool COUNT, bool LISTS, bool SPHERES = true, bool QUANT = false>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_TRACE_WAVES, PATHED_TRACE_WAVES))) void k_trace(RenderParams p)
 {
     extern __shared__ float4 ldsRaw[];
@@ -353,8 +354,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_T
     stack.overflowStride = (size_t)gridDim.x * kBlock;
     stack.overflow = p.stackOverflow + ((size_t)blockIdx.x * kBlock + threadIdx.x);
 
+    static_assert(!(QUANT && LDS_SCENE), "the LDS copy of a small tree is the uncompressed one");
     TraceGeometry geometry;
-    geometry.nodes = p.scene.nodes;
+    geometry.nodes = QUANT ? p.scene.nodesQ : p.scene.nodes;
     geometry.tris = p.scene.leafTris;
     geometry.nNodes = p.scene.nNodes;
     geometry.nTris = p.scene.nTris;
@@ -584,7 +586,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_T
                 if (active && ray.pendingLeaf != 0) { done = leafStep<COUNT, STACK, kBlock, SPHERES>(geometry, stack, ray, &counters); }
             } else {
                 if (active && ray.pendingLeaf == 0) {
-                    done = (geometry.nNodes == 0) || innerStep<COUNT, STACK, kBlock, PATHED_WARM_LINES && !LDS_SCENE>(geometry, stack, p.maxStack, ray, &counters);
+                    done = (geometry.nNodes == 0) || innerStep<COUNT, STACK, kBlock, PATHED_WARM_LINES && !LDS_SCENE, QUANT>(geometry, stack, p.maxStack, ray, &counters);
                 }
             }
             if (COUNT) {
@@ -928,8 +930,8 @@ __global__ __launch_bounds__(kBlock) void k_trace_small(RenderParams p, SmallTri
     }
 }
 
-// test hook kernel behind pathed_hip_trace: plain grid, arbitrary ray intervals
-template <int STACK>
+// test hook kernel behind pathed_hip_trace: plain grid, arbitrary ray intervals (QUANT: over the compressed nodes)
+template <int STACK, bool QUANT>
 __global__ __launch_bounds__(kBlock) void k_trace_rays(
     DScene scene, const float4 *rays, int n, int anyHit, float4 *hitsOut, int *occludedOut,
     int *stackOverflow, int maxStack
@@ -941,7 +943,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_rays(
     stack.overflow = stackOverflow + ((size_t)blockIdx.x * kBlock + threadIdx.x);
 
     TraceGeometry geometry;
-    geometry.nodes = scene.nodes;
+    geometry.nodes = QUANT ? scene.nodesQ : scene.nodes;
     geometry.tris = scene.leafTris;
     geometry.nNodes = scene.nNodes;
     geometry.nTris = scene.nTris;
@@ -956,11 +958,11 @@ __global__ __launch_bounds__(kBlock) void k_trace_rays(
     hit.t = 0.f; hit.u = 0.f; hit.v = 0.f; hit.prim = -1;
     TraceCounters counters;
     if (anyHit) {
-        const bool occluded = traverse<false, STACK, kBlock>(
+        const bool occluded = traverse<false, STACK, kBlock, QUANT>(
             geometry, stack, maxStack, v3(ro.x, ro.y, ro.z), v3(rd.x, rd.y, rd.z), ro.w, rd.w, true, &hit, &counters);
         occludedOut[i] = occluded ? 1 : 0;
     } else {
-        const bool found = traverse<false, STACK, kBlock>(
+        const bool found = traverse<false, STACK, kBlock, QUANT>(
             geometry, stack, maxStack, v3(ro.x, ro.y, ro.z), v3(rd.x, rd.y, rd.z), ro.w, rd.w, false, &hit, &counters);
         if (!found) { hit.t = 0.f; hit.u = 0.f; hit.v = 0.f; hit.prim = -1; }
         hitsOut[i] = make_float4(hit.t, hit.u, hit.v, intAsFloat(hit.prim));
@@ -3397,6 +3399,55 @@ __global__ __launch_bounds__(kBlock) void k_build_tri_shade(
     // the 16-byte record (makeIsect): geometric normal + material, read for the triangles of the scene's plain ranges
     const V3 normal = triangleNormal(v3(p0[0], p0[1], p0[2]), v3(p1[0], p1[1], p1[2]), v3(p2[0], p2[1], p2[2]));
     triCompact[i] = make_float4(normal.x, normal.y, normal.z, intAsFloat(triMaterial[i]));
+}
+
+// The compressed form of the tree (trace.h: nodeQ), one thread per node, after any of the three builders.  Per axis:
+// origin = the smallest lower bound of the node's children, scale = the smallest power of two with 253 * scale >= extent,
+// q = the plane's grid index (computed exactly, in double) rounded outward past an extra 1/256 of a step (that covers the
+// rounding of the traversal's q * (scale / d) + (origin / d - o / d), <= 2^-16 of a step within the node; further away
+// the traversal's 1.0000004 factor covers both forms alike).  The refs are copied.
+__global__ __launch_bounds__(kBlock) void k_compress_nodes(const float4 *nodes, int nNodes, float4 *nodesQ)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= nNodes) { return; }
+    const float4 *node = nodes + (size_t)8 * i;
+    const float4 refBits = node[6];
+    const int ref[4] = { floatAsInt(refBits.x), floatAsInt(refBits.y), floatAsInt(refBits.z), floatAsInt(refBits.w) };
+    float origin[3], scale[3];
+    unsigned int qlo[3], qhi[3];
+    #pragma unroll
+    for (int a = 0; a < 3; a++) {
+        const float4 lo4 = node[a], hi4 = node[3 + a];
+        const float lo[4] = { lo4.x, lo4.y, lo4.z, lo4.w }, hi[4] = { hi4.x, hi4.y, hi4.z, hi4.w };
+        float low = INFINITY, high = -INFINITY;
+        for (int c = 0; c < 4; c++) {
+            if (ref[c] != kEmptyChild) { low = fminf(low, lo[c]); high = fmaxf(high, hi[c]); }
+        }
+        if (!(low <= high)) { low = 0.f; high = 0.f; }   // no children
+        const double extent = (double)high - (double)low;    // exact
+        int exponent = 0;
+        (void)frexp(extent / 253.0, &exponent);            // extent / 253 = m * 2^exponent with m < 1
+        const float step = extent > 0.0 ? ldexpf(1.f, exponent) : 0.f;
+        const double perStep = step > 0.f ? 1.0 / (double)step : 0.0;   // exact: a power of two
+        origin[a] = low;
+        scale[a] = step;
+        qlo[a] = 0u;
+        qhi[a] = 0u;
+        for (int c = 0; c < 4; c++) {
+            if (ref[c] == kEmptyChild) { continue; }
+            const double below = floor(((double)lo[c] - (double)low) * perStep - 1.0 / 256.0);
+            const double above = ceil(((double)hi[c] - (double)low) * perStep + 1.0 / 256.0);
+            const unsigned int qBelow = (unsigned int)fmin(fmax(below, 0.0), 255.0);
+            const unsigned int qAbove = step > 0.f ? (unsigned int)fmin(fmax(above, 0.0), 255.0) : 0u;
+            qlo[a] |= qBelow << (8 * c);
+            qhi[a] |= qAbove << (8 * c);
+        }
+    }
+    float4 *out = nodesQ + (size_t)4 * i;
+    out[0] = make_float4(origin[0], origin[1], origin[2], scale[0]);
+    out[1] = make_float4(scale[1], scale[2], intAsFloat((int)qlo[0]), intAsFloat((int)qlo[1]));
+    out[2] = make_float4(intAsFloat((int)qlo[2]), intAsFloat((int)qhi[0]), intAsFloat((int)qhi[1]), intAsFloat((int)qhi[2]));
+    out[3] = refBits;
 }
 
 // ------------------------------------------------------------------------- bandwidth probe

@@ -158,7 +158,7 @@ struct PathedScene {
     int bvhBuilder = PATHED_BVH_SAH_HOST;
     double bvhBuildMs = 0.0;
 
-    DeviceBuffer<float4> nodes, leafTris, triShade, triCompact, envRgba, texels;
+    DeviceBuffer<float4> nodes, nodesQ, leafTris, triShade, triCompact, envRgba, texels;
     DeviceBuffer<DSphere> spheres;
     DeviceBuffer<DMaterial> materials;
     DeviceBuffer<DLight> lights;
@@ -196,6 +196,7 @@ struct PathedScene {
     bool lambertianTriangles = false;   // constant-albedo Lambertian surfaces, triangle lights, no spheres, no environment: k_path_small<.., TraitsLambertianTriangles>
     bool lambertianPlasticSpheres = false;   // the Veach scene's set (shading.h)
     bool lambertianGlassContainer = false;   // the reference's volume scene's set
+    bool quantNodes = false;                 // k_trace walks the compressed nodes (trace.h: nodeQ)
     bool envOnly = false;     // the one light is the environment and no material emits: k_shade<.., ENV_ONLY> (kernels.h)
     bool splitShade = false;  // k_vertex + k_regen over the hit / miss lists the trace kernel writes (kernels.h: split shade stage)
     int vertexGrid = 0, regenGrid = 0;   // their persistent grids, blocks
@@ -472,6 +473,11 @@ void launchTraceStack(PathedScene *scene, const RenderParams &params, hipStream_
         }
         return;
     }
+    if (scene->quantNodes) {
+        if (scene->countMode) { hipLaunchKernelGGL((k_trace<STACK, false, true, false, false, true>), grid, block, lds, stream, params); }
+        else { hipLaunchKernelGGL((k_trace<STACK, false, false, false, false, true>), grid, block, lds, stream, params); }
+        return;
+    }
     if (!scene->sceneInLds && scene->device.nSpheres == 0 && !scene->options.generic_kernels && !getenv("PATHED_NO_SCENE_TRAITS")) {
         if (scene->countMode) { hipLaunchKernelGGL((k_trace<STACK, false, true, false, false>), grid, block, lds, stream, params); }
         else { hipLaunchKernelGGL((k_trace<STACK, false, false, false, false>), grid, block, lds, stream, params); }
@@ -629,6 +635,10 @@ extern "C" {
 
 const char *pathed_hip_last_error(void) { return g_error.c_str(); }
 
+// what node_format 0 picks for the scenes the compressed tree serves (DESIGN.md has the measurement)
+#ifndef PATHED_DEFAULT_COMPRESSED_NODES
+#define PATHED_DEFAULT_COMPRESSED_NODES 0
+#endif
 #define PATHED_STRINGIFY2(x) #x
 #define PATHED_STRINGIFY(x) PATHED_STRINGIFY2(x)
 const char *pathed_hip_version(void) { return "pathed_hip 0.3.0 (gfx950, abi " PATHED_STRINGIFY(PATHED_ABI_VERSION) ")"; }
@@ -1042,6 +1052,7 @@ int pathed_hip_scene_create_ex(const PathedSceneDesc *desc, const PathedSceneOpt
         if (optionsIn->struct_size != sizeof(PathedSceneOptions)) { return fail(PATHED_E_INVALID, "PathedSceneOptions.struct_size mismatch"); }
         options = *optionsIn;
         if (options.generic_kernels != 0 && options.generic_kernels != 1) { return fail(PATHED_E_INVALID, "generic_kernels must be 0 or 1"); }
+        if (options.node_format < 0 || options.node_format > 2) { return fail(PATHED_E_INVALID, "node_format must be 0 (automatic), 1 (128-byte nodes) or 2 (compressed 64-byte nodes)"); }
         if (options.build_threads < 0 || options.build_threads > 4096) { return fail(PATHED_E_INVALID, "build_threads must be 0..4096"); }
         if (options.unit_order < 0 || options.unit_order > 3) { return fail(PATHED_E_INVALID, "unit_order must be 0..3"); }
         if (options.bvh_builder < 0 || options.bvh_builder > PATHED_BVH_PLOC_DEVICE + 1) { return fail(PATHED_E_INVALID, "unknown BVH builder"); }
@@ -1344,6 +1355,7 @@ int pathed_hip_scene_create_ex(const PathedSceneDesc *desc, const PathedSceneOpt
     if ((status = scene->phiRecords.upload(phiRecords)) != hipSuccess) { return fail_cleanup(status, "upload env cdf"); }
 
     d.nodes = scene->nodes.ptr;
+    d.nodesQ = nullptr;
     d.leafTris = scene->leafTris.ptr;
     d.nNodes = scene->bvh.nodeCount;
     d.nTris = (int)desc->n_triangles;
@@ -1453,6 +1465,29 @@ int pathed_hip_scene_create_ex(const PathedSceneDesc *desc, const PathedSceneOpt
     }
     scene->splitShade = shadeKernel == 4;
     configureTrace(scene);
+    {
+        // the compressed tree: sphere-free scenes whose tree stays in HBM, walked by the per-slot pipeline's trace kernel
+        int nodeFormat = options.node_format;
+        if (const char *text = getenv("PATHED_NODE_FORMAT")) {   // experiments: "wide" | "compressed"
+            if (!strcmp(text, "wide")) { nodeFormat = 1; }
+            else if (!strcmp(text, "compressed")) { nodeFormat = 2; }
+        }
+        const bool eligible = !scene->bruteForce && !scene->sceneInLds && !scene->splitShade && scene->device.nSpheres == 0
+            && scene->device.nNodes > 0 && options.generic_kernels == 0;
+        if (nodeFormat == 2 && !eligible) {
+            delete scene;
+            return fail(PATHED_E_INVALID, "compressed nodes serve sphere-free scenes whose tree is walked in HBM by the per-slot pipeline (not generic_kernels, not the split stage)");
+        }
+        if (eligible && nodeFormat != 1 && PATHED_DEFAULT_COMPRESSED_NODES + (nodeFormat == 2) > 0) {
+            const size_t nNodes = (size_t)scene->device.nNodes;
+            if ((status = scene->nodesQ.allocate(4 * nNodes)) != hipSuccess) { return fail_cleanup(status, "allocate compressed nodes"); }
+            hipLaunchKernelGGL(k_compress_nodes, dim3((unsigned)((nNodes + kBlock - 1) / kBlock)), dim3(kBlock), 0, nullptr,
+                               scene->nodes.ptr, (int)nNodes, scene->nodesQ.ptr);
+            if ((status = hipDeviceSynchronize()) != hipSuccess) { return fail_cleanup(status, "compress nodes"); }
+            scene->device.nodesQ = scene->nodesQ.ptr;
+            scene->quantNodes = true;
+        }
+    }
     // persistent grids of the split stage: k_vertex at PATHED_VERTEX_WAVES blocks per CU, k_regen at PATHED_REGEN_WAVES
     scene->vertexGrid = scene->computeUnits * PATHED_VERTEX_WAVES;
     scene->regenGrid = scene->computeUnits * PATHED_REGEN_WAVES;
@@ -2057,11 +2092,21 @@ int pathed_hip_trace(PathedScene *scene, const float *rays, size_t n, int any_hi
         const size_t overflowRows = (size_t)(scene->maxStack > scene->stackRows ? scene->maxStack - scene->stackRows : 0);
         status = hipMalloc((void **)&deviceOverflow, (size_t)grid.x * kBlock * (overflowRows ? overflowRows : 1) * sizeof(int));
         if (status == hipSuccess) {
-            switch (scene->stackRows) {
-            case 8: hipLaunchKernelGGL((k_trace_rays<8>), grid, block, lds, 0, scene->device, deviceRays, (int)n, any_hit, deviceHits, deviceOccluded, deviceOverflow, scene->maxStack); break;
-            case 16: hipLaunchKernelGGL((k_trace_rays<16>), grid, block, lds, 0, scene->device, deviceRays, (int)n, any_hit, deviceHits, deviceOccluded, deviceOverflow, scene->maxStack); break;
-            default: hipLaunchKernelGGL((k_trace_rays<22>), grid, block, lds, 0, scene->device, deviceRays, (int)n, any_hit, deviceHits, deviceOccluded, deviceOverflow, scene->maxStack); break;
+            #define PATHED_HOOK(STACK, QUANT) hipLaunchKernelGGL((k_trace_rays<STACK, QUANT>), grid, block, lds, 0, scene->device, deviceRays, (int)n, any_hit, deviceHits, deviceOccluded, deviceOverflow, scene->maxStack)
+            if (scene->quantNodes) {
+                switch (scene->stackRows) {
+                case 8: PATHED_HOOK(8, true); break;
+                case 16: PATHED_HOOK(16, true); break;
+                default: PATHED_HOOK(22, true); break;
+                }
+            } else {
+                switch (scene->stackRows) {
+                case 8: PATHED_HOOK(8, false); break;
+                case 16: PATHED_HOOK(16, false); break;
+                default: PATHED_HOOK(22, false); break;
+                }
             }
+            #undef PATHED_HOOK
             status = hipGetLastError();
             if (status == hipSuccess) { status = hipDeviceSynchronize(); }
         }
@@ -2181,6 +2226,19 @@ int pathed_hip_scene_export_bvh(PathedScene *scene, float *nodes, size_t *n_node
     }
     *n_nodes = nodeCount;
     *n_tris = triCount;
+    return PATHED_OK;
+}
+
+int pathed_hip_scene_export_compressed_nodes(PathedScene *scene, uint32_t *nodes, size_t *n_nodes)
+{
+    if (!scene || !n_nodes) { return fail(PATHED_E_INVALID, "null argument"); }
+    SELECT_DEVICE(scene);
+    const size_t nodeCount = scene->quantNodes ? (size_t)scene->bvh.nodeCount : 0;
+    if (nodes && nodeCount > 0) {
+        if (*n_nodes < nodeCount) { return fail(PATHED_E_INVALID, "node buffer too small"); }
+        HIP_TRY(hipMemcpy(nodes, scene->nodesQ.ptr, nodeCount * 16 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    }
+    *n_nodes = nodeCount;
     return PATHED_OK;
 }
 

@@ -6,6 +6,12 @@
 //          (lo.x[4]) (lo.y[4]) (lo.z[4]) (hi.x[4]) (hi.y[4]) (hi.z[4]) (ref[4]) (-)
 //          ref >= 0: inner node index; ref <= -2: leaf, -ref - 1 = (first triangle << 3) | count;
 //          ref == kEmptyChild: empty slot
+//   nodeQ  4 x float4 = 64 B, the COMPRESSED form of the same node (same index, same refs; k_compress_nodes): the
+//          children's boxes on an 8-bit grid over their union,
+//          (origin.xyz, scale.x) (scale.y, scale.z, qlo.x[4], qlo.y[4]) (qlo.z[4], qhi.x[4], qhi.y[4], qhi.z[4]) (ref[4])
+//          plane = origin + q * scale, scale a power of two; q rounded OUTWARD plus 1/256 of a step, so the grid box
+//          contains the float box and hits stay bit-exact (the triangle test decides, box tests only cull).  Half the
+//          bytes per visit and four 16-byte loads per lane instead of seven, for one v_cvt_f32_ubyte per plane.
 //   tri    3 x float4 = 48 B: (v0.xyz, prim) (e1.xyz, -) (e2.xyz, -), leaf order
 // Per-lane traversal stack: the first ROWS entries live in LDS, laid out [row][thread] so a
 // wave's 64 lanes hit 64 consecutive dwords (bank-conflict-free ds_read_b32 / ds_write_b32);
@@ -226,35 +232,17 @@ __device__ inline void warmLine(const LaneStack &stack, const float4 *address)
 // are hit sorted leaves-first then near-to-far, the first becomes the lane's next piece of work,
 // the others are stacked far-to-near.  Returns true when the BVH part of the query is complete.
 // `maxStack` is the tree's bound on stack entries (3 per level).
-template <bool COUNT, int ROWS, int STRIDE, bool WARM = false>
+template <bool COUNT, int ROWS, int STRIDE, bool WARM = false, bool QUANT = false>
 __device__ inline bool innerStep(
     const TraceGeometry &g, const LaneStack &stack, int maxStack, LaneRay &ray, TraceCounters *counters
 ) {
-    // all 112 used bytes of the node in one round trip
-    const float4 *node = g.nodes + 8 * ray.current;
-    const float4 lox = node[0], loy = node[1], loz = node[2];
-    const float4 hix = node[3], hiy = node[4], hiz = node[5];
-    const float4 refBits = node[6];
-    pinLoaded(lox); pinLoaded(loy); pinLoaded(loz);
-    pinLoaded(hix); pinLoaded(hiy); pinLoaded(hiz);
-    pinLoaded(refBits);
-
-    const float lx[4] = { lox.x, lox.y, lox.z, lox.w }, ly[4] = { loy.x, loy.y, loy.z, loy.w }, lz[4] = { loz.x, loz.y, loz.z, loz.w };
-    const float hx[4] = { hix.x, hix.y, hix.z, hix.w }, hy[4] = { hiy.x, hiy.y, hiy.z, hiy.w }, hz[4] = { hiz.x, hiz.y, hiz.z, hiz.w };
-    int ref[4] = { floatAsInt(refBits.x), floatAsInt(refBits.y), floatAsInt(refBits.z), floatAsInt(refBits.w) };
-
+    const float4 *node = g.nodes + (QUANT ? 4 : 8) * ray.current;
+    int ref[4];
     // sort key: misses last, leaves before inner nodes (they shrink `best`), then entry distance,
     // then the child slot (keys are distinct, so the order is total and the same everywhere)
     unsigned int key[4];
     int hits = 0;
-    #pragma unroll
-    for (int c = 0; c < 4; c++) {
-        const float tx0 = fmaf(lx[c], ray.invD.x, -ray.oInvD.x);
-        const float tx1 = fmaf(hx[c], ray.invD.x, -ray.oInvD.x);
-        const float ty0 = fmaf(ly[c], ray.invD.y, -ray.oInvD.y);
-        const float ty1 = fmaf(hy[c], ray.invD.y, -ray.oInvD.y);
-        const float tz0 = fmaf(lz[c], ray.invD.z, -ray.oInvD.z);
-        const float tz1 = fmaf(hz[c], ray.invD.z, -ray.oInvD.z);
+    auto classify = [&](int c, float tx0, float tx1, float ty0, float ty1, float tz0, float tz1) {
         // fminf/fmaxf return the non-NaN operand, which is what a conservative test wants
         const float tmin = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), ray.tnear));
         const float tmax = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fminf(fmaxf(tz0, tz1), ray.best));
@@ -264,6 +252,46 @@ __device__ inline bool innerStep(
         const unsigned int inner = ref[c] >= 0 ? 0x80000000u : 0u;
         key[c] = hit ? (inner | (((unsigned int)floatAsInt(tmin) >> 1) & 0x7FFFFFFCu) | (unsigned int)c) : 0xFFFFFFFFu;
         hits += hit ? 1 : 0;
+    };
+    if (QUANT) {
+        // all 64 bytes of the node in one round trip
+        const float4 head = node[0], mid = node[1], tail = node[2];
+        const float4 refBits = node[3];
+        pinLoaded(head); pinLoaded(mid); pinLoaded(tail); pinLoaded(refBits);
+        ref[0] = floatAsInt(refBits.x); ref[1] = floatAsInt(refBits.y); ref[2] = floatAsInt(refBits.z); ref[3] = floatAsInt(refBits.w);
+        // t(plane q) = (origin + q * scale - o) / d = q * (scale / d) + (origin / d - o / d); scale / d is exact
+        const float ax = head.w * ray.invD.x, ay = mid.x * ray.invD.y, az = mid.y * ray.invD.z;
+        const float bx = fmaf(head.x, ray.invD.x, -ray.oInvD.x);
+        const float by = fmaf(head.y, ray.invD.y, -ray.oInvD.y);
+        const float bz = fmaf(head.z, ray.invD.z, -ray.oInvD.z);
+        const unsigned int qlx = (unsigned int)floatAsInt(mid.z), qly = (unsigned int)floatAsInt(mid.w), qlz = (unsigned int)floatAsInt(tail.x);
+        const unsigned int qhx = (unsigned int)floatAsInt(tail.y), qhy = (unsigned int)floatAsInt(tail.z), qhz = (unsigned int)floatAsInt(tail.w);
+        #pragma unroll
+        for (int c = 0; c < 4; c++) {
+            // (x >> 8c) & 255 -> float is one v_cvt_f32_ubyte<c>
+            classify(c,
+                fmaf((float)((qlx >> (8 * c)) & 255u), ax, bx), fmaf((float)((qhx >> (8 * c)) & 255u), ax, bx),
+                fmaf((float)((qly >> (8 * c)) & 255u), ay, by), fmaf((float)((qhy >> (8 * c)) & 255u), ay, by),
+                fmaf((float)((qlz >> (8 * c)) & 255u), az, bz), fmaf((float)((qhz >> (8 * c)) & 255u), az, bz));
+        }
+    } else {
+        // all 112 used bytes of the node in one round trip
+        const float4 lox = node[0], loy = node[1], loz = node[2];
+        const float4 hix = node[3], hiy = node[4], hiz = node[5];
+        const float4 refBits = node[6];
+        pinLoaded(lox); pinLoaded(loy); pinLoaded(loz);
+        pinLoaded(hix); pinLoaded(hiy); pinLoaded(hiz);
+        pinLoaded(refBits);
+        const float lx[4] = { lox.x, lox.y, lox.z, lox.w }, ly[4] = { loy.x, loy.y, loy.z, loy.w }, lz[4] = { loz.x, loz.y, loz.z, loz.w };
+        const float hx[4] = { hix.x, hix.y, hix.z, hix.w }, hy[4] = { hiy.x, hiy.y, hiy.z, hiy.w }, hz[4] = { hiz.x, hiz.y, hiz.z, hiz.w };
+        ref[0] = floatAsInt(refBits.x); ref[1] = floatAsInt(refBits.y); ref[2] = floatAsInt(refBits.z); ref[3] = floatAsInt(refBits.w);
+        #pragma unroll
+        for (int c = 0; c < 4; c++) {
+            classify(c,
+                fmaf(lx[c], ray.invD.x, -ray.oInvD.x), fmaf(hx[c], ray.invD.x, -ray.oInvD.x),
+                fmaf(ly[c], ray.invD.y, -ray.oInvD.y), fmaf(hy[c], ray.invD.y, -ray.oInvD.y),
+                fmaf(lz[c], ray.invD.z, -ray.oInvD.z), fmaf(hz[c], ray.invD.z, -ray.oInvD.z));
+        }
     }
 
     // 5-comparator sorting network on (key, ref)
@@ -301,7 +329,7 @@ __device__ inline bool innerStep(
         const int leaf0 = -ref[0] - 1, leaf1 = -ref[1] - 1;
         const float4 *nearLeaf = (ref[0] < 0 && (leaf0 & 7) != 0) ? g.tris + 3 * (leaf0 >> 3) : node;
         const float4 *nextEntry = hits < 2 ? node
-            : (ref[1] >= 0 ? g.nodes + 8 * ref[1] : ((leaf1 & 7) != 0 ? g.tris + 3 * (leaf1 >> 3) : node));
+            : (ref[1] >= 0 ? g.nodes + (QUANT ? 4 : 8) * ref[1] : ((leaf1 & 7) != 0 ? g.tris + 3 * (leaf1 >> 3) : node));
         warmLine<ROWS, STRIDE>(stack, nearLeaf);
         warmLine<ROWS, STRIDE>(stack, nextEntry);
     }
@@ -378,7 +406,7 @@ __device__ inline void finishRay(const TraceGeometry &g, LaneRay &ray)
 }
 
 // One whole ray on one lane (test hook / simple callers).
-template <bool COUNT, int ROWS, int STRIDE>
+template <bool COUNT, int ROWS, int STRIDE, bool QUANT = false>
 __device__ inline bool traverse(
     const TraceGeometry &g, const LaneStack &stack, int maxStack,
     V3 o, V3 d, float tnear, float tfar, bool anyHit,
@@ -391,7 +419,7 @@ __device__ inline bool traverse(
         while (!done) {
             done = ray.pendingLeaf
                 ? leafStep<COUNT, ROWS, STRIDE>(g, stack, ray, counters)
-                : innerStep<COUNT, ROWS, STRIDE>(g, stack, maxStack, ray, counters);
+                : innerStep<COUNT, ROWS, STRIDE, false, QUANT>(g, stack, maxStack, ray, counters);
         }
     }
     finishRay(g, ray);

@@ -495,6 +495,85 @@ def test_large_mesh_intersector_and_render_parity(libs):
     assert rel <= 2e-3 and bad <= 2e-3, (rel, bad)
 
 
+def _unpack_compressed(words):
+    """(origin (n,3), scale (n,3), qlo (n,3,4), qhi (n,3,4), refs (n,4)) of exported compressed nodes (include/pathed_hip.h)"""
+    as_float = words.view(np.float32)
+    origin = as_float[:, 0:3].astype(np.float64)
+    scale = as_float[:, 3:6].astype(np.float64)
+    shifts = np.arange(4, dtype=np.uint32) * 8
+    qlo = ((words[:, 6:9, None] >> shifts) & 255).astype(np.float64)
+    qhi = ((words[:, 9:12, None] >> shifts) & 255).astype(np.float64)
+    return origin, scale, qlo, qhi, words[:, 12:16].view(np.int32)
+
+
+@pytest.mark.parametrize("builder", ["sah", "lbvh", "ploc"])
+def test_compressed_nodes_contain_the_float_boxes_and_change_no_hit(libs, builder):
+    """node_format "compressed" (trace.h: nodeQ): every child's 8-bit grid box contains its float box (exported and checked
+    here in float64), the refs are the float tree's, so the triangle tests -- which alone decide a hit -- see a superset
+    of the leaves: hits, occlusion and images are the bits of the 128-byte nodes and of the oracle."""
+    oracle_lib, HipScene, LoadedScene = libs
+    scene = LoadedScene("assets/dragon-standin-6.json", 96, 54)
+    wide = HipScene(scene.desc, device=0, bvh_builder=builder, node_format="wide")
+    packed = HipScene(scene.desc, device=0, bvh_builder=builder, node_format="compressed")
+    assert wide.export_compressed_nodes().shape[0] == 0
+    nodes, _ = wide.export_bvh()
+    words = packed.export_compressed_nodes()
+    assert words.shape == (nodes.shape[0], 16)
+    origin, scale, qlo, qhi, refs = _unpack_compressed(words)
+    float_refs = nodes[:, 24:28].view(np.int32)
+    assert np.array_equal(refs, float_refs)
+    valid = float_refs != np.int32(-2 ** 31)                                  # (n, 4)
+    lo = nodes[:, 0:12].reshape(-1, 3, 4).astype(np.float64)               # (n, axis, child)
+    hi = nodes[:, 12:24].reshape(-1, 3, 4).astype(np.float64)
+    grid_lo = origin[:, :, None] + qlo * scale[:, :, None]
+    grid_hi = origin[:, :, None] + qhi * scale[:, :, None]
+    mask = np.broadcast_to(valid[:, None, :], lo.shape)
+    assert (grid_lo[mask] <= lo[mask]).all() and (grid_hi[mask] >= hi[mask]).all()
+    # ... and not by much: at most two grid steps of slack per plane (one of rounding outward, the 1/256 on top)
+    step = np.broadcast_to(scale[:, :, None], lo.shape)
+    assert ((lo - grid_lo)[mask] <= 2 * step[mask]).all() and ((grid_hi - hi)[mask] <= 2 * step[mask]).all()
+    assert (scale == 2.0 ** np.round(np.log2(np.maximum(scale, 1e-300))))[scale > 0].all()   # powers of two
+
+    rng = np.random.default_rng(4)
+    n = 100000
+    rays = np.zeros((n, 8), dtype=np.float32)
+    rays[:, 0:3] = rng.normal(size=(n, 3)) * 120 + [0, 0, 25]
+    target = rng.normal(size=(n, 3)) * 30 + [0, 0, 25]
+    direction = target - rays[:, 0:3]
+    rays[:, 4:7] = direction / np.linalg.norm(direction, axis=1, keepdims=True)
+    rays[:, 3] = 1e-3
+    rays[:, 7] = 1e5
+    # axis-parallel rays and rays that start on the mesh: the slab edge cases
+    rays[:1000, 4:7] = np.eye(3, dtype=np.float32)[rng.integers(0, 3, 1000)] * rng.choice([-1.0, 1.0], (1000, 1)).astype(np.float32)
+    cpu = oracle_lib.OracleScene(scene.desc)
+    expected = cpu.trace(rays)
+    on_mesh = expected[:, 3].view(np.int32) >= 0
+    rays[on_mesh, 0:3] = rays[on_mesh, 0:3] + rays[on_mesh, 4:7] * expected[on_mesh, 0:1]
+    rays[on_mesh, 4:7] = -rays[on_mesh, 4:7]
+    expected = cpu.trace(rays)
+    assert np.array_equal(packed.trace(rays).view(np.int32), expected.view(np.int32))
+    assert np.array_equal(wide.trace(rays).view(np.int32), expected.view(np.int32))
+    assert np.array_equal(packed.trace(rays, any_hit=True), cpu.trace(rays, any_hit=True))
+    packed.set_stats_mode(count=True)
+    wide.set_stats_mode(count=True)
+    assert np.array_equal(packed.render(1, 0, 8, 0, 10), wide.render(1, 0, 8, 0, 10))
+    # the grid boxes are a little larger: a few more boxes accepted, never fewer; the same primitives... or more
+    assert wide.stats()["nodes_visited"] <= packed.stats()["nodes_visited"] <= 1.15 * wide.stats()["nodes_visited"]
+    assert packed.stats()["closest_rays"] == wide.stats()["closest_rays"]
+
+
+def test_compressed_nodes_are_refused_where_they_do_not_apply(libs):
+    oracle_lib, HipScene, LoadedScene = libs
+    for path, options in (("scenes/cornell.json", {}), ("scenes/mis-pbrt.json", {"intersector": "bvh"}),
+                          ("scenes/teapot.json", {"shade_kernel": "split"}), ("scenes/teapot.json", {"generic_kernels": 1})):
+        scene = LoadedScene(path, 32, 32)
+        with pytest.raises(RuntimeError, match="compressed nodes"):
+            HipScene(scene.desc, device=0, node_format="compressed", **options)
+    scene = LoadedScene("scenes/teapot.json", 64, 64)
+    assert np.array_equal(HipScene(scene.desc, device=0, node_format="compressed").render(2, 0, 8, 0, 10),
+                          HipScene(scene.desc, device=0, node_format="wide").render(2, 0, 8, 0, 10))
+
+
 def test_threaded_bvh_build_gives_the_sequential_tree(libs):
     """Meshes of >= 200 000 triangles are built with the top of the tree on one thread and its
     subtrees on the others; the exported tree must be the one a single thread builds."""

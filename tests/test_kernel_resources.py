@@ -35,8 +35,11 @@ def test_vgpr_budgets_of_the_hot_kernels(tmp_path):
                 usage[name][key.split(" ")[0]] = int(value.group(1))
     shade = [v for k, v in usage.items() if "k_shadeILb1" in k]      # generic and ENV_ONLY instantiations
     assert len(shade) == 2 and all(v["VGPRs"] <= 104 and v["ScratchSize"] == 0 for v in shade), shade
-    traces = [v for k, v in usage.items() if re.search(r"k_traceILi\d+ELb[01]ELb0ELb[01]", k)]   # the non-counting variants (plain, list-writing, sphere-free)
-    assert len(traces) == 15 and all(v["VGPRs"] <= 96 for v in traces), traces
+    traces = [v for k, v in usage.items() if re.search(r"k_traceILi\d+ELb[01]ELb0ELb[01]", k)]   # the non-counting variants (plain, list-writing, sphere-free, compressed nodes)
+    assert len(traces) == 18 and all(v["VGPRs"] <= 96 for v in traces), traces
+    # the variant over compressed nodes holds 16 dwords of node instead of 28: nothing spills
+    packed = [v for k, v in usage.items() if re.search(r"k_traceILi\d+ELb0ELb0ELb0ELb0ELb1", k)]
+    assert len(packed) == 3 and all(v["ScratchSize"] <= 8 for v in packed), packed
     # the list-writing variant must not spill more than a few dwords beyond the plain one: every value its list code kept
     # alive across the traversal loop was a reload inside it (+45 % kernel time, profiles/r3_ab_split_shade.log)
     plain = [v for k, v in usage.items() if re.search(r"k_traceILi22ELb0ELb0ELb0ELb1", k)][0]

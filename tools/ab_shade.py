@@ -32,10 +32,13 @@ for name in args.scenes.split(","):
     accum = torch.zeros((h, w, 3), dtype=torch.float32, device="cuda")
     reference = None
     for variant in args.variants.split(","):
-        # variant = kernel[:stage slots][/pools], e.g. staged:1024/1
-        spec, _, pools = variant.partition("/")
+        # variant = kernel[:stage slots][/pools][@node format], e.g. staged:1024/1, per-slot@compressed
+        variant_spec, _, node_format = variant.partition("@")
+        spec, _, pools = variant_spec.partition("/")
         kernel, _, slots = spec.partition(":")
         options = {"shade_kernel": kernel}
+        if node_format:
+            options["node_format"] = node_format
         if slots:
             options["stage_slots"] = int(slots)
         if pools or args.pools:
@@ -66,6 +69,6 @@ for name in args.scenes.split(","):
         torch.cuda.synchronize()
         s = gpu.stats()
         n = max(s["trace_launches"], 1)
-        print("%-8s %-12s %7.1f Msamples/s  trace %6.1f us  shade %6.1f us per launch (%d launches)  image identical to first variant: %s" % (
+        print("%-8s %-20s %7.1f Msamples/s  trace %6.1f us  shade %6.1f us per launch (%d launches)  image identical to first variant: %s" % (
             name, variant, w * h * spp / best / 1e6, s["trace_ms"] / n * 1e3, s["shade_ms"] / n * 1e3, s["trace_launches_all"], identical), flush=True)
         gpu.close()
