@@ -277,8 +277,9 @@ typedef struct PathedSceneOptions {
     int32_t generic_kernels;    /* 1: never pick a scene-specialised kernel instantiation (k_shade<.., ENV_ONLY> for scenes whose
                                    one light is the environment and whose materials do not emit): A/B runs and tests */
     int32_t node_format;        /* the tree the trace kernel walks: 0 automatic; 1 128-byte nodes (four float boxes); 2 compressed
-                                   64-byte nodes (the boxes on an 8-bit grid over their union, rounded outward: same hits) --
-                                   sphere-free scenes whose tree stays in HBM, per-slot pipeline; an error elsewhere */
+                                   64-byte nodes (the boxes on an 8-bit grid over their union, rounded outward: same hits);
+                                   3 compressed 8-wide nodes (128 bytes, up to eight children: grandchildren pulled up) --
+                                   2 and 3: sphere-free scenes whose tree stays in HBM, per-slot pipeline; an error elsewhere */
 } PathedSceneOptions;
 int pathed_hip_scene_create_ex(const PathedSceneDesc *desc, const PathedSceneOptions *options, PathedScene **out);
 int pathed_hip_scene_device(const PathedScene *scene);   /* the HIP device the scene lives on, or a negative error */
@@ -358,12 +359,15 @@ int pathed_hip_reset_stats(PathedScene *scene);
 int pathed_hip_scene_export_bvh(PathedScene *scene,
                                 float *nodes, size_t *n_nodes,
                                 float *tris, size_t *n_tris);
-/* The compressed form of the same nodes (PathedSceneOptions.node_format 2), same indices and refs: 16 words per node,
+/* The compressed form of the same nodes, same indices.
+ * node_format 2, 16 words per node, same refs:
  *   (origin.xyz, scale.x) (scale.y, scale.z, qlo.x, qlo.y) (qlo.z, qhi.x, qhi.y, qhi.z) (ref[4])
- * origin / scale are floats, every q word holds the four children's 8-bit grid indices (child c in bits 8c .. 8c+7):
+ * node_format 3, 32 words per node, up to eight children (children of children pulled up; nodes no ref reaches are dead):
+ *   (origin.xyz, scale.x) (scale.y, scale.z, qlo.x[2]) (qlo.y[2], qlo.z[2]) (qhi.x[2], qhi.y[2]) (qhi.z[2], -, -) (ref[0..3]) (ref[4..7]) (-)
+ * origin / scale are floats, a q word holds four children's 8-bit grid indices (child c in bits 8(c mod 4) .. of word c / 4):
  * child c spans [origin + qlo * scale, origin + qhi * scale] per axis and CONTAINS its float box.
- * *n_nodes comes back 0 for a scene that does not carry the compressed form.  Pass NULL to query the size. */
-int pathed_hip_scene_export_compressed_nodes(PathedScene *scene, uint32_t *nodes, size_t *n_nodes);
+ * *n_nodes comes back 0 for a scene that does not carry a compressed form.  Pass NULL to query the sizes. */
+int pathed_hip_scene_export_compressed_nodes(PathedScene *scene, uint32_t *nodes, size_t *n_nodes, size_t *words_per_node);
 
 /* Measurement aid: what a plain streaming kernel reaches on THIS device, as a
  * second denominator beside the 8 TB/s HBM3E spec figure.  Allocates two probe buffers of `bytes`

@@ -286,7 +286,7 @@ def load_hip():
         vp, C.POINTER(C.c_float), C.POINTER(C.c_size_t), C.POINTER(C.c_float), C.POINTER(C.c_size_t)
     ]
     lib.pathed_hip_scene_export_bvh.restype = C.c_int
-    lib.pathed_hip_scene_export_compressed_nodes.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_size_t)]
+    lib.pathed_hip_scene_export_compressed_nodes.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
     lib.pathed_hip_scene_export_compressed_nodes.restype = C.c_int
     lib.pathed_hip_measure_bandwidth.argtypes = [C.c_size_t, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.pathed_hip_measure_bandwidth.restype = C.c_int

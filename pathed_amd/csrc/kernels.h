@@ -342,8 +342,8 @@ __device__ inline void deferSlot(const RenderParams &p, int list, bool defer, un
 // list (see kCtrListCount); a miss writes no hit record; a closest-hit ray that is parked puts its slot on hold itself
 // (no shade kernel visits a slot that is on no list).
 // SPHERES = false: scenes without sphere primitives (the mesh configurations): no sphere code in the kernel
-// QUANT: the tree is walked in its compressed form (trace.h: nodeQ, 64 bytes per node)
-template <int STACK, bool LDS_SCENE, bool COUNT, bool LISTS, bool SPHERES = true, bool QUANT = false>
+// FORMAT: the tree is walked as 0 its 128-byte float nodes, 1 nodeQ (64-byte compressed), 2 node8 (8-wide compressed) (trace.h)
+template <int STACK, bool LDS_SCENE, bool COUNT, bool LISTS, bool SPHERES = true, int FORMAT = 0>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_TRACE_WAVES, PATHED_TRACE_WAVES))) void k_trace(RenderParams p)
 {
     extern __shared__ float4 ldsRaw[];
@@ -354,9 +354,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_T
     stack.overflowStride = (size_t)gridDim.x * kBlock;
     stack.overflow = p.stackOverflow + ((size_t)blockIdx.x * kBlock + threadIdx.x);
 
-    static_assert(!(QUANT && LDS_SCENE), "the LDS copy of a small tree is the uncompressed one");
+    static_assert(!(FORMAT != 0 && LDS_SCENE), "the LDS copy of a small tree is the uncompressed one");
     TraceGeometry geometry;
-    geometry.nodes = QUANT ? p.scene.nodesQ : p.scene.nodes;
+    geometry.nodes = FORMAT != 0 ? p.scene.nodesQ : p.scene.nodes;
     geometry.tris = p.scene.leafTris;
     geometry.nNodes = p.scene.nNodes;
     geometry.nTris = p.scene.nTris;
@@ -586,7 +586,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_T
                 if (active && ray.pendingLeaf != 0) { done = leafStep<COUNT, STACK, kBlock, SPHERES>(geometry, stack, ray, &counters); }
             } else {
                 if (active && ray.pendingLeaf == 0) {
-                    done = (geometry.nNodes == 0) || innerStep<COUNT, STACK, kBlock, PATHED_WARM_LINES && !LDS_SCENE, QUANT>(geometry, stack, p.maxStack, ray, &counters);
+                    done = (geometry.nNodes == 0)
+                        || (FORMAT == 2 ? innerStep8<COUNT, STACK, kBlock>(geometry, stack, p.maxStack, ray, &counters)
+                                        : innerStep<COUNT, STACK, kBlock, PATHED_WARM_LINES && !LDS_SCENE, FORMAT == 1>(geometry, stack, p.maxStack, ray, &counters));
                 }
             }
             if (COUNT) {
@@ -930,8 +932,8 @@ __global__ __launch_bounds__(kBlock) void k_trace_small(RenderParams p, SmallTri
     }
 }
 
-// test hook kernel behind pathed_hip_trace: plain grid, arbitrary ray intervals (QUANT: over the compressed nodes)
-template <int STACK, bool QUANT>
+// test hook kernel behind pathed_hip_trace: plain grid, arbitrary ray intervals (FORMAT: as k_trace's)
+template <int STACK, int FORMAT>
 __global__ __launch_bounds__(kBlock) void k_trace_rays(
     DScene scene, const float4 *rays, int n, int anyHit, float4 *hitsOut, int *occludedOut,
     int *stackOverflow, int maxStack
@@ -943,7 +945,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_rays(
     stack.overflow = stackOverflow + ((size_t)blockIdx.x * kBlock + threadIdx.x);
 
     TraceGeometry geometry;
-    geometry.nodes = QUANT ? scene.nodesQ : scene.nodes;
+    geometry.nodes = FORMAT != 0 ? scene.nodesQ : scene.nodes;
     geometry.tris = scene.leafTris;
     geometry.nNodes = scene.nNodes;
     geometry.nTris = scene.nTris;
@@ -958,11 +960,11 @@ __global__ __launch_bounds__(kBlock) void k_trace_rays(
     hit.t = 0.f; hit.u = 0.f; hit.v = 0.f; hit.prim = -1;
     TraceCounters counters;
     if (anyHit) {
-        const bool occluded = traverse<false, STACK, kBlock, QUANT>(
+        const bool occluded = traverse<false, STACK, kBlock, FORMAT>(
             geometry, stack, maxStack, v3(ro.x, ro.y, ro.z), v3(rd.x, rd.y, rd.z), ro.w, rd.w, true, &hit, &counters);
         occludedOut[i] = occluded ? 1 : 0;
     } else {
-        const bool found = traverse<false, STACK, kBlock, QUANT>(
+        const bool found = traverse<false, STACK, kBlock, FORMAT>(
             geometry, stack, maxStack, v3(ro.x, ro.y, ro.z), v3(rd.x, rd.y, rd.z), ro.w, rd.w, false, &hit, &counters);
         if (!found) { hit.t = 0.f; hit.u = 0.f; hit.v = 0.f; hit.prim = -1; }
         hitsOut[i] = make_float4(hit.t, hit.u, hit.v, intAsFloat(hit.prim));
@@ -3448,6 +3450,99 @@ __global__ __launch_bounds__(kBlock) void k_compress_nodes(const float4 *nodes, 
     out[1] = make_float4(scale[1], scale[2], intAsFloat((int)qlo[0]), intAsFloat((int)qlo[1]));
     out[2] = make_float4(intAsFloat((int)qlo[2]), intAsFloat((int)qhi[0]), intAsFloat((int)qhi[1]), intAsFloat((int)qhi[2]));
     out[3] = refBits;
+}
+
+// The 8-wide compressed form (trace.h: node8), one thread per node of the 4-wide tree, each on its own: node i gathers its
+// children, then, largest box first, replaces an inner child by that child's children while the total stays within eight.
+// Whatever the other threads decide, the refs it ends up with are nodes of the 4-wide tree, and those become 8-wide nodes
+// the same way under their own index; a node that was pulled into its parent is computed too and never visited.  The tree
+// gets no deeper.  Grid and rounding as in k_compress_nodes.
+struct WidenEntry {
+    float lo[3], hi[3];
+    int ref;
+    int expandable;
+};
+
+__device__ inline int widenLoadChildren(const float4 *nodes, int index, WidenEntry *out)
+{
+    const float4 *node = nodes + (size_t)8 * index;
+    const float4 refBits = node[6];
+    const int ref[4] = { floatAsInt(refBits.x), floatAsInt(refBits.y), floatAsInt(refBits.z), floatAsInt(refBits.w) };
+    float lo[3][4], hi[3][4];
+    for (int a = 0; a < 3; a++) {
+        const float4 l = node[a], h = node[3 + a];
+        lo[a][0] = l.x; lo[a][1] = l.y; lo[a][2] = l.z; lo[a][3] = l.w;
+        hi[a][0] = h.x; hi[a][1] = h.y; hi[a][2] = h.z; hi[a][3] = h.w;
+    }
+    int count = 0;
+    for (int c = 0; c < 4; c++) {
+        if (ref[c] == kEmptyChild) { continue; }
+        for (int a = 0; a < 3; a++) { out[count].lo[a] = lo[a][c]; out[count].hi[a] = hi[a][c]; }
+        out[count].ref = ref[c];
+        out[count].expandable = ref[c] >= 0 ? 1 : 0;
+        count++;
+    }
+    return count;
+}
+
+__global__ __launch_bounds__(kBlock) void k_widen_nodes(const float4 *nodes, int nNodes, float4 *nodes8)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= nNodes) { return; }
+    WidenEntry entry[8];
+    int n = widenLoadChildren(nodes, i, entry);
+    while (true) {
+        int best = -1;
+        float bestArea = -1.f;
+        for (int k = 0; k < n; k++) {
+            if (!entry[k].expandable) { continue; }
+            const float dx = entry[k].hi[0] - entry[k].lo[0], dy = entry[k].hi[1] - entry[k].lo[1], dz = entry[k].hi[2] - entry[k].lo[2];
+            const float area = dx * dy + dy * dz + dz * dx;
+            if (best < 0 || area > bestArea) { best = k; bestArea = area; }
+        }
+        if (best < 0) { break; }
+        WidenEntry kids[4];
+        const int m = widenLoadChildren(nodes, entry[best].ref, kids);
+        if (m == 0 || n - 1 + m > 8) { entry[best].expandable = 0; continue; }
+        entry[best] = kids[0];
+        for (int k = 1; k < m; k++) { entry[n++] = kids[k]; }
+    }
+
+    float origin[3], scale[3];
+    unsigned int qlo[3][2] = { { 0u, 0u }, { 0u, 0u }, { 0u, 0u } }, qhi[3][2] = { { 0u, 0u }, { 0u, 0u }, { 0u, 0u } };
+    for (int a = 0; a < 3; a++) {
+        float low = INFINITY, high = -INFINITY;
+        for (int k = 0; k < n; k++) { low = fminf(low, entry[k].lo[a]); high = fmaxf(high, entry[k].hi[a]); }
+        if (!(low <= high)) { low = 0.f; high = 0.f; }
+        const double extent = (double)high - (double)low;
+        int exponent = 0;
+        (void)frexp(extent / 253.0, &exponent);
+        const float step = extent > 0.0 ? ldexpf(1.f, exponent) : 0.f;
+        const double perStep = step > 0.f ? 1.0 / (double)step : 0.0;
+        origin[a] = low;
+        scale[a] = step;
+        for (int k = 0; k < n; k++) {
+            const double below = floor(((double)entry[k].lo[a] - (double)low) * perStep - 1.0 / 256.0);
+            const double above = ceil(((double)entry[k].hi[a] - (double)low) * perStep + 1.0 / 256.0);
+            const unsigned int qBelow = (unsigned int)fmin(fmax(below, 0.0), 255.0);
+            const unsigned int qAbove = step > 0.f ? (unsigned int)fmin(fmax(above, 0.0), 255.0) : 0u;
+            qlo[a][k >> 2] |= qBelow << (8 * (k & 3));
+            qhi[a][k >> 2] |= qAbove << (8 * (k & 3));
+        }
+    }
+    int ref[8];
+    for (int k = 0; k < 8; k++) { ref[k] = k < n ? entry[k].ref : kEmptyChild; }
+    float4 *out = nodes8 + (size_t)8 * i;
+    #define PATHED_BITS(x) intAsFloat((int)(x))
+    out[0] = make_float4(origin[0], origin[1], origin[2], scale[0]);
+    out[1] = make_float4(scale[1], scale[2], PATHED_BITS(qlo[0][0]), PATHED_BITS(qlo[0][1]));
+    out[2] = make_float4(PATHED_BITS(qlo[1][0]), PATHED_BITS(qlo[1][1]), PATHED_BITS(qlo[2][0]), PATHED_BITS(qlo[2][1]));
+    out[3] = make_float4(PATHED_BITS(qhi[0][0]), PATHED_BITS(qhi[0][1]), PATHED_BITS(qhi[1][0]), PATHED_BITS(qhi[1][1]));
+    out[4] = make_float4(PATHED_BITS(qhi[2][0]), PATHED_BITS(qhi[2][1]), 0.f, 0.f);
+    out[5] = make_float4(PATHED_BITS(ref[0]), PATHED_BITS(ref[1]), PATHED_BITS(ref[2]), PATHED_BITS(ref[3]));
+    out[6] = make_float4(PATHED_BITS(ref[4]), PATHED_BITS(ref[5]), PATHED_BITS(ref[6]), PATHED_BITS(ref[7]));
+    out[7] = make_float4(0.f, 0.f, 0.f, 0.f);
+    #undef PATHED_BITS
 }
 
 // ------------------------------------------------------------------------- bandwidth probe

@@ -196,7 +196,7 @@ struct PathedScene {
     bool lambertianTriangles = false;   // constant-albedo Lambertian surfaces, triangle lights, no spheres, no environment: k_path_small<.., TraitsLambertianTriangles>
     bool lambertianPlasticSpheres = false;   // the Veach scene's set (shading.h)
     bool lambertianGlassContainer = false;   // the reference's volume scene's set
-    bool quantNodes = false;                 // k_trace walks the compressed nodes (trace.h: nodeQ)
+    int nodeFormat = 0;                      // what k_trace walks (trace.h): 0 the 128-byte float nodes, 1 nodeQ, 2 node8
     bool envOnly = false;     // the one light is the environment and no material emits: k_shade<.., ENV_ONLY> (kernels.h)
     bool splitShade = false;  // k_vertex + k_regen over the hit / miss lists the trace kernel writes (kernels.h: split shade stage)
     int vertexGrid = 0, regenGrid = 0;   // their persistent grids, blocks
@@ -473,9 +473,14 @@ void launchTraceStack(PathedScene *scene, const RenderParams &params, hipStream_
         }
         return;
     }
-    if (scene->quantNodes) {
-        if (scene->countMode) { hipLaunchKernelGGL((k_trace<STACK, false, true, false, false, true>), grid, block, lds, stream, params); }
-        else { hipLaunchKernelGGL((k_trace<STACK, false, false, false, false, true>), grid, block, lds, stream, params); }
+    if (scene->nodeFormat == 1) {
+        if (scene->countMode) { hipLaunchKernelGGL((k_trace<STACK, false, true, false, false, 1>), grid, block, lds, stream, params); }
+        else { hipLaunchKernelGGL((k_trace<STACK, false, false, false, false, 1>), grid, block, lds, stream, params); }
+        return;
+    }
+    if (scene->nodeFormat == 2) {
+        if (scene->countMode) { hipLaunchKernelGGL((k_trace<STACK, false, true, false, false, 2>), grid, block, lds, stream, params); }
+        else { hipLaunchKernelGGL((k_trace<STACK, false, false, false, false, 2>), grid, block, lds, stream, params); }
         return;
     }
     if (!scene->sceneInLds && scene->device.nSpheres == 0 && !scene->options.generic_kernels && !getenv("PATHED_NO_SCENE_TRAITS")) {
@@ -571,14 +576,33 @@ void launchVolume(int stackRows, bool small, bool narrowed, const RenderParams &
     }
 }
 
+// what node_format 0 picks for the scenes the compressed trees serve: 0 float nodes, 1 nodeQ, 2 node8 (DESIGN.md has the measurements)
+#ifndef PATHED_DEFAULT_NODE_FORMAT
+#define PATHED_DEFAULT_NODE_FORMAT 0
+#endif
+
+// PathedSceneOptions.node_format with the experiments' override: 0 automatic, 1 float nodes, 2 compressed, 3 compressed 8-wide
+int requestedNodeFormat(const PathedSceneOptions &options)
+{
+    if (const char *text = getenv("PATHED_NODE_FORMAT")) {
+        if (!strcmp(text, "wide")) { return 1; }
+        if (!strcmp(text, "compressed")) { return 2; }
+        if (!strcmp(text, "compressed8")) { return 3; }
+    }
+    return options.node_format;
+}
+
 void configureTrace(PathedScene *scene)
 {
     // a 4-wide node stacks up to three children: 3 entries per level bound the stack.  22 rows
     // (+1 scratch, +8 KB staging = 31 KB per block) keep five blocks per CU possible; the rare
     // deeper entries spill to HBM.
-    scene->maxStack = 3 * scene->bvh.maxDepth + 1;
-    scene->stackRows = scene->maxStack <= 8 ? 8 : scene->maxStack <= 16 ? 16 : 22;
+    // (an 8-wide node stacks all of its up to eight hits and pops one back: 7 per level, 8 for a moment)
     const PathedSceneOptions &options = scene->options;
+    const int requested = requestedNodeFormat(options);
+    const bool mayWalkNode8 = requested == 3 || (requested == 0 && PATHED_DEFAULT_NODE_FORMAT == 2);
+    scene->maxStack = mayWalkNode8 ? 7 * scene->bvh.maxDepth + 9 : 3 * scene->bvh.maxDepth + 1;
+    scene->stackRows = scene->maxStack <= 8 ? 8 : scene->maxStack <= 16 ? 16 : 22;
     if (options.stack_rows == 8 || options.stack_rows == 16 || options.stack_rows == 22) { scene->stackRows = options.stack_rows; }
     if (const char *override = getenv("PATHED_STACK_ROWS")) {   // experiments: force the HBM spill path
         const int value = atoi(override);
@@ -635,10 +659,6 @@ extern "C" {
 
 const char *pathed_hip_last_error(void) { return g_error.c_str(); }
 
-// what node_format 0 picks for the scenes the compressed tree serves (DESIGN.md has the measurement)
-#ifndef PATHED_DEFAULT_COMPRESSED_NODES
-#define PATHED_DEFAULT_COMPRESSED_NODES 0
-#endif
 #define PATHED_STRINGIFY2(x) #x
 #define PATHED_STRINGIFY(x) PATHED_STRINGIFY2(x)
 const char *pathed_hip_version(void) { return "pathed_hip 0.3.0 (gfx950, abi " PATHED_STRINGIFY(PATHED_ABI_VERSION) ")"; }
@@ -1052,7 +1072,7 @@ int pathed_hip_scene_create_ex(const PathedSceneDesc *desc, const PathedSceneOpt
         if (optionsIn->struct_size != sizeof(PathedSceneOptions)) { return fail(PATHED_E_INVALID, "PathedSceneOptions.struct_size mismatch"); }
         options = *optionsIn;
         if (options.generic_kernels != 0 && options.generic_kernels != 1) { return fail(PATHED_E_INVALID, "generic_kernels must be 0 or 1"); }
-        if (options.node_format < 0 || options.node_format > 2) { return fail(PATHED_E_INVALID, "node_format must be 0 (automatic), 1 (128-byte nodes) or 2 (compressed 64-byte nodes)"); }
+        if (options.node_format < 0 || options.node_format > 3) { return fail(PATHED_E_INVALID, "node_format must be 0 (automatic), 1 (128-byte float nodes), 2 (compressed 64-byte nodes) or 3 (compressed 8-wide nodes)"); }
         if (options.build_threads < 0 || options.build_threads > 4096) { return fail(PATHED_E_INVALID, "build_threads must be 0..4096"); }
         if (options.unit_order < 0 || options.unit_order > 3) { return fail(PATHED_E_INVALID, "unit_order must be 0..3"); }
         if (options.bvh_builder < 0 || options.bvh_builder > PATHED_BVH_PLOC_DEVICE + 1) { return fail(PATHED_E_INVALID, "unknown BVH builder"); }
@@ -1467,25 +1487,23 @@ int pathed_hip_scene_create_ex(const PathedSceneDesc *desc, const PathedSceneOpt
     configureTrace(scene);
     {
         // the compressed tree: sphere-free scenes whose tree stays in HBM, walked by the per-slot pipeline's trace kernel
-        int nodeFormat = options.node_format;
-        if (const char *text = getenv("PATHED_NODE_FORMAT")) {   // experiments: "wide" | "compressed"
-            if (!strcmp(text, "wide")) { nodeFormat = 1; }
-            else if (!strcmp(text, "compressed")) { nodeFormat = 2; }
-        }
+        const int nodeFormat = requestedNodeFormat(options);
         const bool eligible = !scene->bruteForce && !scene->sceneInLds && !scene->splitShade && scene->device.nSpheres == 0
             && scene->device.nNodes > 0 && options.generic_kernels == 0;
-        if (nodeFormat == 2 && !eligible) {
+        if (nodeFormat >= 2 && !eligible) {
             delete scene;
             return fail(PATHED_E_INVALID, "compressed nodes serve sphere-free scenes whose tree is walked in HBM by the per-slot pipeline (not generic_kernels, not the split stage)");
         }
-        if (eligible && nodeFormat != 1 && PATHED_DEFAULT_COMPRESSED_NODES + (nodeFormat == 2) > 0) {
+        const int chosen = !eligible || nodeFormat == 1 ? 0 : nodeFormat == 0 ? PATHED_DEFAULT_NODE_FORMAT : nodeFormat - 1;
+        if (chosen != 0) {
             const size_t nNodes = (size_t)scene->device.nNodes;
-            if ((status = scene->nodesQ.allocate(4 * nNodes)) != hipSuccess) { return fail_cleanup(status, "allocate compressed nodes"); }
-            hipLaunchKernelGGL(k_compress_nodes, dim3((unsigned)((nNodes + kBlock - 1) / kBlock)), dim3(kBlock), 0, nullptr,
-                               scene->nodes.ptr, (int)nNodes, scene->nodesQ.ptr);
+            const unsigned blocks = (unsigned)((nNodes + kBlock - 1) / kBlock);
+            if ((status = scene->nodesQ.allocate((chosen == 2 ? 8 : 4) * nNodes)) != hipSuccess) { return fail_cleanup(status, "allocate compressed nodes"); }
+            if (chosen == 2) { hipLaunchKernelGGL(k_widen_nodes, dim3(blocks), dim3(kBlock), 0, nullptr, scene->nodes.ptr, (int)nNodes, scene->nodesQ.ptr); }
+            else { hipLaunchKernelGGL(k_compress_nodes, dim3(blocks), dim3(kBlock), 0, nullptr, scene->nodes.ptr, (int)nNodes, scene->nodesQ.ptr); }
             if ((status = hipDeviceSynchronize()) != hipSuccess) { return fail_cleanup(status, "compress nodes"); }
             scene->device.nodesQ = scene->nodesQ.ptr;
-            scene->quantNodes = true;
+            scene->nodeFormat = chosen;
         }
     }
     // persistent grids of the split stage: k_vertex at PATHED_VERTEX_WAVES blocks per CU, k_regen at PATHED_REGEN_WAVES
@@ -2092,20 +2110,15 @@ int pathed_hip_trace(PathedScene *scene, const float *rays, size_t n, int any_hi
         const size_t overflowRows = (size_t)(scene->maxStack > scene->stackRows ? scene->maxStack - scene->stackRows : 0);
         status = hipMalloc((void **)&deviceOverflow, (size_t)grid.x * kBlock * (overflowRows ? overflowRows : 1) * sizeof(int));
         if (status == hipSuccess) {
-            #define PATHED_HOOK(STACK, QUANT) hipLaunchKernelGGL((k_trace_rays<STACK, QUANT>), grid, block, lds, 0, scene->device, deviceRays, (int)n, any_hit, deviceHits, deviceOccluded, deviceOverflow, scene->maxStack)
-            if (scene->quantNodes) {
-                switch (scene->stackRows) {
-                case 8: PATHED_HOOK(8, true); break;
-                case 16: PATHED_HOOK(16, true); break;
-                default: PATHED_HOOK(22, true); break;
-                }
-            } else {
-                switch (scene->stackRows) {
-                case 8: PATHED_HOOK(8, false); break;
-                case 16: PATHED_HOOK(16, false); break;
-                default: PATHED_HOOK(22, false); break;
-                }
-            }
+            #define PATHED_HOOK(STACK, FORMAT) hipLaunchKernelGGL((k_trace_rays<STACK, FORMAT>), grid, block, lds, 0, scene->device, deviceRays, (int)n, any_hit, deviceHits, deviceOccluded, deviceOverflow, scene->maxStack)
+            #define PATHED_HOOK_ROWS(FORMAT) switch (scene->stackRows) { \
+                case 8: PATHED_HOOK(8, FORMAT); break; \
+                case 16: PATHED_HOOK(16, FORMAT); break; \
+                default: PATHED_HOOK(22, FORMAT); break; }
+            if (scene->nodeFormat == 2) { PATHED_HOOK_ROWS(2) }
+            else if (scene->nodeFormat == 1) { PATHED_HOOK_ROWS(1) }
+            else { PATHED_HOOK_ROWS(0) }
+            #undef PATHED_HOOK_ROWS
             #undef PATHED_HOOK
             status = hipGetLastError();
             if (status == hipSuccess) { status = hipDeviceSynchronize(); }
@@ -2229,16 +2242,18 @@ int pathed_hip_scene_export_bvh(PathedScene *scene, float *nodes, size_t *n_node
     return PATHED_OK;
 }
 
-int pathed_hip_scene_export_compressed_nodes(PathedScene *scene, uint32_t *nodes, size_t *n_nodes)
+int pathed_hip_scene_export_compressed_nodes(PathedScene *scene, uint32_t *nodes, size_t *n_nodes, size_t *words_per_node)
 {
     if (!scene || !n_nodes) { return fail(PATHED_E_INVALID, "null argument"); }
     SELECT_DEVICE(scene);
-    const size_t nodeCount = scene->quantNodes ? (size_t)scene->bvh.nodeCount : 0;
+    const size_t nodeCount = scene->nodeFormat != 0 ? (size_t)scene->bvh.nodeCount : 0;
+    const size_t words = scene->nodeFormat == 2 ? 32 : 16;
     if (nodes && nodeCount > 0) {
         if (*n_nodes < nodeCount) { return fail(PATHED_E_INVALID, "node buffer too small"); }
-        HIP_TRY(hipMemcpy(nodes, scene->nodesQ.ptr, nodeCount * 16 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(nodes, scene->nodesQ.ptr, nodeCount * words * sizeof(uint32_t), hipMemcpyDeviceToHost));
     }
     *n_nodes = nodeCount;
+    if (words_per_node) { *words_per_node = nodeCount > 0 ? words : 0; }
     return PATHED_OK;
 }
 

@@ -12,6 +12,11 @@
 //          plane = origin + q * scale, scale a power of two; q rounded OUTWARD plus 1/256 of a step, so the grid box
 //          contains the float box and hits stay bit-exact (the triangle test decides, box tests only cull).  Half the
 //          bytes per visit and four 16-byte loads per lane instead of seven, for one v_cvt_f32_ubyte per plane.
+//   node8  8 x float4 = 128 B, the 8-WIDE compressed form (k_widen_nodes): node i keeps its index and takes the place of
+//          its 4-wide node; children of its children are pulled up while they fit (largest box first), the nodes they came
+//          from are simply never referenced again.  Same grid as nodeQ, two q words per plane (children 0-3, 4-7):
+//          (origin.xyz, scale.x) (scale.y, scale.z, qlo.x[8]) (qlo.y[8], qlo.z[8]) (qhi.x[8], qhi.y[8]) (qhi.z[8], -, -)
+//          (ref[0..3]) (ref[4..7]) (-)
 //   tri    3 x float4 = 48 B: (v0.xyz, prim) (e1.xyz, -) (e2.xyz, -), leaf order
 // Per-lane traversal stack: the first ROWS entries live in LDS, laid out [row][thread] so a
 // wave's 64 lanes hit 64 consecutive dwords (bank-conflict-free ds_read_b32 / ds_write_b32);
@@ -336,6 +341,80 @@ __device__ inline bool innerStep(
     return false;
 }
 
+// Visit ONE 8-wide compressed node.  Same contract as innerStep; the up-to-eight hits are not sorted in registers: every
+// child's RANK among the keys (28 compares) is its distance from the top of the stack, each child writes its own stack
+// row (misses write the scratch row), and the nearest is popped back -- an LDS round trip instead of a 19-comparator network.
+template <bool COUNT, int ROWS, int STRIDE>
+__device__ inline bool innerStep8(
+    const TraceGeometry &g, const LaneStack &stack, int maxStack, LaneRay &ray, TraceCounters *counters
+) {
+    const float4 *node = g.nodes + 8 * ray.current;
+    const float4 w0 = node[0], w1 = node[1], w2 = node[2], w3 = node[3], w4 = node[4];
+    const float4 refLow = node[5], refHigh = node[6];
+    pinLoaded(w0); pinLoaded(w1); pinLoaded(w2); pinLoaded(w3); pinLoaded(w4);
+    pinLoaded(refLow); pinLoaded(refHigh);
+    const int ref[8] = { floatAsInt(refLow.x), floatAsInt(refLow.y), floatAsInt(refLow.z), floatAsInt(refLow.w),
+                         floatAsInt(refHigh.x), floatAsInt(refHigh.y), floatAsInt(refHigh.z), floatAsInt(refHigh.w) };
+    const float ax = w0.w * ray.invD.x, ay = w1.x * ray.invD.y, az = w1.y * ray.invD.z;
+    const float bx = fmaf(w0.x, ray.invD.x, -ray.oInvD.x);
+    const float by = fmaf(w0.y, ray.invD.y, -ray.oInvD.y);
+    const float bz = fmaf(w0.z, ray.invD.z, -ray.oInvD.z);
+    // [plane][half]: lo.x, lo.y, lo.z, hi.x, hi.y, hi.z
+    const unsigned int q[6][2] = {
+        { (unsigned int)floatAsInt(w1.z), (unsigned int)floatAsInt(w1.w) }, { (unsigned int)floatAsInt(w2.x), (unsigned int)floatAsInt(w2.y) },
+        { (unsigned int)floatAsInt(w2.z), (unsigned int)floatAsInt(w2.w) }, { (unsigned int)floatAsInt(w3.x), (unsigned int)floatAsInt(w3.y) },
+        { (unsigned int)floatAsInt(w3.z), (unsigned int)floatAsInt(w3.w) }, { (unsigned int)floatAsInt(w4.x), (unsigned int)floatAsInt(w4.y) } };
+    unsigned int key[8];
+    int hits = 0;
+    #pragma unroll
+    for (int c = 0; c < 8; c++) {
+        const int half = c >> 2, shift = 8 * (c & 3);
+        const float tx0 = fmaf((float)((q[0][half] >> shift) & 255u), ax, bx), tx1 = fmaf((float)((q[3][half] >> shift) & 255u), ax, bx);
+        const float ty0 = fmaf((float)((q[1][half] >> shift) & 255u), ay, by), ty1 = fmaf((float)((q[4][half] >> shift) & 255u), ay, by);
+        const float tz0 = fmaf((float)((q[2][half] >> shift) & 255u), az, bz), tz1 = fmaf((float)((q[5][half] >> shift) & 255u), az, bz);
+        const float tmin = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), ray.tnear));
+        const float tmax = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fminf(fmaxf(tz0, tz1), ray.best));
+        const bool valid = ref[c] != kEmptyChild;
+        const bool hit = valid && (tmin <= tmax * 1.0000004f);
+        if (COUNT) { counters->boxes += valid ? 1u : 0u; }
+        const unsigned int inner = ref[c] >= 0 ? 0x80000000u : 0u;
+        // leaves first, then entry distance, then the slot: distinct among the hits
+        key[c] = hit ? (inner | (((unsigned int)floatAsInt(tmin) >> 1) & 0x7FFFFFF8u) | (unsigned int)c) : 0xFFFFFFFFu;
+        hits += hit ? 1 : 0;
+    }
+    if (hits == 0) { return popWork<ROWS, STRIDE>(stack, ray); }
+
+    // rank[c] = number of children whose key is below key[c]: for i < j the pair adds one to exactly one of the two
+    int rank[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    #pragma unroll
+    for (int i = 0; i < 8; i++) {
+        #pragma unroll
+        for (int j = i + 1; j < 8; j++) {
+            const int below = key[i] < key[j] ? 1 : 0;   // equal only for two misses, whose rows are the scratch row anyway
+            rank[j] += below;
+            rank[i] += 1 - below;
+        }
+    }
+    // all hits go on the stack, the nearest on top, and the nearest is popped back
+    const int top = ray.sp + hits;
+    if (top <= ROWS) {
+        #pragma unroll
+        for (int c = 0; c < 8; c++) {
+            const int row = rank[c] < hits ? top - 1 - rank[c] : ROWS;
+            stack.lds[row * STRIDE] = ref[c];
+        }
+        ray.sp = top;
+    } else {
+        #pragma unroll
+        for (int c = 0; c < 8; c++) {
+            const int index = top - 1 - rank[c];
+            if (rank[c] < hits && index < maxStack) { stackWrite<ROWS, STRIDE>(stack, index, ref[c]); }
+        }
+        ray.sp = top < maxStack ? top : maxStack;
+    }
+    return popWork<ROWS, STRIDE>(stack, ray);
+}
+
 // One sphere against the lane's ray, same acceptance rule as the triangles (prim id = nTris + sphere index).
 // Returns true when an any-hit query is decided.
 __device__ inline bool testSphere(const TraceGeometry &g, LaneRay &ray, int index)
@@ -406,7 +485,8 @@ __device__ inline void finishRay(const TraceGeometry &g, LaneRay &ray)
 }
 
 // One whole ray on one lane (test hook / simple callers).
-template <bool COUNT, int ROWS, int STRIDE, bool QUANT = false>
+// FORMAT: 0 the 128-byte float nodes, 1 nodeQ, 2 node8
+template <bool COUNT, int ROWS, int STRIDE, int FORMAT = 0>
 __device__ inline bool traverse(
     const TraceGeometry &g, const LaneStack &stack, int maxStack,
     V3 o, V3 d, float tnear, float tfar, bool anyHit,
@@ -419,7 +499,8 @@ __device__ inline bool traverse(
         while (!done) {
             done = ray.pendingLeaf
                 ? leafStep<COUNT, ROWS, STRIDE>(g, stack, ray, counters)
-                : innerStep<COUNT, ROWS, STRIDE, false, QUANT>(g, stack, maxStack, ray, counters);
+                : (FORMAT == 2 ? innerStep8<COUNT, ROWS, STRIDE>(g, stack, maxStack, ray, counters)
+                               : innerStep<COUNT, ROWS, STRIDE, false, FORMAT == 1>(g, stack, maxStack, ray, counters));
         }
     }
     finishRay(g, ray);

@@ -68,7 +68,7 @@ class HipScene:
     Keyword options map onto PathedSceneOptions (include/pathed_hip.h): stack_rows, pools,
     suspend_lanes, suspend_patience, park_min_cards, max_slots, build_threads, generic_kernels, intersector ("auto" | "bvh"),
     trace_blocks_per_cu, shade_kernel ("auto" | "per-slot" | "staged" | "fused" | "split"), stage_slots,
-    unit_order ("auto" | "stripes" | "stripes-tiled" | "tiles"), node_format ("auto" | "wide" | "compressed").  `device=None` keeps the device of an earlier pathed_hip_init.
+    unit_order ("auto" | "stripes" | "stripes-tiled" | "tiles"), node_format ("auto" | "wide" | "compressed" | "compressed8").  `device=None` keeps the device of an earlier pathed_hip_init.
     """
 
     BVH_BUILDERS = {"sah": 0, "lbvh": 1, "ploc": 2}  # PATHED_BVH_SAH_HOST / _LBVH_DEVICE / _PLOC_DEVICE
@@ -82,7 +82,7 @@ class HipScene:
         intersector = options.pop("intersector", "auto")
         packed.intersector = {"auto": 0, "bvh": 1}[intersector]
         packed.shade_kernel = {"auto": 0, "per-slot": 1, "staged": 2, "fused": 3, "split": 4}[options.pop("shade_kernel", "auto")]
-        packed.node_format = {"auto": 0, "wide": 1, "compressed": 2}[options.pop("node_format", "auto")]
+        packed.node_format = {"auto": 0, "wide": 1, "compressed": 2, "compressed8": 3}[options.pop("node_format", "auto")]
         packed.unit_order = {"auto": 0, "stripes": 1, "stripes-tiled": 2, "tiles": 3}[options.pop("unit_order", "auto")]
         for name in ("stack_rows", "pools", "suspend_lanes", "suspend_patience", "park_min_cards", "max_slots", "trace_blocks_per_cu", "stage_slots", "build_threads", "generic_kernels"):
             if name in options:
@@ -176,14 +176,14 @@ class HipScene:
         return nodes, tris
 
     def export_compressed_nodes(self):
-        """(n, 16) uint32 words of the compressed nodes (include/pathed_hip.h), n = 0 when the scene carries none"""
-        n_nodes = C.c_size_t(0)
-        _check(self._lib, self._lib.pathed_hip_scene_export_compressed_nodes(self._handle, None, C.byref(n_nodes)),
+        """(n, 16) or (n, 32) uint32 words of the compressed nodes (include/pathed_hip.h), n = 0 when the scene carries none"""
+        n_nodes, words = C.c_size_t(0), C.c_size_t(0)
+        _check(self._lib, self._lib.pathed_hip_scene_export_compressed_nodes(self._handle, None, C.byref(n_nodes), C.byref(words)),
                "pathed_hip_scene_export_compressed_nodes")
-        nodes = np.zeros((n_nodes.value, 16), dtype=np.uint32)
+        nodes = np.zeros((n_nodes.value, words.value or 16), dtype=np.uint32)
         if n_nodes.value:
             _check(self._lib, self._lib.pathed_hip_scene_export_compressed_nodes(
-                self._handle, nodes.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(n_nodes)), "pathed_hip_scene_export_compressed_nodes")
+                self._handle, nodes.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(n_nodes), C.byref(words)), "pathed_hip_scene_export_compressed_nodes")
         return nodes
 
 

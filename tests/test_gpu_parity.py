@@ -562,6 +562,114 @@ def test_compressed_nodes_contain_the_float_boxes_and_change_no_hit(libs, builde
     assert packed.stats()["closest_rays"] == wide.stats()["closest_rays"]
 
 
+def _unpack_compressed8(words):
+    as_float = words.view(np.float32)
+    origin = as_float[:, 0:3].astype(np.float64)
+    scale = as_float[:, 3:6].astype(np.float64)
+    shifts = np.arange(4, dtype=np.uint32) * 8
+    planes = ((words[:, 6:18].reshape(-1, 6, 2)[:, :, :, None] >> shifts) & 255).reshape(-1, 6, 8).astype(np.float64)
+    return origin, scale, planes[:, 0:3], planes[:, 3:6], words[:, 20:28].view(np.int32)
+
+
+@pytest.mark.parametrize("builder", ["sah", "ploc"])
+def test_eight_wide_compressed_tree_covers_every_triangle_once_and_changes_no_hit(libs, builder):
+    """node_format "compressed8" (trace.h: node8): walked from the root, the 8-wide tree reaches every leaf of the 4-wide
+    tree exactly once, gets no deeper, and every child's grid box contains the triangles below it (checked on the exported
+    words, level by level, in float64); hits, occlusion and image are the bits of the float nodes and of the oracle."""
+    oracle_lib, HipScene, LoadedScene = libs
+    scene = LoadedScene("assets/dragon-standin-6.json", 96, 54)
+    wide = HipScene(scene.desc, device=0, bvh_builder=builder, node_format="wide")
+    packed = HipScene(scene.desc, device=0, bvh_builder=builder, node_format="compressed8")
+    nodes, tris = wide.export_bvh()
+    words = packed.export_compressed_nodes()
+    assert words.shape == (nodes.shape[0], 32)
+    origin, scale, qlo, qhi, refs = _unpack_compressed8(words)
+    empty = np.int32(-2 ** 31)
+    # triangle bounds per leaf-ordered triangle
+    v0, e1, e2 = tris[:, 0:3].astype(np.float64), tris[:, 4:7].astype(np.float64), tris[:, 8:11].astype(np.float64)
+    corners = np.stack([v0, (tris[:, 0:3] + tris[:, 4:7]).astype(np.float64), (tris[:, 0:3] + tris[:, 8:11]).astype(np.float64)])
+    del e1, e2
+    tri_lo, tri_hi = corners.min(axis=0), corners.max(axis=0)
+    slack = 4e-6 * np.abs(corners).max()          # v0 + e rounds: the builders bound the ORIGINAL corners
+    # level-order walk; per node the bounds of everything below it come back up afterwards
+    order, level, depth = [], np.array([0]), 0
+    seen_leaves = []
+    while level.size:
+        order.append(level)
+        child = refs[level]                      # (m, 8)
+        seen_leaves.append(child[(child <= -2) & (child != empty)])
+        level = child[child >= 0]
+        depth += 1
+    assert depth <= wide.stats()["bvh_max_depth"]
+    leaves = -np.concatenate(seen_leaves).astype(np.int64) - 1
+    first, count = leaves >> 3, leaves & 7
+    covered = np.zeros(tris.shape[0], dtype=np.int32)
+    for k in range(1, 8):
+        chosen = first[count >= k] + (k - 1)
+        np.add.at(covered, chosen, 1)
+    assert (covered == 1).all()
+    visited = np.concatenate(order)
+    assert np.unique(visited).size == visited.size and visited.size <= nodes.shape[0]
+    # bounds bottom-up
+    below_lo = np.full((nodes.shape[0], 3), np.inf)
+    below_hi = np.full((nodes.shape[0], 3), -np.inf)
+    for level in reversed(order):
+        child = refs[level]
+        for c in range(8):
+            ref = child[:, c]
+            grid_lo = origin[level] + qlo[level][:, :, c] * scale[level]
+            grid_hi = origin[level] + qhi[level][:, :, c] * scale[level]
+            lo = np.full((level.size, 3), np.inf)
+            hi = np.full((level.size, 3), -np.inf)
+            inner = ref >= 0
+            lo[inner], hi[inner] = below_lo[ref[inner]], below_hi[ref[inner]]
+            leaf = (ref <= -2) & (ref != empty)
+            code = -ref[leaf].astype(np.int64) - 1
+            leaf_lo, leaf_hi = np.full((code.size, 3), np.inf), np.full((code.size, 3), -np.inf)
+            for k in range(7):
+                has = (code & 7) > k
+                index = (code >> 3)[has] + k
+                leaf_lo[has] = np.minimum(leaf_lo[has], tri_lo[index])
+                leaf_hi[has] = np.maximum(leaf_hi[has], tri_hi[index])
+            lo[leaf], hi[leaf] = leaf_lo, leaf_hi
+            present = inner | leaf
+            assert (grid_lo[present] <= lo[present] + slack).all() and (grid_hi[present] >= hi[present] - slack).all()
+            below_lo[level] = np.minimum(below_lo[level], np.where(present[:, None], lo, np.inf))
+            below_hi[level] = np.maximum(below_hi[level], np.where(present[:, None], hi, -np.inf))
+    filled = (refs[visited] != empty).sum(axis=1)
+    # the nodes above the bottom are nearly full; a node whose children are all leaves has nothing to pull up
+    has_inner = (refs[visited] >= 0).any(axis=1)
+    assert filled[has_inner].mean() > 6.0 and filled.mean() > 4.5, (filled[has_inner].mean(), filled.mean())
+
+    rng = np.random.default_rng(5)
+    n = 100000
+    rays = np.zeros((n, 8), dtype=np.float32)
+    rays[:, 0:3] = rng.normal(size=(n, 3)) * 120 + [0, 0, 25]
+    target = rng.normal(size=(n, 3)) * 30 + [0, 0, 25]
+    direction = target - rays[:, 0:3]
+    rays[:, 4:7] = direction / np.linalg.norm(direction, axis=1, keepdims=True)
+    rays[:, 3] = 1e-3
+    rays[:, 7] = 1e5
+    rays[:1000, 4:7] = np.eye(3, dtype=np.float32)[rng.integers(0, 3, 1000)] * rng.choice([-1.0, 1.0], (1000, 1)).astype(np.float32)
+    cpu = oracle_lib.OracleScene(scene.desc)
+    expected = cpu.trace(rays)
+    assert np.array_equal(packed.trace(rays).view(np.int32), expected.view(np.int32))
+    assert np.array_equal(packed.trace(rays, any_hit=True), cpu.trace(rays, any_hit=True))
+    # with 8 LDS rows the deeper stacks of the 8-wide walk spill to HBM, and parked rays carry them
+    spilling = HipScene(scene.desc, device=0, bvh_builder=builder, node_format="compressed8", stack_rows=8, trace_blocks_per_cu=1,
+                        suspend_lanes=64, suspend_patience=-1, park_min_cards=-1)
+    assert np.array_equal(spilling.trace(rays).view(np.int32), expected.view(np.int32))
+    image = wide.render(1, 0, 8, 0, 10)
+    packed.set_stats_mode(count=True)
+    wide.set_stats_mode(count=True)
+    assert np.array_equal(packed.render(1, 0, 8, 0, 10), image)
+    assert np.array_equal(wide.render(1, 0, 8, 0, 10), image)
+    spilling.set_stats_mode(count=True)
+    assert np.array_equal(spilling.render(1, 0, 8, 0, 10), image)
+    assert spilling.stats()["parked_rays"] > 0
+    assert packed.stats()["closest_rays"] == wide.stats()["closest_rays"]
+
+
 def test_compressed_nodes_are_refused_where_they_do_not_apply(libs):
     oracle_lib, HipScene, LoadedScene = libs
     for path, options in (("scenes/cornell.json", {}), ("scenes/mis-pbrt.json", {"intersector": "bvh"}),
