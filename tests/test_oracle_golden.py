@@ -87,3 +87,4 @@ def test_reference_known_answer_tests():
     n = (n / norm).astype(np.float32)
     frame = oracle_lib.evaluate("frame", [n[0], n[1], n[2], 1.0, 0.0, 0.0]).reshape(3, 3)
     assert frame[:, 1].tolist() == n.tolist()
+
