@@ -3012,6 +3012,64 @@ __device__ __forceinline__ bool volumeQuerySmall(const VolumeContext<MaterialTab
 }
 
 
+// The two queries a vertex makes along rays that leave the SAME point, in one pass over the pair records
+// (smallCandidatesPair: 12 + 2 x 21 packed operations per two triangles instead of 2 x 33): the closest-hit query of the
+// vertex's BSDF sample -- `modeA` per lane: kQueryVolumeClosest where direct lighting wants it, kQueryRegular where only the
+// path's next segment does -- and the occlusion query of its light sample.  Lanes pass wantA / wantB = false for a ray
+// they do not have.  Candidates are resolved as in volumeQuerySmall, ray by ray: same hits, same events.
+template <typename MaterialTable>
+__device__ __forceinline__ void volumeQueryPairSmall(const VolumeContext<MaterialTable> &c, const f2 *pairRecords, V3 o,
+                                                     bool wantA, int modeA, V3 dA, RayHit *hitA, bool *foundA, VolumeEvents *eventsA,
+                                                     bool wantB, V3 dB, float tfarB, bool *occludedB, VolumeEvents *eventsB)
+{
+    unsigned int lowA = 0u, highA = 0u, lowB = 0u, highB = 0u;
+    smallCandidatesPair(pairRecords, c.geometry.nTris, o, dA, dB, &lowA, &highA, &lowB, &highB);
+    if (!wantA) { lowA = 0u; highA = 0u; }
+    if (!wantB) { lowB = 0u; highB = 0u; }
+    auto resolve = [&](int mode, LaneRay &ray, VolumeEvents &events, unsigned int low, unsigned int high, bool want) {
+        bool decided = false;
+        while (__ballot((low | high) != 0u) != 0ull) {
+            if ((low | high) != 0u) {
+                int k;  // triangle k of a word is bit 31 - (k & 31): take the highest set bit first
+                if (low != 0u) { k = __clz((int)low); low &= ~(0x80000000u >> k); }
+                else { k = __clz((int)high); high &= ~(0x80000000u >> k); k += 32; }
+                const float4 t0 = c.geometry.tris[3 * k + 0];
+                const float4 t1 = c.geometry.tris[3 * k + 1];
+                const float4 t2 = c.geometry.tris[3 * k + 2];
+                float t, u, v;
+                if (intersectTriangle(ray.o, ray.d, v3(t0.x, t0.y, t0.z), v3(t1.x, t1.y, t1.z), v3(t2.x, t2.y, t2.z), &t, &u, &v)) {
+                    if (volumeAccept(c, mode, ray, events, t, u, v, floatAsInt(t0.w))) { decided = true; low = 0u; high = 0u; }
+                }
+            }
+        }
+        if (want && !decided) {
+            for (int i = 0; i < c.geometry.nSpheres; i++) {
+                if (volumeSphere(c, mode, ray, events, i)) { break; }
+            }
+        }
+    };
+    {
+        LaneRay ray;
+        laneRayInit(ray, o, dA, PATHED_TNEAR, PATHED_TFAR, false);
+        VolumeEvents events;
+        eventsClear(events);
+        resolve(modeA, ray, events, lowA, highA, wantA);
+        if (modeA == kQueryVolumeClosest) { eventsClip(events, ray.best); }
+        *eventsA = events;
+        hitA->t = ray.best; hitA->u = ray.bestU; hitA->v = ray.bestV; hitA->prim = ray.bestPrim;
+        *foundA = ray.bestPrim >= 0;
+    }
+    {
+        LaneRay ray;
+        laneRayInit(ray, o, dB, PATHED_TNEAR, tfarB, true);
+        VolumeEvents events;
+        eventsClear(events);
+        resolve(kQueryVolumeOccluded, ray, events, lowB, highB, wantB);
+        *eventsB = events;
+        *occludedB = ray.occluded;
+    }
+}
+
 // k_path_volume: SampleIntegrator::samplePixel + VolumePathTracer::L (see volume.h), one path per lane, persistent waves,
 // work units as in k_path_small.  Arithmetic on a path's values follows the reference statement by statement; on a
 // scene without media the result is PathTracer's, bit for bit (the two share their direct-lighting arithmetic; GPU test).
@@ -3102,21 +3160,32 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_V
     segmentHit.t = 0.f; segmentHit.u = 0.f; segmentHit.v = 0.f; segmentHit.prim = -1;
     bool segmentFound = false, segmentKnown = false;
 
-    // DirectLightingHelper::Ld, src/direct_lighting_helper.cpp:37-187
-    auto directLighting = [&](const Isect &isect, int medium, const DMaterial &material, const BSDFSample &bsdfSample, Rng &random) -> Rgb {
-        segmentKnown = false;
-        if (material.type == PATHED_MAT_PASSTHROUGH) { return rgb(0.f); }
-        if (!isBlack(matEmit(material))) { return rgb(0.f); }
-        Rgb result = rgb(0.f);
-        // directSampleLights, :74-134
-        Rgb lightContribution = rgb(0.f);
-        if (!volumeIsDelta(material) && scene.nLights != 0) {
+    // What a vertex asks of the scene, all along rays that leave isect.point: DirectLightingHelper::Ld
+    // (src/direct_lighting_helper.cpp:37-187; `direct`: the bounce counts) -- the occlusion query of its light sample and the
+    // volumetric closest-hit query of its BSDF sample -- and the path's next segment (`needSegment`: the loop goes on), which
+    // is that same BSDF-sample ray under Scene::testIntersect.  ONE pass answers all of it: the closest-hit query runs for
+    // every lane, per lane in the mode its vertex needs (a vertex without direct lighting -- a container's surface, an
+    // emitter, a bounce outside the window -- asks the regular question; the others get the regular answer from the
+    // container the volumetric query skipped), paired with the light sample's occlusion ray (volumeQueryPairSmall).
+    // The reference's statements in the reference's order on every value; only the queries moved.
+    auto vertexLighting = [&](const Isect &isect, int medium, const DMaterial &material, const BSDFSample &bsdfSample, Rng &random,
+                              bool direct, bool needSegment) -> Rgb {
+        SHADE_REGION(5, direct);   // (profile builds) direct lighting at a vertex
+        const bool lit = direct && material.type != PATHED_MAT_PASSTHROUGH && isBlack(matEmit(material));
+        // directSampleLights, :74-134, up to its occlusion query
+        bool wantShadow = false;
+        DLight light;
+        light.kind = 0; light.index = 0;
+        SurfaceSample surfaceSample;
+        surfaceSample.point = isect.point; surfaceSample.normal = v3(0.f, 0.f, 0.f); surfaceSample.invPDF = 1.f; surfaceSample.solidAngle = 1;
+        int lightMaterial = 0;
+        float invPDF = 1.f, lightDistance = 0.f;
+        V3 lightDirection = v3(0.f, 0.f, 0.f), wiWorld = bsdfSample.wiWorld;
+        if (lit && !volumeIsDelta(material) && scene.nLights != 0) {
             const int lightCount = scene.nLights;
             int lightIndex = (int)floorf(random.next() * lightCount);
             lightIndex = imin(lightIndex, lightCount - 1);
-            const DLight light = scene.lights[lightIndex];
-            SurfaceSample surfaceSample;
-            int lightMaterial = 0;
+            light = scene.lights[lightIndex];
             if (TRAITS::triangleLights && light.kind == 0) {
                 const TriShade tri = loadTriCorners(scene, light.index);
                 surfaceSample = triangleSample(tri.p0, tri.p1, tri.p2, random);
@@ -3131,60 +3200,98 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_V
                 surfaceSample.point = isect.point; surfaceSample.normal = v3(0.f, 0.f, 0.f); surfaceSample.invPDF = 1.f; surfaceSample.solidAngle = 1;
             }
             const float lightChoicePDF = 1.f / lightCount;
-            const float invPDF = surfaceSample.invPDF * (1.f / lightChoicePDF);
-            const V3 lightDirection = surfaceSample.point - isect.point;
-            const V3 wiWorld = normalized(lightDirection);
+            invPDF = surfaceSample.invPDF * (1.f / lightChoicePDF);
+            lightDirection = surfaceSample.point - isect.point;
+            wiWorld = normalized(lightDirection);
             if (!(dot(surfaceSample.normal, wiWorld) >= 0.f)) {
-                const float lightDistance = length(lightDirection);
-                VolumeEvents events;
-                RayHit unused;
-                const bool occluded = query(kQueryVolumeOccluded, isect.point, wiWorld, lightDistance - 1e-3f, &unused, &events);
-                if (!occluded) {
-                    const Rgb transmittance = rayTransmission(context.media, isect.point, wiWorld, events, medium);
-                    float pdf;
-                    if (surfaceSample.solidAngle) {
-                        pdf = 1.f / invPDF;
-                    } else {
-                        const V3 lightWoForPdf = -normalized(lightDirection);
-                        const float distance2 = lightDistance * lightDistance;
-                        const float projectedArea = smax(0.f, dot(surfaceSample.normal, lightWoForPdf));
-                        pdf = (1.f / invPDF) * distance2 / projectedArea;
-                    }
-                    float brdfPDF;
-                    const Rgb f = materialF<TRAITS>(material, isect, wiWorld, &brdfPDF);
-                    const float lightWeight = (1 * pdf) / (1 * pdf + 1 * brdfPDF);
-                    const V3 lightWo = -normalized(lightDirection);
-                    Rgb emitted;
-                    if (TRAITS::env && light.kind == 2) { emitted = envEmit(scene.env, lightWo); }
-                    else { emitted = matEmit(materials[lightMaterial]); }
-                    lightContribution = emitted
-                        * transmittance
-                        * lightWeight
-                        * f
-                        * fabsf(dot(isect.shadingNormal, wiWorld))
-                        / pdf;
-                }
+                lightDistance = length(lightDirection);
+                wantShadow = true;
             }
         }
+
+        // the queries
+        const bool wantClosest = lit || needSegment;
+        const int closestMode = lit ? kQueryVolumeClosest : kQueryRegular;
+        RayHit bounceHit;
+        bounceHit.t = 0.f; bounceHit.u = 0.f; bounceHit.v = 0.f; bounceHit.prim = -1;
+        bool found = false, occluded = false;
+        VolumeEvents skipped, events;
+        eventsClear(skipped);
+        eventsClear(events);
+        // directSampleLights, :74-134, from its occlusion query on
+        auto finishLight = [&]() -> Rgb {
+            if (!wantShadow || occluded) { return rgb(0.f); }
+            const Rgb transmittance = rayTransmission(context.media, isect.point, wiWorld, events, medium);
+            float pdf;
+            if (surfaceSample.solidAngle) {
+                pdf = 1.f / invPDF;
+            } else {
+                const V3 lightWoForPdf = -normalized(lightDirection);
+                const float distance2 = lightDistance * lightDistance;
+                const float projectedArea = smax(0.f, dot(surfaceSample.normal, lightWoForPdf));
+                pdf = (1.f / invPDF) * distance2 / projectedArea;
+            }
+            float brdfPDF;
+            const Rgb f = materialF<TRAITS>(material, isect, wiWorld, &brdfPDF);
+            const float lightWeight = (1 * pdf) / (1 * pdf + 1 * brdfPDF);
+            const V3 lightWo = -normalized(lightDirection);
+            Rgb emitted;
+            if (TRAITS::env && light.kind == 2) { emitted = envEmit(scene.env, lightWo); }
+            else { emitted = matEmit(materials[lightMaterial]); }
+            return emitted
+                * transmittance
+                * lightWeight
+                * f
+                * fabsf(dot(isect.shadingNormal, wiWorld))
+                / pdf;
+        };
+        Rgb lightContribution = rgb(0.f);
+        if constexpr (SMALL) {
+            SHADE_REGION(7, wantClosest);   // the closest-hit query of the BSDF sample / next segment
+            SHADE_REGION(6, wantShadow);    // the light sample's occlusion query (same pass)
+            if (__ballot(wantShadow) != 0ull) {
+                volumeQueryPairSmall(context, (const f2 *)smallTris.data, isect.point,
+                                     wantClosest, closestMode, bsdfSample.wiWorld, &bounceHit, &found, &skipped,
+                                     wantShadow, wiWorld, lightDistance - 1e-3f, &occluded, &events);
+            } else if (__ballot(wantClosest) != 0ull) {
+                // no lane of the wave has a light sample to test (delta materials, containers): the one-ray pass
+                if (wantClosest) { found = query(closestMode, isect.point, bsdfSample.wiWorld, PATHED_TFAR, &bounceHit, &skipped); }
+            }
+            lightContribution = finishLight();
+        } else {
+            // a per-lane walk of the tree per query: the light sample is finished before the second walk starts
+            if (wantShadow) {
+                SHADE_REGION(6, true);
+                RayHit unused;
+                occluded = query(kQueryVolumeOccluded, isect.point, wiWorld, lightDistance - 1e-3f, &unused, &events);
+            }
+            lightContribution = finishLight();
+            if (wantClosest) {
+                SHADE_REGION(7, true);
+                found = query(closestMode, isect.point, bsdfSample.wiWorld, PATHED_TFAR, &bounceHit, &skipped);
+            }
+        }
+
+        Rgb result = rgb(0.f);
         result = result + lightContribution;
+
+        // the path's next segment: the nearest surface of any kind along the BSDF sample
+        segmentHit = bounceHit;
+        segmentFound = found;
+        if (lit && skipped.containerPrim >= 0) {
+            const bool nearer = !found || skipped.containerT < bounceHit.t
+                || (skipped.containerT == bounceHit.t && skipped.containerPrim < bounceHit.prim);
+            if (nearer) {
+                segmentHit.t = skipped.containerT; segmentHit.u = skipped.containerU; segmentHit.v = skipped.containerV;
+                segmentHit.prim = skipped.containerPrim;
+                segmentFound = true;
+            }
+        }
+        segmentKnown = wantClosest;
+
         // directSampleBSDF, :136-187: the query skips containers; no transmittance is applied (as in the reference)
         Rgb bsdfTerm = rgb(0.f);
-        {
-            RayHit bounceHit;
-            VolumeEvents skipped;
-            const bool found = query(kQueryVolumeClosest, isect.point, bsdfSample.wiWorld, PATHED_TFAR, &bounceHit, &skipped);
-            segmentHit = bounceHit;
-            segmentFound = found;
-            if (skipped.containerPrim >= 0) {
-                const bool nearer = !found || skipped.containerT < bounceHit.t
-                    || (skipped.containerT == bounceHit.t && skipped.containerPrim < bounceHit.prim);
-                if (nearer) {
-                    segmentHit.t = skipped.containerT; segmentHit.u = skipped.containerU; segmentHit.v = skipped.containerV;
-                    segmentHit.prim = skipped.containerPrim;
-                    segmentFound = true;
-                }
-            }
-            segmentKnown = true;
+        if (lit) {
             if (found) {
                 const Isect bounce = makeIsect<TRAITS>(scene, isect.point, bsdfSample.wiWorld,
                                                make_float4(bounceHit.t, bounceHit.u, bounceHit.v, intAsFloat(bounceHit.prim)));
@@ -3246,6 +3353,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_V
         const float lightDistance = length(sampleDirection);
         VolumeEvents events;
         RayHit unused;
+        SHADE_REGION(4, true);   // medium event: its light sample's occlusion query
         if (query(kQueryVolumeOccluded, samplePoint, wiWorld, lightDistance - 1e-3f, &unused, &events)) { return rgb(0.f); }
         float pdf;
         if (surfaceSample.solidAngle) {
@@ -3283,6 +3391,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_V
 
         Rgb color = rgb(0.f);
         RayHit hit;
+        SHADE_REGION(1, true);   // camera ray query
         if (!query(kQueryRegular, rayOrigin, rayDirection, PATHED_TFAR, &hit, nullptr)) {
             return color + environmentL<TRAITS>(scene, rayDirection);
         }
@@ -3295,6 +3404,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_V
                 // what is seen through the container, src/sample_integrator.cpp:35-51
                 VolumeEvents events;
                 RayHit through;
+                SHADE_REGION(8, true);   // what is seen through a container
                 const bool found = query(kQueryVolumeClosest, rayOrigin, rayDirection, PATHED_TFAR, &through, &events);
                 const Rgb transmittance = rayTransmission(context.media, rayOrigin, rayDirection, events, -1);
                 if (found) { color = color + matEmit(materials[primMaterial(context, through.prim)]) * transmittance; }
@@ -3307,23 +3417,27 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_V
         random.dimension = vertexBase(1);
         BSDFSample bsdfSample = volumeMaterialSample<TRAITS>(materials[last.material], last, random);
         Rgb result = rgb(0.f);
-        if (checkCounts(p.startBounce, p.lastBounce, 1)) {
+        {
+            const bool direct = checkCounts(p.startBounce, p.lastBounce, 1);
             random.dimension = vertexBase(1) + 3;
-            result = directLighting(last, medium, materials[last.material], bsdfSample, random);
+            const Rgb Ld = vertexLighting(last, medium, materials[last.material], bsdfSample, random, direct, !checkDone(p.lastBounce, 2));
+            if (direct) { result = Ld; }
         }
         Rgb modulation = rgb(1.f);
         for (int bounce = 2; !checkDone(p.lastBounce, bounce); bounce++) {
+            SHADE_REGION(2, true);   // bounce-loop iterations
             // refraction: the medium changes (:43-51)
             if (dot(last.wo, bsdfSample.wiWorld) < 0.f) {
                 if (dot(last.normal, bsdfSample.wiWorld) < 0.f) { medium = context.primMedium[last.prim]; }
                 else { medium = -1; }
             }
             if (segmentKnown) {
+                // the previous vertex's pass has answered it (vertexLighting)
                 segmentKnown = false;
                 if (!segmentFound) { break; }
                 hit = segmentHit;
-            } else if (!query(kQueryRegular, last.point, bsdfSample.wiWorld, PATHED_TFAR, &hit, nullptr)) {
-                break;
+            } else {
+                break;   // not reached: every vertex whose path goes on has asked for its segment (needSegment)
             }
             const Isect next = makeIsect<TRAITS>(scene, last.point, bsdfSample.wiWorld, make_float4(hit.t, hit.u, hit.v, intAsFloat(hit.prim)));
             const float invPDF = 1.f / bsdfSample.pdf;
@@ -3340,10 +3454,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_V
             random.dimension = vertexBase(bounce);
             bsdfSample = volumeMaterialSample<TRAITS>(materials[next.material], next, random);
             last = next;
-            if (checkCounts(p.startBounce, p.lastBounce, bounce)) {
+            {
+                const bool direct = checkCounts(p.startBounce, p.lastBounce, bounce);
                 random.dimension = vertexBase(bounce) + 3;
-                const Rgb Ld = directLighting(last, medium, materials[last.material], bsdfSample, random);
-                result = result + Ld * modulation;
+                const Rgb Ld = vertexLighting(last, medium, materials[last.material], bsdfSample, random, direct, !checkDone(p.lastBounce, bounce + 1));
+                if (direct) { result = result + Ld * modulation; }
             }
         }
         return color + result;
@@ -3358,6 +3473,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_V
             unitSamples(p, unit, &pixel, &first, &end);
             float4 partial = make_float4(0.f, 0.f, 0.f, 0.f);
             for (uint32_t sample = first; sample < end; sample++) {
+                SHADE_REGION(0, true);   // samples
                 const Rgb color = samplePixel(pixel, sample);
                 // radianceLookup += color, src/sample_integrator.cpp:61-63; non-finite samples dropped
                 if (isfinite(color.r) && isfinite(color.g) && isfinite(color.b)) {

@@ -2200,6 +2200,16 @@ int pathed_hip_get_stats(PathedScene *scene, PathedStats *out)
                     device[kStatShadeProfile] ? (double)waves / (double)device[kStatShadeProfile] : 0.0, waves ? (double)lanes / (double)waves : 0.0);
         }
     }
+    if (getenv("PATHED_VOLUME_PROFILE")) {   // the same counters in k_path_volume (-DPATHED_SHADE_PROFILE builds)
+        static const char *regions[9] = { "samples", "camera-ray query", "bounce-loop iterations", "segment query (no direct lighting before)",
+                                          "medium event: occlusion query", "direct lighting at a vertex", "light sample: occlusion query",
+                                          "BSDF sample: closest query", "seen through a container: query" };
+        for (int r = 0; r < 9; r++) {
+            const unsigned long long waves = device[kStatShadeProfile + 2 * r], lanes = device[kStatShadeProfile + 2 * r + 1];
+            fprintf(stderr, "[pathed] k_path_volume %-44s waves %12llu  (%.3f per sample-wave)  lanes per wave %.1f\n", regions[r], waves,
+                    device[kStatShadeProfile] ? (double)waves / (double)device[kStatShadeProfile] : 0.0, waves ? (double)lanes / (double)waves : 0.0);
+        }
+    }
     if (getenv("PATHED_DEBUG_STATS")) {
         fprintf(stderr, "[pathed] wave steps %llu lane steps %llu (lane utilisation %.3f) refill rounds %llu\n",
                 device[kStatWaveSteps], device[kStatLaneSteps],
