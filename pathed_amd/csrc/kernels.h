@@ -2741,6 +2741,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_F
     }
 
     while (true) {
+        SHADE_REGION(0, alive);        // (profile builds, tools/fused_profile.py) iterations / live lanes
+        SHADE_REGION(1, startNext);    // camera ray
         if (startNext) {
             makeKey(seed, pixel, sample, &random.k0, &random.k1);
             random.dimension = 0;
@@ -2771,6 +2773,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_F
             LaneRay shadowRay;
             laneRayInit(shadowRay, o, shadowDirection, PATHED_TNEAR, shadowTfar, true);
             unsigned int candidatesLow = 0, candidatesHigh = 0, shadowLow = 0, shadowHigh = 0;
+            SHADE_REGION(2, traceShadow);   // passes that carry shadow rays / lanes with one
             if (__ballot(traceShadow) != 0ull) {
                 if (alive) {
                     smallCandidatesPair(smallTris.data, nTris, o, d, shadowDirection, &candidatesLow, &candidatesHigh, &shadowLow, &shadowHigh);
@@ -2809,8 +2812,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_F
             bool haveVertex = false;
             Isect isect;
             const int vertex = rayBounce + 1;
+            SHADE_REGION(3, !miss);        // makeIsect
             if (!miss) { isect = makeIsect<TRAITS>(scene, o, d, h); }
 
+            SHADE_REGION(4, rayBounce == 0);   // camera-ray vertex
             if (rayBounce == 0) {
                 // SampleIntegrator::samplePixel, src/sample_integrator.cpp:18-59
                 if (miss) {
@@ -2833,6 +2838,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_F
                     Rgb bsdfTerm = rgb(0.f);
                     if (!miss) {
                         const Rgb emit = matEmit(materials[isect.material]);
+                        SHADE_REGION(5, !isBlack(emit) && dot(isect.wo, isect.shadingNormal) >= 0.f);   // BSDF sample met an emitter: lightsPDF
                         if (!isBlack(emit) && dot(isect.wo, isect.shadingNormal) >= 0.f) {
                             const float lightPDF = lightsPDF<TRAITS>(scene, o, isect);
                             const float brdfWeight = (st & kStDelta)
@@ -2872,6 +2878,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_F
                 }
             }
 
+            SHADE_REGION(6, haveVertex);   // new vertex: BSDF sample
             if (haveVertex) {
                 // PathTracer::L: sample the BSDF, then direct(), src/path_tracer.cpp:30-36, 60-73
                 const DMaterial &material = materials[isect.material];
@@ -2885,6 +2892,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_F
                 const bool wantContinue = !checkDone(p.lastBounce, vertex + 1);
 
                 Rgb lightTerm = rgb(0.f);
+                SHADE_REGION(7, wantDirect);   // light sampling
                 if (wantDirect) {
                     random.dimension = vertexBase(vertex) + 3;
                     lightTerm = sampleLightsTerm<false, TRAITS>(scene, materials, isect, material, random, &shadow);
@@ -2925,6 +2933,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_F
         // ---- end of a sample: radianceLookup += color (src/sample_integrator.cpp:61-63; non-finite samples
         // dropped), then the unit's next sample or the next unit
         bool needUnit = false;
+        SHADE_REGION(8, alive && finished);   // sample finished
         if (alive && finished) {
             const bool finite = isfinite(color.r) && isfinite(color.g) && isfinite(color.b);
             if (finite) {

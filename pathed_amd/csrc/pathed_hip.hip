@@ -2200,6 +2200,16 @@ int pathed_hip_get_stats(PathedScene *scene, PathedStats *out)
                     device[kStatShadeProfile] ? (double)waves / (double)device[kStatShadeProfile] : 0.0, waves ? (double)lanes / (double)waves : 0.0);
         }
     }
+    if (getenv("PATHED_FUSED_PROFILE")) {   // the same counters in k_path_small (-DPATHED_SHADE_PROFILE builds)
+        static const char *regions[9] = { "iterations (live lanes)", "camera ray", "passes with shadow rays (lanes with one)", "makeIsect (hit)",
+                                          "camera-ray vertex", "BSDF sample met an emitter: lightsPDF", "new vertex: BSDF sample", "light sampling",
+                                          "sample finished" };
+        for (int r = 0; r < 9; r++) {
+            const unsigned long long waves = device[kStatShadeProfile + 2 * r], lanes = device[kStatShadeProfile + 2 * r + 1];
+            fprintf(stderr, "[pathed] k_path_small %-44s waves %12llu  (%.3f of the iterations)  lanes per wave %.1f\n", regions[r], waves,
+                    device[kStatShadeProfile] ? (double)waves / (double)device[kStatShadeProfile] : 0.0, waves ? (double)lanes / (double)waves : 0.0);
+        }
+    }
     if (getenv("PATHED_VOLUME_PROFILE")) {   // the same counters in k_path_volume (-DPATHED_SHADE_PROFILE builds)
         static const char *regions[9] = { "samples", "camera-ray query", "bounce-loop iterations", "segment query (no direct lighting before)",
                                           "medium event: occlusion query", "direct lighting at a vertex", "light sample: occlusion query",
