@@ -3083,7 +3083,7 @@ __device__ __forceinline__ void volumeQueryPairSmall(const VolumeContext<Materia
 // work units as in k_path_small.  Arithmetic on a path's values follows the reference statement by statement; on a
 // scene without media the result is PathTracer's, bit for bit (the two share their direct-lighting arithmetic; GPU test).
 #ifndef PATHED_VOLUME_WAVES
-#define PATHED_VOLUME_WAVES 4   // 128 registers per lane + scratch; 3 / 4 / 5 waves: 787 / 845 / 799 (Cornell), 732 / 787 / 707 (cornell-medium), 368 / 388 / 382 (teapot) Msamples/s; uncapped the kernel takes 220-260 registers and runs one or two waves
+#define PATHED_VOLUME_WAVES 4   // 128 registers per lane + scratch; 3 / 4 / 5 waves: 787 / 845 / 799 (Cornell), 732 / 787 / 707 (cornell-medium), 368 / 388 / 382 (teapot) Msamples/s; uncapped the kernel takes 220-260 registers and runs one or two waves; with one pass per vertex (round 3) 3 / 4 waves: 1 139 / 1 225 (Cornell), 901 / 985 (cornell-medium)
 #endif
 template <bool LDS_MATERIALS, int STACK, bool SMALL, typename TRAITS = TraitsAll>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_VOLUME_WAVES, PATHED_VOLUME_WAVES))) void k_path_volume(RenderParams p, SmallTris smallTris)
