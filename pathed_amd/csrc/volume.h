@@ -179,7 +179,10 @@ __device__ __forceinline__ bool volumeQuery(const VolumeContext<MaterialTable> &
 __device__ inline Rgb mediumTransmittance(const DMedium &medium, V3 pointA, V3 pointB)
 {
     const float distance = length(pointB - pointA);
-    return rgb(expf(-medium.sigmaT[0] * distance), expf(-medium.sigmaT[1] * distance), expf(-medium.sigmaT[2] * distance));
+    // the three channels of sigma_t are equal (the reference asserts it, scene creation refuses anything else): the three
+    // expf of the reference are one value
+    const float channel = expf(-medium.sigmaT[0] * distance);
+    return rgb(channel, channel, channel);
 }
 
 // VolumeHelper::rayTransmission, src/volume_helper.cpp:71-123
