@@ -706,12 +706,24 @@ __device__ inline f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a
 // u det >= 0, v det >= 0, (det - u - v) det >= 0, t det >= 0, taken as "not (min < 0)" so that -0,
 // underflow and NaN all err on the side of keeping the candidate; phase 2 decides.  Bits are shifted in
 // (cand = 2 cand + bit), so triangle k of a 32-triangle word ends up at bit 31 - (k & 31).
-__device__ __forceinline__ void smallCandidates(const f2 *pairRecords, int nTris, V3 origin, V3 direction, unsigned int *low, unsigned int *high)
+// INTERVAL: a candidate must also lie inside the ray's interval, loosely: t >= tnearLow and (FAR) t <= tfarHigh in the same
+// det units, (t - tnearLow) det^2 >= 0 and (tfarHigh - t) det^2 >= 0, one and two packed operations more.  The bounds are
+// the query's own moved OUTWARD by half of tnear (candidateBounds), far more than the two evaluations of t can differ by, so
+// phase 2 still sees every triangle it could accept; what goes are the triangle the ray starts on (t = 0) and, for a
+// shadow ray, the light's own triangle and everything behind it -- two of the three candidates of a shadow ray in the
+// Cornell box, one of the two of a path's ray, and with them half of the turns of the resolve loops.
+__device__ inline float candidateNear(float tnear) { return 0.5f * tnear; }
+__device__ inline float candidateFar(float tfar) { return tfar + 0.5f * PATHED_TNEAR + 1e-5f * fabsf(tfar); }
+
+template <bool FAR = false>
+__device__ __forceinline__ void smallCandidates(const f2 *pairRecords, int nTris, V3 origin, V3 direction, unsigned int *low, unsigned int *high,
+                                                float tnearLow = 0.f, float tfarHigh = 0.f)
 {
     const int nPairs = (nTris + 1) / 2;
     unsigned int candidatesLow = 0, candidatesHigh = 0;
     const f2 dx = splat2(direction.x), dy = splat2(direction.y), dz = splat2(direction.z);
     const f2 ox = splat2(origin.x), oy = splat2(origin.y), oz = splat2(origin.z);
+    const f2 nearLow = splat2(-tnearLow), farHigh = splat2(tfarHigh);
     // one pair of triangles: returns (bit of a) * 2 + bit of b
     auto testPair = [&](int pair) -> unsigned int {
         // uniform index into the kernarg segment -> scalar loads, broadcast to the wave
@@ -732,9 +744,14 @@ __device__ __forceinline__ void smallCandidates(const f2 *pairRecords, int nTris
         const f2 qz = fma2(tx, e1y, -(ty * e1x));
         const f2 vScaled = fma2(dx, qx, fma2(dy, qy, dz * qz));
         const f2 tScaled = fma2(e2x, qx, fma2(e2y, qy, e2z * qz));
-        const f2 a = uScaled * det, b = vScaled * det, c = (det - (uScaled + vScaled)) * det, e = tScaled * det;
-        const float worstA = fminf(fminf(a.x, b.x), fminf(c.x, e.x));
-        const float worstB = fminf(fminf(a.y, b.y), fminf(c.y, e.y));
+        const f2 a = uScaled * det, b = vScaled * det, c = (det - (uScaled + vScaled)) * det, e = fma2(nearLow, det, tScaled) * det;
+        float worstA = fminf(fminf(a.x, b.x), fminf(c.x, e.x));
+        float worstB = fminf(fminf(a.y, b.y), fminf(c.y, e.y));
+        if (FAR) {
+            const f2 g = fma2(farHigh, det, -tScaled) * det;
+            worstA = fminf(worstA, g.x);
+            worstB = fminf(worstB, g.y);
+        }
         return ((worstA < 0.f) ? 0u : 2u) | ((worstB < 0.f) ? 0u : 1u);
     };
     const int lowPairs = nPairs < 16 ? nPairs : 16;
@@ -760,14 +777,17 @@ __device__ __forceinline__ void smallCandidates(const f2 *pairRecords, int nTris
 // Phase 1 for TWO rays that leave the same point (a vertex's continuation ray and its shadow ray): tvec = o - v0,
 // qvec = tvec x e1 and t det = e2 . qvec do not depend on the direction, so the pair costs 12 + 2 x 21 packed
 // operations per two triangles instead of 2 x 33.  Same expressions as smallCandidates, ray by ray.
+// Ray B is the shadow ray: its candidates are also held to its far bound (smallCandidates: INTERVAL).
 __device__ __forceinline__ void smallCandidatesPair(const f2 *pairRecords, int nTris, V3 origin, V3 directionA, V3 directionB,
-                                                    unsigned int *lowA, unsigned int *highA, unsigned int *lowB, unsigned int *highB)
+                                                    unsigned int *lowA, unsigned int *highA, unsigned int *lowB, unsigned int *highB,
+                                                    float tnearLow = 0.f, float tfarHighB = 3e38f)
 {
     const int nPairs = (nTris + 1) / 2;
     unsigned int aLow = 0, aHigh = 0, bLow = 0, bHigh = 0;
     const f2 ax = splat2(directionA.x), ay = splat2(directionA.y), az = splat2(directionA.z);
     const f2 bx = splat2(directionB.x), by = splat2(directionB.y), bz = splat2(directionB.z);
     const f2 ox = splat2(origin.x), oy = splat2(origin.y), oz = splat2(origin.z);
+    const f2 nearLow = splat2(-tnearLow), farHighB = splat2(tfarHighB);
     auto testPair = [&](int pair, unsigned int *bitsA, unsigned int *bitsB) {
         const f2 *record = pairRecords + kSmallPairWords * pair;
         const f2 v0x = record[0], v0y = record[1], v0z = record[2];
@@ -779,7 +799,7 @@ __device__ __forceinline__ void smallCandidatesPair(const f2 *pairRecords, int n
         const f2 qy = fma2(tz, e1x, -(tx * e1z));
         const f2 qz = fma2(tx, e1y, -(ty * e1x));
         const f2 tScaled = fma2(e2x, qx, fma2(e2y, qy, e2z * qz));
-        auto oneRay = [&](f2 dx, f2 dy, f2 dz) -> unsigned int {
+        auto oneRay = [&](f2 dx, f2 dy, f2 dz, bool far) -> unsigned int {
             // pvec = d x e2, det = e1 . pvec
             const f2 px = fma2(dy, e2z, -(dz * e2y));
             const f2 py = fma2(dz, e2x, -(dx * e2z));
@@ -787,13 +807,18 @@ __device__ __forceinline__ void smallCandidatesPair(const f2 *pairRecords, int n
             const f2 det = fma2(e1x, px, fma2(e1y, py, e1z * pz));
             const f2 uScaled = fma2(tx, px, fma2(ty, py, tz * pz));
             const f2 vScaled = fma2(dx, qx, fma2(dy, qy, dz * qz));
-            const f2 a = uScaled * det, b = vScaled * det, c = (det - (uScaled + vScaled)) * det, e = tScaled * det;
-            const float worstA = fminf(fminf(a.x, b.x), fminf(c.x, e.x));
-            const float worstB = fminf(fminf(a.y, b.y), fminf(c.y, e.y));
+            const f2 a = uScaled * det, b = vScaled * det, c = (det - (uScaled + vScaled)) * det, e = fma2(nearLow, det, tScaled) * det;
+            float worstA = fminf(fminf(a.x, b.x), fminf(c.x, e.x));
+            float worstB = fminf(fminf(a.y, b.y), fminf(c.y, e.y));
+            if (far) {
+                const f2 g = fma2(farHighB, det, -tScaled) * det;
+                worstA = fminf(worstA, g.x);
+                worstB = fminf(worstB, g.y);
+            }
             return ((worstA < 0.f) ? 0u : 2u) | ((worstB < 0.f) ? 0u : 1u);
         };
-        *bitsA = oneRay(ax, ay, az);
-        *bitsB = oneRay(bx, by, bz);
+        *bitsA = oneRay(ax, ay, az, false);
+        *bitsB = oneRay(bx, by, bz, true);
     };
     const int lowPairs = nPairs < 16 ? nPairs : 16;
     for (int pair = 0; pair < lowPairs; pair++) {
@@ -905,7 +930,8 @@ __global__ __launch_bounds__(kBlock) void k_trace_small(RenderParams p, SmallTri
         // triangle k of a 32-triangle word ends up at bit 31 - (k & 31).
         unsigned int candidatesLow = 0, candidatesHigh = 0;
         if (valid) {
-            smallCandidates(smallTris.data, nTris, ray.o, ray.d, &candidatesLow, &candidatesHigh);
+            smallCandidates<true>(smallTris.data, nTris, ray.o, ray.d, &candidatesLow, &candidatesHigh,
+                                  candidateNear(ray.tnear), ray.anyHit ? candidateFar(ray.tfar) : 3e38f);
             if (COUNT) { trisTested += (unsigned int)nTris; }
         }
 
@@ -1398,8 +1424,23 @@ __global__ __launch_bounds__(kBlock) void k_resolve(RenderParams p)
             atomicAdd(&p.stats[kStatShadeProfile + 2 * (index) + 1], (unsigned long long)__popcll(mask_));    \
         }                                                                                                     \
     } while (0)
+// ... and for a resolve loop (smallResolve): its iterations (the wave's largest candidate count) and the candidates it tests
+#define RESOLVE_PROBE(index, low, high)                                                                       \
+    do {                                                                                                      \
+        int most_ = __popc(low) + __popc(high), all_ = most_;                                                 \
+        for (int step_ = 32; step_ >= 1; step_ >>= 1) {                                                       \
+            const int other_ = __shfl_xor(most_, step_, 64);                                                  \
+            most_ = other_ > most_ ? other_ : most_;                                                          \
+            all_ += __shfl_xor(all_, step_, 64);                                                              \
+        }                                                                                                     \
+        if ((threadIdx.x & 63) == 0) {                                                                        \
+            atomicAdd(&p.stats[kStatShadeProfile + 2 * (index)], (unsigned long long)most_);                  \
+            atomicAdd(&p.stats[kStatShadeProfile + 2 * (index) + 1], (unsigned long long)all_);               \
+        }                                                                                                     \
+    } while (0)
 #else
 #define SHADE_REGION(index, predicate) do { } while (0)
+#define RESOLVE_PROBE(index, low, high) do { } while (0)
 #endif
 
 template <bool LDS_MATERIALS>
@@ -2776,17 +2817,20 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_F
             SHADE_REGION(2, traceShadow);   // passes that carry shadow rays / lanes with one
             if (__ballot(traceShadow) != 0ull) {
                 if (alive) {
-                    smallCandidatesPair(smallTris.data, nTris, o, d, shadowDirection, &candidatesLow, &candidatesHigh, &shadowLow, &shadowHigh);
+                    smallCandidatesPair(smallTris.data, nTris, o, d, shadowDirection, &candidatesLow, &candidatesHigh, &shadowLow, &shadowHigh,
+                                        candidateNear(PATHED_TNEAR), candidateFar(shadowTfar));
                     if (!traceShadow) { shadowLow = 0u; shadowHigh = 0u; }
                 }
             } else if (alive) {
-                smallCandidates(smallTris.data, nTris, o, d, &candidatesLow, &candidatesHigh);
+                smallCandidates(smallTris.data, nTris, o, d, &candidatesLow, &candidatesHigh, candidateNear(PATHED_TNEAR));
             }
             if (COUNT && alive) {
                 trisTested += (unsigned int)nTris * (traceShadow ? 2u : 1u);
                 closestRays++;
                 if (traceShadow) { shadowRays++; }
             }
+            RESOLVE_PROBE(9, candidatesLow, candidatesHigh);   // (profile builds) the resolve loops: iterations, candidates
+            RESOLVE_PROBE(10, shadowLow, shadowHigh);
             smallResolve(geometry, ray, candidatesLow, candidatesHigh);
             smallResolve(geometry, shadowRay, shadowLow, shadowHigh);
             if (alive) { finishRay(geometry, ray); }
@@ -2989,7 +3033,7 @@ __device__ __forceinline__ bool volumeQuerySmall(const VolumeContext<MaterialTab
     VolumeEvents events;
     eventsClear(events);
     unsigned int low = 0u, high = 0u;
-    smallCandidates(pairRecords, c.geometry.nTris, o, d, &low, &high);
+    smallCandidates<true>(pairRecords, c.geometry.nTris, o, d, &low, &high, candidateNear(PATHED_TNEAR), anyHit ? candidateFar(tfar) : 3e38f);
     bool decided = false;
     while (__ballot((low | high) != 0u) != 0ull) {
         if ((low | high) != 0u) {
@@ -3032,7 +3076,7 @@ __device__ __forceinline__ void volumeQueryPairSmall(const VolumeContext<Materia
                                                      bool wantB, V3 dB, float tfarB, bool *occludedB, VolumeEvents *eventsB)
 {
     unsigned int lowA = 0u, highA = 0u, lowB = 0u, highB = 0u;
-    smallCandidatesPair(pairRecords, c.geometry.nTris, o, dA, dB, &lowA, &highA, &lowB, &highB);
+    smallCandidatesPair(pairRecords, c.geometry.nTris, o, dA, dB, &lowA, &highA, &lowB, &highB, candidateNear(PATHED_TNEAR), candidateFar(tfarB));
     if (!wantA) { lowA = 0u; highA = 0u; }
     if (!wantB) { lowB = 0u; highB = 0u; }
     auto resolve = [&](int mode, LaneRay &ray, VolumeEvents &events, unsigned int low, unsigned int high, bool want) {

@@ -2209,6 +2209,12 @@ int pathed_hip_get_stats(PathedScene *scene, PathedStats *out)
             fprintf(stderr, "[pathed] k_path_small %-44s waves %12llu  (%.3f of the iterations)  lanes per wave %.1f\n", regions[r], waves,
                     device[kStatShadeProfile] ? (double)waves / (double)device[kStatShadeProfile] : 0.0, waves ? (double)lanes / (double)waves : 0.0);
         }
+        static const char *loops[2] = { "resolve loop of the path's ray", "resolve loop of the shadow ray" };
+        for (int r = 0; r < 2; r++) {
+            const unsigned long long turns = device[kStatShadeProfile + 2 * (9 + r)], candidates = device[kStatShadeProfile + 2 * (9 + r) + 1];
+            fprintf(stderr, "[pathed] k_path_small %-44s %.2f turns per iteration, %.2f candidates per turn (of 64 lanes)\n", loops[r],
+                    device[kStatShadeProfile] ? (double)turns / (double)device[kStatShadeProfile] : 0.0, turns ? (double)candidates / (double)turns : 0.0);
+        }
     }
     if (getenv("PATHED_VOLUME_PROFILE")) {   // the same counters in k_path_volume (-DPATHED_SHADE_PROFILE builds)
         static const char *regions[9] = { "samples", "camera-ray query", "bounce-loop iterations", "segment query (no direct lighting before)",
