@@ -187,7 +187,7 @@ struct RenderParams {
     unsigned int nGroups;              // what the queues share out: chunks per pixel (stripes) or ceil(nPixels / kUnitGroup) (tiles)
     unsigned int lastGroupPixels;      // tiles: pixels of group nGroups - 1 (1 .. kUnitGroup)
     unsigned int groupUnits;           // units of one owned item: nPixels (stripes) or kUnitGroup * chunksPerPixel (tiles)
-    FastDiv divStride, divGroupUnits, divBand;   // by unitsPerQueue, by groupUnits, by 8 * image width
+    FastDiv divStride, divGroupUnits, divBand, divWidth;   // by unitsPerQueue, by groupUnits, by 8 * image width, by the image width
     unsigned int queueUnits[kUnitQueues];        // units each queue of this pool holds
     int nQueues;           // min(kUnitQueues, shade blocks): every queue has a consumer
     unsigned int unitsPerQueue;        // stride of the unit ids: unit = queue * unitsPerQueue + position in the queue
@@ -1222,7 +1222,7 @@ __device__ inline Rgb sampleLightsTerm(
 __device__ inline void startSample(const RenderParams &p, uint32_t pixel, uint32_t sample, int sampleInUnit, float4 *rayO, float4 *rayD)
 {
     const int width = p.scene.camera.resX;
-    const int row = (int)pixel / width;
+    const int row = (int)fastDivide((unsigned int)pixel, p.divWidth);   // pixel / width, exactly
     const int col = (int)pixel - row * width;
     Rng random;
     makeKey(((uint64_t)p.seedHi << 32) | p.seedLo, pixel, sample, &random.k0, &random.k1);
@@ -2788,7 +2788,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_F
             makeKey(seed, pixel, sample, &random.k0, &random.k1);
             random.dimension = 0;
             const int width = scene.camera.resX;
-            const int row = (int)pixel / width;
+            const int row = (int)fastDivide((unsigned int)pixel, p.divWidth);   // pixel / width, exactly
             const int col = (int)pixel - row * width;
             const float jitterX = random.next() - 0.5f;
             const float jitterY = random.next() - 0.5f;
@@ -3435,7 +3435,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_V
         makeKey(seed, pixel, sample, &random.k0, &random.k1);
         random.dimension = 0;
         const int width = scene.camera.resX;
-        const int row = (int)pixel / width;
+        const int row = (int)fastDivide((unsigned int)pixel, p.divWidth);   // pixel / width, exactly
         const int col = (int)pixel - row * width;
         const float jitterX = random.next() - 0.5f;
         const float jitterY = random.next() - 0.5f;

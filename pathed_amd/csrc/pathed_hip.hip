@@ -1581,6 +1581,7 @@ static bool fillUnitOrder(RenderParams &q, int order, int width, int height, int
     q.divStride = makeFastDiv((unsigned int)stride);
     q.divGroupUnits = makeFastDiv((unsigned int)itemUnits);
     q.divBand = makeFastDiv(8u * (unsigned int)width);
+    q.divWidth = makeFastDiv((unsigned int)width);
     unsigned long long total = 0;
     for (int k = 0; k < kUnitQueues; k++) {
         unsigned long long units = 0;
