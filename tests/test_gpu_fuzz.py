@@ -14,7 +14,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def build_scene(seed, size=40):
+def build_scene(seed, size=40, tiny=False):
     from pathed_amd import _capi
     from scene_builder import BuiltScene
     rng = np.random.default_rng(seed)
@@ -35,7 +35,8 @@ def build_scene(seed, size=40):
         materials.append(built.material(_capi.MAT_LAMBERTIAN, texture=texture))
     light = built.material(_capi.MAT_LAMBERTIAN, diffuse=(0, 0, 0), emit=rng.uniform(2.0, 12.0, 3))
 
-    n = int(rng.integers(80, 1500))
+    # tiny: at most 64 triangles and 16 spheres in all, the scenes the all-triangles intersector serves
+    n = int(rng.integers(36, 61)) if tiny else int(rng.integers(80, 1500))
     centres = rng.normal(size=(n, 3)) * scale
     spans = scale * 10.0 ** rng.uniform(-2.0, -0.3, size=(n, 1, 1))
     corners = centres[:, None, :] + rng.normal(size=(n, 3, 3)) * spans
@@ -112,3 +113,28 @@ def test_random_scene_parity(seed):
     assert rel <= 1e-2 and bad <= 5e-3, (seed, rel, bad)
     stats = gpu.stats()
     assert stats["dropped_samples"] <= 0.02 * size * size * 8
+
+
+@pytest.mark.parametrize("seed", range(200, 212))
+def test_random_tiny_scene_all_triangles_intersector_equals_tree_walk(seed):
+    """Scenes of at most 64 triangles take the all-triangles intersector, whose first phase holds candidates to the ray's
+    interval only LOOSELY (kernels.h: smallCandidates, candidateNear / candidateFar) and whose second phase decides: at
+    any scale (0.1 .. 100 here), with needles, duplicates and zero-area triangles, the fused path kernel and the per-slot
+    wavefront over it must produce the image of the tree walk, bit for bit, and stay within tolerance of the oracle."""
+    import oracle_lib
+    from pathed_amd.integrator import HipScene
+    built, desc, scale = build_scene(seed, tiny=True)
+    assert desc.contents.n_triangles <= 64
+    size = 40
+    fused = HipScene(desc, device=0)
+    assert fused.stats()["scene_in_lds"] == 2                  # the all-triangles intersector
+    image = fused.render(7, 0, 16, 0, 6)
+    assert np.array_equal(HipScene(desc, device=0, shade_kernel="per-slot").render(7, 0, 16, 0, 6), image)
+    walked = HipScene(desc, device=0, intersector="bvh")
+    assert walked.stats()["scene_in_lds"] != 2
+    assert np.array_equal(walked.render(7, 0, 16, 0, 6), image)
+    cpu = oracle_lib.OracleScene(desc)
+    expected, _ = cpu.render(size, size, 7, 0, 16, 0, 6, threads=os.cpu_count())
+    rel = float(np.linalg.norm(image - expected) / max(np.linalg.norm(expected), 1e-30))
+    bad = float((np.abs(image - expected) > 1e-2 * np.maximum(np.abs(expected), 1e-3)).any(axis=2).mean())
+    assert rel <= 1e-2 and bad <= 5e-3, (seed, rel, bad)
