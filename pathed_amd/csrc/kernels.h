@@ -1149,18 +1149,18 @@ __device__ inline Rgb sampleLightsTerm(
     SurfaceSample surfaceSample;
     int lightMaterial = 0;
     if (ENV_ONLY) {
-        surfaceSample = envSample(scene.env, isect.point, random);
+        surfaceSample = envSample<TRAITS::pairedTrig>(scene.env, isect.point, random);
     } else if (TRAITS::triangleLights && (light.kind == 0 || (!TRAITS::spheres && !TRAITS::env))) {
         const TriShade tri = loadTriCorners(scene, light.index);
         surfaceSample = triangleSample(tri.p0, tri.p1, tri.p2, random);
         lightMaterial = tri.material;
     } else if (TRAITS::spheres && (light.kind == 1 || !TRAITS::env)) {
         const DSphere sphere = scene.spheres[light.index];
-        surfaceSample = sphereSample(
+        surfaceSample = sphereSample<TRAITS::pairedTrig>(
             v3(sphere.centerSample[0], sphere.centerSample[1], sphere.centerSample[2]), sphere.radius, isect.point, random);
         lightMaterial = sphere.material;
     } else if (TRAITS::env) {
-        surfaceSample = envSample(scene.env, isect.point, random);
+        surfaceSample = envSample<TRAITS::pairedTrig>(scene.env, isect.point, random);
     } else {   // not reached: a light of a kind the instantiation's scene set does not contain
         surfaceSample.point = isect.point;
         surfaceSample.normal = v3(0.f, 0.f, 0.f);
@@ -3245,10 +3245,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_V
                 lightMaterial = tri.material;
             } else if (TRAITS::spheres && light.kind == 1) {
                 const DSphere sphere = scene.spheres[light.index];
-                surfaceSample = sphereSample(v3(sphere.centerSample[0], sphere.centerSample[1], sphere.centerSample[2]), sphere.radius, isect.point, random);
+                surfaceSample = sphereSample<TRAITS::pairedTrig>(v3(sphere.centerSample[0], sphere.centerSample[1], sphere.centerSample[2]), sphere.radius, isect.point, random);
                 lightMaterial = sphere.material;
             } else if (TRAITS::env) {
-                surfaceSample = envSample(scene.env, isect.point, random);
+                surfaceSample = envSample<TRAITS::pairedTrig>(scene.env, isect.point, random);
             } else {   // not reached: a light of a kind the instantiation's scene set does not contain
                 surfaceSample.point = isect.point; surfaceSample.normal = v3(0.f, 0.f, 0.f); surfaceSample.invPDF = 1.f; surfaceSample.solidAngle = 1;
             }
@@ -3391,10 +3391,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_V
             lightMaterial = tri.material;
         } else if (TRAITS::spheres && light.kind == 1) {
             const DSphere sphere = scene.spheres[light.index];
-            surfaceSample = sphereSample(v3(sphere.centerSample[0], sphere.centerSample[1], sphere.centerSample[2]), sphere.radius, samplePoint, random);
+            surfaceSample = sphereSample<TRAITS::pairedTrig>(v3(sphere.centerSample[0], sphere.centerSample[1], sphere.centerSample[2]), sphere.radius, samplePoint, random);
             lightMaterial = sphere.material;
         } else if (TRAITS::env) {
-            surfaceSample = envSample(scene.env, samplePoint, random);
+            surfaceSample = envSample<TRAITS::pairedTrig>(scene.env, samplePoint, random);
         } else {   // not reached
             surfaceSample.point = samplePoint; surfaceSample.normal = v3(0.f, 0.f, 0.f); surfaceSample.invPDF = 1.f; surfaceSample.solidAngle = 1;
         }

@@ -17,20 +17,23 @@ namespace pathed {
 // instructions skipped (a uniform branch skips them anyway) but about the registers the compiler reserves for code that
 // never runs: the fused path kernel lives at 128 VGPRs with spills.  The launch picks the narrowest instantiation whose set
 // contains the scene's (pathed_hip.hip: sceneTraits).  Results cannot differ: absent kinds are absent.
-template <unsigned MATERIALS, bool ENV, bool TRIANGLE_LIGHTS, bool SPHERES, bool VARYING_ALBEDO>
+template <unsigned MATERIALS, bool ENV, bool TRIANGLE_LIGHTS, bool SPHERES, bool VARYING_ALBEDO, bool PAIRED_TRIG = false>
 struct SceneTraits {
     static constexpr unsigned materials = MATERIALS;       // bit t: material type t (PATHED_MAT_*) may occur
     static constexpr bool env = ENV;                        // an environment light
     static constexpr bool triangleLights = TRIANGLE_LIGHTS; // emissive triangles
     static constexpr bool spheres = SPHERES;                // sphere primitives (as geometry or as lights)
     static constexpr bool varyingAlbedo = VARYING_ALBEDO;   // checkerboard / image-texture albedo
+    // cosf and sinf of one angle through ONE sincosf (cosSin below): the same bits, fewer instructions -- for the fused path
+    // kernel's instantiations only: in k_shade the smaller kernel upsets the balance of the two pools
+    static constexpr bool pairedTrig = PAIRED_TRIG;
     static constexpr bool has(int type) { return ((MATERIALS >> type) & 1u) != 0u; }
 };
 typedef SceneTraits<0x7Fu, true, true, true, true> TraitsAll;
 // Cornell-box-like scenes: constant-albedo Lambertian surfaces, triangle lights, nothing else
-typedef SceneTraits<1u << 0, false, true, false, false> TraitsLambertianTriangles;
+typedef SceneTraits<1u << 0, false, true, false, false, true> TraitsLambertianTriangles;
 // the Veach MIS scene: Lambertian + plastic surfaces (constant albedo) lit by emissive spheres
-typedef SceneTraits<(1u << 0) | (1u << 3), false, false, true, false> TraitsLambertianPlasticSpheres;
+typedef SceneTraits<(1u << 0) | (1u << 3), false, false, true, false, true> TraitsLambertianPlasticSpheres;
 // the reference's VolumePathTracer scene (scenes/cornell-medium.json): Lambertian walls, a glass sphere, a passthrough container, triangle lights
 typedef SceneTraits<(1u << 0) | (1u << 4) | (1u << 6), false, true, true, false> TraitsLambertianGlassContainer;
 
@@ -189,14 +192,27 @@ __device__ inline float sinFromCos(float cosTheta)
 
 // ----------------------------------------------------------------------- samplers
 
+// cosf and sinf of ONE angle.  PAIRED: from one argument reduction -- ocml's sincosf returns the bits of its sinf and cosf
+// (tools/sincos_identity.hip compares them on the GPU: every float in (-8, 8), every 97th beyond), so it is the
+// reference's pair of calls at half the instructions (static: 124 against 239).  Which kernels take it: SceneTraits.
+template <bool PAIRED>
+__device__ inline void cosSin(float angle, float *cosine, float *sine)
+{
+    if (PAIRED) { sincosf(angle, sine, cosine); }
+    else { *cosine = cosf(angle); *sine = sinf(angle); }
+}
+
 // src/monte_carlo.cpp:24-41
+template <bool PAIRED = false>
 __device__ inline V3 cosineSampleHemisphere(Rng &random)
 {
     const float xi1 = random.next();
     const float r = sqrtf(xi1);
     const float phi = twoPiTimes(random.next());
-    const float x = r * cosf(phi);
-    const float z = r * sinf(phi);
+    float cosPhi, sinPhi;
+    cosSin<PAIRED>(phi, &cosPhi, &sinPhi);
+    const float x = r * cosPhi;
+    const float z = r * sinPhi;
     const float y = sqrtf(1.f - xi1);
     return v3(x, y, z);
 }
@@ -214,11 +230,14 @@ __device__ inline void cartesianToSpherical(V3 cartesian, float *phi, float *the
 }
 
 // src/coordinate.cpp:25-32
+template <bool PAIRED = false>
 __device__ inline V3 sphericalToCartesian(float phi, float cosTheta, float sinTheta)
 {
     const float y = cosTheta;
-    const float x = sinTheta * cosf(phi);
-    const float z = sinTheta * sinf(phi);
+    float cosPhi, sinPhi;
+    cosSin<PAIRED>(phi, &cosPhi, &sinPhi);
+    const float x = sinTheta * cosPhi;
+    const float z = sinTheta * sinPhi;
     return v3(x, y, z);
 }
 
@@ -325,10 +344,10 @@ __device__ inline Rgb lambertianF(const DMaterial &m, const Isect &isect, V3 wiW
 }
 
 // src/lambertian.cpp:42-58
-template <bool VARYING_ALBEDO = true>
+template <bool VARYING_ALBEDO = true, bool PAIRED = false>
 __device__ inline BSDFSample lambertianSample(const DMaterial &m, const Isect &isect, Rng &random)
 {
-    const V3 localSample = cosineSampleHemisphere(random);
+    const V3 localSample = cosineSampleHemisphere<PAIRED>(random);
     const V3 worldSample = toWorld(isect.frame, localSample);
     BSDFSample sample;
     sample.wiWorld = worldSample;
@@ -369,9 +388,10 @@ __device__ inline Rgb orenNayarF(const DMaterial &m, const Isect &isect, V3 wiWo
 }
 
 // src/oren_nayar.cpp:69-85
+template <bool PAIRED = false>
 __device__ inline BSDFSample orenNayarSample(const DMaterial &m, const Isect &isect, Rng &random)
 {
-    const V3 localSample = cosineSampleHemisphere(random);
+    const V3 localSample = cosineSampleHemisphere<PAIRED>(random);
     const V3 worldSample = toWorld(isect.frame, localSample);
     BSDFSample sample;
     sample.wiWorld = worldSample;
@@ -424,6 +444,7 @@ __device__ inline float beckmannG(float alpha, V3 wo, V3 wi)
 }
 
 // src/beckmann.cpp:13-43: phi is drawn first, then the tan^2 variate
+template <bool PAIRED = false>
 __device__ inline V3 beckmannSampleWh(float alpha, Rng &random)
 {
     const float phi = twoPiTimes(random.next());
@@ -435,7 +456,7 @@ __device__ inline V3 beckmannSampleWh(float alpha, Rng &random)
 
     const float cosTheta = 1.f / sqrtf(1.f + tan2Theta);
     const float sinTheta = sinFromCos(cosTheta);
-    return sphericalToCartesian(phi, cosTheta, sinTheta);
+    return sphericalToCartesian<PAIRED>(phi, cosTheta, sinTheta);
 }
 
 // src/ggx.cpp:27-46
@@ -462,6 +483,7 @@ __device__ inline float ggxG1(float alpha, V3 v)
 }
 
 // src/ggx.cpp:13-25: theta variate first, then phi (the opposite of Beckmann)
+template <bool PAIRED = false>
 __device__ inline V3 ggxSampleWh(float alpha, Rng &random)
 {
     const float xi1 = random.next();
@@ -470,7 +492,9 @@ __device__ inline V3 ggxSampleWh(float alpha, Rng &random)
     const float denominator = sqrtf(1.f - xi1);
     const float theta = atanf(numerator / denominator);
     const float phi = PATHED_TWO_PI * xi2;
-    return sphericalToCartesian(phi, cosf(theta), sinf(theta));
+    float cosTheta, sinTheta;
+    cosSin<PAIRED>(theta, &cosTheta, &sinTheta);
+    return sphericalToCartesian<PAIRED>(phi, cosTheta, sinTheta);
 }
 
 // MicrofacetDistribution dispatch (include/microfacet_distribution.h)
@@ -483,9 +507,10 @@ __device__ inline float distributionG(const DMaterial &m, V3 wo, V3 wi)
 {
     return m.distribution == PATHED_DIST_GGX ? ggxG1(m.alpha, wo) * ggxG1(m.alpha, wi) : beckmannG(m.alpha, wo, wi);
 }
+template <bool PAIRED = false>
 __device__ inline V3 distributionSampleWh(const DMaterial &m, Rng &random)
 {
-    return m.distribution == PATHED_DIST_GGX ? ggxSampleWh(m.alpha, random) : beckmannSampleWh(m.alpha, random);
+    return m.distribution == PATHED_DIST_GGX ? ggxSampleWh<PAIRED>(m.alpha, random) : beckmannSampleWh<PAIRED>(m.alpha, random);
 }
 
 // src/microfacet.cpp:12-57 (Fresnel eta hard-coded to 1.5 at :41)
@@ -516,10 +541,11 @@ __device__ inline Rgb microfacetF(const DMaterial &m, const Isect &isect, V3 wiW
 }
 
 // src/microfacet.cpp:59-78
+template <bool PAIRED = false>
 __device__ inline BSDFSample microfacetSample(const DMaterial &m, const Isect &isect, Rng &random)
 {
     const V3 wo = toLocal(isect.frame, isect.wo);
-    const V3 wh = distributionSampleWh(m, random);
+    const V3 wh = distributionSampleWh<PAIRED>(m, random);
     const V3 wi = reflect(wo, wh);
     const V3 wiWorld = toWorld(isect.frame, wi);
 
@@ -541,6 +567,7 @@ __device__ inline Rgb plasticF(const DMaterial &m, const Isect &isect, V3 wiWorl
 }
 
 // src/plastic.cpp:35-66
+template <bool PAIRED = false>
 __device__ inline BSDFSample plasticSample(const DMaterial &m, const Isect &isect, Rng &random)
 {
     const float xi = random.next();
@@ -548,10 +575,10 @@ __device__ inline BSDFSample plasticSample(const DMaterial &m, const Isect &isec
     float otherPDF;
     Rgb otherThroughput;
     if (xi > 0.5f) {
-        sample = lambertianSample(m, isect, random);
+        sample = lambertianSample<true, PAIRED>(m, isect, random);
         otherThroughput = microfacetF(m, isect, sample.wiWorld, &otherPDF);
     } else {
-        sample = microfacetSample(m, isect, random);
+        sample = microfacetSample<PAIRED>(m, isect, random);
         otherThroughput = lambertianF(m, isect, sample.wiWorld, &otherPDF);
     }
     BSDFSample out;
@@ -626,10 +653,10 @@ template <typename TRAITS = TraitsAll>
 __device__ inline BSDFSample materialSample(const DMaterial &m, const Isect &isect, Rng &random)
 {
     switch (m.type) {
-    case PATHED_MAT_LAMBERTIAN: if (TRAITS::has(PATHED_MAT_LAMBERTIAN)) { return lambertianSample<TRAITS::varyingAlbedo>(m, isect, random); } break;
-    case PATHED_MAT_OREN_NAYAR: if (TRAITS::has(PATHED_MAT_OREN_NAYAR)) { return orenNayarSample(m, isect, random); } break;
-    case PATHED_MAT_MICROFACET: if (TRAITS::has(PATHED_MAT_MICROFACET)) { return microfacetSample(m, isect, random); } break;
-    case PATHED_MAT_PLASTIC: if (TRAITS::has(PATHED_MAT_PLASTIC)) { return plasticSample(m, isect, random); } break;
+    case PATHED_MAT_LAMBERTIAN: if (TRAITS::has(PATHED_MAT_LAMBERTIAN)) { return lambertianSample<TRAITS::varyingAlbedo, TRAITS::pairedTrig>(m, isect, random); } break;
+    case PATHED_MAT_OREN_NAYAR: if (TRAITS::has(PATHED_MAT_OREN_NAYAR)) { return orenNayarSample<TRAITS::pairedTrig>(m, isect, random); } break;
+    case PATHED_MAT_MICROFACET: if (TRAITS::has(PATHED_MAT_MICROFACET)) { return microfacetSample<TRAITS::pairedTrig>(m, isect, random); } break;
+    case PATHED_MAT_PLASTIC: if (TRAITS::has(PATHED_MAT_PLASTIC)) { return plasticSample<TRAITS::pairedTrig>(m, isect, random); } break;
     case PATHED_MAT_GLASS: if (TRAITS::has(PATHED_MAT_GLASS)) { return glassSample(m, isect, random); } break;
     default: break;
     }
@@ -708,12 +735,15 @@ __device__ inline float uniformConePdf(float cosThetaMax)
 }
 
 // src/sphere.cpp:54-70
+template <bool PAIRED = false>
 __device__ inline SurfaceSample sphereSampleArea(V3 center, float radius, Rng &random)
 {
     const float z = 1 - 2 * random.next();
     const float r = sqrtf(fmaxf(0, 1 - z * z));
     const float phi = twoPiTimes(random.next());
-    const V3 v = v3(r * cosf(phi), r * sinf(phi), z);
+    float cosPhi, sinPhi;
+    cosSin<PAIRED>(phi, &cosPhi, &sinPhi);
+    const V3 v = v3(r * cosPhi, r * sinPhi, z);
 
     SurfaceSample sample;
     sample.point = center + v * radius;
@@ -724,11 +754,12 @@ __device__ inline SurfaceSample sphereSampleArea(V3 center, float radius, Rng &r
 }
 
 // src/sphere.cpp:77-128 (samples about the UNTRANSFORMED centre, as the reference does)
+template <bool PAIRED = false>
 __device__ inline SurfaceSample sphereSample(V3 center, float radius, V3 referencePoint, Rng &random)
 {
     const float centerDistance = length(center - referencePoint);
     const float centerDistance2 = centerDistance * centerDistance;
-    if (centerDistance <= radius) { return sphereSampleArea(center, radius, random); }
+    if (centerDistance <= radius) { return sphereSampleArea<PAIRED>(center, radius, random); }
 
     const float radius2 = radius * radius;
     const float sin2ThetaMax = radius * radius / centerDistance2;
@@ -749,7 +780,7 @@ __device__ inline SurfaceSample sphereSample(V3 center, float radius, V3 referen
         0.f, 1.f);
     const float sinAlpha = sinFromCos(cosAlpha);
 
-    const V3 localSample = sphericalToCartesian(phi, cosAlpha, sinAlpha);
+    const V3 localSample = sphericalToCartesian<PAIRED>(phi, cosAlpha, sinAlpha);
     const Frame localToWorld = normalToWorldSpace1(normalized(referencePoint - center));
     const V3 worldSample = normalized(toWorld(localToWorld, localSample));
 
@@ -855,6 +886,7 @@ __device__ inline Rgb envEmit(const DEnv &env, V3 lightWo)
 }
 
 // EnvironmentLight::sample, src/environment_light.cpp:82-105
+template <bool PAIRED = false>
 __device__ inline SurfaceSample envSample(const DEnv &env, V3 point, Rng &random)
 {
     float thetaPDF, phiPDF;
@@ -869,9 +901,11 @@ __device__ inline SurfaceSample envSample(const DEnv &env, V3 point, Rng &random
     const float phi = phiCanonical * PATHED_TWO_PI;
     const float theta = (float)((double)thetaCanonical * 3.14159265358979323846);   // M_PI is a double: src/environment_light.cpp:92
 
-    const float pdf = thetaPDF * phiPDF * env.width * env.height / (sinf(theta) * PATHED_TWO_PI * PATHED_PI);
+    float cosTheta, sinTheta;
+    cosSin<PAIRED>(theta, &cosTheta, &sinTheta);
+    const float pdf = thetaPDF * phiPDF * env.width * env.height / (sinTheta * PATHED_TWO_PI * PATHED_PI);
 
-    const V3 direction = apply3x3(env.mapToWorld, sphericalToCartesian(phi, cosf(theta), sinf(theta)));
+    const V3 direction = apply3x3(env.mapToWorld, sphericalToCartesian<PAIRED>(phi, cosTheta, sinTheta));
 
     SurfaceSample out;
     out.point = point + direction * 10000.f;
