@@ -280,6 +280,10 @@ typedef struct PathedSceneOptions {
                                    64-byte nodes (the boxes on an 8-bit grid over their union, rounded outward: same hits);
                                    3 compressed 8-wide nodes (128 bytes, up to eight children: grandchildren pulled up) --
                                    2 and 3: sphere-free scenes whose tree stays in HBM, per-slot pipeline; an error elsewhere */
+    int32_t small_phase1;       /* the fused kernel's conservative all-triangles pass (phase 1 of rtcIntersect1 / rtcOccluded1,
+                                   reference src/scene.cpp:113,374): 0 automatic; 1 on the VALU (packed Moeller-Trumbore);
+                                   2 on the matrix pipe (v_mfma_f32_32x32x2_f32 over Pluecker rows, mfma_candidates.h) --
+                                   phase 2 decides either way: hits and images are bit-identical */
 } PathedSceneOptions;
 int pathed_hip_scene_create_ex(const PathedSceneDesc *desc, const PathedSceneOptions *options, PathedScene **out);
 int pathed_hip_scene_device(const PathedScene *scene);   /* the HIP device the scene lives on, or a negative error */
@@ -340,6 +344,15 @@ int pathed_hip_set_samples_per_unit(PathedScene *scene, int samples);
  *               hits = n * int32 (1 = occluded). */
 int pathed_hip_trace(PathedScene *scene, const float *rays, size_t n,
                      int any_hit, void *hits);
+
+/* Test hook onto phase 1 of the all-triangles intersector (scenes of <= 64 triangles; the stand-in for
+ * rtcIntersect1 / rtcOccluded1 on such scenes, reference src/scene.cpp:113,374).
+ * rays: n * 10 floats (origin.xyz, continuation direction.xyz, shadow direction.xyz, shadow tfar), host memory.
+ * out:  n * 6 x uint64, bit k = leaf-ordered triangle k:
+ *       candidates of the VALU phase 1 (continuation, shadow), candidates of the matrix-pipe phase 1 (continuation,
+ *       shadow), triangles phase 2 accepts (continuation: t in (1e-3, 1e5]; shadow: t in (1e-3, tfar]).
+ * Phase 1 is correct iff accepted is a subset of candidates for every ray. */
+int pathed_hip_debug_small_candidates(PathedScene *scene, const float *rays, size_t n, uint64_t *out);
 
 /* Bit 0: the counting variants of the trace kernel (nodes_visited / tris_tested); off by default, the
  * timed path never counts.  Bit 1: HIP-event pairs around every trace and shade launch (trace_ms,

@@ -154,6 +154,7 @@ class PathedSceneOptions(C.Structure):
         ("build_threads", C.c_int32),
         ("generic_kernels", C.c_int32),
         ("node_format", C.c_int32),
+        ("small_phase1", C.c_int32),
     ]
 
 
@@ -176,6 +177,7 @@ HIP_SYMBOLS = [
     "pathed_hip_render",
     "pathed_hip_render_device",
     "pathed_hip_trace",
+    "pathed_hip_debug_small_candidates",
     "pathed_hip_set_samples_per_unit",
     "pathed_hip_set_integrator",
     "pathed_hip_set_stats_mode",
@@ -272,6 +274,8 @@ def load_hip():
     lib.pathed_hip_render_device.restype = C.c_int
     lib.pathed_hip_trace.argtypes = [vp, C.POINTER(C.c_float), C.c_size_t, C.c_int, vp]
     lib.pathed_hip_trace.restype = C.c_int
+    lib.pathed_hip_debug_small_candidates.argtypes = [vp, C.POINTER(C.c_float), C.c_size_t, C.POINTER(C.c_uint64)]
+    lib.pathed_hip_debug_small_candidates.restype = C.c_int
     lib.pathed_hip_set_samples_per_unit.argtypes = [vp, C.c_int]
     lib.pathed_hip_set_samples_per_unit.restype = C.c_int
     lib.pathed_hip_set_integrator.argtypes = [vp, C.c_int]

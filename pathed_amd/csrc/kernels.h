@@ -24,6 +24,7 @@
 // State is SoA-of-float4 in HBM so a wave reads 1 KiB contiguous per stream.
 #pragma once
 
+#include "mfma_candidates.h"
 #include "shading.h"
 #include "trace.h"
 #include "volume.h"
@@ -197,6 +198,8 @@ struct RenderParams {
     uint32_t seedLo, seedHi;
     uint32_t sppBegin, sppEnd;
     int startBounce, lastBounce;
+    const float *mfmaTable;   // k_path_small<.., MFMA>: the A-side rows of the matrix-pipe phase 1 (mfma_candidates.h), kMfmaTableFloats
+    MfmaFrame mfmaFrame;
 };
 
 // BounceController, reference src/bounce_controller.cpp:14-25
@@ -2688,10 +2691,16 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_R
 #define PATHED_FUSED_WAVES 4
 #endif
 // TRAITS: the compile-time set of material / light / albedo kinds the scene may contain (shading.h: SceneTraits)
-template <bool LDS_MATERIALS, bool COUNT, typename TRAITS>
+// MFMA: phase 1 of both ray queries on the matrix pipe (mfma_candidates.h) instead of smallCandidatesPair
+template <bool LDS_MATERIALS, bool COUNT, typename TRAITS, bool MFMA = false>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_FUSED_WAVES, PATHED_FUSED_WAVES))) void k_path_small(RenderParams p, SmallTris smallTris)
 {
     extern __shared__ float4 ldsDynamic[];           // LDS_MATERIALS: the material table, nMaterials x 96 B
+    __shared__ float mfmaRows[MFMA ? kMfmaTableFloats : 1];
+    if (MFMA) {
+        for (int i = threadIdx.x; i < kMfmaTableFloats; i += kBlock) { mfmaRows[i] = p.mfmaTable[i]; }
+        if (!LDS_MATERIALS) { __syncthreads(); }
+    }
     MaterialAccess<LDS_MATERIALS> materials;
     if (LDS_MATERIALS) {
         const int words = p.scene.nMaterials * (int)(sizeof(DMaterial) / 4);
@@ -2815,7 +2824,13 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_F
             laneRayInit(shadowRay, o, shadowDirection, PATHED_TNEAR, shadowTfar, true);
             unsigned int candidatesLow = 0, candidatesHigh = 0, shadowLow = 0, shadowHigh = 0;
             SHADE_REGION(2, traceShadow);   // passes that carry shadow rays / lanes with one
-            if (__ballot(traceShadow) != 0ull) {
+            if (MFMA) {
+                // every lane takes part (the matrix instructions are the wave's); words: even / odd triangles
+                mfmaCandidatesPair(mfmaRows, nTris, p.mfmaFrame, __ballot(traceShadow) != 0ull, o, d, shadowDirection,
+                                   candidateNear(PATHED_TNEAR), candidateFar(shadowTfar), &candidatesLow, &candidatesHigh, &shadowLow, &shadowHigh);
+                if (!alive) { candidatesLow = 0u; candidatesHigh = 0u; }
+                if (!traceShadow) { shadowLow = 0u; shadowHigh = 0u; }
+            } else if (__ballot(traceShadow) != 0ull) {
                 if (alive) {
                     smallCandidatesPair(smallTris.data, nTris, o, d, shadowDirection, &candidatesLow, &candidatesHigh, &shadowLow, &shadowHigh,
                                         candidateNear(PATHED_TNEAR), candidateFar(shadowTfar));
@@ -2831,8 +2846,13 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_F
             }
             RESOLVE_PROBE(9, candidatesLow, candidatesHigh);   // (profile builds) the resolve loops: iterations, candidates
             RESOLVE_PROBE(10, shadowLow, shadowHigh);
-            smallResolve(geometry, ray, candidatesLow, candidatesHigh);
-            smallResolve(geometry, shadowRay, shadowLow, shadowHigh);
+            if (MFMA) {
+                mfmaResolve(geometry, ray, candidatesLow, candidatesHigh);
+                mfmaResolve(geometry, shadowRay, shadowLow, shadowHigh);
+            } else {
+                smallResolve(geometry, ray, candidatesLow, candidatesHigh);
+                smallResolve(geometry, shadowRay, shadowLow, shadowHigh);
+            }
             if (alive) { finishRay(geometry, ray); }
             if (traceShadow) {
                 finishRay(geometry, shadowRay);
@@ -3014,6 +3034,44 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_F
         atomicAdd(&p.stats[kStatTris], (unsigned long long)trisTested);
         atomicAdd(&p.stats[kStatClosest], (unsigned long long)closestRays);
         atomicAdd(&p.stats[kStatShadow], (unsigned long long)shadowRays);
+    }
+}
+
+// Test hook behind pathed_hip_debug_small_candidates: for every ray pair (origin, continuation direction, shadow direction,
+// shadow far bound) the candidate sets of both phase-1 forms and the set phase 2 would accept, one bit per leaf-ordered
+// triangle.  n is padded to whole waves by the host (the matrix instructions need every lane).
+__global__ __launch_bounds__(kBlock) void k_debug_small_candidates(DScene scene, SmallTris smallTris, const float *mfmaTable, MfmaFrame frame,
+                                                                   const float *rays, int n, unsigned long long *out)
+{
+    __shared__ float mfmaRows[kMfmaTableFloats];
+    for (int i = threadIdx.x; i < kMfmaTableFloats; i += kBlock) { mfmaRows[i] = mfmaTable[i]; }
+    __syncthreads();
+    const int index = blockIdx.x * kBlock + threadIdx.x;
+    const float *r = rays + (size_t)10 * index;
+    const V3 o = v3(r[0], r[1], r[2]), dA = v3(r[3], r[4], r[5]), dB = v3(r[6], r[7], r[8]);
+    const float tfarB = r[9];
+    const int nTris = scene.nTris;
+
+    unsigned int aLow, aHigh, bLow, bHigh;
+    smallCandidatesPair(smallTris.data, nTris, o, dA, dB, &aLow, &aHigh, &bLow, &bHigh, candidateNear(PATHED_TNEAR), candidateFar(tfarB));
+    unsigned int evenA, oddA, evenB, oddB;
+    mfmaCandidatesPair(mfmaRows, nTris, frame, true, o, dA, dB, candidateNear(PATHED_TNEAR), candidateFar(tfarB), &evenA, &oddA, &evenB, &oddB);
+
+    unsigned long long valuA = 0, valuB = 0, mfmaA = 0, mfmaB = 0, acceptA = 0, acceptB = 0;
+    for (int k = 0; k < nTris; k++) {
+        const unsigned long long bit = 1ull << k;
+        if (((k < 32 ? aLow : aHigh) >> (31 - (k & 31))) & 1u) { valuA |= bit; }
+        if (((k < 32 ? bLow : bHigh) >> (31 - (k & 31))) & 1u) { valuB |= bit; }
+        if ((((k & 1) ? oddA : evenA) >> (k >> 1)) & 1u) { mfmaA |= bit; }
+        if ((((k & 1) ? oddB : evenB) >> (k >> 1)) & 1u) { mfmaB |= bit; }
+        const float4 t0 = scene.leafTris[3 * k + 0], t1 = scene.leafTris[3 * k + 1], t2 = scene.leafTris[3 * k + 2];
+        float t, u, v;
+        if (intersectTriangle(o, dA, v3(t0.x, t0.y, t0.z), v3(t1.x, t1.y, t1.z), v3(t2.x, t2.y, t2.z), &t, &u, &v) && t > PATHED_TNEAR && t <= PATHED_TFAR) { acceptA |= bit; }
+        if (intersectTriangle(o, dB, v3(t0.x, t0.y, t0.z), v3(t1.x, t1.y, t1.z), v3(t2.x, t2.y, t2.z), &t, &u, &v) && t > PATHED_TNEAR && t <= tfarB) { acceptB |= bit; }
+    }
+    if (index < n) {
+        unsigned long long *row = out + (size_t)6 * index;
+        row[0] = valuA; row[1] = valuB; row[2] = mfmaA; row[3] = mfmaB; row[4] = acceptA; row[5] = acceptB;
     }
 }
 

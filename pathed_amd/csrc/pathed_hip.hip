@@ -48,6 +48,11 @@ struct DeviceBuffer {
     T *ptr = nullptr;
     size_t count = 0;
 
+    DeviceBuffer() = default;
+    DeviceBuffer(const DeviceBuffer &) = delete;              // owns its allocation: a member added to PathedScene
+    DeviceBuffer &operator=(const DeviceBuffer &) = delete;   // is freed with it, whether or not ~PathedScene names it
+    ~DeviceBuffer() { release(); }
+
     hipError_t allocate(size_t n)
     {
         const bool report = getenv("PATHED_DEBUG_ALLOC") != nullptr && n * sizeof(T) >= ((size_t)1 << 28);
@@ -145,6 +150,8 @@ struct EventRing {
 }  // namespace
 
 static const int kMaxPools = 4;
+static const int kDefaultSmallPhase1 = 1;   // PathedSceneOptions.small_phase1 = 0: 1 VALU, 2 matrix pipe
+
 
 struct PathedScene {
     DScene device;
@@ -209,6 +216,9 @@ struct PathedScene {
     bool sceneInLds = false;
     bool bruteForce = false;      // <= kBruteForceMaxTris triangles: test them all, no BVH walk
     SmallTris smallTris;          // their records, passed to k_trace_small as a kernel argument
+    bool mfmaPhase1 = false;      // k_path_small<.., MFMA>: phase 1 on the matrix pipe (mfma_candidates.h)
+    DeviceBuffer<float> mfmaTable;   // its A-side rows
+    MfmaFrame mfmaFrame;
     size_t traceLdsBytes = 0;
     int traceGrid = 0;
     int suspendLanes = kSuspendLanes;  // PATHED_SUSPEND_LANES overrides (0 = off)
@@ -226,7 +236,7 @@ struct PathedScene {
 
     ~PathedScene()
     {
-        nodes.release(); leafTris.release(); triShade.release(); triCompact.release(); envRgba.release(); texels.release();
+        nodes.release(); nodesQ.release(); leafTris.release(); triShade.release(); triCompact.release(); envRgba.release(); texels.release();
         spheres.release(); materials.release(); lights.release();
         thetaCdf.release(); phiCdf.release(); phiEmpty.release(); thetaGuide.release(); phiGuide.release();
         media.release(); primMedium.release(); volumeOverflow.release();
@@ -1083,6 +1093,7 @@ int pathed_hip_scene_create_ex(const PathedSceneDesc *desc, const PathedSceneOpt
         if (options.max_slots < 0 || (options.max_slots != 0 && options.max_slots < kBlock)) { return fail(PATHED_E_INVALID, "max_slots must be 0 or >= 256"); }
         if (options.shade_kernel < 0 || options.shade_kernel > 4) { return fail(PATHED_E_INVALID, "shade_kernel must be 0..4"); }
         if (options.stage_slots != 0 && options.stage_slots != 512 && options.stage_slots != 1024) { return fail(PATHED_E_INVALID, "stage_slots must be 0, 512 or 1024"); }
+        if (options.small_phase1 < 0 || options.small_phase1 > 2) { return fail(PATHED_E_INVALID, "small_phase1 must be 0 (automatic), 1 (VALU) or 2 (matrix pipe)"); }
     }
     int deviceId = options.device;
     if (deviceId == PATHED_DEVICE_CURRENT) {
@@ -1534,6 +1545,21 @@ int pathed_hip_scene_create_ex(const PathedSceneDesc *desc, const PathedSceneOpt
             }
         }
     }
+    scene->mfmaPhase1 = false;
+    std::memset(&scene->mfmaFrame, 0, sizeof scene->mfmaFrame);
+    if (scene->bruteForce && scene->fusedPath) {
+        int phase1 = options.small_phase1;
+        if (const char *text = getenv("PATHED_SMALL_PHASE1")) {
+            if (!strcmp(text, "valu")) { phase1 = 1; } else if (!strcmp(text, "mfma")) { phase1 = 2; }
+        }
+        if (phase1 == 0) { phase1 = kDefaultSmallPhase1; }
+        if (phase1 == 2 && scene->device.nTris > 0) {
+            std::vector<float> table;
+            buildMfmaTable(scene->bvh.leafTris.data(), scene->device.nTris, scene->device.camera.origin, 1, &table, &scene->mfmaFrame);
+            if ((status = scene->mfmaTable.upload(table)) != hipSuccess) { return fail_cleanup(status, "upload the matrix-pipe rows"); }
+            scene->mfmaPhase1 = true;
+        }
+    }
     scene->unitOrder = unitOrderFromEnvironment(options.unit_order == 2 ? kOrderStripesTiled : options.unit_order == 3 ? kOrderTiles : kOrderStripes);
     if (options.max_slots >= kBlock) { scene->maxSlots = options.max_slots; scene->adaptiveSlots = false; }
     if (const char *slots = getenv("PATHED_MAX_SLOTS")) {
@@ -1665,7 +1691,21 @@ static int renderPassFused(PathedScene *scene, uint64_t seed, uint32_t begin, ui
         (void)hipEventRecord(scene->traceEvents.start[timed], stream);
     }
     // the narrowest instantiation whose compile-time scene set contains this scene's (shading.h: SceneTraits)
-    if (scene->lambertianTriangles) {
+    params.mfmaTable = scene->mfmaTable.ptr;
+    params.mfmaFrame = scene->mfmaFrame;
+    if (scene->mfmaPhase1 && ldsMaterials) {
+        // phase 1 on the matrix pipe: the same instantiations with MFMA = true
+        if (scene->lambertianTriangles) {
+            if (scene->countMode) { hipLaunchKernelGGL((k_path_small<true, true, TraitsLambertianTriangles, true>), grid, block, lds, stream, params, scene->smallTris); }
+            else { hipLaunchKernelGGL((k_path_small<true, false, TraitsLambertianTriangles, true>), grid, block, lds, stream, params, scene->smallTris); }
+        } else if (scene->lambertianPlasticSpheres) {
+            if (scene->countMode) { hipLaunchKernelGGL((k_path_small<true, true, TraitsLambertianPlasticSpheres, true>), grid, block, lds, stream, params, scene->smallTris); }
+            else { hipLaunchKernelGGL((k_path_small<true, false, TraitsLambertianPlasticSpheres, true>), grid, block, lds, stream, params, scene->smallTris); }
+        } else {
+            if (scene->countMode) { hipLaunchKernelGGL((k_path_small<true, true, TraitsAll, true>), grid, block, lds, stream, params, scene->smallTris); }
+            else { hipLaunchKernelGGL((k_path_small<true, false, TraitsAll, true>), grid, block, lds, stream, params, scene->smallTris); }
+        }
+    } else if (scene->lambertianTriangles) {
         if (ldsMaterials) {
             if (scene->countMode) { hipLaunchKernelGGL((k_path_small<true, true, TraitsLambertianTriangles>), grid, block, lds, stream, params, scene->smallTris); }
             else { hipLaunchKernelGGL((k_path_small<true, false, TraitsLambertianTriangles>), grid, block, lds, stream, params, scene->smallTris); }
@@ -2135,6 +2175,35 @@ int pathed_hip_trace(PathedScene *scene, const float *rays, size_t n, int any_hi
     if (deviceOccluded) { (void)hipFree(deviceOccluded); }
     if (deviceOverflow) { (void)hipFree(deviceOverflow); }
     if (status != hipSuccess) { return fail(PATHED_E_DEVICE, hipGetErrorString(status)); }
+    return PATHED_OK;
+}
+
+int pathed_hip_debug_small_candidates(PathedScene *scene, const float *rays, size_t n, uint64_t *out)
+{
+    if (!scene) { return fail(PATHED_E_INVALID, "null scene"); }
+    if (!scene->bruteForce || scene->device.nTris < 1) { return fail(PATHED_E_UNSUPPORTED, "the all-triangles intersector serves scenes of 1..64 triangles"); }
+    if (n == 0) { return PATHED_OK; }
+    if (!rays || !out) { return fail(PATHED_E_INVALID, "null ray or output buffer"); }
+    if (n > (size_t)1 << 24) { return fail(PATHED_E_INVALID, "too many rays in one call"); }
+    SELECT_DEVICE(scene);
+    if (!scene->mfmaTable.ptr) {
+        std::vector<float> table;
+        buildMfmaTable(scene->bvh.leafTris.data(), scene->device.nTris, scene->device.camera.origin, 1, &table, &scene->mfmaFrame);
+        HIP_TRY(scene->mfmaTable.upload(table));
+    }
+    const size_t padded = (n + kBlock - 1) / kBlock * kBlock;   // whole blocks: every lane of a wave issues the matrix instructions
+    std::vector<float> hostRays(padded * 10, 0.f);
+    std::memcpy(hostRays.data(), rays, n * 10 * sizeof(float));
+    for (size_t i = n; i < padded; i++) { hostRays[10 * i + 5] = 1.f; hostRays[10 * i + 8] = 1.f; }
+    DeviceBuffer<float> deviceRays;
+    DeviceBuffer<unsigned long long> deviceOut;
+    HIP_TRY(deviceRays.upload(hostRays));
+    HIP_TRY(deviceOut.allocate(n * 6));
+    hipLaunchKernelGGL(k_debug_small_candidates, dim3((unsigned)(padded / kBlock)), dim3(kBlock), 0, nullptr, scene->device, scene->smallTris,
+                       scene->mfmaTable.ptr, scene->mfmaFrame, deviceRays.ptr, (int)n, deviceOut.ptr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, deviceOut.ptr, n * 6 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return PATHED_OK;
 }
 

@@ -68,7 +68,7 @@ class HipScene:
     Keyword options map onto PathedSceneOptions (include/pathed_hip.h): stack_rows, pools,
     suspend_lanes, suspend_patience, park_min_cards, max_slots, build_threads, generic_kernels, intersector ("auto" | "bvh"),
     trace_blocks_per_cu, shade_kernel ("auto" | "per-slot" | "staged" | "fused" | "split"), stage_slots,
-    unit_order ("auto" | "stripes" | "stripes-tiled" | "tiles"), node_format ("auto" | "wide" | "compressed" | "compressed8").  `device=None` keeps the device of an earlier pathed_hip_init.
+    unit_order ("auto" | "stripes" | "stripes-tiled" | "tiles"), node_format ("auto" | "wide" | "compressed" | "compressed8"), small_phase1 ("auto" | "valu" | "mfma").  `device=None` keeps the device of an earlier pathed_hip_init.
     """
 
     BVH_BUILDERS = {"sah": 0, "lbvh": 1, "ploc": 2}  # PATHED_BVH_SAH_HOST / _LBVH_DEVICE / _PLOC_DEVICE
@@ -84,6 +84,7 @@ class HipScene:
         packed.shade_kernel = {"auto": 0, "per-slot": 1, "staged": 2, "fused": 3, "split": 4}[options.pop("shade_kernel", "auto")]
         packed.node_format = {"auto": 0, "wide": 1, "compressed": 2, "compressed8": 3}[options.pop("node_format", "auto")]
         packed.unit_order = {"auto": 0, "stripes": 1, "stripes-tiled": 2, "tiles": 3}[options.pop("unit_order", "auto")]
+        packed.small_phase1 = {"auto": 0, "valu": 1, "mfma": 2}[options.pop("small_phase1", "auto")]
         for name in ("stack_rows", "pools", "suspend_lanes", "suspend_patience", "park_min_cards", "max_slots", "trace_blocks_per_cu", "stage_slots", "build_threads", "generic_kernels"):
             if name in options:
                 setattr(packed, name, int(options.pop(name)))
@@ -134,6 +135,16 @@ class HipScene:
             self._handle, rays.ctypes.data_as(C.POINTER(C.c_float)), n, 1 if any_hit else 0,
             out.ctypes.data_as(C.c_void_p))
         _check(self._lib, code, "pathed_hip_trace")
+        return out
+
+    def small_candidates(self, rays):
+        """Phase-1 candidate sets of both forms and the set phase 2 accepts (pathed_hip_debug_small_candidates): rays (n, 10) =
+        origin, continuation direction, shadow direction, shadow tfar -> (n, 6) uint64, bit k = leaf-ordered triangle k."""
+        rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 10)
+        out = np.zeros((rays.shape[0], 6), dtype=np.uint64)
+        code = self._lib.pathed_hip_debug_small_candidates(
+            self._handle, rays.ctypes.data_as(C.POINTER(C.c_float)), rays.shape[0], out.ctypes.data_as(C.POINTER(C.c_uint64)))
+        _check(self._lib, code, "pathed_hip_debug_small_candidates")
         return out
 
     def set_samples_per_unit(self, samples):
