@@ -23,7 +23,7 @@ HOST_HDR  = $(wildcard pathed_amd/host/*.h) include/pathed_hip.h
 HIP_SRC   = $(wildcard pathed_amd/csrc/*.hip)
 HIP_HDR   = $(wildcard pathed_amd/csrc/*.h) include/pathed_hip.h
 
-.PHONY: all host hip oracle ref assets clean
+.PHONY: all host hip oracle ref assets experiments clean
 
 all: hip host oracle ref assets
 
@@ -34,6 +34,14 @@ oracle: oracle/liboracle.so
 $(LIBDIR)/libpathed_hip.so: $(HIP_SRC) $(HIP_HDR)
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(HIP_SRC)
+
+# The measured-and-rejected kernel organisations (kernels_experiments.h: staged and split shade stages, compressed node
+# formats, the matrix-pipe phase 1, the clocked VALU probe) are NOT part of `make all`.  Load the result with
+# PATHED_HIP_LIB=pathed_amd/lib/libpathed_hip_experiments.so (pathed_amd/_capi.py); tests: pytest -m experiments.
+experiments: $(LIBDIR)/libpathed_hip_experiments.so
+$(LIBDIR)/libpathed_hip_experiments.so: $(HIP_SRC) $(HIP_HDR)
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) $(HIPFLAGS) -DPATHED_EXPERIMENTS=1 -shared -o $@ $(HIP_SRC)
 
 $(LIBDIR)/libpathed_host.so: $(HOST_LIB_SRC) $(HOST_HDR) $(LIBDIR)/libpathed_hip.so
 	@mkdir -p $(LIBDIR)

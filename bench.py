@@ -48,8 +48,10 @@ def parse_args():
     parser.add_argument("--scene", default="scenes/cornell.json")
     parser.add_argument("--last-bounce", type=int, default=10)
     parser.add_argument("--seed", type=int, default=1)
-    parser.add_argument("--bvh-builder", default="sah", choices=["sah", "lbvh", "ploc"],
-                        help="host binned-SAH build (default) or an on-GPU build; only matters for scenes of more than 64 triangles")
+    parser.add_argument("--bvh-builder", default="auto", choices=["auto", "sah", "lbvh", "ploc"],
+                        help="auto: the host binned-SAH build on one GPU, the on-GPU PLOC build when several ranks each need the tree of a "
+                             "mesh of more than a million triangles (N host builds side by side would be seconds of serial time per rank); "
+                             "only matters for scenes of more than 64 triangles")
     parser.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                         help="collective backend: nccl (= RCCL over xGMI); gloo stages the reduce through host memory (rehearsals)")
     parser.add_argument("--share-gpu", action="store_true",
@@ -171,16 +173,48 @@ def scene_description(scene, stats):
         desc.n_triangles, desc.n_spheres, ", ".join(kinds[k] for k in used), lights, intersector)
 
 
+def usable_cores():
+    """Host threads this process can really run at once: the scheduler affinity, cut to the cgroup's CPU quota (a GPU
+    box hands a job a share of its cores; os.cpu_count() reports the whole machine, and 256 threads on a 16-core share
+    is what made earlier rounds' baseline scale 10x on "256 threads")."""
+    try:
+        count = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        count = os.cpu_count() or 1
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as handle:   # cgroup v2: "<quota|max> <period>"
+            first, period = handle.read().split()[:2]
+            if first != "max":
+                quota = float(first) / float(period)
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as q, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as p:
+                value = float(q.read())
+                if value > 0:
+                    quota = value / float(p.read())
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        count = max(1, min(count, int(quota + 0.999)))
+    return count
+
+
 def cpu_baseline(scene, args):
     """Time the CPU oracle on the same workload at reduced spp (rate is spp-independent)."""
     sys.path.insert(0, os.path.join(REPO_ROOT, "tests"))
     import oracle_lib  # the checker; used here only as the reported CPU baseline
 
-    cores = os.cpu_count() or 1
+    allowed = usable_cores()
     oracle = oracle_lib.OracleScene(scene.desc)
-    t0 = time.perf_counter()
-    oracle.render(args.width, args.height, args.seed, 0, 1, 0, args.last_bounce, threads=cores)
-    one = time.perf_counter() - t0
+    # the thread count that is fastest HERE: a box may report more hardware threads than the share of it this job runs on
+    one, cores = None, allowed
+    for candidate in sorted({min(count, allowed) for count in (16, 32, 64, 128, allowed)}):
+        t0 = time.perf_counter()
+        oracle.render(args.width, args.height, args.seed, 0, 1, 0, args.last_bounce, threads=candidate)
+        took = time.perf_counter() - t0
+        if one is None or took < one:
+            one, cores = took, candidate
     spp = max(1, min(64, int(15.0 / max(one, 1e-3))))
     t0 = time.perf_counter()
     oracle.render(args.width, args.height, args.seed, 1, spp, 0, args.last_bounce, threads=cores)
@@ -201,15 +235,19 @@ def cpu_baseline(scene, args):
                 break
     except OSError:
         pass
+    rate, single_rate = samples / elapsed / 1e6, 256 * 256 * 2 / single / 1e6
     return {
-        "value": samples / elapsed / 1e6,
+        "value": rate,
         "unit": "Msamples/s",
         "cores": cores,
+        "threads": cores,
+        "machine_threads": os.cpu_count(),
         "cpu_model": model,
-        "single_thread": 256 * 256 * 2 / single / 1e6,
+        "single_thread": single_rate,
+        "parallel_efficiency": rate / (cores * single_rate),
         "kind": "port",
-        "sample": "%s %dx%d, %d spp, lastBounce %d, OpenMP over rows, %.1f s" % (
-            args.scene, args.width, args.height, spp, args.last_bounce, elapsed),
+        "sample": "%s %dx%d, %d spp, lastBounce %d, OpenMP over rows (dynamic), %d threads (the fastest of 16 / 32 / 64 / 128 / all usable on this box), %.1f s" % (
+            args.scene, args.width, args.height, spp, args.last_bounce, cores, elapsed),
     }
 
 
@@ -412,8 +450,12 @@ def run_rank(args):
     from pathed_amd.integrator import HipScene, measure_bandwidth
     from pathed_amd.scene import LoadedScene
 
+    setup_begin = time.perf_counter()
     scene = LoadedScene(args.scene, args.width, args.height)
+    if args.bvh_builder == "auto":
+        args.bvh_builder = "ploc" if (world_size > 1 and scene.n_triangles > 1000000) else "sah"
     gpu = HipScene(scene.desc, device=local_rank, bvh_builder=args.bvh_builder)
+    setup_s = time.perf_counter() - setup_begin   # scene file -> flat description -> BVH -> upload, this rank
     stream = torch.cuda.current_stream().cuda_stream
 
     accum = torch.zeros((args.height, args.width, 3), dtype=torch.float32, device="cuda")
@@ -492,7 +534,7 @@ def run_rank(args):
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
 
-    per_rank = [[rendered, reduced - rendered, elapsed]]
+    per_rank = [[rendered, reduced - rendered, elapsed, setup_s]]
     if distributed:
         mine = torch.tensor(per_rank[0], dtype=torch.float64, device="cpu" if staged else "cuda")
         gathered = [torch.zeros_like(mine) for _ in range(world_size)]
@@ -540,37 +582,40 @@ def run_rank(args):
                 # reaches on THIS box with independent v_fma_f32 on VGPR operands (pathed_hip_measure_valu_modes);
                 # numerator: SQ_INSTS_VALU per camera sample from the committed PMC pass x the samples of the timed
                 # region / the kernels' own time, measured live with HIP events (fused kernel: every launch).
-                from pathed_amd.integrator import VALU_MODES, measure_valu_clocks, measure_valu_modes
+                from pathed_amd.integrator import VALU_MODES, measure_valu_modes
                 probes = {waves: measure_valu_modes(waves, repeats=5) for waves in (1, 4, 8)}
-                # the same instruction with the probe's own clocks, 2 / 4 / 8 waves per SIMD x 8 / 16 independent chains:
-                # cycles per instruction at the frequency the chip really ran at (it drops to ~2.2 GHz under this load)
-                clock_probe = {"%d waves, %d chains" % (waves, chains): measure_valu_clocks(waves, chains, repeats=5)
-                               for waves in (2, 4, 8) for chains in (8, 16)}
-                peak = max(max(row[2] for row in probes.values()), max(entry["rate"] for entry in clock_probe.values()))
-                peak_guide = 1228.8e9   # MI355X_MICROARCH.md constants table: v_fma_f32 wave64 2 cycles, 1024 SIMDs, 2.4 GHz
+                measured = max(row[2] for row in probes.values())
+                # the denominator is the GUIDE's: MI355X_MICROARCH.md constants table, v_fma_f32 wave64 2 cycles, 1 024 SIMDs, 2.4 GHz.
+                # What this box reaches with independent v_fma_f32 (it clocks ~2.2 GHz under the load and issues every ~2.5
+                # cycles) is reported beside it as peak_measured / frac_of_measured.
+                peak_guide = 1228.8e9
                 issued = pmc["valu_wave_instructions_per_sample"] * my_samples if pmc else None
                 kernel_s = (timed["trace_ms"] * 1e-3) if fused and timed["trace_ms"] > 0 else rendered
+                if hbm is None and traffic is not None and launches:
+                    # "report HBM fraction anyway and say the kernel is ALU-bound" -- the counter bytes of a launch
+                    # (partial sums out, scene records in) over the launch's own time
+                    per_launch_s = kernel_s / launches
+                    hbm = {"achieved": traffic / per_launch_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": traffic / per_launch_s / 1e9 / HBM_PEAK_GBS, "bytes_per_launch": traffic,
+                           "note": "the fused kernel keeps whole paths in registers: HBM sees the partial sums and the scene records only; "
+                                   "VALU issue bounds it, not memory"}
                 roofline = {
                     "bound": "valu",
                     "kernel": "k_path_small (fused: camera ray .. termination in registers, one persistent launch per pass)" if fused
                               else "whole wavefront pipeline (k_trace_small + shade kernel, both pools)",
                     "achieved": (issued / kernel_s / 1e9) if issued else None,
-                    "peak": peak / 1e9,
+                    "peak": peak_guide / 1e9,
                     "unit": "G wave-instr/s",
-                    "frac": (issued / kernel_s / peak) if issued else None,
-                    "peak_guide": peak_guide / 1e9,
-                    "frac_of_guide": (issued / kernel_s / peak_guide) if issued else None,
+                    "frac": (issued / kernel_s / peak_guide) if issued else None,
+                    "peak_measured": measured / 1e9,
+                    "frac_of_measured": (issued / kernel_s / measured) if issued else None,
                     "traffic": traffic,
                     "kernel_seconds": kernel_s, "launches": launches,
                     "rays_per_sample": (counted["closest_rays"] + counted["shadow_rays"]) / float(counted_samples),
-                    "peak_note": "peak = best rate any probe reaches on this box (v_fma_f32, three VGPR operands, 8 or 16 independent chains, "
-                                 "1..8 waves per SIMD); peak_guide = the guide's 2 cycles per instruction at 2.4 GHz",
+                    "peak_note": "peak = the guide's 2 cycles per v_fma_f32 per SIMD at 2.4 GHz; peak_measured = best rate of "
+                                 "pathed_hip_measure_valu_modes on this box (v_fma_f32, three VGPR operands, 8 chains, 1 / 4 / 8 waves per SIMD)",
                     "peak_probe": {"modes": list(VALU_MODES),
-                                   "waves_per_simd": {str(waves): [rate / 1e9 for rate in row] for waves, row in probes.items()},
-                                   "with_clocks": {key: {"g_instr_per_s": entry["rate"] / 1e9, "shader_clock_mhz": entry["shader_clock_mhz"],
-                                                         "cycles_per_instruction": entry["cycles_per_instruction_events"]}
-                                                   for key, entry in clock_probe.items()},
-                                   "note": "cycles_per_instruction = SIMDs x measured shader clock / rate; the guide's 2 cycles at 2.4 GHz is peak_guide"},
+                                   "waves_per_simd": {str(waves): [rate / 1e9 for rate in row] for waves, row in probes.items()}},
                     "instructions_source": None if not pmc else {
                         "file": "profiles/pmc_per_sample.json", "valu_wave_instructions_per_sample": pmc["valu_wave_instructions_per_sample"],
                         "stale": pmc["stale"]},
@@ -618,7 +663,9 @@ def run_rank(args):
                                    "reduce staged through host memory (gloo)" if staged else "RCCL reduce") if distributed else ", no exchange"),
                 "collective": None if not distributed else "%s, world size %d" % ("gloo (host-staged)" if staged else "nccl (RCCL)", world_size),
             },
-            "per_rank_s": {"render": [row[0] for row in per_rank], "reduce": [row[1] for row in per_rank], "total": [row[2] for row in per_rank]},
+            "per_rank_s": {"render": [row[0] for row in per_rank], "reduce": [row[1] for row in per_rank], "total": [row[2] for row in per_rank],
+                           "setup": [row[3] for row in per_rank]},
+            "bvh_builder": args.bvh_builder,
             "roofline": roofline,
             "cpu_baseline": baseline,
             "image_mean_rgb": mean,

@@ -354,6 +354,12 @@ int pathed_hip_trace(PathedScene *scene, const float *rays, size_t n,
  * Phase 1 is correct iff accepted is a subset of candidates for every ray. */
 int pathed_hip_debug_small_candidates(PathedScene *scene, const float *rays, size_t n, uint64_t *out);
 
+/* 1 in libpathed_hip_experiments.so (`make experiments`), 0 in the product library.  The experiments build adds the
+ * kernel organisations that were measured and rejected: shade_kernel 2 (staged) and 4 (split),
+ * node_format 2 / 3 (compressed nodes), small_phase1 2 (matrix pipe), pathed_hip_measure_valu_clocks and
+ * pathed_hip_debug_small_candidates.  The product library answers PATHED_E_UNSUPPORTED to each of them. */
+int pathed_hip_has_experiments(void);
+
 /* Bit 0: the counting variants of the trace kernel (nodes_visited / tris_tested); off by default, the
  * timed path never counts.  Bit 1: HIP-event pairs around every trace and shade launch (trace_ms,
  * shade_ms, trace_launches).  Bit 2: ... around every 8th launch only: the event pairs keep a pool's

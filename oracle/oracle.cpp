@@ -2260,12 +2260,15 @@ int oracle_render_chunked(OracleScene *scene, uint64_t seed, uint32_t spp_begin,
     if (threads > 1) { omp_set_num_threads(threads); }
 #endif
     /* rows in parallel, columns inside — src/sample_integrator.cpp:99-110; samples of a
-     * pixel are added in index order like the reference's wave loop (integrator.cpp:42) */
+     * pixel are added in index order like the reference's wave loop (integrator.cpp:42).
+     * The reference's loop is schedule(static); rows differ in cost by several times (walls vs
+     * the boxes), so the timed baseline hands rows out dynamically — a pixel's sum does not
+     * depend on which thread computes it, counters are per thread. */
 #pragma omp parallel if (threads > 1)
     {
         Counters local;
         std::memset(&local, 0, sizeof local);
-#pragma omp for schedule(static)
+#pragma omp for schedule(dynamic, 1)
         for (int row = 0; row < height; row++) {
             for (int col_ = 0; col_ < width; col_++) {
                 float *pixel = accum + 3 * ((size_t)row * width + col_);

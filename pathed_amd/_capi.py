@@ -178,6 +178,7 @@ HIP_SYMBOLS = [
     "pathed_hip_render_device",
     "pathed_hip_trace",
     "pathed_hip_debug_small_candidates",
+    "pathed_hip_has_experiments",
     "pathed_hip_set_samples_per_unit",
     "pathed_hip_set_integrator",
     "pathed_hip_set_stats_mode",
@@ -276,6 +277,8 @@ def load_hip():
     lib.pathed_hip_trace.restype = C.c_int
     lib.pathed_hip_debug_small_candidates.argtypes = [vp, C.POINTER(C.c_float), C.c_size_t, C.POINTER(C.c_uint64)]
     lib.pathed_hip_debug_small_candidates.restype = C.c_int
+    lib.pathed_hip_has_experiments.argtypes = []
+    lib.pathed_hip_has_experiments.restype = C.c_int
     lib.pathed_hip_set_samples_per_unit.argtypes = [vp, C.c_int]
     lib.pathed_hip_set_samples_per_unit.restype = C.c_int
     lib.pathed_hip_set_integrator.argtypes = [vp, C.c_int]

@@ -5,6 +5,12 @@
 
 #include "bvh_build.h"
 #include "kernels.h"
+#ifndef PATHED_EXPERIMENTS
+#define PATHED_EXPERIMENTS 0   // 1: `make experiments` -- the measured-and-rejected kernel organisations (kernels_experiments.h)
+#endif
+#if PATHED_EXPERIMENTS
+#include "kernels_experiments.h"
+#endif
 #include "lbvh.h"
 
 #include <hip/hip_runtime.h>
@@ -209,6 +215,7 @@ struct PathedScene {
     int vertexGrid = 0, regenGrid = 0;   // their persistent grids, blocks
     unsigned int listCap = 0;            // list blocks per shard
     DeviceBuffer<unsigned int> slotLists, deferredLists;
+    size_t deferredSlots = 0;            // slots deferredLists was sized for
     int stageRounds = 2;      // staged kernel: a block owns stageRounds x 256 slots
 
     int stackRows = 8;    // LDS rows of the per-lane traversal stack (8 / 16 / 22)
@@ -447,7 +454,11 @@ int ensureRenderState(PathedScene *scene, int nSlots, size_t chunkEntries)
         if (cap > scene->listCap || !scene->slotLists.ptr) {
             scene->listCap = cap;
             HIP_TRY(scene->slotLists.allocate((size_t)kMaxPools * 2 * (size_t)cap * kListShards * 64));
+        }
+        // sized and indexed with the slot count itself (cap rounds per 32 blocks: nSlots can grow without cap growing)
+        if ((size_t)scene->nSlots > scene->deferredSlots || !scene->deferredLists.ptr) {
             HIP_TRY(scene->deferredLists.allocate((size_t)kMaxPools * 4 * (size_t)scene->nSlots));
+            scene->deferredSlots = (size_t)scene->nSlots;
         }
     }
     if (!scene->counters.ptr) { HIP_TRY(scene->counters.allocate(kMaxPools * kCtrCount)); }
@@ -473,6 +484,7 @@ void launchTraceStack(PathedScene *scene, const RenderParams &params, hipStream_
 {
     const dim3 grid((unsigned)scene->traceGrid), block(kBlock);
     const size_t lds = scene->traceLdsBytes;
+#if PATHED_EXPERIMENTS
     if (scene->splitShade) {
         if (scene->sceneInLds) {
             if (scene->countMode) { hipLaunchKernelGGL((k_trace<STACK, true, true, true>), grid, block, lds, stream, params); }
@@ -493,6 +505,7 @@ void launchTraceStack(PathedScene *scene, const RenderParams &params, hipStream_
         else { hipLaunchKernelGGL((k_trace<STACK, false, false, false, false, 2>), grid, block, lds, stream, params); }
         return;
     }
+#endif
     if (!scene->sceneInLds && scene->device.nSpheres == 0 && !scene->options.generic_kernels && !getenv("PATHED_NO_SCENE_TRAITS")) {
         if (scene->countMode) { hipLaunchKernelGGL((k_trace<STACK, false, true, false, false>), grid, block, lds, stream, params); }
         else { hipLaunchKernelGGL((k_trace<STACK, false, false, false, false>), grid, block, lds, stream, params); }
@@ -526,6 +539,7 @@ void launchTrace(PathedScene *scene, const RenderParams &params, hipStream_t str
 
 void launchShade(PathedScene *scene, const RenderParams &params, hipStream_t stream)
 {
+#if PATHED_EXPERIMENTS
     if (scene->splitShade && !PATHED_EXP_LISTS_ONLY) {
         const bool ldsMaterials = scene->device.nMaterials <= kMaxLdsMaterials;
         const size_t lds = ldsMaterials ? (size_t)scene->device.nMaterials * sizeof(DMaterial) : 0;
@@ -550,6 +564,7 @@ void launchShade(PathedScene *scene, const RenderParams &params, hipStream_t str
         }
         return;
     }
+#endif
     const dim3 grid((unsigned)(params.nSlots / kBlock)), block(kBlock);
     if (scene->device.nMaterials <= kMaxLdsMaterials) {
         // (k_shade narrowed further to {Lambertian, plastic, environment} -- 88 VGPRs against 92 -- shortens the shade launches of
@@ -801,6 +816,10 @@ int pathed_hip_measure_valu_modes(int waves_per_simd, int repeats, double *rates
 
 int pathed_hip_measure_valu_clocks(int waves_per_simd, int chains, int repeats, PathedValuClocks *out)
 {
+#if !PATHED_EXPERIMENTS
+    (void)waves_per_simd; (void)chains; (void)repeats; (void)out;
+    return fail(PATHED_E_UNSUPPORTED, "the clocked VALU probe lives in libpathed_hip_experiments.so (`make experiments`)");
+#else
     if (!out || repeats < 1 || repeats > 1000) { return fail(PATHED_E_INVALID, "bad argument"); }
     if (waves_per_simd < 1 || waves_per_simd > 8) { return fail(PATHED_E_INVALID, "waves_per_simd must be 1..8"); }
     if (chains != 8 && chains != 16) { return fail(PATHED_E_INVALID, "chains must be 8 or 16"); }
@@ -865,6 +884,7 @@ int pathed_hip_measure_valu_clocks(int waves_per_simd, int chains, int repeats, 
     if (stop) { (void)hipEventDestroy(stop); }
     if (status != hipSuccess) { return fail(PATHED_E_DEVICE, std::string("VALU clock probe: ") + hipGetErrorString(status)); }
     return PATHED_OK;
+#endif
 }
 
 int pathed_hip_accum_alloc(PathedScene *scene, size_t count, float **out)
@@ -1490,6 +1510,13 @@ int pathed_hip_scene_create_ex(const PathedSceneDesc *desc, const PathedSceneOpt
         delete scene;
         return fail(PATHED_E_INVALID, "the fused path kernel serves scenes of at most 64 triangles that take the all-triangles intersector");
     }
+#if !PATHED_EXPERIMENTS
+    if (shadeKernel == 2 || shadeKernel == 4 || requestedNodeFormat(options) >= 2 || options.small_phase1 == 2) {
+        delete scene;
+        return fail(PATHED_E_UNSUPPORTED, "the staged and split shade stages, the compressed node formats and the matrix-pipe phase 1 are measured-and-rejected "
+                                          "experiments: build libpathed_hip_experiments.so (`make experiments`) and load it instead");
+    }
+#endif
     if (shadeKernel == 4 && scene->bruteForce) {
         delete scene;
         return fail(PATHED_E_INVALID, "the split shade stage follows the BVH trace kernel: scenes of at most 64 triangles take the fused, per-slot or staged kernels");
@@ -1506,6 +1533,7 @@ int pathed_hip_scene_create_ex(const PathedSceneDesc *desc, const PathedSceneOpt
             return fail(PATHED_E_INVALID, "compressed nodes serve sphere-free scenes whose tree is walked in HBM by the per-slot pipeline (not generic_kernels, not the split stage)");
         }
         const int chosen = !eligible || nodeFormat == 1 ? 0 : nodeFormat == 0 ? PATHED_DEFAULT_NODE_FORMAT : nodeFormat - 1;
+#if PATHED_EXPERIMENTS
         if (chosen != 0) {
             const size_t nNodes = (size_t)scene->device.nNodes;
             const unsigned blocks = (unsigned)((nNodes + kBlock - 1) / kBlock);
@@ -1516,10 +1544,15 @@ int pathed_hip_scene_create_ex(const PathedSceneDesc *desc, const PathedSceneOpt
             scene->device.nodesQ = scene->nodesQ.ptr;
             scene->nodeFormat = chosen;
         }
+#else
+        (void)chosen;
+#endif
     }
     // persistent grids of the split stage: k_vertex at PATHED_VERTEX_WAVES blocks per CU, k_regen at PATHED_REGEN_WAVES
+#if PATHED_EXPERIMENTS
     scene->vertexGrid = scene->computeUnits * PATHED_VERTEX_WAVES;
     scene->regenGrid = scene->computeUnits * PATHED_REGEN_WAVES;
+#endif
     if (const char *text = getenv("PATHED_VERTEX_GRID")) { const int value = atoi(text); if (value >= 1 && value <= 65536) { scene->vertexGrid = value; } }
     if (const char *text = getenv("PATHED_REGEN_GRID")) { const int value = atoi(text); if (value >= 1 && value <= 65536) { scene->regenGrid = value; } }
     scene->fusedPath = scene->bruteForce && (shadeKernel == 0 || shadeKernel == 3);
@@ -1693,6 +1726,7 @@ static int renderPassFused(PathedScene *scene, uint64_t seed, uint32_t begin, ui
     // the narrowest instantiation whose compile-time scene set contains this scene's (shading.h: SceneTraits)
     params.mfmaTable = scene->mfmaTable.ptr;
     params.mfmaFrame = scene->mfmaFrame;
+#if PATHED_EXPERIMENTS
     if (scene->mfmaPhase1 && ldsMaterials) {
         // phase 1 on the matrix pipe: the same instantiations with MFMA = true
         if (scene->lambertianTriangles) {
@@ -1705,7 +1739,9 @@ static int renderPassFused(PathedScene *scene, uint64_t seed, uint32_t begin, ui
             if (scene->countMode) { hipLaunchKernelGGL((k_path_small<true, true, TraitsAll, true>), grid, block, lds, stream, params, scene->smallTris); }
             else { hipLaunchKernelGGL((k_path_small<true, false, TraitsAll, true>), grid, block, lds, stream, params, scene->smallTris); }
         }
-    } else if (scene->lambertianTriangles) {
+    } else
+#endif
+    if (scene->lambertianTriangles) {
         if (ldsMaterials) {
             if (scene->countMode) { hipLaunchKernelGGL((k_path_small<true, true, TraitsLambertianTriangles>), grid, block, lds, stream, params, scene->smallTris); }
             else { hipLaunchKernelGGL((k_path_small<true, false, TraitsLambertianTriangles>), grid, block, lds, stream, params, scene->smallTris); }
@@ -2156,9 +2192,12 @@ int pathed_hip_trace(PathedScene *scene, const float *rays, size_t n, int any_hi
                 case 8: PATHED_HOOK(8, FORMAT); break; \
                 case 16: PATHED_HOOK(16, FORMAT); break; \
                 default: PATHED_HOOK(22, FORMAT); break; }
+#if PATHED_EXPERIMENTS
             if (scene->nodeFormat == 2) { PATHED_HOOK_ROWS(2) }
             else if (scene->nodeFormat == 1) { PATHED_HOOK_ROWS(1) }
-            else { PATHED_HOOK_ROWS(0) }
+            else
+#endif
+            { PATHED_HOOK_ROWS(0) }
             #undef PATHED_HOOK_ROWS
             #undef PATHED_HOOK
             status = hipGetLastError();
@@ -2178,8 +2217,14 @@ int pathed_hip_trace(PathedScene *scene, const float *rays, size_t n, int any_hi
     return PATHED_OK;
 }
 
+int pathed_hip_has_experiments(void) { return PATHED_EXPERIMENTS ? 1 : 0; }
+
 int pathed_hip_debug_small_candidates(PathedScene *scene, const float *rays, size_t n, uint64_t *out)
 {
+#if !PATHED_EXPERIMENTS
+    (void)scene; (void)rays; (void)n; (void)out;
+    return fail(PATHED_E_UNSUPPORTED, "the matrix-pipe phase 1 and its test hook live in libpathed_hip_experiments.so (`make experiments`)");
+#else
     if (!scene) { return fail(PATHED_E_INVALID, "null scene"); }
     if (!scene->bruteForce || scene->device.nTris < 1) { return fail(PATHED_E_UNSUPPORTED, "the all-triangles intersector serves scenes of 1..64 triangles"); }
     if (n == 0) { return PATHED_OK; }
@@ -2205,6 +2250,7 @@ int pathed_hip_debug_small_candidates(PathedScene *scene, const float *rays, siz
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(out, deviceOut.ptr, n * 6 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return PATHED_OK;
+#endif
 }
 
 int pathed_hip_set_stats_mode(PathedScene *scene, int enabled)

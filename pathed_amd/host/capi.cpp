@@ -100,6 +100,7 @@ int pathed_host_parse_mtl(const char *path, char *out, size_t capacity)
 #include <fstream>
 #include <iomanip>
 #include <iostream>
+#include <iterator>
 #include <thread>
 
 int runJob(const std::string &jobPath, const std::string &assetRootOverride)
@@ -114,12 +115,17 @@ int runJob(const std::string &jobPath, const std::string &assetRootOverride)
         Image image(width, height, job.outputDirectory());
 
         const std::string assetRoot = !assetRootOverride.empty() ? assetRootOverride : job.assetRoot();
-        const std::string builder = job.bvhBuilder();
-        const int builderCode = builder == "ploc" ? PATHED_BVH_PLOC_DEVICE : builder == "lbvh" ? PATHED_BVH_LBVH_DEVICE : PATHED_BVH_SAH_HOST;
-        if (builder != "sah" && builder != "lbvh" && builder != "ploc") { throw std::runtime_error("job: unknown bvh_builder: " + builder); }
+        std::string builder = job.bvhBuilder();
+        if (builder != "auto" && builder != "sah" && builder != "lbvh" && builder != "ploc") { throw std::runtime_error("job: unknown bvh_builder: " + builder); }
         const std::vector<int> devices = job.devices();
         const auto loadBegin = std::chrono::steady_clock::now();
         FlatScene flat = loadScene(job.scene(), width, height, assetRoot);
+        if (builder == "auto") {
+            // several replicas of a large mesh: each GPU builds its own tree in milliseconds (PLOC) instead of N host SAH
+            // builds competing for the cores before the first sample (include/pathed_hip.h: PATHED_BVH_*)
+            builder = (devices.size() > 1 && flat.desc().n_triangles > 1000000u) ? "ploc" : "sah";
+        }
+        const int builderCode = builder == "ploc" ? PATHED_BVH_PLOC_DEVICE : builder == "lbvh" ? PATHED_BVH_LBVH_DEVICE : PATHED_BVH_SAH_HOST;
         const auto uploadBegin = std::chrono::steady_clock::now();
         // one replica of the scene per device; the device travels with the scene handle, so the
         // render thread below (and its per-device workers) need no device selection of their own
@@ -129,7 +135,16 @@ int runJob(const std::string &jobPath, const std::string &assetRootOverride)
         std::shared_ptr<Integrator> integrator = job.integrator();
         integrator->configure(job.spp(), job.seed(), job.sppPerLaunch(), job.outputDirectory());
         integrator->setStateFile(job.outputDirectory() + "auto.state", job.resume());
-        integrator->setStateIdentity(job.scene() + "|" + job.integratorName());
+        {
+            // what the sums depend on besides resolution, seed and bounce window (those are in the state header): the scene
+            // FILE's bytes (edited in place = another render), where its assets come from, the integrator
+            std::string sceneBytes;
+            for (const std::string &candidate : { assetRoot.empty() ? job.scene() : assetRoot + "/" + job.scene(), job.scene() }) {
+                std::ifstream in(candidate, std::ios::binary);
+                if (in) { sceneBytes.assign(std::istreambuf_iterator<char>(in), std::istreambuf_iterator<char>()); break; }
+            }
+            integrator->setStateIdentity(job.scene() + "|" + job.integratorName() + "|" + assetRoot + "|" + sceneBytes);
+        }
         const std::string reduce = job.reduceMethod();
         if (reduce != "rccl" && reduce != "peer-copy") { throw std::runtime_error("job: \"reduce\" must be \"rccl\" or \"peer-copy\""); }
         integrator->setUseRccl(reduce == "rccl");

@@ -1,5 +1,6 @@
 #include "integrator.h"
 
+#include <algorithm>
 #include <chrono>
 #include <condition_variable>
 #include <cstdio>
@@ -220,7 +221,17 @@ void Integrator::run(
         if (m_useRccl && pathed_hip_comm_init((int)replicas, scene.devices().data(), &comm) != PATHED_OK) {
             comm = nullptr;
             m_metrics.reduceFallback = pathed_hip_last_error();
-            std::cout << "[" << m_logPrefix << "] RCCL reduce unavailable (" << m_metrics.reduceFallback << "): using peer copies" << std::endl;
+            // replicas that SHARE a device cannot form a communicator (rehearsals on one GPU): peer copies.  On distinct
+            // devices -- a real node -- "reduce": "rccl" means RCCL: a silent fall-back would hide a broken xGMI / RCCL setup
+            // behind a slower path, so the job stops here ("reduce": "peer-copy" asks for the copies explicitly).
+            std::vector<int> ids = scene.devices();
+            std::sort(ids.begin(), ids.end());
+            const bool distinct = std::adjacent_find(ids.begin(), ids.end()) == ids.end();
+            if (distinct) {
+                throw std::runtime_error("job asks for the RCCL reduce over " + std::to_string(replicas) + " distinct GPUs and RCCL is unavailable: "
+                                         + m_metrics.reduceFallback + " (set \"reduce\": \"peer-copy\" to use peer copies)");
+            }
+            std::cout << "[" << m_logPrefix << "] RCCL reduce unavailable (" << m_metrics.reduceFallback << "): replicas share a device, using peer copies" << std::endl;
         }
         if (!comm) {
             if (pathed_hip_accum_alloc(scene.handle(0), floats, &staging) != PATHED_OK) { throw std::runtime_error(hipError("pathed_hip_accum_alloc")); }

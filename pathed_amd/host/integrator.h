@@ -94,10 +94,11 @@ public:
     // <outdir>/auto.state: fp32 radiance sums + sample count, rewritten whenever an image is published.
     // With resume the run continues from it (a missing file means "start at 0").
     void setStateFile(const std::string &path, bool resume) { m_statePath = path; m_resume = resume; }
-    // everything besides resolution, seed and bounce window that the sums depend on (scene file, integrator name,
-    // samples per unit): a state file of another identity is refused
+    // what the sums depend on besides resolution, seed and bounce window (which the state header carries itself): the
+    // caller passes scene path + integrator name + asset root + the scene file's BYTES; a state file of another identity is refused
     void setStateIdentity(const std::string &identity);
-    // job key "reduce": "rccl" (default; falls back to peer copies when RCCL cannot be used) or "peer-copy"
+    // job key "reduce": "rccl" (default: ONE ncclReduce; an error when RCCL is unavailable on distinct devices, peer copies only
+    // for replicas that share a device) or "peer-copy"
     void setUseRccl(bool use) { m_useRccl = use; }
     const RenderMetrics &metrics() const { return m_metrics; }
 

@@ -5,7 +5,9 @@
 //   "seed" (1), "gpu" (0), "asset_root" (directory paths resolve in),
 //   "spp_per_launch" (1024): samples per render call.  A call drains its last paths before it returns (a few ms on a
 //               BVH scene: 64 spp per call cost 4 %, 256 and more < 1 %); checkpoints still bound a call,
-//   "bvh_builder" ("sah" | "lbvh" | "ploc": include/pathed_hip.h PATHED_BVH_*),
+//   "bvh_builder" ("auto" | "sah" | "lbvh" | "ploc": include/pathed_hip.h PATHED_BVH_*; "auto" = the host SAH build on one
+//               GPU, the device PLOC build when several GPUs each need the tree of a mesh of more than a million triangles:
+//               N replicas would otherwise run N host builds side by side, seconds of serial time before the first sample),
 //   "gpus" (1): a count N -> devices gpu .. gpu+N-1, or an explicit list of device ids (an id may
 //               repeat: several replicas on one GPU); the samples of every batch are split over them,
 //   "resume" (false): continue from <output_directory>/auto.state if it exists.
@@ -64,7 +66,7 @@ public:
     std::vector<int> devices() const;
     int gpu() const { return m_json["gpu"].isNumber() ? m_json["gpu"].asInt() : 0; }
     std::string assetRoot() const { return m_json["asset_root"].isString() ? m_json["asset_root"].asString() : ""; }
-    std::string bvhBuilder() const { return m_json["bvh_builder"].isString() ? m_json["bvh_builder"].asString() : "sah"; }
+    std::string bvhBuilder() const { return m_json["bvh_builder"].isString() ? m_json["bvh_builder"].asString() : "auto"; }
     // fan-in of several devices' sums: "rccl" (one ncclReduce; falls back to peer copies where RCCL cannot be used) | "peer-copy"
     std::string reduceMethod() const { return m_json["reduce"].isString() ? m_json["reduce"].asString() : "rccl"; }
     // metrics.json: "full" (default) adds rays per sample, Mrays/s, algorithmic bytes and the roofline fraction from a

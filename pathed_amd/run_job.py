@@ -86,14 +86,22 @@ def main(argv=None):
         raise SystemExit("spp_per_launch must be >= 1")
 
     scene = LoadedScene(job["scene"], width, height, asset_root if asset_root is not None else job.get("asset_root"))
-    gpu = HipScene(scene.desc, device=local_rank, bvh_builder=job.get("bvh_builder", "sah"))
+    gpu = HipScene(scene.desc, device=local_rank, bvh_builder=(lambda name: ("ploc" if world_size > 1 and scene.n_triangles > 1000000 else "sah") if name == "auto" else name)(job.get("bvh_builder", "auto")))
     gpu.set_integrator(job["integrator"])
     host = _capi.load_host()
     stream = torch.cuda.current_stream().cuda_stream
 
     # this rank's sums; they keep growing, and are reduced only when an image is due: at the power-of-two
-    # checkpoints (src/integrator.cpp:87-92) and at the end.  The union over ranks of what has been
-    # rendered is always exactly the samples [0, done).
+    # checkpoints (src/integrator.cpp:87-92).  The union over ranks of what has been rendered is always exactly
+    # the samples [0, done).  The reference's loop runs all `spp` waves and saves at the powers of two only
+    # (src/integrator.cpp:42, :87-92); samples past the last power of two would reach no file here, so the loop
+    # stops at the last power of two <= spp instead of rendering them on every rank for nothing.
+    last_power = 1
+    while last_power * 2 <= spp:
+        last_power *= 2
+    if last_power != spp and rank == 0:
+        print("[%s] spp %d is not a power of two: rendering the %d samples of the last checkpoint" % (out_dir, spp, last_power))
+    spp = last_power
     accum = torch.zeros((height, width, 3), dtype=torch.float32, device="cuda")
     total = torch.zeros_like(accum)
     done = 0

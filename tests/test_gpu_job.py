@@ -239,3 +239,29 @@ def test_bench_runs_as_a_one_rank_rccl_process_group():
     line = json.loads(result.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 1 and line["value"] > 0 and line["config"]["collective"] == "nccl (RCCL), world size 1"
     assert len(line["per_rank_s"]["reduce"]) == 1 and 0.05 < line["image_mean_rgb"][0] < 0.4
+
+
+def test_bench_rehearses_many_ranks_on_one_gpu():
+    """The driver's 2/4/8-GPU scaling run, rehearsed with what one box allows: `bench.py --gpus 5 --share-gpu --backend gloo`
+    starts five child ranks on device 0 (a box admits six processes on its card and this test process is one of them, so
+    five is the most a test may start), every step's samples are split five ways (ragged: 1024 = 4 x 205 + 204), the sums are
+    reduced to rank 0 inside the timed region and the per-rank times gathered.  The reduced image is the single-rank image
+    up to fp32 summation order (additive waves: reference src/integrator.cpp:42-51)."""
+    import sys
+    from pathed_amd import _capi
+    common = ["--steps", "1", "--warmup", "1", "--spp-per-step", "1024", "--width", "64", "--height", "48",
+              "--no-cpu-baseline", "--no-large-bvh", "--no-kernel-timing"]
+    bench = os.path.join(_capi.REPO_ROOT, "bench.py")
+    many = subprocess.run([sys.executable, bench, "--gpus", "5", "--share-gpu", "--backend", "gloo"] + common,
+                          capture_output=True, text=True, timeout=900)
+    assert many.returncode == 0, many.stdout + many.stderr
+    line = json.loads(many.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 5 and line["scaling"] == "strong" and line["config"]["collective"] == "gloo (host-staged), world size 5"
+    for key in ("render", "reduce", "total", "setup"):
+        assert len(line["per_rank_s"][key]) == 5 and all(value >= 0 for value in line["per_rank_s"][key]), key
+    assert line["config"]["total_samples"] == 64 * 48 * 1024
+    one = subprocess.run([sys.executable, bench] + common, capture_output=True, text=True, timeout=900)
+    assert one.returncode == 0, one.stdout + one.stderr
+    single = json.loads(one.stdout.strip().splitlines()[-1])
+    for a, b in zip(line["image_mean_rgb"], single["image_mean_rgb"]):
+        assert abs(a - b) <= 1e-5 * abs(b), (line["image_mean_rgb"], single["image_mean_rgb"])

@@ -9,7 +9,7 @@ in-plane directions, origins on triangles and at the camera); and the fused kern
 import numpy as np
 import pytest
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.experiments]   # mfma_candidates.h is compiled into libpathed_hip_experiments.so only
 
 
 @pytest.fixture(scope="module")

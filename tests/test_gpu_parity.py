@@ -312,9 +312,10 @@ def test_unit_orders_are_bit_identical(libs, scene_path, width, height, spp):
     scene = LoadedScene(scene_path, width, height)
     expected = HipScene(scene.desc, device=0).render(3, 1, spp, 0, 8)
     assert expected.any()
+    from conftest import has_experiments
+    staged = ({"unit_order": "stripes-tiled", "shade_kernel": "staged"}, {"unit_order": "tiles", "shade_kernel": "staged", "max_slots": 4096})
     for options in ({"unit_order": "stripes-tiled"}, {"unit_order": "tiles"}, {"unit_order": "tiles", "pools": 1},
-                    {"unit_order": "tiles", "shade_kernel": "per-slot", "pools": 3},
-                    {"unit_order": "stripes-tiled", "shade_kernel": "staged"}, {"unit_order": "tiles", "shade_kernel": "staged", "max_slots": 4096}):
+                    {"unit_order": "tiles", "shade_kernel": "per-slot", "pools": 3}) + (staged if has_experiments() else ()):
         gpu = HipScene(scene.desc, device=0, **options)
         assert np.array_equal(gpu.render(3, 1, spp, 0, 8), expected), options
     coarse = HipScene(scene.desc, device=0)
@@ -342,19 +343,28 @@ def test_shade_kernels_are_bit_identical(libs, scene_path, size, spp, last_bounc
     _, HipScene, LoadedScene = libs
     scene = LoadedScene(scene_path, size, size)
     per_slot = HipScene(scene.desc, device=0, shade_kernel="per-slot")
+    from conftest import has_experiments
+    from pathed_amd.integrator import PathedError
+    experiments = has_experiments()   # the staged and split organisations live in libpathed_hip_experiments.so
     expected = per_slot.render(7, 3, spp, 0, last_bounce)
     assert expected.any() and per_slot.stats()["path_kernel"] == 1
-    for options in ({"stage_slots": 512}, {"stage_slots": 1024}, {"stage_slots": 512, "pools": 1, "max_slots": 4096},
-                    {"stage_slots": 1024, "pools": 3}):
-        staged = HipScene(scene.desc, device=0, shade_kernel="staged", **options)
-        assert np.array_equal(staged.render(7, 3, spp, 0, last_bounce), expected), options
-        assert staged.stats()["path_kernel"] == 2
+    if experiments:
+        for options in ({"stage_slots": 512}, {"stage_slots": 1024}, {"stage_slots": 512, "pools": 1, "max_slots": 4096},
+                        {"stage_slots": 1024, "pools": 3}):
+            staged = HipScene(scene.desc, device=0, shade_kernel="staged", **options)
+            assert np.array_equal(staged.render(7, 3, spp, 0, last_bounce), expected), options
+            assert staged.stats()["path_kernel"] == 2
+    else:
+        for kind in ("staged", "split"):
+            with pytest.raises(PathedError, match="experiments"):
+                HipScene(scene.desc, device=0, shade_kernel=kind)
     # bounce windows and units of several samples (the default is one sample per unit, the reference's summation order)
-    staged = HipScene(scene.desc, device=0, shade_kernel="staged")
-    staged.set_samples_per_unit(4)
     per_slot.set_samples_per_unit(4)
     windowed = per_slot.render(2, 0, 3, 1, 2)
-    assert np.array_equal(staged.render(2, 0, 3, 1, 2), windowed)
+    if experiments:
+        staged = HipScene(scene.desc, device=0, shade_kernel="staged")
+        staged.set_samples_per_unit(4)
+        assert np.array_equal(staged.render(2, 0, 3, 1, 2), windowed)
     automatic = HipScene(scene.desc, device=0)
     if automatic.stats()["scene_in_lds"] == 2:
         # the default for tiny scenes is the fused kernel
@@ -369,11 +379,9 @@ def test_shade_kernels_are_bit_identical(libs, scene_path, size, spp, last_bounc
         automatic.set_samples_per_unit(7)
         per_slot.set_samples_per_unit(7)
         assert np.array_equal(automatic.render(9, 5, 23, 0, last_bounce), per_slot.render(9, 5, 23, 0, last_bounce))   # ragged last unit
-        from pathed_amd.integrator import PathedError
         with pytest.raises(PathedError):
             HipScene(scene.desc, device=0, shade_kernel="split")   # the split stage follows the BVH trace kernel
     else:
-        from pathed_amd.integrator import PathedError
         # the default for BVH scenes is the per-slot kernel; the split shade stage (k_vertex + k_regen over the trace
         # kernel's hit / miss lists) is selectable
         assert automatic.stats()["path_kernel"] == 1
@@ -381,6 +389,8 @@ def test_shade_kernels_are_bit_identical(libs, scene_path, size, spp, last_bounc
         # code compiled out): the same floats as the generic instantiation
         generic = HipScene(scene.desc, device=0, shade_kernel="per-slot", generic_kernels=1)
         assert np.array_equal(generic.render(7, 3, spp, 0, last_bounce), expected)
+        if not experiments:
+            return
         split = HipScene(scene.desc, device=0, shade_kernel="split")
         assert np.array_equal(split.render(7, 3, spp, 0, last_bounce), expected)
         split.set_samples_per_unit(4)
@@ -506,6 +516,7 @@ def _unpack_compressed(words):
     return origin, scale, qlo, qhi, words[:, 12:16].view(np.int32)
 
 
+@pytest.mark.experiments
 @pytest.mark.parametrize("builder", ["sah", "lbvh", "ploc"])
 def test_compressed_nodes_contain_the_float_boxes_and_change_no_hit(libs, builder):
     """node_format "compressed" (trace.h: nodeQ): every child's 8-bit grid box contains its float box (exported and checked
@@ -571,6 +582,7 @@ def _unpack_compressed8(words):
     return origin, scale, planes[:, 0:3], planes[:, 3:6], words[:, 20:28].view(np.int32)
 
 
+@pytest.mark.experiments
 @pytest.mark.parametrize("builder", ["sah", "ploc"])
 def test_eight_wide_compressed_tree_covers_every_triangle_once_and_changes_no_hit(libs, builder):
     """node_format "compressed8" (trace.h: node8): walked from the root, the 8-wide tree reaches every leaf of the 4-wide
@@ -670,6 +682,7 @@ def test_eight_wide_compressed_tree_covers_every_triangle_once_and_changes_no_hi
     assert packed.stats()["closest_rays"] == wide.stats()["closest_rays"]
 
 
+@pytest.mark.experiments
 def test_compressed_nodes_are_refused_where_they_do_not_apply(libs):
     oracle_lib, HipScene, LoadedScene = libs
     for path, options in (("scenes/cornell.json", {}), ("scenes/mis-pbrt.json", {"intersector": "bvh"}),
@@ -818,6 +831,7 @@ def test_set_camera_is_a_fresh_scene_with_that_camera(libs):
             gpu.set_camera(wrong)
 
 
+@pytest.mark.experiments
 def test_valu_clock_probe_reports_consistent_clocks():
     """pathed_hip_measure_valu_clocks: the rate from HIP events and the cycles per instruction from the waves' own clocks
     describe the same run; bad arguments are PATHED_E_INVALID."""
