@@ -245,6 +245,14 @@ int pathed_hip_init(int device_id);
 int pathed_hip_scene_create(const PathedSceneDesc *desc, PathedScene **out);
 void pathed_hip_scene_destroy(PathedScene *scene);
 
+/* Refit: new vertex positions -- and optionally normals -- over an UNCHANGED topology, what
+ * rtcCommitScene (reference src/scene.cpp:39) repeats for a deforming mesh.  The tree keeps its shape: leaf triangle
+ * records, shading records and every node's child boxes are recomputed bottom-up on the device (milliseconds for millions
+ * of triangles), boxes padded as the builders pad them.  positions: 3 * n_vertices floats, normals: the same or NULL (keep),
+ * host memory; n_vertices must be the scene's.  device_ms (may be NULL): HIP-event time of the refit kernels, uploads excluded.
+ * Needs PathedSceneOptions.refittable at creation; PATHED_E_UNSUPPORTED for scenes of <= 64 triangles (recreate those). */
+int pathed_hip_scene_refit(PathedScene *scene, const float *positions, const float *normals, uint32_t n_vertices, float *device_ms);
+
 /* Per-scene options.  Zero-initialise, set struct_size = sizeof(PathedSceneOptions), then set only
  * what you need: every field's "automatic" value is 0 except where stated, so a zeroed struct
  * means "all defaults" -- EXCEPT `device`, where 0 is device 0; use PATHED_DEVICE_CURRENT (-1) for
@@ -284,6 +292,8 @@ typedef struct PathedSceneOptions {
                                    reference src/scene.cpp:113,374): 0 automatic; 1 on the VALU (packed Moeller-Trumbore);
                                    2 on the matrix pipe (v_mfma_f32_32x32x2_f32 over Pluecker rows, mfma_candidates.h) --
                                    phase 2 decides either way: hits and images are bit-identical */
+    int32_t refittable;         /* 1: keep the triangle soup (positions, normals, uvs, indices: 44 bytes per triangle or so) on the
+                                   device so that pathed_hip_scene_refit can move the vertices later; BVH scenes only */
 } PathedSceneOptions;
 int pathed_hip_scene_create_ex(const PathedSceneDesc *desc, const PathedSceneOptions *options, PathedScene **out);
 int pathed_hip_scene_device(const PathedScene *scene);   /* the HIP device the scene lives on, or a negative error */

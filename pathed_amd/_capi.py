@@ -155,6 +155,7 @@ class PathedSceneOptions(C.Structure):
         ("generic_kernels", C.c_int32),
         ("node_format", C.c_int32),
         ("small_phase1", C.c_int32),
+        ("refittable", C.c_int32),
     ]
 
 
@@ -179,6 +180,7 @@ HIP_SYMBOLS = [
     "pathed_hip_trace",
     "pathed_hip_debug_small_candidates",
     "pathed_hip_has_experiments",
+    "pathed_hip_scene_refit",
     "pathed_hip_set_samples_per_unit",
     "pathed_hip_set_integrator",
     "pathed_hip_set_stats_mode",
@@ -277,6 +279,8 @@ def load_hip():
     lib.pathed_hip_trace.restype = C.c_int
     lib.pathed_hip_debug_small_candidates.argtypes = [vp, C.POINTER(C.c_float), C.c_size_t, C.POINTER(C.c_uint64)]
     lib.pathed_hip_debug_small_candidates.restype = C.c_int
+    lib.pathed_hip_scene_refit.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_uint32, C.POINTER(C.c_float)]
+    lib.pathed_hip_scene_refit.restype = C.c_int
     lib.pathed_hip_has_experiments.argtypes = []
     lib.pathed_hip_has_experiments.restype = C.c_int
     lib.pathed_hip_set_samples_per_unit.argtypes = [vp, C.c_int]

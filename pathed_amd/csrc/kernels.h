@@ -2698,24 +2698,111 @@ __global__ __launch_bounds__(kBlock) void k_build_tri_shade(
     const float *positions, const float *normals, const float *uvs, const uint32_t *indices, const int *triMaterial,
     uint32_t nTriangles, float4 *triShade, float4 *triCompact)
 {
-    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    // EIGHT lanes per triangle, one per float4 of its record: a wave's store is 1 KiB of contiguous bytes (one thread per
+    // triangle wrote 16 bytes at a 128-byte stride per instruction and ran at < 1 TB/s: 1.46 ms for 5.2 M triangles, the
+    // larger half of a refit; now a third of that)
+    const size_t thread = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    const size_t i = thread >> 3;
+    const int q = (int)(thread & 7);
     if (i >= nTriangles) { return; }
-    const size_t i0 = indices[3 * (size_t)i + 0], i1 = indices[3 * (size_t)i + 1], i2 = indices[3 * (size_t)i + 2];
-    const float *p0 = positions + 3 * i0, *p1 = positions + 3 * i1, *p2 = positions + 3 * i2;
-    const float *n0 = normals + 3 * i0, *n1 = normals + 3 * i1, *n2 = normals + 3 * i2;
-    const float *t0 = uvs + 2 * i0, *t1 = uvs + 2 * i1, *t2 = uvs + 2 * i2;
-    float4 *q = triShade + (size_t)kTriShadeQuads * i;
-    q[0] = make_float4(p0[0], p0[1], p0[2], intAsFloat(triMaterial[i]));
-    q[1] = make_float4(p1[0], p1[1], p1[2], t0[0]);
-    q[2] = make_float4(p2[0], p2[1], p2[2], t0[1]);
-    q[3] = make_float4(n0[0], n0[1], n0[2], t1[0]);
-    q[4] = make_float4(n1[0], n1[1], n1[2], t1[1]);
-    q[5] = make_float4(n2[0], n2[1], n2[2], t2[0]);
-    q[6] = make_float4(t2[1], 0.f, 0.f, 0.f);
-    q[7] = make_float4(0.f, 0.f, 0.f, 0.f);
-    // the 16-byte record (makeIsect): geometric normal + material, read for the triangles of the scene's plain ranges
-    const V3 normal = triangleNormal(v3(p0[0], p0[1], p0[2]), v3(p1[0], p1[1], p1[2]), v3(p2[0], p2[1], p2[2]));
-    triCompact[i] = make_float4(normal.x, normal.y, normal.z, intAsFloat(triMaterial[i]));
+    const int corner = q < 3 ? q : q < 6 ? q - 3 : 0;   // the vertex this lane's xyz comes from
+    const size_t vertex = indices[3 * i + corner];
+    const float *source = (q < 3 ? positions : normals) + 3 * vertex;
+    float x = 0.f, y = 0.f, z = 0.f, w = 0.f;
+    if (q < 6) { x = source[0]; y = source[1]; z = source[2]; }
+    // .w: q0 material, q1 uv0.u, q2 uv0.v, q3 uv1.u, q4 uv1.v, q5 uv2.u; q6.x = uv2.v
+    if (q == 0) { w = intAsFloat(triMaterial[i]); }
+    else if (q <= 6) {
+        const int uvCorner = (q - 1) >> 1, component = (q - 1) & 1;
+        const float value = uvs[2 * (size_t)indices[3 * i + uvCorner] + component];
+        if (q == 6) { x = value; } else { w = value; }
+    }
+    triShade[(size_t)kTriShadeQuads * i + q] = make_float4(x, y, z, w);
+    // the 16-byte record (makeIsect): geometric normal + material, read for the triangles of the scene's plain ranges.
+    // Lanes 0..2 of the group hold the corners: lane 0 collects them.
+    const int lane = threadIdx.x & 63, base = lane & ~7;
+    const float x1 = __shfl(x, base + 1), y1 = __shfl(y, base + 1), z1 = __shfl(z, base + 1);
+    const float x2 = __shfl(x, base + 2), y2 = __shfl(y, base + 2), z2 = __shfl(z, base + 2);
+    if (q == 0) {
+        const V3 normal = triangleNormal(v3(x, y, z), v3(x1, y1, z1), v3(x2, y2, z2));
+        triCompact[i] = make_float4(normal.x, normal.y, normal.z, w);
+    }
+}
+
+// ------------------------------------------------------------------------- refit
+// New vertex positions over an UNCHANGED topology: what rtcCommitScene (reference src/scene.cpp:39) does again for an animated
+// mesh, without rebuilding.  One thread per 4-wide node, level-synchronous like the builders' own fitting pass (lbvh.hip:
+// k_lbvh_fit_pass): a pass gives every node whose inner children had their bounds BEFORE the pass its four child boxes --
+// leaf children straight from the moved vertices (and rewrites their (v0, prim) (e1) (e2) records), inner children from the
+// UNPADDED bounds kept beside the nodes -- pads them exactly as the builders do (bvh_build.h padBox) and records its own
+// unpadded bounds; double-buffered flags keep a node from being read in the pass that writes it, kernel boundaries make a
+// pass visible to the next.  As many passes as the tree has 4-wide levels.  Boxes are the ones a fresh build over the same
+// topology would store; hits do not depend on them anyway (the triangle test decides).
+__global__ __launch_bounds__(kBlock) void k_refit_pass(
+    float4 *nodes, int nNodes, float4 *leafTris, const float *positions, const uint32_t *indices, const DSphere *spheres,
+    float4 *boundsLo, float4 *boundsHi, const unsigned char *readyIn, unsigned char *readyOut)
+{
+    const int n = blockIdx.x * kBlock + threadIdx.x;
+    if (n >= nNodes) { return; }
+    if (readyIn[n]) { readyOut[n] = 1; return; }
+    float4 *node = nodes + (size_t)8 * n;
+    const float4 refWords = node[6];
+    const int refs[4] = { floatAsInt(refWords.x), floatAsInt(refWords.y), floatAsInt(refWords.z), floatAsInt(refWords.w) };
+    for (int k = 0; k < 4; k++) {
+        if (refs[k] >= 0 && !readyIn[refs[k]]) { readyOut[n] = 0; return; }   // an inner child is not fitted yet
+    }
+    const float inf = __builtin_huge_valf();
+    float lo[3][4], hi[3][4];
+    float ownLo[3] = { inf, inf, inf }, ownHi[3] = { -inf, -inf, -inf };
+    for (int k = 0; k < 4; k++) {
+        const int ref = refs[k];
+        float low[3] = { inf, inf, inf }, high[3] = { -inf, -inf, -inf };
+        const bool present = ref != kEmptyChild;
+        if (ref >= 0) {
+            const float4 a = boundsLo[ref], b = boundsHi[ref];
+            low[0] = a.x; low[1] = a.y; low[2] = a.z; high[0] = b.x; high[1] = b.y; high[2] = b.z;
+        } else if (present) {
+            const int code = -ref - 1;
+            const int first = code >> 3, count = code & 7;
+            if (count == 0) {
+                // a sphere leaf (bvh_build.h: its bounds are padded once on their own)
+                const DSphere sphere = spheres[first - 1];
+                const float radius = fabsf(sphere.radius);
+                for (int a = 0; a < 3; a++) {
+                    const float reach = radius * 1.00001f + 1e-5f * fabsf(sphere.centerWorld[a]);
+                    low[a] = sphere.centerWorld[a] - reach;
+                    high[a] = sphere.centerWorld[a] + reach;
+                }
+            }
+            for (int t = 0; t < count; t++) {
+                float4 *record = leafTris + (size_t)3 * (first + t);
+                const int prim = floatAsInt(record[0].w);
+                const float *v0 = positions + 3 * (size_t)indices[3 * (size_t)prim + 0];
+                const float *v1 = positions + 3 * (size_t)indices[3 * (size_t)prim + 1];
+                const float *v2 = positions + 3 * (size_t)indices[3 * (size_t)prim + 2];
+                record[0] = make_float4(v0[0], v0[1], v0[2], intAsFloat(prim));
+                record[1] = make_float4(v1[0] - v0[0], v1[1] - v0[1], v1[2] - v0[2], 0.f);
+                record[2] = make_float4(v2[0] - v0[0], v2[1] - v0[1], v2[2] - v0[2], 0.f);
+                for (int a = 0; a < 3; a++) {
+                    low[a] = fminf(low[a], fminf(v0[a], fminf(v1[a], v2[a])));
+                    high[a] = fmaxf(high[a], fmaxf(v0[a], fmaxf(v1[a], v2[a])));
+                }
+            }
+        }
+        for (int a = 0; a < 3; a++) {
+            const float pad = 1e-5f * fmaxf(1.f, fmaxf(fabsf(low[a]), fabsf(high[a])));
+            lo[a][k] = present ? low[a] - pad : 0.f;
+            hi[a][k] = present ? high[a] + pad : 0.f;
+            if (present) { ownLo[a] = fminf(ownLo[a], low[a]); ownHi[a] = fmaxf(ownHi[a], high[a]); }
+        }
+    }
+    for (int a = 0; a < 3; a++) {
+        node[a] = make_float4(lo[a][0], lo[a][1], lo[a][2], lo[a][3]);
+        node[3 + a] = make_float4(hi[a][0], hi[a][1], hi[a][2], hi[a][3]);
+    }
+    boundsLo[n] = make_float4(ownLo[0], ownLo[1], ownLo[2], 0.f);
+    boundsHi[n] = make_float4(ownHi[0], ownHi[1], ownHi[2], 0.f);
+    readyOut[n] = 1;
 }
 
 // ------------------------------------------------------------------------- bandwidth probe

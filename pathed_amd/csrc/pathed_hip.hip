@@ -223,6 +223,14 @@ struct PathedScene {
     bool sceneInLds = false;
     bool bruteForce = false;      // <= kBruteForceMaxTris triangles: test them all, no BVH walk
     SmallTris smallTris;          // their records, passed to k_trace_small as a kernel argument
+    // PathedSceneOptions.refittable: the triangle soup stays on the device for pathed_hip_scene_refit
+    bool refittable = false;
+    DeviceBuffer<float> soupPositions, soupNormals, soupUvs;
+    DeviceBuffer<uint32_t> soupIndices;
+    DeviceBuffer<int> soupTriMaterial;
+    DeviceBuffer<float4> refitLo, refitHi;          // unpadded bounds per node (refit working memory, allocated on first use)
+    DeviceBuffer<unsigned char> refitReady;         // two flag arrays
+    size_t soupVertices = 0;
     bool mfmaPhase1 = false;      // k_path_small<.., MFMA>: phase 1 on the matrix pipe (mfma_candidates.h)
     DeviceBuffer<float> mfmaTable;   // its A-side rows
     MfmaFrame mfmaFrame;
@@ -1113,6 +1121,7 @@ int pathed_hip_scene_create_ex(const PathedSceneDesc *desc, const PathedSceneOpt
         if (options.max_slots < 0 || (options.max_slots != 0 && options.max_slots < kBlock)) { return fail(PATHED_E_INVALID, "max_slots must be 0 or >= 256"); }
         if (options.shade_kernel < 0 || options.shade_kernel > 4) { return fail(PATHED_E_INVALID, "shade_kernel must be 0..4"); }
         if (options.stage_slots != 0 && options.stage_slots != 512 && options.stage_slots != 1024) { return fail(PATHED_E_INVALID, "stage_slots must be 0, 512 or 1024"); }
+        if (options.refittable != 0 && options.refittable != 1) { return fail(PATHED_E_INVALID, "refittable must be 0 or 1"); }
         if (options.small_phase1 < 0 || options.small_phase1 > 2) { return fail(PATHED_E_INVALID, "small_phase1 must be 0 (automatic), 1 (VALU) or 2 (matrix pipe)"); }
     }
     int deviceId = options.device;
@@ -1321,7 +1330,7 @@ int pathed_hip_scene_create_ex(const PathedSceneDesc *desc, const PathedSceneOpt
         if (status == hipSuccess) { status = hipMemcpy(deviceIndices.ptr, desc->indices, 3 * nt * sizeof(uint32_t), hipMemcpyHostToDevice); }
         if (status == hipSuccess) { status = hipMemcpy(deviceTriMaterial.ptr, desc->tri_material, nt * sizeof(int), hipMemcpyHostToDevice); }
         if (status == hipSuccess) {
-            hipLaunchKernelGGL(k_build_tri_shade, dim3((unsigned)((nt + kBlock - 1) / kBlock)), dim3(kBlock), 0, nullptr,
+            hipLaunchKernelGGL(k_build_tri_shade, dim3((unsigned)((8 * nt + kBlock - 1) / kBlock)), dim3(kBlock), 0, nullptr,
                                devicePositions.ptr, deviceNormals.ptr, deviceUvs.ptr, deviceIndices.ptr, deviceTriMaterial.ptr,
                                (uint32_t)nt, scene->triShade.ptr, scene->triCompact.ptr);
             status = hipGetLastError();
@@ -1368,6 +1377,14 @@ int pathed_hip_scene_create_ex(const PathedSceneDesc *desc, const PathedSceneOpt
         if ((status = scene->leafTris.upload(tris)) != hipSuccess) { releaseSoup(); return fail_cleanup(status, "upload triangles"); }
     }
     status = hipDeviceSynchronize();   // the shading-record gather reads the soup
+    if (status == hipSuccess && options.refittable && desc->n_triangles > 0) {
+        // pathed_hip_scene_refit moves the vertices later: the soup stays (the buffers change owner, nothing is copied)
+        auto adopt = [](auto &to, auto &from) { to.ptr = from.ptr; to.count = from.count; from.ptr = nullptr; from.count = 0; };
+        adopt(scene->soupPositions, devicePositions); adopt(scene->soupNormals, deviceNormals); adopt(scene->soupUvs, deviceUvs);
+        adopt(scene->soupIndices, deviceIndices); adopt(scene->soupTriMaterial, deviceTriMaterial);
+        scene->soupVertices = desc->n_vertices;
+        scene->refittable = true;
+    }
     releaseSoup();
     if (status != hipSuccess) { return fail_cleanup(status, "build shading records"); }
     if ((status = scene->spheres.upload(spheres)) != hipSuccess) { return fail_cleanup(status, "upload spheres"); }
@@ -2251,6 +2268,67 @@ int pathed_hip_debug_small_candidates(PathedScene *scene, const float *rays, siz
     HIP_TRY(hipMemcpy(out, deviceOut.ptr, n * 6 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return PATHED_OK;
 #endif
+}
+
+int pathed_hip_scene_refit(PathedScene *scene, const float *positions, const float *normals, uint32_t n_vertices, float *device_ms)
+{
+    if (!scene || !positions) { return fail(PATHED_E_INVALID, "null scene or positions"); }
+    if (!scene->refittable) { return fail(PATHED_E_INVALID, "create the scene with PathedSceneOptions.refittable = 1: the refit needs the triangle soup on the device"); }
+    if ((size_t)n_vertices != scene->soupVertices) { return fail(PATHED_E_INVALID, "refit keeps the topology: the vertex count must be the scene's"); }
+    if (scene->bruteForce) { return fail(PATHED_E_UNSUPPORTED, "scenes of at most 64 triangles carry no tree to refit: create the scene again (microseconds)"); }
+    if (scene->nodeFormat != 0) { return fail(PATHED_E_UNSUPPORTED, "refit serves the 128-byte float nodes"); }
+    SELECT_DEVICE(scene);
+    const int nNodes = scene->device.nNodes;
+    const size_t nTris = (size_t)scene->device.nTris;
+    if (nNodes <= 0 || nTris == 0) { return fail(PATHED_E_INVALID, "the scene has no tree"); }
+    if (!scene->refitLo.ptr) {
+        HIP_TRY(scene->refitLo.allocate((size_t)nNodes));
+        HIP_TRY(scene->refitHi.allocate((size_t)nNodes));
+        HIP_TRY(scene->refitReady.allocate(2 * (size_t)nNodes));
+    }
+    HIP_TRY(hipMemcpy(scene->soupPositions.ptr, positions, 3 * (size_t)n_vertices * sizeof(float), hipMemcpyHostToDevice));
+    if (normals) { HIP_TRY(hipMemcpy(scene->soupNormals.ptr, normals, 3 * (size_t)n_vertices * sizeof(float), hipMemcpyHostToDevice)); }
+    hipEvent_t start = nullptr, stop = nullptr;
+    HIP_TRY(hipEventCreate(&start));
+    hipError_t status = hipEventCreate(&stop);
+    if (status == hipSuccess) { status = hipEventRecord(start, nullptr); }
+    if (status == hipSuccess) {
+        // shading records (corners, normals, uvs) of every primitive, then the tree bottom-up
+        hipLaunchKernelGGL(k_build_tri_shade, dim3((unsigned)((8 * nTris + kBlock - 1) / kBlock)), dim3(kBlock), 0, nullptr,
+                           scene->soupPositions.ptr, scene->soupNormals.ptr, scene->soupUvs.ptr, scene->soupIndices.ptr, scene->soupTriMaterial.ptr,
+                           (uint32_t)nTris, scene->triShade.ptr, scene->triCompact.ptr);
+        status = hipMemsetAsync(scene->refitReady.ptr, 0, 2 * (size_t)nNodes, nullptr);
+    }
+    int passes = 0;
+    unsigned char rootReady = 0;
+    const dim3 grid((unsigned)((nNodes + kBlock - 1) / kBlock)), block(kBlock);
+    auto runPasses = [&](int count) {
+        for (int k = 0; k < count; k++, passes++) {
+            unsigned char *in = scene->refitReady.ptr + (size_t)(passes & 1) * nNodes, *out = scene->refitReady.ptr + (size_t)((passes + 1) & 1) * nNodes;
+            hipLaunchKernelGGL(k_refit_pass, grid, block, 0, nullptr, scene->nodes.ptr, nNodes, scene->leafTris.ptr, scene->soupPositions.ptr,
+                               scene->soupIndices.ptr, scene->spheres.ptr, scene->refitLo.ptr, scene->refitHi.ptr, in, out);
+        }
+    };
+    // one pass per 4-wide level, back to back (no look at the flags in between: a host round trip costs more than a pass)
+    if (status == hipSuccess) { runPasses(scene->bvh.maxDepth > 0 ? scene->bvh.maxDepth + 1 : 16); status = hipGetLastError(); }
+    float ms = 0.f;
+    if (status == hipSuccess) { status = hipEventRecord(stop, nullptr); }
+    if (status == hipSuccess) { status = hipEventSynchronize(stop); }
+    if (status == hipSuccess) { status = hipEventElapsedTime(&ms, start, stop); }
+    if (status == hipSuccess) { status = hipMemcpy(&rootReady, scene->refitReady.ptr + (size_t)(passes & 1) * nNodes, 1, hipMemcpyDeviceToHost); }
+    while (status == hipSuccess && !rootReady && passes < 4096) {
+        // (a tree deeper than its recorded depth: keep going, four passes per look at the root's flag)
+        runPasses(4);
+        status = hipGetLastError();
+        if (status == hipSuccess) { status = hipMemcpy(&rootReady, scene->refitReady.ptr + (size_t)(passes & 1) * nNodes, 1, hipMemcpyDeviceToHost); }
+    }
+    (void)hipEventDestroy(start);
+    if (stop) { (void)hipEventDestroy(stop); }
+    if (status != hipSuccess) { return fail(PATHED_E_DEVICE, std::string("refit: ") + hipGetErrorString(status)); }
+    if (!rootReady) { return fail(PATHED_E_DEVICE, "refit: the root was never reached (a cycle in the tree?)"); }
+    scene->bvhOnHost = false;   // exports download the refitted tree
+    if (device_ms) { *device_ms = ms; }
+    return PATHED_OK;
 }
 
 int pathed_hip_set_stats_mode(PathedScene *scene, int enabled)

@@ -85,7 +85,7 @@ class HipScene:
         packed.node_format = {"auto": 0, "wide": 1, "compressed": 2, "compressed8": 3}[options.pop("node_format", "auto")]
         packed.unit_order = {"auto": 0, "stripes": 1, "stripes-tiled": 2, "tiles": 3}[options.pop("unit_order", "auto")]
         packed.small_phase1 = {"auto": 0, "valu": 1, "mfma": 2}[options.pop("small_phase1", "auto")]
-        for name in ("stack_rows", "pools", "suspend_lanes", "suspend_patience", "park_min_cards", "max_slots", "trace_blocks_per_cu", "stage_slots", "build_threads", "generic_kernels"):
+        for name in ("stack_rows", "pools", "suspend_lanes", "suspend_patience", "park_min_cards", "max_slots", "trace_blocks_per_cu", "stage_slots", "build_threads", "generic_kernels", "refittable"):
             if name in options:
                 setattr(packed, name, int(options.pop(name)))
         if options:
@@ -146,6 +146,21 @@ class HipScene:
             self._handle, rays.ctypes.data_as(C.POINTER(C.c_float)), rays.shape[0], out.ctypes.data_as(C.POINTER(C.c_uint64)))
         _check(self._lib, code, "pathed_hip_debug_small_candidates")
         return out
+
+    def refit(self, positions, normals=None):
+        """New vertex positions (and normals) over the same topology (pathed_hip_scene_refit; scenes created with refittable=1).
+        Returns the device time of the refit kernels in milliseconds."""
+        positions = np.ascontiguousarray(positions, dtype=np.float32).reshape(-1, 3)
+        normal_pointer = None
+        if normals is not None:
+            normals = np.ascontiguousarray(normals, dtype=np.float32).reshape(-1, 3)
+            assert normals.shape == positions.shape
+            normal_pointer = normals.ctypes.data_as(C.POINTER(C.c_float))
+        ms = C.c_float(0.0)
+        code = self._lib.pathed_hip_scene_refit(self._handle, positions.ctypes.data_as(C.POINTER(C.c_float)), normal_pointer,
+                                                positions.shape[0], C.byref(ms))
+        _check(self._lib, code, "pathed_hip_scene_refit")
+        return float(ms.value)
 
     def set_samples_per_unit(self, samples):
         """Summation granularity (see include/pathed_hip.h); 1 = the reference's exact order."""

@@ -40,6 +40,6 @@ def generated_assets(request):
     # whenever a GPU test is among the selected ones (with -m gpu, -k ..., or a file name on the command line)
     if any(item.get_closest_marker("gpu") is not None for item in request.session.items):
         import subprocess
-        subprocess.run([sys.executable, os.path.join(REPO_ROOT, "tools", "make_assets.py"), "--dragon-variants", "6,7,9"],
+        subprocess.run([sys.executable, os.path.join(REPO_ROOT, "tools", "make_assets.py"), "--dragon-variants", "6,7,9,10"],
                        check=True, stdout=subprocess.DEVNULL)
     yield

@@ -267,6 +267,50 @@ def test_full_size_properties(libs):
     assert lit.shape[0] > 1000 and torch.equal(lit, torch.tensor([17.0, 12.0, 4.0], device="cuda").expand_as(lit))
 
 
+@pytest.mark.parametrize("scene_path,width,height,spp,tolerance", [
+    ("scenes/mis-pbrt.json", 1024, 1024, 8, 0.05),                 # BASELINE config 3: plastic + Beckmann plates, sphere lights
+    ("scenes/teapot.json", 1024, 1024, 8, 0.05),                   # config 4: glass + checkerboard + environment light
+    ("assets/dragon-standin-9.json", 1920, 1080, 2, 0.05),         # config 5: the 5.2 M-triangle stand-in at 1080p
+])
+def test_full_size_properties_of_the_other_configurations(libs, scene_path, width, height, spp, tolerance):
+    """BASELINE configurations 3-5 at THEIR resolutions (the oracle comparisons run at 96^2 / 128x72): size-independent
+    properties.  Energy: the image mean equals the mean of an oracle rendering of the same camera at a sixteenth of the
+    resolution (pixels are Monte Carlo estimates of one integral over the image plane, whatever the grid).  Window additivity:
+    a vertex's contribution does not depend on the window it is counted in and lastBounce only cuts paths after it, so
+    [0, 2] = [0, 10] - [3, 10] up to the unconditional environment term of missed camera rays (reference
+    src/bounce_controller.cpp:14-25).  Nothing is dropped, everything is finite and >= 0."""
+    import torch
+    oracle_lib, HipScene, LoadedScene = libs
+    scene = LoadedScene(scene_path, width, height)
+    gpu = HipScene(scene.desc, device=0, bvh_builder="ploc" if scene.n_triangles > 1000000 else "sah")
+    full = torch.zeros((height, width, 3), dtype=torch.float32, device="cuda")
+    gpu.render_device(1, 0, spp, 0, 10, full.data_ptr())
+    torch.cuda.synchronize()
+    assert torch.isfinite(full).all() and (full >= 0).all()
+    assert gpu.stats()["dropped_samples"] == 0
+    mean = (full / spp).mean(dim=(0, 1)).cpu().numpy()
+    small = LoadedScene(scene_path, width // 4, height // 4)
+    expected, _ = oracle_lib.OracleScene(small.desc).render(width // 4, height // 4, 1, 0, 4 * spp, 0, 10, threads=os.cpu_count())
+    expected_mean = (expected / (4 * spp)).reshape(-1, 3).mean(axis=0)
+    assert np.allclose(mean, expected_mean, rtol=tolerance), (mean, expected_mean)
+    upper = torch.zeros_like(full)
+    gpu.render_device(1, 0, spp, 3, 10, upper.data_ptr())
+    lower = torch.zeros_like(full)
+    gpu.render_device(1, 0, spp, 0, 2, lower.data_ptr())
+    torch.cuda.synchronize()
+    # a camera ray that misses everything returns the environment WHATEVER the window (reference src/sample_integrator.cpp:
+    # the miss branch is not gated by checkCounts): that term E is in all three images, so full - upper = lower - E; with
+    # nothing emissive in view of the camera (these three scenes with an environment), E is the [0, 0] window's image
+    miss = torch.zeros_like(full)
+    if bool(scene.desc.contents.env):
+        gpu.render_device(1, 0, spp, 0, 0, miss.data_ptr())
+        torch.cuda.synchronize()
+    # additivity holds per pixel up to the rounding of the sums; a handful of glass / plastic pixels carry large values
+    difference = (full - upper - lower + miss).abs()
+    scale = torch.maximum(full.abs(), torch.tensor(1.0, device="cuda"))
+    assert (difference <= 1e-3 * scale).float().mean().item() > 0.9999, float((difference / scale).max())
+
+
 def _render_with_options(libs, options, scene_path, size, seed, spp, count=False):
     """Scene-creation-time switches travel in PathedSceneOptions (include/pathed_hip.h)."""
     _, HipScene, LoadedScene = libs
