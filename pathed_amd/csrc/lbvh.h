@@ -33,7 +33,9 @@ static const int kDeviceBuilderPloc = 2;   // PATHED_BVH_PLOC_DEVICE
 
 // positions / indices are DEVICE pointers (3 floats per vertex, 3 indices per triangle).
 // triangleCount must exceed 4 (smaller meshes go through the host builder).
+// spheres: DEVICE pointer to (centre.xyz, radius) per sphere, or null with sphereCount 0; every sphere becomes a leaf of its
+// own (bvh_build.h does the same on the host; reference src/sphere.cpp:16-48 gives each one to Embree as a geometry).
 hipError_t buildBvhOnDevice(int builder, const float *positions, const uint32_t *indices, uint32_t triangleCount,
-                            hipStream_t stream, DeviceBvh *out, std::string *error);
+                            const float4 *spheres, uint32_t sphereCount, hipStream_t stream, DeviceBvh *out, std::string *error);
 
 }  // namespace pathed

@@ -34,6 +34,11 @@ constexpr unsigned int kLeafFlag = 0x80000000u;   // child reference: a single s
 constexpr unsigned int kNoChild = 0xFFFFFFFFu;
 constexpr int kLbvhMaxLeaf = 4;                   // as the host builder's default leaf size
 constexpr int kEmptyRef = (int)0x80000000u;       // trace.h kEmptyChild
+// "count" of a subtree: the triangles below it, and in the top bit whether a SPHERE is below it.  A sphere gets a leaf of
+// its own (bvh_build.h; reference src/sphere.cpp:16-48 hands each one to Embree as a geometry): a subtree with the bit set
+// never becomes a triangle leaf, and as an unsigned number it is "more than kLbvhMaxLeaf" wherever that is the question.
+constexpr unsigned int kHasSphere = 0x80000000u;
+__host__ __device__ inline unsigned int mergeCounts(unsigned int a, unsigned int b) { return ((a & ~kHasSphere) + (b & ~kHasSphere)) | ((a | b) & kHasSphere); }
 
 // float <-> unsigned with the same order
 __device__ inline unsigned int orderedBits(float v)
@@ -107,6 +112,42 @@ __global__ __launch_bounds__(kLbvhBlock) void k_lbvh_prims(
     }
 }
 
+// spheres join the primitives behind the triangles: primitive triangleCount + s, bounds as bvh_build.h gives them
+// (centre +- (radius * 1.00001 + 1e-5 |centre|): a hit point computed in fp32 may sit an ulp outside the exact bounds)
+__global__ __launch_bounds__(kLbvhBlock) void k_lbvh_sphere_prims(
+    const float4 *spheres, uint32_t sphereCount, uint32_t triangleCount, float4 *boxLo, float4 *boxHi, unsigned int *centroidBounds)
+{
+    const uint32_t s = blockIdx.x * kLbvhBlock + threadIdx.x;
+    if (s >= sphereCount) { return; }
+    const float4 sphere = spheres[s];
+    const float centre[3] = { sphere.x, sphere.y, sphere.z };
+    const float radius = fabsf(sphere.w);
+    float lo[3], hi[3];
+    #pragma unroll
+    for (int a = 0; a < 3; a++) {
+        const float reach = radius * 1.00001f + 1e-5f * fabsf(centre[a]);
+        lo[a] = centre[a] - reach;
+        hi[a] = centre[a] + reach;
+        const float middle = 0.5f * (lo[a] + hi[a]);
+        if (middle == middle) {   // few spheres: one atomic pair each
+            atomicMin(&centroidBounds[a], orderedBits(middle));
+            atomicMax(&centroidBounds[3 + a], orderedBits(middle));
+        }
+    }
+    boxLo[triangleCount + s] = make_float4(lo[0], lo[1], lo[2], 0.f);
+    boxHi[triangleCount + s] = make_float4(hi[0], hi[1], hi[2], 0.f);
+}
+
+// triangles (1) and spheres (kHasSphere) of the sorted order, for the prefix sums the Karras hierarchy takes its counts from
+__global__ __launch_bounds__(kLbvhBlock) void k_lbvh_kinds(const unsigned int *sorted, uint32_t n, uint32_t triangleCount, unsigned int *isTriangle, unsigned int *isSphere)
+{
+    const uint32_t i = blockIdx.x * kLbvhBlock + threadIdx.x;
+    if (i >= n) { return; }
+    const bool sphere = sorted[i] >= triangleCount;
+    isTriangle[i] = sphere ? 0u : 1u;
+    isSphere[i] = sphere ? 1u : 0u;
+}
+
 __device__ inline unsigned long long spread21(unsigned long long v)
 {
     v &= 0x1FFFFFull;
@@ -151,7 +192,8 @@ __device__ inline int commonPrefix(const unsigned long long *keys, int n, unsign
 
 // Karras 2012, "Maximizing parallelism in the construction of BVHs, octrees, and k-d trees", §3-4
 __global__ __launch_bounds__(kLbvhBlock) void k_lbvh_hierarchy(
-    const unsigned long long *keys, int n,
+    const unsigned long long *keys, int n, const unsigned int *trianglesBefore, const unsigned int *spheresBefore,
+    const unsigned int *sorted, uint32_t triangleCount,
     uint2 *children, unsigned int *count, int *parentOfInternal, int *parentOfLeaf)
 {
     const int i = blockIdx.x * kLbvhBlock + threadIdx.x;
@@ -181,7 +223,12 @@ __global__ __launch_bounds__(kLbvhBlock) void k_lbvh_hierarchy(
     if (last == gamma + 1) { right = (unsigned int)(gamma + 1) | kLeafFlag; parentOfLeaf[gamma + 1] = i; }
     else { right = (unsigned int)(gamma + 1); parentOfInternal[gamma + 1] = i; }
     children[i] = make_uint2(left, right);
-    count[i] = (unsigned int)(last - first + 1);   // the subtree's triangles are sorted entries first..last
+    // the subtree's primitives are sorted entries first..last: triangles among them, and whether a sphere is
+    // (exclusive prefix sums over the sorted order; entry `last` itself is added by its kind)
+    const bool lastIsSphere = sorted[last] >= triangleCount;
+    const unsigned int triangles = trianglesBefore[last] - trianglesBefore[first] + (lastIsSphere ? 0u : 1u);
+    const unsigned int spheres = spheresBefore[last] - spheresBefore[first] + (lastIsSphere ? 1u : 0u);
+    count[i] = triangles | (spheres ? kHasSphere : 0u);
     if (i == 0) { parentOfInternal[0] = -1; }
 }
 
@@ -238,7 +285,7 @@ struct PlocClusters {
 };
 
 __global__ __launch_bounds__(kLbvhBlock) void k_ploc_init(
-    uint32_t n, const unsigned int *sorted, const float4 *boxLo, const float4 *boxHi, PlocClusters clusters)
+    uint32_t n, uint32_t triangleCount, const unsigned int *sorted, const float4 *boxLo, const float4 *boxHi, PlocClusters clusters)
 {
     const uint32_t i = blockIdx.x * kLbvhBlock + threadIdx.x;
     if (i >= n) { return; }
@@ -246,7 +293,7 @@ __global__ __launch_bounds__(kLbvhBlock) void k_ploc_init(
     clusters.lo[i] = boxLo[tri];
     clusters.hi[i] = boxHi[tri];
     clusters.node[i] = i | kLeafFlag;
-    clusters.count[i] = 1u;
+    clusters.count[i] = tri >= triangleCount ? kHasSphere : 1u;
 }
 
 __global__ __launch_bounds__(kLbvhBlock) void k_ploc_nearest(PlocClusters clusters, unsigned int c, int radius, unsigned int *nearest)
@@ -313,7 +360,7 @@ __global__ __launch_bounds__(kLbvhBlock) void k_ploc_merge(
         hi = make_float4(fmaxf(hi.x, ohi.x), fmaxf(hi.y, ohi.y), fmaxf(hi.z, ohi.z), 0.f);
         const unsigned int id = nodeBase + mergeIndex[i];
         children[id] = make_uint2(node, from.node[j]);   // i < j: Morton order is kept left to right
-        triangles += from.count[j];
+        triangles = mergeCounts(triangles, from.count[j]);
         count[id] = triangles;
         nodeLo[id] = lo;
         nodeHi[id] = hi;
@@ -354,17 +401,20 @@ struct WideInputs {
     const unsigned int *sorted;
     const float *positions;
     const uint32_t *indices;
+    uint32_t triangleCount;          // primitives at or beyond it are spheres
 };
 
-__device__ inline unsigned int trianglesBelow(const WideInputs &in, unsigned int ref)
+// the packed count of a child reference (triangles below | kHasSphere)
+__device__ inline unsigned int countBelow(const WideInputs &in, unsigned int ref)
 {
     if (ref == kNoChild) { return 0u; }
-    return (ref & kLeafFlag) ? 1u : in.count[ref];
+    if (ref & kLeafFlag) { return in.sorted[ref & ~kLeafFlag] >= in.triangleCount ? kHasSphere : 1u; }
+    return in.count[ref];
 }
 
 __device__ inline bool isInnerRef(const WideInputs &in, unsigned int ref)
 {
-    return ref != kNoChild && !(ref & kLeafFlag) && in.count[ref] > (unsigned int)kLbvhMaxLeaf;
+    return ref != kNoChild && !(ref & kLeafFlag) && in.count[ref] > (unsigned int)kLbvhMaxLeaf;   // a sphere below counts as "more"
 }
 
 // A wide node adopts the two children of its binary root, then keeps replacing the inner child
@@ -450,7 +500,8 @@ __global__ __launch_bounds__(kLbvhBlock) void k_lbvh_wide_emit(
         refs[k] = kEmptyRef;
         const bool present = ref != kNoChild;
         if (present) {
-            const unsigned int triangles = trianglesBelow(in, ref);
+            const unsigned int packed = countBelow(in, ref);
+            const unsigned int triangles = packed & ~kHasSphere;
             if (ref & kLeafFlag) {
                 const unsigned int tri = in.sorted[ref & ~kLeafFlag];
                 boxLow = in.boxLo[tri];
@@ -459,7 +510,11 @@ __global__ __launch_bounds__(kLbvhBlock) void k_lbvh_wide_emit(
                 boxLow = in.nodeLo[ref];
                 boxHigh = in.nodeHi[ref];
             }
-            if (triangles <= (unsigned int)kLbvhMaxLeaf) {
+            if ((ref & kLeafFlag) && (packed & kHasSphere)) {
+                // a sphere: a leaf of its own, count 0, first = sphere + 1 (bvh_build.h; trace.h tests it); no place in leaf order
+                const unsigned int sphere = in.sorted[ref & ~kLeafFlag] - in.triangleCount;
+                refs[k] = -(int)(((sphere + 1u) << 3) | 0u) - 1;
+            } else if (packed <= (unsigned int)kLbvhMaxLeaf) {
                 refs[k] = -(int)((first << 3) | triangles) - 1;   // trace.h encodeLeaf
                 writeLeafTriangles(in, ref, first, leafTris);
             } else {
@@ -519,7 +574,7 @@ unsigned int buildTopSah(std::vector<TopItem> &items, size_t begin, size_t end, 
             clo[a] = std::min(clo[a], centre);
             chi[a] = std::max(chi[a], centre);
         }
-        triangles += items[i].triangles;
+        triangles = mergeCounts(triangles, items[i].triangles);
     }
     auto halfArea = [](const float *l, const float *h) {
         const float dx = h[0] - l[0], dy = h[1] - l[1], dz = h[2] - l[2];
@@ -543,7 +598,7 @@ unsigned int buildTopSah(std::vector<TopItem> &items, size_t begin, size_t end, 
             int b = (int)((0.5f * (items[i].lo[axis] + items[i].hi[axis]) - clo[axis]) * scale);
             b = b < 0 ? 0 : b > kBins - 1 ? kBins - 1 : b;
             for (int a = 0; a < 3; a++) { binLo[b][a] = std::min(binLo[b][a], items[i].lo[a]); binHi[b][a] = std::max(binHi[b][a], items[i].hi[a]); }
-            binTriangles[b] += items[i].triangles;
+            binTriangles[b] += (items[i].triangles & ~kHasSphere) + ((items[i].triangles & kHasSphere) ? 1u : 0u);   // SAH weight
             binItems[b]++;
         }
         float rightArea[kBins];
@@ -622,7 +677,7 @@ inline unsigned int blocksFor(size_t n) { return (unsigned int)((n + kLbvhBlock 
 }  // namespace
 
 hipError_t buildBvhOnDevice(int builder, const float *positions, const uint32_t *indices, uint32_t triangleCount,
-                            hipStream_t stream, DeviceBvh *out, std::string *error)
+                            const float4 *spheres, uint32_t sphereCount, hipStream_t stream, DeviceBvh *out, std::string *error)
 {
     auto failed = [&](hipError_t status, const char *what) {
         if (error) { *error = std::string("device bvh: ") + what + ": " + hipGetErrorString(status); }
@@ -631,10 +686,11 @@ hipError_t buildBvhOnDevice(int builder, const float *positions, const uint32_t 
         return status == hipSuccess ? hipErrorInvalidValue : status;
     };
     *out = DeviceBvh();
-    const uint32_t n = triangleCount;
+    const uint32_t n = triangleCount + sphereCount;   // primitives: triangles, then spheres
     if (builder != kDeviceBuilderLbvh && builder != kDeviceBuilderPloc) { return failed(hipErrorInvalidValue, "unknown builder"); }
-    if (n <= (uint32_t)kLbvhMaxLeaf) { return failed(hipErrorInvalidValue, "fewer than five triangles"); }
-    if (n >= (1u << 28)) { return failed(hipErrorInvalidValue, "more than 2^28 triangles"); }
+    if (triangleCount <= (uint32_t)kLbvhMaxLeaf) { return failed(hipErrorInvalidValue, "fewer than five triangles"); }
+    if (n >= (1u << 28) || n < triangleCount) { return failed(hipErrorInvalidValue, "more than 2^28 primitives"); }
+    if (sphereCount > 0 && !spheres) { return failed(hipErrorInvalidValue, "null sphere array"); }
 
     hipEvent_t started = nullptr, finished = nullptr;
     hipError_t status;
@@ -667,7 +723,11 @@ hipError_t buildBvhOnDevice(int builder, const float *positions, const uint32_t 
         if ((status = hipStreamSynchronize(stream)) != hipSuccess) { return failed(status, "init"); }   // `init` is on this stack frame
     }
     const unsigned int reduceGrid = blocksFor(n) < kReduceBlocks ? blocksFor(n) : kReduceBlocks;
-    hipLaunchKernelGGL(k_lbvh_prims, dim3(reduceGrid), dim3(kLbvhBlock), 0, stream, positions, indices, n, boxLo, boxHi, words);
+    const unsigned int triangleGrid = blocksFor(triangleCount) < kReduceBlocks ? blocksFor(triangleCount) : kReduceBlocks;
+    hipLaunchKernelGGL(k_lbvh_prims, dim3(triangleGrid), dim3(kLbvhBlock), 0, stream, positions, indices, triangleCount, boxLo, boxHi, words);
+    if (sphereCount > 0) {
+        hipLaunchKernelGGL(k_lbvh_sphere_prims, dim3(blocksFor(sphereCount)), dim3(kLbvhBlock), 0, stream, spheres, sphereCount, triangleCount, boxLo, boxHi, words);
+    }
     hipLaunchKernelGGL(k_lbvh_morton, dim3(blocksFor(n)), dim3(kLbvhBlock), 0, stream, boxLo, boxHi, n, words, keysIn, valuesIn);
 
     // 3: sort
@@ -693,8 +753,23 @@ hipError_t buildBvhOnDevice(int builder, const float *positions, const uint32_t 
         unsigned int *pending = scratch.get<unsigned int>(64);
         if (scratch.status != hipSuccess) { return failed(scratch.status, "scratch allocation"); }
         if ((status = hipMemsetAsync(ready[0], 0, (size_t)n, stream)) != hipSuccess) { return failed(status, "memset"); }
+        // triangles / spheres before every sorted entry (exclusive scans): a node's count is read off its sorted range
+        unsigned int *isTriangle = scratch.get<unsigned int>(n), *isSphere = scratch.get<unsigned int>(n);
+        unsigned int *trianglesBefore = scratch.get<unsigned int>(n), *spheresBefore = scratch.get<unsigned int>(n);
+        if (scratch.status != hipSuccess) { return failed(scratch.status, "scratch allocation"); }
+        hipLaunchKernelGGL(k_lbvh_kinds, dim3(blocksFor(n)), dim3(kLbvhBlock), 0, stream, sorted, n, triangleCount, isTriangle, isSphere);
+        {
+            size_t kindBytes = 0;
+            if ((status = rocprim::exclusive_scan(nullptr, kindBytes, isTriangle, trianglesBefore, 0u, (size_t)n, rocprim::plus<unsigned int>(), stream)) != hipSuccess) { return failed(status, "scan (query)"); }
+            void *kindTemporary = scratch.get<unsigned char>(kindBytes);
+            if (scratch.status != hipSuccess) { return failed(scratch.status, "scan scratch"); }
+            size_t bytes = kindBytes;
+            if ((status = rocprim::exclusive_scan(kindTemporary, bytes, isTriangle, trianglesBefore, 0u, (size_t)n, rocprim::plus<unsigned int>(), stream)) != hipSuccess) { return failed(status, "scan"); }
+            bytes = kindBytes;
+            if ((status = rocprim::exclusive_scan(kindTemporary, bytes, isSphere, spheresBefore, 0u, (size_t)n, rocprim::plus<unsigned int>(), stream)) != hipSuccess) { return failed(status, "scan"); }
+        }
         hipLaunchKernelGGL(k_lbvh_hierarchy, dim3(blocksFor(n - 1)), dim3(kLbvhBlock), 0, stream,
-                           keysOut, (int)n, children, count, parentOfInternal, parentOfLeaf);
+                           keysOut, (int)n, trianglesBefore, spheresBefore, sorted, triangleCount, children, count, parentOfInternal, parentOfLeaf);
         // boxes: one pass per level; the count of nodes still waiting is read back every eighth pass
         const int passesPerCheck = 8;
         bool fitted = false;
@@ -734,7 +809,7 @@ hipError_t buildBvhOnDevice(int builder, const float *positions, const uint32_t 
             const int value = atoi(text);
             if (value >= 1 && value <= kPlocMaxRadius) { radius = value; }
         }
-        hipLaunchKernelGGL(k_ploc_init, dim3(blocksFor(n)), dim3(kLbvhBlock), 0, stream, n, sorted, boxLo, boxHi, a);
+        hipLaunchKernelGGL(k_ploc_init, dim3(blocksFor(n)), dim3(kLbvhBlock), 0, stream, n, triangleCount, sorted, boxLo, boxHi, a);
         unsigned int topLimit = 1024;   // clusters left to the host's SAH build (0: cluster all the way); 1 024: fewer rounds AND a better top
         if (const char *text = getenv("PATHED_PLOC_TOP")) {
             const int value = atoi(text);
@@ -803,7 +878,7 @@ hipError_t buildBvhOnDevice(int builder, const float *positions, const uint32_t 
     if (capacity == 0) { return failed(hipErrorInvalidValue, "empty hierarchy"); }
 
     if ((status = hipMalloc((void **)&out->nodes, (size_t)capacity * 8 * sizeof(float4))) != hipSuccess) { return failed(status, "node allocation"); }
-    if ((status = hipMalloc((void **)&out->leafTris, (size_t)n * 3 * sizeof(float4))) != hipSuccess) { return failed(status, "triangle allocation"); }
+    if ((status = hipMalloc((void **)&out->leafTris, (size_t)triangleCount * 3 * sizeof(float4))) != hipSuccess) { return failed(status, "triangle allocation"); }
     out->nodeCapacity = capacity;
 
     uint2 *frontierA = scratch.get<uint2>(capacity);
@@ -829,6 +904,7 @@ hipError_t buildBvhOnDevice(int builder, const float *positions, const uint32_t 
     inputs.sorted = sorted;
     inputs.positions = positions;
     inputs.indices = indices;
+    inputs.triangleCount = triangleCount;
 
     {
         const uint2 rootEntry = make_uint2(root, 0u);   // (binary node, first triangle in leaf order)

@@ -1305,8 +1305,6 @@ int pathed_hip_scene_create_ex(const PathedSceneDesc *desc, const PathedSceneOpt
     }
     // tiny meshes take the all-triangles kernel, which wants the host copy of the records
     if (desc->n_triangles <= (uint32_t)kBruteForceMaxTris) { builder = PATHED_BVH_SAH_HOST; }
-    // the device builders take triangles only: scenes with many spheres are built on the host, where spheres become leaves
-    if (desc->n_spheres > (uint32_t)kBruteForceMaxSpheres) { builder = PATHED_BVH_SAH_HOST; }
     scene->bvhBuilder = builder;
     // the triangle soup on the device: input of the device builders and of the shading-record gather
     DeviceBuffer<float> devicePositions, deviceNormals, deviceUvs;
@@ -1342,8 +1340,18 @@ int pathed_hip_scene_create_ex(const PathedSceneDesc *desc, const PathedSceneOpt
         // rtcCommitScene's stand-in on the device (lbvh.h): build, keep the result in place
         DeviceBvh built;
         std::string message;
+        // spheres join the tree as one-sphere leaves, as on the host (reference src/sphere.cpp:16-48: each is a geometry of its own)
+        DeviceBuffer<float4> sphereBounds;
+        if (desc->n_spheres > 0) {
+            std::vector<float4> bounds(desc->n_spheres);
+            for (uint32_t i = 0; i < desc->n_spheres; i++) {
+                bounds[i] = make_float4(desc->spheres[i].center_world[0], desc->spheres[i].center_world[1], desc->spheres[i].center_world[2], desc->spheres[i].radius);
+            }
+            if ((status = sphereBounds.upload(bounds)) != hipSuccess) { releaseSoup(); return fail_cleanup(status, "upload sphere bounds"); }
+            scene->spheresInTree = true;
+        }
         status = buildBvhOnDevice(builder == PATHED_BVH_PLOC_DEVICE ? kDeviceBuilderPloc : kDeviceBuilderLbvh,
-                                  devicePositions.ptr, deviceIndices.ptr, desc->n_triangles, nullptr, &built, &message);
+                                  devicePositions.ptr, deviceIndices.ptr, desc->n_triangles, sphereBounds.ptr, desc->n_spheres, nullptr, &built, &message);
         if (status != hipSuccess) { releaseSoup(); return fail_cleanup(status, message.empty() ? "device BVH build" : message.c_str()); }
         scene->nodes.ptr = built.nodes;
         scene->nodes.count = built.nodeCapacity * 8;

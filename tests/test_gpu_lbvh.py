@@ -210,3 +210,59 @@ def test_tiny_meshes_keep_the_host_path(libs):
     gpu = HipScene(scene.desc, device=0, bvh_builder="lbvh")
     assert gpu.stats()["bvh_builder"] == 0 and gpu.stats()["scene_in_lds"] == 2
     assert gpu.render(1, 0, 2, 0, 4).any()
+
+
+@pytest.mark.parametrize("builder", ["lbvh", "ploc"])
+def test_spheres_are_leaves_of_the_device_built_tree(builder):
+    """Spheres go to the device builders as primitives of their own (the host builder's rule; the reference hands each one to
+    Embree as a geometry, src/sphere.cpp:16-48): a scene with far more than 16 spheres stays on the device, every sphere is
+    the single content of exactly one leaf reference, and closest hits, occlusion and image are the host SAH tree's and the
+    oracle's bit for bit -- sphere hits included (primitive ids >= the triangle count)."""
+    import oracle_lib
+    from pathed_amd import _capi
+    from pathed_amd.integrator import HipScene
+    from scene_builder import BuiltScene
+    rng = np.random.default_rng(41)
+    built = BuiltScene(48, 32, (0.0, 2.0, 14.0), (0.0, 1.0, 0.0), fov_degrees=40.0)
+    grey = built.material(_capi.MAT_LAMBERTIAN, diffuse=(0.6, 0.6, 0.55))
+    glass = built.material(_capi.MAT_GLASS, ior=1.5)
+    mirror = built.material(_capi.MAT_MIRROR)
+    light = built.material(_capi.MAT_LAMBERTIAN, diffuse=(0, 0, 0), emit=(9.0, 8.0, 7.0))
+    # a bumpy floor of a few hundred triangles, a light, and 150 spheres of three materials scattered over it (some overlapping)
+    grid = 14
+    xs, zs = np.meshgrid(np.linspace(-6, 6, grid), np.linspace(-6, 6, grid), indexing="ij")
+    ys = 0.3 * np.sin(xs) * np.cos(zs)
+    vertices = np.stack([xs, ys, zs], axis=-1).reshape(-1, 3)
+    faces = []
+    for i in range(grid - 1):
+        for j in range(grid - 1):
+            a, b, c, d = i * grid + j, (i + 1) * grid + j, (i + 1) * grid + j + 1, i * grid + j + 1
+            faces += [(a, c, b), (a, d, c)]
+    built.mesh(vertices, faces, grey)
+    built.quad([(-3, 7, -3), (3, 7, -3), (3, 7, 3), (-3, 7, 3)], light)
+    n_spheres = 150
+    for k in range(n_spheres):
+        centre = (float(rng.uniform(-5.5, 5.5)), float(rng.uniform(0.4, 3.5)), float(rng.uniform(-5.5, 5.5)))
+        built.sphere(centre, float(rng.uniform(0.08, 0.6)), (grey, glass, mirror)[k % 3])
+    desc = built.finish()
+    n_triangles = desc.contents.n_triangles
+    assert n_triangles > 64 and desc.contents.n_spheres == n_spheres
+    host = HipScene(desc, device=0, bvh_builder="sah")
+    device = HipScene(desc, device=0, bvh_builder=builder)
+    assert device.stats()["bvh_builder"] == {"lbvh": 1, "ploc": 2}[builder]      # not redirected to the host any more
+    nodes, tris = device.export_bvh()
+    refs = nodes[:, 24:28].view(np.int32).reshape(-1)
+    leaves = refs[(refs <= -2) & (refs != EMPTY)]
+    codes = -leaves.astype(np.int64) - 1
+    sphere_leaves = np.sort((codes[(codes & 7) == 0] >> 3) - 1)
+    assert np.array_equal(sphere_leaves, np.arange(n_spheres))                   # each sphere once, in a leaf of its own
+    triangle_leaves = codes[(codes & 7) != 0]
+    assert int((triangle_leaves & 7).sum()) == n_triangles and tris.shape[0] == n_triangles
+    rays = _rays(60000, 3, (0.0, 2.0, 0.0), 7.0)
+    cpu = oracle_lib.OracleScene(desc)
+    expected = cpu.trace(rays)
+    assert (expected[:, 3].view(np.int32) >= n_triangles).mean() > 0.05           # a fair share of sphere hits
+    assert np.array_equal(device.trace(rays).view(np.int32), expected.view(np.int32))
+    assert np.array_equal(host.trace(rays).view(np.int32), expected.view(np.int32))
+    assert np.array_equal(device.trace(rays, any_hit=True), cpu.trace(rays, any_hit=True))
+    assert np.array_equal(device.render(5, 0, 8, 0, 8), host.render(5, 0, 8, 0, 8))
