@@ -205,11 +205,11 @@ def cpu_baseline(scene, args):
     sys.path.insert(0, os.path.join(REPO_ROOT, "tests"))
     import oracle_lib  # the checker; used here only as the reported CPU baseline
 
-    allowed = usable_cores()
+    allowed = min(usable_cores(), oracle_lib.host_threads())   # oracle_lib never starts more than that
     oracle = oracle_lib.OracleScene(scene.desc)
     # the thread count that is fastest HERE: a box may report more hardware threads than the share of it this job runs on
     one, cores = None, allowed
-    for candidate in sorted({min(count, allowed) for count in (16, 32, 64, 128, allowed)}):
+    for candidate in sorted({min(count, allowed) for count in (8, 16, 24, 32, allowed)}):
         t0 = time.perf_counter()
         oracle.render(args.width, args.height, args.seed, 0, 1, 0, args.last_bounce, threads=candidate)
         took = time.perf_counter() - t0
@@ -246,7 +246,7 @@ def cpu_baseline(scene, args):
         "single_thread": single_rate,
         "parallel_efficiency": rate / (cores * single_rate),
         "kind": "port",
-        "sample": "%s %dx%d, %d spp, lastBounce %d, OpenMP over rows (dynamic), %d threads (the fastest of 16 / 32 / 64 / 128 / all usable on this box), %.1f s" % (
+        "sample": "%s %dx%d, %d spp, lastBounce %d, OpenMP over rows (dynamic), %d threads (the fastest of 8 / 16 / 24 / 32 on this box), %.1f s" % (
             args.scene, args.width, args.height, spp, args.last_bounce, cores, elapsed),
     }
 

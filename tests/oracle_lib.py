@@ -54,6 +54,32 @@ def load():
     return lib
 
 
+_threads = None
+
+
+def host_threads():
+    """Threads worth starting: the scheduler affinity cut to the cgroup's CPU quota and, where neither says less, to 32 -- a GPU
+    box reports 256 hardware threads and lets a job run on a 16-core share of them (bench.py measures which count is
+    fastest for its baseline; tests only need a sane one)."""
+    global _threads
+    if _threads is not None:
+        return _threads
+    try:
+        count = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        count = os.cpu_count() or 1
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as handle:
+            first, period = handle.read().split()[:2]
+            if first != "max":
+                count = max(1, min(count, int(float(first) / float(period) + 0.999)))
+    except (OSError, ValueError):
+        pass
+    override = os.environ.get("PATHED_ORACLE_THREADS")
+    _threads = int(override) if override else min(count, 32)
+    return _threads
+
+
 def _fptr(array):
     return array.ctypes.data_as(C.POINTER(C.c_float))
 
@@ -78,6 +104,7 @@ class OracleScene:
         if accum is None:
             accum = np.zeros((height, width, 3), dtype=np.float32)
         stats = (C.c_uint64 * 8)()
+        threads = max(1, min(int(threads), host_threads()))   # callers pass os.cpu_count(): never more than the job may run
         code = self.lib.oracle_render_chunked(self.handle, seed, spp_begin, spp_count, start_bounce, last_bounce,
                                               _fptr(accum), threads, stats, chunk)
         if code != 0:

@@ -47,7 +47,7 @@ def main():
     full_spp = {"C1": 16, "C2": 4096, "C3": 1024, "C4": 2048, "C5": 8192, "VOL": 1024}
     subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_assets.py"), "--dragon", str(args.dragon)], check=True,
                    stdout=subprocess.DEVNULL)
-    cores = os.cpu_count()
+    cores = oracle_lib.host_threads()   # what the job may run at once (oracle_lib), not the machine's 256 hardware threads
     rows = []
     for name, path, w, h, spp, cpu_spp, note, *integrator in CONFIGS:
         integrator = integrator[0] if integrator else "PathTracer"
