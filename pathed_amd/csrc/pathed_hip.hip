@@ -1681,6 +1681,18 @@ static bool fillUnitOrder(RenderParams &q, int order, int width, int height, int
     return true;
 }
 
+// VolumePathTracer on a scene WITHOUT media and without passthrough containers is PathTracer: the reference's two integrators
+// share their direct-lighting arithmetic statement for statement (src/direct_lighting_helper.cpp:37-187 against
+// src/path_tracer.cpp:79-216), every volumetric query degenerates to the regular one and no segment scatters -- the oracle's
+// two integrators and k_path_volume / the path-tracer kernels give the same floats there (tests/test_gpu_volume.py).  Such a
+// scene therefore runs the path tracer's kernels (fused or wavefront: one path per lane with no refill is 0.5-0.6x of them);
+// PathedSceneOptions.generic_kernels = 1 keeps k_path_volume, for that very comparison.
+static bool usesVolumeKernel(const PathedScene *scene)
+{
+    if (scene->integrator != PATHED_INTEGRATOR_VOLUME_PATH_TRACER) { return false; }
+    return scene->hasContainers || scene->device.nMedia > 0 || scene->options.generic_kernels != 0;
+}
+
 // One internal pass of the fused path kernel (scenes of <= 64 triangles): a single persistent launch
 // renders every unit of the pass; no slot pool, no iteration loop, no polling.
 static int renderPassFused(PathedScene *scene, uint64_t seed, uint32_t begin, uint32_t count,
@@ -2122,7 +2134,7 @@ int pathed_hip_render_device(PathedScene *scene, uint64_t seed,
     uint32_t done = 0;
     while (done < spp_count) {
         const uint32_t count = (spp_count - done < perPass) ? (spp_count - done) : perPass;
-        const int code = scene->integrator == PATHED_INTEGRATOR_VOLUME_PATH_TRACER
+        const int code = usesVolumeKernel(scene)
             ? renderPassVolume(scene, seed, spp_begin + done, count, start_bounce, last_bounce, d_accum_rgb_sum, stream)
             : scene->fusedPath
                 ? renderPassFused(scene, seed, spp_begin + done, count, start_bounce, last_bounce, d_accum_rgb_sum, stream)
@@ -2391,7 +2403,7 @@ int pathed_hip_get_stats(PathedScene *scene, PathedStats *out)
     out->bvh_build_ms = scene->bvhBuildMs;
     out->bvh_builder = (uint32_t)scene->bvhBuilder;
     out->trace_launches_all = (uint32_t)scene->traceLaunchesAll;
-    out->path_kernel = scene->integrator == PATHED_INTEGRATOR_VOLUME_PATH_TRACER ? 4u : scene->fusedPath ? 3u : scene->splitShade ? 5u : (scene->stagedShade ? 2u : 1u);
+    out->path_kernel = usesVolumeKernel(scene) ? 4u : scene->fusedPath ? 3u : scene->splitShade ? 5u : (scene->stagedShade ? 2u : 1u);
     if (getenv("PATHED_SHADE_PROFILE")) {   // counters exist in -DPATHED_SHADE_PROFILE builds only
         static const char *regions[11] = { "all waves", "active slots", "makeIsect (hit)", "camera-ray vertex", "finish previous MIS term",
                                            "new vertex: BSDF sample", "light sampling", "sample finished", "startSample (regeneration)", "shadow ray pushed",
