@@ -358,9 +358,11 @@ int pathed_hip_trace(PathedScene *scene, const float *rays, size_t n,
 /* Test hook onto phase 1 of the all-triangles intersector (scenes of <= 64 triangles; the stand-in for
  * rtcIntersect1 / rtcOccluded1 on such scenes, reference src/scene.cpp:113,374).
  * rays: n * 10 floats (origin.xyz, continuation direction.xyz, shadow direction.xyz, shadow tfar), host memory.
- * out:  n * 6 x uint64, bit k = leaf-ordered triangle k:
- *       candidates of the VALU phase 1 (continuation, shadow), candidates of the matrix-pipe phase 1 (continuation,
- *       shadow), triangles phase 2 accepts (continuation: t in (1e-3, 1e5]; shadow: t in (1e-3, tfar]).
+ * out:  n * 8 x uint64, bit p = ORIGINAL primitive id p (triangle ids of such scenes are < 64):
+ *       candidates of the pair-of-triangles phase 1 (continuation, shadow), of the matrix-pipe phase 1 (continuation,
+ *       shadow; zero in the product library), triangles phase 2 accepts (continuation: t in (1e-3, 1e5]; shadow: t in
+ *       (1e-3, tfar]), candidates of the ITEM phase 1 the fused kernel runs -- parallelograms for the triangle pairs that
+ *       form one (pathed_amd/csrc/small_items.h) -- (continuation, shadow).
  * Phase 1 is correct iff accepted is a subset of candidates for every ray. */
 int pathed_hip_debug_small_candidates(PathedScene *scene, const float *rays, size_t n, uint64_t *out);
 

@@ -24,7 +24,11 @@
 // State is SoA-of-float4 in HBM so a wave reads 1 KiB contiguous per stream.
 #pragma once
 
+#ifndef PATHED_EXPERIMENTS
+#define PATHED_EXPERIMENTS 0   // 1: `make experiments` -- the measured-and-rejected kernel organisations (kernels_experiments.h)
+#endif
 #include "mfma_candidates.h"
+#include "small_items.h"
 #include "shading.h"
 #include "trace.h"
 #include "volume.h"
@@ -198,6 +202,8 @@ struct RenderParams {
     uint32_t seedLo, seedHi;
     uint32_t sppBegin, sppEnd;
     int startBounce, lastBounce;
+    int smallQuads;           // k_path_small: parallelograms among the phase-1 records (small_items.h), item-order triangles 2 q, 2 q + 1
+    float smallKappaT;        // ... and the absolute slack of their t bounds per det^2
     const float *mfmaTable;   // k_path_small<.., MFMA>: the A-side rows of the matrix-pipe phase 1 (mfma_candidates.h), kMfmaTableFloats
     MfmaFrame mfmaFrame;
 };
@@ -853,6 +859,130 @@ __device__ __forceinline__ void smallCandidatesPair(const f2 *pairRecords, int n
         aHigh = 0u;
         bHigh = 0u;
     }
+    *lowA = aLow; *highA = aHigh; *lowB = bLow; *highB = bHigh;
+}
+
+// Phase 1 over the ITEM records of the fused kernel (small_items.h): first the parallelograms -- one Moeller-Trumbore
+// evaluation for the two triangles of a quad, every bound with the tolerance derived there -- then the triangles that found
+// no partner, two per packed instruction with the exact test above.  Bits are shifted in in item order (triangle k of a word
+// ends up at bit 31 - (k & 31), as smallCandidates leaves them); phase 2 indexes the item-ordered copy of the triangle records.
+// SHADOW: ray B (the vertex's shadow ray, held to its far bound) exists; otherwise only ray A is tested.
+// QUADS / LONE: which of the two sections the instantiation contains (a scene made of quads only needs no code, and no
+// registers, for the other test).
+template <bool SHADOW, bool QUADS = true, bool LONE = true>
+__device__ __forceinline__ void smallCandidatesItems(const f2 *records, int nQuads, int nTris, float kappaT, V3 origin, V3 directionA, V3 directionB,
+                                                     unsigned int *lowA, unsigned int *highA, unsigned int *lowB, unsigned int *highB,
+                                                     float tnearLow, float tfarHighB)
+{
+    unsigned int aLow = 0, aHigh = 0, bLow = 0, bHigh = 0;
+    const f2 ax = splat2(directionA.x), ay = splat2(directionA.y), az = splat2(directionA.z);
+    const f2 bx = splat2(directionB.x), by = splat2(directionB.y), bz = splat2(directionB.z);
+    const f2 ox = splat2(origin.x), oy = splat2(origin.y), oz = splat2(origin.z);
+    const f2 nearLow = splat2(-tnearLow), farHighB = splat2(fminf(tfarHighB, 1e30f));
+    const f2 kappa = splat2(kSmallKappa), kappaLength = splat2(kappaT);
+    int done = 0;   // item-order triangles whose bits are in
+    auto append = [&](unsigned int bitsA, unsigned int bitsB, int count) {
+        if (done < 32) { aLow = (aLow << count) | bitsA; bLow = (bLow << count) | bitsB; }
+        else { aHigh = (aHigh << count) | bitsA; bHigh = (bHigh << count) | bitsB; }
+        done += count;
+    };
+
+    // ---- parallelograms, two per packed instruction
+    const int nQuadPairs = QUADS ? (nQuads + 1) >> 1 : 0;
+    for (int pair = 0; QUADS && pair < nQuadPairs; pair++) {
+        const f2 *record = records + kSmallQuadWords * pair;   // uniform index into the kernarg segment: scalar loads
+        const f2 c0x = record[0], c0y = record[1], c0z = record[2];
+        const f2 a1x = record[3], a1y = record[4], a1z = record[5];
+        const f2 a2x = record[6], a2y = record[7], a2z = record[8];
+        const f2 k2UV = record[9], k0UV = record[10], k2T = record[11], k0T = record[12], cD = record[13], detTrusted = record[14];
+        const f2 tx = ox - c0x, ty = oy - c0y, tz = oz - c0z;
+        const f2 qx = fma2(ty, a1z, -(tz * a1y));
+        const f2 qy = fma2(tz, a1x, -(tx * a1z));
+        const f2 qz = fma2(tx, a1y, -(ty * a1x));
+        const f2 tScaled = fma2(a2x, qx, fma2(a2y, qy, a2z * qz));
+        // the part of the tolerances that grows with the distance of the origin (small_items.h): K2 |o - c0|^2 + K0
+        const f2 tt = fma2(tx, tx, fma2(ty, ty, tz * tz));
+        const f2 originUV = fma2(k2UV, tt, k0UV), originT = fma2(k2T, tt, k0T);
+        auto oneRay = [&](f2 dx, f2 dy, f2 dz, bool far) -> unsigned int {
+            const f2 px = fma2(dy, a2z, -(dz * a2y));
+            const f2 py = fma2(dz, a2x, -(dx * a2z));
+            const f2 pz = fma2(dx, a2y, -(dy * a2x));
+            const f2 det = fma2(a1x, px, fma2(a1y, py, a1z * pz));
+            const f2 uScaled = fma2(tx, px, fma2(ty, py, tz * pz));     // alpha det
+            const f2 vScaled = fma2(dx, qx, fma2(dy, qy, dz * qz));     // beta det
+            const f2 dd = det * det;
+            // 0 <= alpha, beta <= 1 in det^2 units, centred: |alpha det^2 - det^2 / 2| <= det^2 / 2 (+ tolerance), the same for beta
+            const f2 half = dd * 0.5f;
+            const f2 uCentred = fma2(uScaled, det, -half), vCentred = fma2(vScaled, det, -half);
+            const f2 diagonal = uCentred - vCentred;                    // (alpha - beta) det^2: >= 0 triangle A, <= 0 triangle B
+            const f2 tolUV = fma2(kappa, dd, originUV);
+            const f2 reach = half + tolUV;
+            const f2 tolT = fma2(kappaLength, dd, originT);
+            const f2 nearBound = fma2(nearLow, det, tScaled) * det;     // (t - tnearLow) det^2
+            // "x > bound" rejects: -0, underflow and NaN all keep the candidate; a det too small to trust its sign keeps it too
+            bool rejectX = (fmaxf(fabsf(uCentred.x), fabsf(vCentred.x)) > reach.x) || (nearBound.x < -tolT.x);
+            bool rejectY = (fmaxf(fabsf(uCentred.y), fabsf(vCentred.y)) > reach.y) || (nearBound.y < -tolT.y);
+            if (far) {
+                const f2 farBound = fma2(farHighB, det, -tScaled) * det;   // (tfarHigh - t) det^2
+                const f2 tolFar = fma2(farHighB, fma2(splat2(kSmallKappaFar), dd, cD), tolT);
+                rejectX = rejectX || (farBound.x < -tolFar.x);
+                rejectY = rejectY || (farBound.y < -tolFar.y);
+            }
+            const bool keepX = !rejectX || !(fabsf(det.x) > detTrusted.x);
+            const bool keepY = !rejectY || !(fabsf(det.y) > detTrusted.y);
+            const float twiceX = 2.f * tolUV.x, twiceY = 2.f * tolUV.y;
+            return ((keepX && !(diagonal.x < -twiceX)) ? 8u : 0u) | ((keepX && !(diagonal.x > twiceX)) ? 4u : 0u)
+                 | ((keepY && !(diagonal.y < -twiceY)) ? 2u : 0u) | ((keepY && !(diagonal.y > twiceY)) ? 1u : 0u);
+        };
+        unsigned int bitsA = oneRay(ax, ay, az, false);
+        __builtin_amdgcn_sched_barrier(0);   // one ray's temporaries at a time: interleaved, the two chains spilled 39 dwords of path state
+        unsigned int bitsB = SHADOW ? oneRay(bx, by, bz, true) : 0u;
+        __builtin_amdgcn_sched_barrier(0);
+        if (2 * pair + 1 < nQuads) { append(bitsA, bitsB, 4); }
+        else { append(bitsA >> 2, bitsB >> 2, 2); }   // an odd count: the last pair's second half is padding
+    }
+
+    // ---- triangles without a partner, two per packed instruction: smallCandidatesPair's test, ray by ray
+    const f2 *lone = records + kSmallQuadWords * nQuadPairs;
+    const int nLone = LONE ? nTris - 2 * nQuads : 0;
+    const int nLonePairs = (nLone + 1) >> 1;
+    for (int pair = 0; LONE && pair < nLonePairs; pair++) {
+        const f2 *record = lone + kSmallPairWords * pair;
+        const f2 v0x = record[0], v0y = record[1], v0z = record[2];
+        const f2 e1x = record[3], e1y = record[4], e1z = record[5];
+        const f2 e2x = record[6], e2y = record[7], e2z = record[8];
+        const f2 tx = ox - v0x, ty = oy - v0y, tz = oz - v0z;
+        const f2 qx = fma2(ty, e1z, -(tz * e1y));
+        const f2 qy = fma2(tz, e1x, -(tx * e1z));
+        const f2 qz = fma2(tx, e1y, -(ty * e1x));
+        const f2 tScaled = fma2(e2x, qx, fma2(e2y, qy, e2z * qz));
+        auto oneRay = [&](f2 dx, f2 dy, f2 dz, bool far) -> unsigned int {
+            const f2 px = fma2(dy, e2z, -(dz * e2y));
+            const f2 py = fma2(dz, e2x, -(dx * e2z));
+            const f2 pz = fma2(dx, e2y, -(dy * e2x));
+            const f2 det = fma2(e1x, px, fma2(e1y, py, e1z * pz));
+            const f2 uScaled = fma2(tx, px, fma2(ty, py, tz * pz));
+            const f2 vScaled = fma2(dx, qx, fma2(dy, qy, dz * qz));
+            const f2 a = uScaled * det, b = vScaled * det, c = (det - (uScaled + vScaled)) * det, e = fma2(nearLow, det, tScaled) * det;
+            float worstA = fminf(fminf(a.x, b.x), fminf(c.x, e.x));
+            float worstB = fminf(fminf(a.y, b.y), fminf(c.y, e.y));
+            if (far) {
+                const f2 g = fma2(splat2(tfarHighB), det, -tScaled) * det;
+                worstA = fminf(worstA, g.x);
+                worstB = fminf(worstB, g.y);
+            }
+            return ((worstA < 0.f) ? 0u : 2u) | ((worstB < 0.f) ? 0u : 1u);
+        };
+        const unsigned int bitsA = oneRay(ax, ay, az, false);
+        const unsigned int bitsB = SHADOW ? oneRay(bx, by, bz, true) : 0u;
+        if (2 * pair + 1 < nLone) { append(bitsA, bitsB, 2); }
+        else { append(bitsA >> 1, bitsB >> 1, 1); }
+    }
+
+    // left-align: the last bit shifted into a word sits at bit 0
+    const int lowBits = nTris < 32 ? nTris : 32, highBits = nTris - lowBits;
+    if (lowBits > 0 && lowBits < 32) { aLow <<= 32 - lowBits; bLow <<= 32 - lowBits; }
+    if (highBits > 0 && highBits < 32) { aHigh <<= 32 - highBits; bHigh <<= 32 - highBits; }
     *lowA = aLow; *highA = aHigh; *lowB = bLow; *highB = bHigh;
 }
 
@@ -1817,12 +1947,18 @@ __global__ __launch_bounds__(kBlock) PATHED_SHADE_ATTRIBUTE void k_shade(RenderP
 #define PATHED_FUSED_WAVES 4
 #endif
 // TRAITS: the compile-time set of material / light / albedo kinds the scene may contain (shading.h: SceneTraits)
-// MFMA: phase 1 of both ray queries on the matrix pipe (mfma_candidates.h) instead of smallCandidatesPair
-template <bool LDS_MATERIALS, bool COUNT, typename TRAITS, bool MFMA = false>
+// MFMA: phase 1 of both ray queries on the matrix pipe (mfma_candidates.h) instead of the VALU pass (experiments build)
+// QUADS: some triangles of the scene are halves of parallelograms (small_items.h): phase 1 runs over the item records
+// (parallelograms, then the triangles without a partner); otherwise the exact pair-of-triangles test over all of them
+template <bool LDS_MATERIALS, bool COUNT, typename TRAITS, bool MFMA = false, bool QUADS = false>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_FUSED_WAVES, PATHED_FUSED_WAVES))) void k_path_small(RenderParams p, SmallTris smallTris)
 {
     extern __shared__ float4 ldsDynamic[];           // LDS_MATERIALS: the material table, nMaterials x 96 B
     __shared__ float mfmaRows[MFMA ? kMfmaTableFloats : 1];
+    // QUADS: what a lane's path carries across the pass over the triangles and does not use in it waits in LDS, 96 bytes per
+    // lane ([quad][thread]: a wave stores 1 KiB contiguous): the parallelogram test needs two dozen registers more than the
+    // pair-of-triangles test, and what the compiler spilled for them went to scratch memory (48 dwords, profiles/r4_ab_quads.log)
+    __shared__ float4 stashRows[QUADS ? 6 * kBlock : 1];
     if (MFMA) {
         for (int i = threadIdx.x; i < kMfmaTableFloats; i += kBlock) { mfmaRows[i] = p.mfmaTable[i]; }
         if (!LDS_MATERIALS) { __syncthreads(); }
@@ -1942,6 +2078,16 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_F
 
         // ---- the path's ray (Scene::testIntersect's rtcIntersect1) and, from the same point, the shadow ray of the
         // vertex it leaves (Scene::testOcclusion's rtcOccluded1): an occluded light sample contributes nothing
+        if (QUADS) {
+            float4 *stash = stashRows + threadIdx.x;
+            stash[0 * kBlock] = make_float4(result.r, result.g, result.b, bsdfPdf);
+            stash[1 * kBlock] = make_float4(modulation.r, modulation.g, modulation.b, cosTheta);
+            stash[2 * kBlock] = make_float4(throughput.r, throughput.g, throughput.b, intAsFloat(st));
+            stash[3 * kBlock] = partial;
+            stash[4 * kBlock] = make_float4(intAsFloat((int)pixel), intAsFloat((int)sample), intAsFloat((int)endSample), intAsFloat((int)unit));
+            stash[5 * kBlock] = make_float4(intAsFloat((int)random.k0), intAsFloat((int)random.k1), intAsFloat(firstEmitMaterial), intAsFloat((int)random.dimension));
+            asm volatile("" ::: "memory");   // the values below are re-read from LDS: the registers are free for the pass
+        }
         LaneRay ray;
         laneRayInit(ray, o, d, PATHED_TNEAR, PATHED_TFAR, false);
         {
@@ -1956,6 +2102,15 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_F
                                    candidateNear(PATHED_TNEAR), candidateFar(shadowTfar), &candidatesLow, &candidatesHigh, &shadowLow, &shadowHigh);
                 if (!alive) { candidatesLow = 0u; candidatesHigh = 0u; }
                 if (!traceShadow) { shadowLow = 0u; shadowHigh = 0u; }
+            } else if (QUADS) {
+                // one instantiation of the pass: a wave without a single shadow ray is rare (3 % of the passes) and pays for
+                // the second ray's arithmetic rather than for a second copy of the loop's registers
+                if (alive) {
+                    smallCandidatesItems<true, true, true>(smallTris.data, p.smallQuads, nTris, p.smallKappaT, o, d, shadowDirection,
+                                                            &candidatesLow, &candidatesHigh, &shadowLow, &shadowHigh,
+                                                            candidateNear(PATHED_TNEAR), candidateFar(shadowTfar));
+                    if (!traceShadow) { shadowLow = 0u; shadowHigh = 0u; }
+                }
             } else if (__ballot(traceShadow) != 0ull) {
                 if (alive) {
                     smallCandidatesPair(smallTris.data, nTris, o, d, shadowDirection, &candidatesLow, &candidatesHigh, &shadowLow, &shadowHigh,
@@ -1985,6 +2140,17 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_F
                 if (shadowRay.occluded) { pend = rgb(0.f); }
             }
             pendingShadow = false;
+        }
+        if (QUADS) {
+            asm volatile("" ::: "memory");
+            const float4 *stash = stashRows + threadIdx.x;
+            const float4 s0 = stash[0 * kBlock], s1 = stash[1 * kBlock], s2 = stash[2 * kBlock], s4 = stash[4 * kBlock], s5 = stash[5 * kBlock];
+            result = rgb(0.f); result.r = s0.x; result.g = s0.y; result.b = s0.z; bsdfPdf = s0.w;
+            modulation.r = s1.x; modulation.g = s1.y; modulation.b = s1.z; cosTheta = s1.w;
+            throughput.r = s2.x; throughput.g = s2.y; throughput.b = s2.z; st = floatAsInt(s2.w);
+            partial = stash[3 * kBlock];
+            pixel = (uint32_t)floatAsInt(s4.x); sample = (uint32_t)floatAsInt(s4.y); endSample = (uint32_t)floatAsInt(s4.z); unit = (unsigned int)floatAsInt(s4.w);
+            random.k0 = (uint32_t)floatAsInt(s5.x); random.k1 = (uint32_t)floatAsInt(s5.y); firstEmitMaterial = floatAsInt(s5.z); random.dimension = (uint32_t)floatAsInt(s5.w);
         }
         const bool miss = ray.bestPrim < 0;
         const float4 h = make_float4(ray.best, ray.bestU, ray.bestV, intAsFloat(ray.bestPrim));
@@ -2160,6 +2326,56 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_F
         atomicAdd(&p.stats[kStatTris], (unsigned long long)trisTested);
         atomicAdd(&p.stats[kStatClosest], (unsigned long long)closestRays);
         atomicAdd(&p.stats[kStatShadow], (unsigned long long)shadowRays);
+    }
+}
+
+// Test hook behind pathed_hip_debug_small_candidates: for every ray pair (origin, continuation direction, shadow direction,
+// shadow far bound) the candidate sets of the phase-1 forms and the set phase 2 accepts, one bit per ORIGINAL primitive id
+// (the forms index the triangles in different orders).  n is padded to whole waves by the host (the matrix instructions of
+// the experiments build need every lane).  Words per ray: pair-of-triangles VALU form (A, B), matrix-pipe form (A, B; zero in
+// the product library), accepted by phase 2 (A, B), item form with parallelograms -- what k_path_small runs -- (A, B).
+__global__ __launch_bounds__(kBlock) void k_debug_small_candidates(DScene scene, SmallTris smallTris, SmallTris smallItems, int nQuads, float kappaT,
+                                                                   const float4 *itemTris, const float *mfmaTable, MfmaFrame frame,
+                                                                   const float *rays, int n, unsigned long long *out)
+{
+#if PATHED_EXPERIMENTS
+    __shared__ float mfmaRows[kMfmaTableFloats];
+    for (int i = threadIdx.x; i < kMfmaTableFloats; i += kBlock) { mfmaRows[i] = mfmaTable[i]; }
+    __syncthreads();
+#endif
+    const int index = blockIdx.x * kBlock + threadIdx.x;
+    const float *r = rays + (size_t)10 * index;
+    const V3 o = v3(r[0], r[1], r[2]), dA = v3(r[3], r[4], r[5]), dB = v3(r[6], r[7], r[8]);
+    const float tfarB = r[9];
+    const int nTris = scene.nTris;
+
+    unsigned int aLow, aHigh, bLow, bHigh;
+    smallCandidatesPair(smallTris.data, nTris, o, dA, dB, &aLow, &aHigh, &bLow, &bHigh, candidateNear(PATHED_TNEAR), candidateFar(tfarB));
+    unsigned int iaLow, iaHigh, ibLow, ibHigh;
+    smallCandidatesItems<true>(smallItems.data, nQuads, nTris, kappaT, o, dA, dB, &iaLow, &iaHigh, &ibLow, &ibHigh, candidateNear(PATHED_TNEAR), candidateFar(tfarB));
+    unsigned int evenA = 0u, oddA = 0u, evenB = 0u, oddB = 0u;
+#if PATHED_EXPERIMENTS
+    mfmaCandidatesPair(mfmaRows, nTris, frame, true, o, dA, dB, candidateNear(PATHED_TNEAR), candidateFar(tfarB), &evenA, &oddA, &evenB, &oddB);
+#endif
+
+    unsigned long long valuA = 0, valuB = 0, mfmaA = 0, mfmaB = 0, acceptA = 0, acceptB = 0, itemsA = 0, itemsB = 0;
+    for (int k = 0; k < nTris; k++) {
+        const float4 t0 = scene.leafTris[3 * k + 0], t1 = scene.leafTris[3 * k + 1], t2 = scene.leafTris[3 * k + 2];
+        const unsigned long long bit = 1ull << (floatAsInt(t0.w) & 63);
+        if (((k < 32 ? aLow : aHigh) >> (31 - (k & 31))) & 1u) { valuA |= bit; }
+        if (((k < 32 ? bLow : bHigh) >> (31 - (k & 31))) & 1u) { valuB |= bit; }
+        if ((((k & 1) ? oddA : evenA) >> (k >> 1)) & 1u) { mfmaA |= bit; }
+        if ((((k & 1) ? oddB : evenB) >> (k >> 1)) & 1u) { mfmaB |= bit; }
+        float t, u, v;
+        if (intersectTriangle(o, dA, v3(t0.x, t0.y, t0.z), v3(t1.x, t1.y, t1.z), v3(t2.x, t2.y, t2.z), &t, &u, &v) && t > PATHED_TNEAR && t <= PATHED_TFAR) { acceptA |= bit; }
+        if (intersectTriangle(o, dB, v3(t0.x, t0.y, t0.z), v3(t1.x, t1.y, t1.z), v3(t2.x, t2.y, t2.z), &t, &u, &v) && t > PATHED_TNEAR && t <= tfarB) { acceptB |= bit; }
+        const unsigned long long itemBit = 1ull << (floatAsInt(itemTris[3 * k].w) & 63);
+        if (((k < 32 ? iaLow : iaHigh) >> (31 - (k & 31))) & 1u) { itemsA |= itemBit; }
+        if (((k < 32 ? ibLow : ibHigh) >> (31 - (k & 31))) & 1u) { itemsB |= itemBit; }
+    }
+    if (index < n) {
+        unsigned long long *row = out + (size_t)8 * index;
+        row[0] = valuA; row[1] = valuB; row[2] = mfmaA; row[3] = mfmaB; row[4] = acceptA; row[5] = acceptB; row[6] = itemsA; row[7] = itemsB;
     }
 }
 

@@ -886,44 +886,6 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_R
     if (lane == 0 && retiredTotal != 0u) { atomicSub(&p.counters[kCtrRemaining], retiredTotal); }
 }
 
-// Test hook behind pathed_hip_debug_small_candidates: for every ray pair (origin, continuation direction, shadow direction,
-// shadow far bound) the candidate sets of both phase-1 forms and the set phase 2 would accept, one bit per leaf-ordered
-// triangle.  n is padded to whole waves by the host (the matrix instructions need every lane).
-__global__ __launch_bounds__(kBlock) void k_debug_small_candidates(DScene scene, SmallTris smallTris, const float *mfmaTable, MfmaFrame frame,
-                                                                   const float *rays, int n, unsigned long long *out)
-{
-    __shared__ float mfmaRows[kMfmaTableFloats];
-    for (int i = threadIdx.x; i < kMfmaTableFloats; i += kBlock) { mfmaRows[i] = mfmaTable[i]; }
-    __syncthreads();
-    const int index = blockIdx.x * kBlock + threadIdx.x;
-    const float *r = rays + (size_t)10 * index;
-    const V3 o = v3(r[0], r[1], r[2]), dA = v3(r[3], r[4], r[5]), dB = v3(r[6], r[7], r[8]);
-    const float tfarB = r[9];
-    const int nTris = scene.nTris;
-
-    unsigned int aLow, aHigh, bLow, bHigh;
-    smallCandidatesPair(smallTris.data, nTris, o, dA, dB, &aLow, &aHigh, &bLow, &bHigh, candidateNear(PATHED_TNEAR), candidateFar(tfarB));
-    unsigned int evenA, oddA, evenB, oddB;
-    mfmaCandidatesPair(mfmaRows, nTris, frame, true, o, dA, dB, candidateNear(PATHED_TNEAR), candidateFar(tfarB), &evenA, &oddA, &evenB, &oddB);
-
-    unsigned long long valuA = 0, valuB = 0, mfmaA = 0, mfmaB = 0, acceptA = 0, acceptB = 0;
-    for (int k = 0; k < nTris; k++) {
-        const unsigned long long bit = 1ull << k;
-        if (((k < 32 ? aLow : aHigh) >> (31 - (k & 31))) & 1u) { valuA |= bit; }
-        if (((k < 32 ? bLow : bHigh) >> (31 - (k & 31))) & 1u) { valuB |= bit; }
-        if ((((k & 1) ? oddA : evenA) >> (k >> 1)) & 1u) { mfmaA |= bit; }
-        if ((((k & 1) ? oddB : evenB) >> (k >> 1)) & 1u) { mfmaB |= bit; }
-        const float4 t0 = scene.leafTris[3 * k + 0], t1 = scene.leafTris[3 * k + 1], t2 = scene.leafTris[3 * k + 2];
-        float t, u, v;
-        if (intersectTriangle(o, dA, v3(t0.x, t0.y, t0.z), v3(t1.x, t1.y, t1.z), v3(t2.x, t2.y, t2.z), &t, &u, &v) && t > PATHED_TNEAR && t <= PATHED_TFAR) { acceptA |= bit; }
-        if (intersectTriangle(o, dB, v3(t0.x, t0.y, t0.z), v3(t1.x, t1.y, t1.z), v3(t2.x, t2.y, t2.z), &t, &u, &v) && t > PATHED_TNEAR && t <= tfarB) { acceptB |= bit; }
-    }
-    if (index < n) {
-        unsigned long long *row = out + (size_t)6 * index;
-        row[0] = valuA; row[1] = valuB; row[2] = mfmaA; row[3] = mfmaB; row[4] = acceptA; row[5] = acceptB;
-    }
-}
-
 // The compressed form of the tree (trace.h: nodeQ), one thread per node, after any of the three builders.  Per axis:
 // origin = the smallest lower bound of the node's children, scale = the smallest power of two with 253 * scale >= extent,
 // q = the plane's grid index (computed exactly, in double) rounded outward past an extra 1/256 of a step (that covers the

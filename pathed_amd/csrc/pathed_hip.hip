@@ -5,9 +5,6 @@
 
 #include "bvh_build.h"
 #include "kernels.h"
-#ifndef PATHED_EXPERIMENTS
-#define PATHED_EXPERIMENTS 0   // 1: `make experiments` -- the measured-and-rejected kernel organisations (kernels_experiments.h)
-#endif
 #if PATHED_EXPERIMENTS
 #include "kernels_experiments.h"
 #endif
@@ -223,6 +220,13 @@ struct PathedScene {
     bool sceneInLds = false;
     bool bruteForce = false;      // <= kBruteForceMaxTris triangles: test them all, no BVH walk
     SmallTris smallTris;          // their records, passed to k_trace_small as a kernel argument
+    // the fused kernel's phase-1 records (small_items.h): parallelograms first, then the triangles without a partner; phase 2
+    // indexes itemTris, the triangle records in the same (item) order
+    SmallTris smallItems;
+    SmallItemsLayout smallLayout;
+    DeviceBuffer<float4> itemTris;
+    std::vector<float> itemTrisHost;       // host copy of itemTris (12 floats per triangle)
+    std::vector<float> smallExtraPoints;   // sphere bounds: where else a ray may start (the camera is added when the records are built)
     // PathedSceneOptions.refittable: the triangle soup stays on the device for pathed_hip_scene_refit
     bool refittable = false;
     DeviceBuffer<float> soupPositions, soupNormals, soupUvs;
@@ -1097,6 +1101,24 @@ static int unitOrderFromEnvironment(int fallback)
     return fallback;
 }
 
+// The fused kernel's phase-1 records depend on the camera (the tolerances of the parallelograms scale with the distance a ray
+// origin may have from a triangle): built at scene_create and again when the camera moves.
+static hipError_t rebuildSmallItems(PathedScene *scene)
+{
+    if (!scene->bruteForce || scene->device.nTris <= 0) { return hipSuccess; }
+    std::vector<float> points = scene->smallExtraPoints;
+    for (int a = 0; a < 3; a++) { points.push_back(scene->device.camera.origin[a]); }
+    // (the parallelogram instantiations of k_path_small keep the material table in LDS: scenes of more than 96 materials pair nothing)
+    const bool pairQuads = scene->options.generic_kernels == 0 && !getenv("PATHED_NO_QUADS") && scene->device.nMaterials <= kMaxLdsMaterials;
+    std::vector<float> ordered;
+    scene->smallLayout = buildSmallItems(scene->bvh.leafTris.data(), scene->device.nTris, points.data(), (int)(points.size() / 3), pairQuads, PATHED_TNEAR,
+                                         reinterpret_cast<float *>(scene->smallItems.data), &ordered);
+    std::vector<float4> records(ordered.size() / 4);
+    std::memcpy(records.data(), ordered.data(), ordered.size() * sizeof(float));
+    scene->itemTrisHost = ordered;
+    return scene->itemTris.upload(records);
+}
+
 int pathed_hip_scene_create_ex(const PathedSceneDesc *desc, const PathedSceneOptions *optionsIn, PathedScene **out)
 {
     if (!out) { return fail(PATHED_E_INVALID, "out pointer is null"); }
@@ -1603,6 +1625,14 @@ int pathed_hip_scene_create_ex(const PathedSceneDesc *desc, const PathedSceneOpt
             }
         }
     }
+    std::memset(&scene->smallItems, 0, sizeof scene->smallItems);
+    scene->smallExtraPoints.clear();
+    for (uint32_t i = 0; i < desc->n_spheres; i++) {
+        for (int sign = -1; sign <= 1; sign += 2) {
+            for (int a = 0; a < 3; a++) { scene->smallExtraPoints.push_back(desc->spheres[i].center_world[a] + sign * std::fabs(desc->spheres[i].radius) * 1.001f); }
+        }
+    }
+    if ((status = rebuildSmallItems(scene)) != hipSuccess) { return fail_cleanup(status, "upload the phase-1 records"); }
     scene->mfmaPhase1 = false;
     std::memset(&scene->mfmaFrame, 0, sizeof scene->mfmaFrame);
     if (scene->bruteForce && scene->fusedPath) {
@@ -1613,7 +1643,8 @@ int pathed_hip_scene_create_ex(const PathedSceneDesc *desc, const PathedSceneOpt
         if (phase1 == 0) { phase1 = kDefaultSmallPhase1; }
         if (phase1 == 2 && scene->device.nTris > 0) {
             std::vector<float> table;
-            buildMfmaTable(scene->bvh.leafTris.data(), scene->device.nTris, scene->device.camera.origin, 1, &table, &scene->mfmaFrame);
+            // rows in ITEM order: phase 2 of the fused kernel indexes the item-ordered triangle records
+            buildMfmaTable(scene->itemTrisHost.data(), scene->device.nTris, scene->device.camera.origin, 1, &table, &scene->mfmaFrame);
             if ((status = scene->mfmaTable.upload(table)) != hipSuccess) { return fail_cleanup(status, "upload the matrix-pipe rows"); }
             scene->mfmaPhase1 = true;
         }
@@ -1763,38 +1794,54 @@ static int renderPassFused(PathedScene *scene, uint64_t seed, uint32_t begin, ui
     // the narrowest instantiation whose compile-time scene set contains this scene's (shading.h: SceneTraits)
     params.mfmaTable = scene->mfmaTable.ptr;
     params.mfmaFrame = scene->mfmaFrame;
+    params.smallQuads = scene->smallLayout.nQuads;
+    params.smallKappaT = scene->smallLayout.kappaT;
+    params.scene.leafTris = scene->itemTris.ptr;   // phase 2 indexes the triangles in the order phase 1's bits come in
 #if PATHED_EXPERIMENTS
     if (scene->mfmaPhase1 && ldsMaterials) {
         // phase 1 on the matrix pipe: the same instantiations with MFMA = true
         if (scene->lambertianTriangles) {
-            if (scene->countMode) { hipLaunchKernelGGL((k_path_small<true, true, TraitsLambertianTriangles, true>), grid, block, lds, stream, params, scene->smallTris); }
-            else { hipLaunchKernelGGL((k_path_small<true, false, TraitsLambertianTriangles, true>), grid, block, lds, stream, params, scene->smallTris); }
+            if (scene->countMode) { hipLaunchKernelGGL((k_path_small<true, true, TraitsLambertianTriangles, true>), grid, block, lds, stream, params, scene->smallItems); }
+            else { hipLaunchKernelGGL((k_path_small<true, false, TraitsLambertianTriangles, true>), grid, block, lds, stream, params, scene->smallItems); }
         } else if (scene->lambertianPlasticSpheres) {
-            if (scene->countMode) { hipLaunchKernelGGL((k_path_small<true, true, TraitsLambertianPlasticSpheres, true>), grid, block, lds, stream, params, scene->smallTris); }
-            else { hipLaunchKernelGGL((k_path_small<true, false, TraitsLambertianPlasticSpheres, true>), grid, block, lds, stream, params, scene->smallTris); }
+            if (scene->countMode) { hipLaunchKernelGGL((k_path_small<true, true, TraitsLambertianPlasticSpheres, true>), grid, block, lds, stream, params, scene->smallItems); }
+            else { hipLaunchKernelGGL((k_path_small<true, false, TraitsLambertianPlasticSpheres, true>), grid, block, lds, stream, params, scene->smallItems); }
         } else {
-            if (scene->countMode) { hipLaunchKernelGGL((k_path_small<true, true, TraitsAll, true>), grid, block, lds, stream, params, scene->smallTris); }
-            else { hipLaunchKernelGGL((k_path_small<true, false, TraitsAll, true>), grid, block, lds, stream, params, scene->smallTris); }
+            if (scene->countMode) { hipLaunchKernelGGL((k_path_small<true, true, TraitsAll, true>), grid, block, lds, stream, params, scene->smallItems); }
+            else { hipLaunchKernelGGL((k_path_small<true, false, TraitsAll, true>), grid, block, lds, stream, params, scene->smallItems); }
         }
     } else
 #endif
+    if (scene->smallLayout.nQuads > 0 && ldsMaterials) {
+        // some triangles are halves of parallelograms: phase 1 tests those as parallelograms (small_items.h)
+        if (scene->lambertianTriangles) {
+            if (scene->countMode) { hipLaunchKernelGGL((k_path_small<true, true, TraitsLambertianTriangles, false, true>), grid, block, lds, stream, params, scene->smallItems); }
+            else { hipLaunchKernelGGL((k_path_small<true, false, TraitsLambertianTriangles, false, true>), grid, block, lds, stream, params, scene->smallItems); }
+        } else if (scene->lambertianPlasticSpheres) {
+            if (scene->countMode) { hipLaunchKernelGGL((k_path_small<true, true, TraitsLambertianPlasticSpheres, false, true>), grid, block, lds, stream, params, scene->smallItems); }
+            else { hipLaunchKernelGGL((k_path_small<true, false, TraitsLambertianPlasticSpheres, false, true>), grid, block, lds, stream, params, scene->smallItems); }
+        } else {
+            if (scene->countMode) { hipLaunchKernelGGL((k_path_small<true, true, TraitsAll, false, true>), grid, block, lds, stream, params, scene->smallItems); }
+            else { hipLaunchKernelGGL((k_path_small<true, false, TraitsAll, false, true>), grid, block, lds, stream, params, scene->smallItems); }
+        }
+    } else
     if (scene->lambertianTriangles) {
         if (ldsMaterials) {
-            if (scene->countMode) { hipLaunchKernelGGL((k_path_small<true, true, TraitsLambertianTriangles>), grid, block, lds, stream, params, scene->smallTris); }
-            else { hipLaunchKernelGGL((k_path_small<true, false, TraitsLambertianTriangles>), grid, block, lds, stream, params, scene->smallTris); }
+            if (scene->countMode) { hipLaunchKernelGGL((k_path_small<true, true, TraitsLambertianTriangles>), grid, block, lds, stream, params, scene->smallItems); }
+            else { hipLaunchKernelGGL((k_path_small<true, false, TraitsLambertianTriangles>), grid, block, lds, stream, params, scene->smallItems); }
         } else {
-            if (scene->countMode) { hipLaunchKernelGGL((k_path_small<false, true, TraitsLambertianTriangles>), grid, block, lds, stream, params, scene->smallTris); }
-            else { hipLaunchKernelGGL((k_path_small<false, false, TraitsLambertianTriangles>), grid, block, lds, stream, params, scene->smallTris); }
+            if (scene->countMode) { hipLaunchKernelGGL((k_path_small<false, true, TraitsLambertianTriangles>), grid, block, lds, stream, params, scene->smallItems); }
+            else { hipLaunchKernelGGL((k_path_small<false, false, TraitsLambertianTriangles>), grid, block, lds, stream, params, scene->smallItems); }
         }
     } else if (scene->lambertianPlasticSpheres && ldsMaterials) {
-        if (scene->countMode) { hipLaunchKernelGGL((k_path_small<true, true, TraitsLambertianPlasticSpheres>), grid, block, lds, stream, params, scene->smallTris); }
-        else { hipLaunchKernelGGL((k_path_small<true, false, TraitsLambertianPlasticSpheres>), grid, block, lds, stream, params, scene->smallTris); }
+        if (scene->countMode) { hipLaunchKernelGGL((k_path_small<true, true, TraitsLambertianPlasticSpheres>), grid, block, lds, stream, params, scene->smallItems); }
+        else { hipLaunchKernelGGL((k_path_small<true, false, TraitsLambertianPlasticSpheres>), grid, block, lds, stream, params, scene->smallItems); }
     } else if (ldsMaterials) {
-        if (scene->countMode) { hipLaunchKernelGGL((k_path_small<true, true, TraitsAll>), grid, block, lds, stream, params, scene->smallTris); }
-        else { hipLaunchKernelGGL((k_path_small<true, false, TraitsAll>), grid, block, lds, stream, params, scene->smallTris); }
+        if (scene->countMode) { hipLaunchKernelGGL((k_path_small<true, true, TraitsAll>), grid, block, lds, stream, params, scene->smallItems); }
+        else { hipLaunchKernelGGL((k_path_small<true, false, TraitsAll>), grid, block, lds, stream, params, scene->smallItems); }
     } else {
-        if (scene->countMode) { hipLaunchKernelGGL((k_path_small<false, true, TraitsAll>), grid, block, lds, stream, params, scene->smallTris); }
-        else { hipLaunchKernelGGL((k_path_small<false, false, TraitsAll>), grid, block, lds, stream, params, scene->smallTris); }
+        if (scene->countMode) { hipLaunchKernelGGL((k_path_small<false, true, TraitsAll>), grid, block, lds, stream, params, scene->smallItems); }
+        else { hipLaunchKernelGGL((k_path_small<false, false, TraitsAll>), grid, block, lds, stream, params, scene->smallItems); }
     }
     if (timed >= 0) { (void)hipEventRecord(scene->traceEvents.stop[timed], stream); }
     scene->traceLaunchesAll++;
@@ -2156,6 +2203,8 @@ int pathed_hip_scene_set_camera(PathedScene *scene, const PathedCamera *camera)
         return fail(PATHED_E_INVALID, "the new camera must keep the scene's resolution (the radiance sums are per pixel)");
     }
     buildCamera(*camera, &scene->device.camera);
+    SELECT_DEVICE(scene);
+    HIP_TRY(rebuildSmallItems(scene));   // tiny scenes: the phase-1 tolerances depend on how far away a ray may start
     return PATHED_OK;
 }
 
@@ -2258,21 +2307,23 @@ int pathed_hip_has_experiments(void) { return PATHED_EXPERIMENTS ? 1 : 0; }
 
 int pathed_hip_debug_small_candidates(PathedScene *scene, const float *rays, size_t n, uint64_t *out)
 {
-#if !PATHED_EXPERIMENTS
-    (void)scene; (void)rays; (void)n; (void)out;
-    return fail(PATHED_E_UNSUPPORTED, "the matrix-pipe phase 1 and its test hook live in libpathed_hip_experiments.so (`make experiments`)");
-#else
     if (!scene) { return fail(PATHED_E_INVALID, "null scene"); }
     if (!scene->bruteForce || scene->device.nTris < 1) { return fail(PATHED_E_UNSUPPORTED, "the all-triangles intersector serves scenes of 1..64 triangles"); }
     if (n == 0) { return PATHED_OK; }
     if (!rays || !out) { return fail(PATHED_E_INVALID, "null ray or output buffer"); }
     if (n > (size_t)1 << 24) { return fail(PATHED_E_INVALID, "too many rays in one call"); }
     SELECT_DEVICE(scene);
-    if (!scene->mfmaTable.ptr) {
-        std::vector<float> table;
-        buildMfmaTable(scene->bvh.leafTris.data(), scene->device.nTris, scene->device.camera.origin, 1, &table, &scene->mfmaFrame);
-        HIP_TRY(scene->mfmaTable.upload(table));
+    // the matrix-pipe rows over the LEAF order (the render's own table, if any, follows the item order)
+    DeviceBuffer<float> table;
+    MfmaFrame frame;
+    std::memset(&frame, 0, sizeof frame);
+#if PATHED_EXPERIMENTS
+    {
+        std::vector<float> rows;
+        buildMfmaTable(scene->bvh.leafTris.data(), scene->device.nTris, scene->device.camera.origin, 1, &rows, &frame);
+        HIP_TRY(table.upload(rows));
     }
+#endif
     const size_t padded = (n + kBlock - 1) / kBlock * kBlock;   // whole blocks: every lane of a wave issues the matrix instructions
     std::vector<float> hostRays(padded * 10, 0.f);
     std::memcpy(hostRays.data(), rays, n * 10 * sizeof(float));
@@ -2280,14 +2331,14 @@ int pathed_hip_debug_small_candidates(PathedScene *scene, const float *rays, siz
     DeviceBuffer<float> deviceRays;
     DeviceBuffer<unsigned long long> deviceOut;
     HIP_TRY(deviceRays.upload(hostRays));
-    HIP_TRY(deviceOut.allocate(n * 6));
+    HIP_TRY(deviceOut.allocate(n * 8));
     hipLaunchKernelGGL(k_debug_small_candidates, dim3((unsigned)(padded / kBlock)), dim3(kBlock), 0, nullptr, scene->device, scene->smallTris,
-                       scene->mfmaTable.ptr, scene->mfmaFrame, deviceRays.ptr, (int)n, deviceOut.ptr);
+                       scene->smallItems, scene->smallLayout.nQuads, scene->smallLayout.kappaT, scene->itemTris.ptr, table.ptr, frame,
+                       deviceRays.ptr, (int)n, deviceOut.ptr);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(out, deviceOut.ptr, n * 6 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out, deviceOut.ptr, n * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return PATHED_OK;
-#endif
 }
 
 int pathed_hip_scene_refit(PathedScene *scene, const float *positions, const float *normals, uint32_t n_vertices, float *device_ms)

@@ -139,9 +139,9 @@ class HipScene:
 
     def small_candidates(self, rays):
         """Phase-1 candidate sets of both forms and the set phase 2 accepts (pathed_hip_debug_small_candidates): rays (n, 10) =
-        origin, continuation direction, shadow direction, shadow tfar -> (n, 6) uint64, bit k = leaf-ordered triangle k."""
+        origin, continuation direction, shadow direction, shadow tfar -> (n, 8) uint64, bit p = primitive id p."""
         rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 10)
-        out = np.zeros((rays.shape[0], 6), dtype=np.uint64)
+        out = np.zeros((rays.shape[0], 8), dtype=np.uint64)
         code = self._lib.pathed_hip_debug_small_candidates(
             self._handle, rays.ctypes.data_as(C.POINTER(C.c_float)), rays.shape[0], out.ctypes.data_as(C.POINTER(C.c_uint64)))
         _check(self._lib, code, "pathed_hip_debug_small_candidates")

@@ -66,7 +66,7 @@ def check_conservative(gpu, camera, seed, n=60000):
     _, tris = gpu.export_bvh()
     rays = adversarial_rays(np.random.default_rng(seed), tris, camera, n)
     out = gpu.small_candidates(rays)
-    valu_a, valu_b, mfma_a, mfma_b, accept_a, accept_b = (out[:, i] for i in range(6))
+    valu_a, valu_b, mfma_a, mfma_b, accept_a, accept_b = (out[:, i] for i in range(6))   # bit p = primitive id p
     assert accept_a.any() and accept_b.any()
     # nothing phase 2 accepts is missing from either phase 1
     assert not (accept_a & ~valu_a).any() and not (accept_b & ~valu_b).any()
