@@ -879,7 +879,7 @@ __device__ __forceinline__ void smallCandidatesItems(const f2 *records, int nQua
     const f2 bx = splat2(directionB.x), by = splat2(directionB.y), bz = splat2(directionB.z);
     const f2 ox = splat2(origin.x), oy = splat2(origin.y), oz = splat2(origin.z);
     const f2 nearLow = splat2(-tnearLow), farHighB = splat2(fminf(tfarHighB, 1e30f));
-    const f2 kappa = splat2(kSmallKappa), kappaLength = splat2(kappaT);
+    const f2 kappaLength = splat2(kappaT);
     int done = 0;   // item-order triangles whose bits are in
     auto append = [&](unsigned int bitsA, unsigned int bitsB, int count) {
         if (done < 32) { aLow = (aLow << count) | bitsA; bLow = (bLow << count) | bitsB; }
@@ -894,7 +894,7 @@ __device__ __forceinline__ void smallCandidatesItems(const f2 *records, int nQua
         const f2 c0x = record[0], c0y = record[1], c0z = record[2];
         const f2 a1x = record[3], a1y = record[4], a1z = record[5];
         const f2 a2x = record[6], a2y = record[7], a2z = record[8];
-        const f2 k2UV = record[9], k0UV = record[10], k2T = record[11], k0T = record[12], cD = record[13], detTrusted = record[14];
+        const f2 k2UV = record[9], k0UV = record[10], k2T = record[11], k0T = record[12], cD = record[13], detTrusted = record[14], kappaUV = record[15];
         const f2 tx = ox - c0x, ty = oy - c0y, tz = oz - c0z;
         const f2 qx = fma2(ty, a1z, -(tz * a1y));
         const f2 qy = fma2(tz, a1x, -(tx * a1z));
@@ -915,7 +915,7 @@ __device__ __forceinline__ void smallCandidatesItems(const f2 *records, int nQua
             const f2 half = dd * 0.5f;
             const f2 uCentred = fma2(uScaled, det, -half), vCentred = fma2(vScaled, det, -half);
             const f2 diagonal = uCentred - vCentred;                    // (alpha - beta) det^2: >= 0 triangle A, <= 0 triangle B
-            const f2 tolUV = fma2(kappa, dd, originUV);
+            const f2 tolUV = fma2(kappaUV, dd, originUV);   // kappaUV: 1e-5 + how far a not-quite-parallelogram sticks out of the unit square
             const f2 reach = half + tolUV;
             const f2 tolT = fma2(kappaLength, dd, originT);
             const f2 nearBound = fma2(nearLow, det, tScaled) * det;     // (t - tnearLow) det^2

@@ -1,6 +1,7 @@
 // The records phase 1 of the all-triangles intersector reads in the fused path kernel (kernels.h: smallCandidatesItems).
 //
-// The scenes that take this intersector are built of QUADS: CornellBox-Original.obj is 18 of them, the Veach scene's plates
+// The scenes that take this intersector are built of QUADS (Cornell: 17 of its 18 -- the left wall is not planar --, of which 4
+// are trapezoids 0.6 % off a parallelogram): CornellBox-Original.obj is 18 of them, the Veach scene's plates
 // and floor are quads, `"type": "quad"` models are quads (reference src/quad.cpp:27-151, src/obj_parser.cpp's (0,1,2),(0,2,3)
 // split).  Two triangles that share a diagonal and form a parallelogram are ONE Moeller-Trumbore evaluation in phase 1: the
 // parallelogram c0 + alpha a1 + beta a2, alpha, beta in [0, 1], holds both (triangle A: beta <= alpha, triangle B: alpha <=
@@ -34,7 +35,7 @@
 
 namespace pathed {
 
-static const int kSmallQuadWords = 15;        // float2 per packed PAIR of parallelograms: c0.xyz, a1.xyz, a2.xyz, K2uv, K0uv, K2t, K0t, cD, Edet
+static const int kSmallQuadWords = 16;        // float2 per packed PAIR of parallelograms: c0.xyz, a1.xyz, a2.xyz, K2uv, K0uv, K2t, K0t, cD, Edet, kappaUV
 static const int kSmallLoneWords = 9;         // float2 per packed pair of lone triangles: v0.xyz, e1.xyz, e2.xyz (kSmallPairWords)
 static const int kSmallItemFloats = 2 * 9 * 32;   // the kernarg array of SmallTris, in floats
 static const float kSmallKappa = 1e-5f;       // relative slack of the barycentric bounds
@@ -82,7 +83,7 @@ inline SmallItemsLayout buildSmallItems(const float *leafTris, int nTris, const 
     auto distance = [](const double *a, const double *b) {
         return std::sqrt((a[0] - b[0]) * (a[0] - b[0]) + (a[1] - b[1]) * (a[1] - b[1]) + (a[2] - b[2]) * (a[2] - b[2]));
     };
-    struct Quad { int a, b; double c0[3], a1[3], a2[3], delta; };
+    struct Quad { int a, b; double c0[3], a1[3], a2[3], delta, excess, amax; };
     std::vector<Quad> quads;
     std::vector<int> partner((size_t)nTris, -1);
     const double unit = 1.0 / 16777216.0;
@@ -106,32 +107,57 @@ inline SmallItemsLayout buildSmallItems(const float *leafTris, int nTris, const 
             }
             if (nShared != 2) { continue; }
             const int restA = 3 - sharedA[0] - sharedA[1], restB = 3 - sharedB[0] - sharedB[1];
-            const double *d0 = corners[a].p[sharedA[0]], *d1 = corners[a].p[sharedA[1]];
             const double *rA = corners[a].p[restA], *rB = corners[b].p[restB];
+            // Either end of the diagonal may be the origin c0.  With the diagonal's other end at c0 + alpha2 (rA - c0) + beta2
+            // (rB - c0), the edges a1 = alpha2 (rA - c0), a2 = beta2 (rB - c0) put it at (1, 1): triangle A = (c0, rA, far end) is
+            // the part beta <= alpha of the quad, B the part alpha <= beta, and the quad lies in [0, max(1, 1 / alpha2)] x
+            // [0, max(1, 1 / beta2)].  A parallelogram has alpha2 = beta2 = 1; a planar quad that is nearly one (the walls of the
+            // Cornell box are trapezoids, 0.6 % off) sticks out of the unit square by `excess`, which joins the relative slack of
+            // the box test.  Take the origin with the smaller excess; quads further off than 5 % are left alone.
             Quad quad;
             quad.a = a; quad.b = b;
-            float c0f[3], a1f[3], a2f[3];
-            for (int x = 0; x < 3; x++) {
-                c0f[x] = (float)d0[x];
-                a1f[x] = (float)(rA[x] - d0[x]);
-                a2f[x] = (float)(rB[x] - d0[x]);
-                quad.c0[x] = c0f[x]; quad.a1[x] = a1f[x]; quad.a2[x] = a2f[x];
+            double bestExcess = 1e300, delta = 0.0, amax = 0.0;
+            for (int end = 0; end < 2; end++) {
+                const double *d0 = corners[a].p[sharedA[end]], *d1 = corners[a].p[sharedA[1 - end]];
+                const double *d0b = corners[b].p[sharedB[end]], *d1b = corners[b].p[sharedB[1 - end]];
+                double e1[3], e2[3], g[3];
+                for (int x = 0; x < 3; x++) { e1[x] = rA[x] - d0[x]; e2[x] = rB[x] - d0[x]; g[x] = d1[x] - d0[x]; }
+                // least squares g = alpha2 e1 + beta2 e2
+                const double m11 = e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2], m22 = e2[0] * e2[0] + e2[1] * e2[1] + e2[2] * e2[2];
+                const double m12 = e1[0] * e2[0] + e1[1] * e2[1] + e1[2] * e2[2];
+                const double r1 = e1[0] * g[0] + e1[1] * g[1] + e1[2] * g[2], r2 = e2[0] * g[0] + e2[1] * g[1] + e2[2] * g[2];
+                const double determinant = m11 * m22 - m12 * m12;
+                if (!(determinant > 1e-12 * m11 * m22)) { continue; }   // rA, c0, rB on a line
+                const double alpha2 = (r1 * m22 - r2 * m12) / determinant, beta2 = (r2 * m11 - r1 * m12) / determinant;
+                if (!(alpha2 > 0.5 && beta2 > 0.5)) { continue; }
+                const double excess = std::max(std::max(1.0 / alpha2, 1.0 / beta2), 1.0) - 1.0;
+                if (!(excess < bestExcess)) { continue; }
+                Quad candidate = quad;
+                for (int x = 0; x < 3; x++) {
+                    candidate.c0[x] = (float)d0[x];
+                    candidate.a1[x] = (float)(alpha2 * e1[x]);
+                    candidate.a2[x] = (float)(beta2 * e2[x]);
+                }
+                // where the stored (float) parallelogram puts the six corners of the two triangles, against where they are
+                double worst = 0.0, longest = 0.0;
+                auto place = [&](double alpha, double beta, double *out) {
+                    for (int x = 0; x < 3; x++) { out[x] = candidate.c0[x] + alpha * candidate.a1[x] + beta * candidate.a2[x]; }
+                };
+                double q[3];
+                place(0.0, 0.0, q); worst = std::max(worst, std::max(distance(d0, q), distance(d0b, q)));
+                place(1.0, 1.0, q); worst = std::max(worst, std::max(distance(d1, q), distance(d1b, q)));
+                place(1.0 / alpha2, 0.0, q); worst = std::max(worst, distance(rA, q));
+                place(0.0, 1.0 / beta2, q); worst = std::max(worst, distance(rB, q));
+                const double zero[3] = { 0.0, 0.0, 0.0 };
+                longest = std::max(std::max(distance(candidate.a1, zero), distance(candidate.a2, zero)), std::max(distance(d1, d0), distance(rA, rB)));
+                candidate.excess = excess;
+                quad = candidate;
+                bestExcess = excess;
+                delta = worst;
+                amax = longest;
             }
-            // the parallelogram's corners against the six corners of the two triangles
-            double q00[3], q10[3], q01[3], q11[3];
-            for (int x = 0; x < 3; x++) {
-                q00[x] = quad.c0[x]; q10[x] = quad.c0[x] + quad.a1[x]; q01[x] = quad.c0[x] + quad.a2[x]; q11[x] = quad.c0[x] + quad.a1[x] + quad.a2[x];
-            }
-            double delta = 0.0;
-            delta = std::max(delta, distance(d0, q00));
-            delta = std::max(delta, distance(corners[b].p[sharedB[0]], q00));
-            delta = std::max(delta, distance(d1, q11));
-            delta = std::max(delta, distance(corners[b].p[sharedB[1]], q11));
-            delta = std::max(delta, distance(rA, q10));
-            delta = std::max(delta, distance(rB, q01));
-            const double zero[3] = { 0.0, 0.0, 0.0 };
-            const double amax = std::max(std::max(distance(quad.a1, zero), distance(quad.a2, zero)), distance(q11, q00));
-            // a parallelogram, up to rounding: the diagonal's far end is where a1 + a2 puts it
+            if (!(bestExcess <= 0.05)) { continue; }
+            // planar and where the parallelogram says, up to rounding
             if (!(delta <= 64.0 * unit * std::max(amax, 1e-30))) { continue; }
             // ... and small enough for the interval test to mean something: a ray that leaves the quad itself sees it at t = 0
             // +- the t tolerance, which for an origin on the quad (|o - c0| <= amax) at cos(theta) = 1/4 is
@@ -141,6 +167,7 @@ inline SmallItemsLayout buildSmallItems(const float *leafTris, int nTris, const 
                 const double selfTolerance = 1.5 * (32.0 * unit) * (32.0 * unit) * 4.0 * amax * amax / (2.0 * kappaT) * 16.0;
                 if (!(selfTolerance <= tnear / 4.0)) { continue; }
             }
+            quad.amax = amax;
             quad.delta = delta;
             partner[a] = b;
             partner[b] = a;
@@ -168,9 +195,7 @@ inline SmallItemsLayout buildSmallItems(const float *leafTris, int nTris, const 
         float *record = records + (size_t)2 * kSmallQuadWords * (q / 2);   // kSmallQuadWords float2 per packed pair
         const int half = q & 1;
         const double zero[3] = { 0.0, 0.0, 0.0 };
-        double far[3];
-        for (int x = 0; x < 3; x++) { far[x] = quad.a1[x] + quad.a2[x]; }
-        const double amax = std::max(std::max(distance(quad.a1, zero), distance(quad.a2, zero)), distance(far, zero));
+        const double amax = quad.amax;
         // errors per unit of r = |o - c0| + amax (header)
         const double eUV = 1.01 * (32.0 * unit * amax + 4.0 * quad.delta);
         // (t det and det are products of BOTH edges: |a1||a2| bounds them, which for a long thin plate is far below amax^2)
@@ -190,6 +215,7 @@ inline SmallItemsLayout buildSmallItems(const float *leafTris, int nTris, const 
         record[2 * 12 + half] = (float)std::max(k2T * amax * amax, 1e-37);
         record[2 * 13 + half] = (float)std::max(cD, 1e-37);
         record[2 * 14 + half] = (float)std::max(eDet, 1e-37);
+        record[2 * 15 + half] = (float)(kappa + 1.0001 * quad.excess);   // relative slack of the box test: kappa + how far the quad sticks out
         std::memcpy(itemTris->data() + (size_t)12 * (2 * q), leafTris + (size_t)12 * quad.a, 12 * sizeof(float));
         std::memcpy(itemTris->data() + (size_t)12 * (2 * q + 1), leafTris + (size_t)12 * quad.b, 12 * sizeof(float));
     }

@@ -58,7 +58,8 @@ def test_item_candidates_contain_every_accepted_hit(libs, scene_path, camera, qu
 @pytest.mark.parametrize("seed", range(400, 410))
 def test_item_candidates_on_random_scenes_with_quads(seed):
     """Random triangle soups (needles, duplicates, zero-area triangles, scales 0.1 .. 100) with random parallelograms mixed
-    in -- some exact, some skewed, some a few ulps off a parallelogram, some folded so that they must NOT pair."""
+    in -- some exact, some trapezoids (planar, a few per cent off a parallelogram, like the walls of the Cornell box), some a few
+    ulps off, some folded so that they must NOT pair."""
     from pathed_amd import _capi
     from pathed_amd.integrator import HipScene
     from scene_builder import BuiltScene
@@ -74,6 +75,8 @@ def test_item_candidates_on_random_scenes_with_quads(seed):
         a2 = rng.normal(size=3) * scale * 10.0 ** rng.uniform(-1.5, 0.0)
         p1, p3 = p0 + a1, p0 + a2
         p2 = p0 + a1 + a2
+        if k % 5 == 2:
+            p2 = p0 + a1 * float(rng.uniform(0.97, 1.03)) + a2 * float(rng.uniform(0.97, 1.03))   # a planar quad that is no parallelogram
         if k % 5 == 3:
             p2 = p2 + rng.normal(size=3) * 3e-7 * scale          # a few ulps off a parallelogram
         if k % 5 == 4:
