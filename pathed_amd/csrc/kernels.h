@@ -894,7 +894,7 @@ __device__ __forceinline__ void smallCandidatesItems(const f2 *records, int nQua
         const f2 c0x = record[0], c0y = record[1], c0z = record[2];
         const f2 a1x = record[3], a1y = record[4], a1z = record[5];
         const f2 a2x = record[6], a2y = record[7], a2z = record[8];
-        const f2 k2UV = record[9], k0UV = record[10], k2T = record[11], k0T = record[12], cD = record[13], detTrusted = record[14], kappaUV = record[15];
+        const f2 k2UV = record[9], k0UV = record[10], k2T = record[11], k0T = record[12], cD = record[13], kappaUV = record[15];
         const f2 tx = ox - c0x, ty = oy - c0y, tz = oz - c0z;
         const f2 qx = fma2(ty, a1z, -(tz * a1y));
         const f2 qy = fma2(tz, a1x, -(tx * a1z));
@@ -919,7 +919,7 @@ __device__ __forceinline__ void smallCandidatesItems(const f2 *records, int nQua
             const f2 reach = half + tolUV;
             const f2 tolT = fma2(kappaLength, dd, originT);
             const f2 nearBound = fma2(nearLow, det, tScaled) * det;     // (t - tnearLow) det^2
-            // "x > bound" rejects: -0, underflow and NaN all keep the candidate; a det too small to trust its sign keeps it too
+            // "x > bound" rejects: -0, underflow and NaN all keep the candidate
             bool rejectX = (fmaxf(fabsf(uCentred.x), fabsf(vCentred.x)) > reach.x) || (nearBound.x < -tolT.x);
             bool rejectY = (fmaxf(fabsf(uCentred.y), fabsf(vCentred.y)) > reach.y) || (nearBound.y < -tolT.y);
             if (far) {
@@ -928,8 +928,7 @@ __device__ __forceinline__ void smallCandidatesItems(const f2 *records, int nQua
                 rejectX = rejectX || (farBound.x < -tolFar.x);
                 rejectY = rejectY || (farBound.y < -tolFar.y);
             }
-            const bool keepX = !rejectX || !(fabsf(det.x) > detTrusted.x);
-            const bool keepY = !rejectY || !(fabsf(det.y) > detTrusted.y);
+            const bool keepX = !rejectX, keepY = !rejectY;   // (a det too small to trust its sign: the tolerances cover it, small_items.h)
             const float twiceX = 2.f * tolUV.x, twiceY = 2.f * tolUV.y;
             return ((keepX && !(diagonal.x < -twiceX)) ? 8u : 0u) | ((keepX && !(diagonal.x > twiceX)) ? 4u : 0u)
                  | ((keepY && !(diagonal.y < -twiceY)) ? 2u : 0u) | ((keepY && !(diagonal.y > twiceY)) ? 1u : 0u);

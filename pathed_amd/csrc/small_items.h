@@ -23,7 +23,7 @@
 // compares against   tol = kappa det^2 + K2 |o - c0|^2 + K0,   K2 = (E / r)^2 / (2 kappa),  K0 = K2 amax^2,
 // kappa = 1e-5 for the barycentric bounds (a relative slack of 1e-5), kappa_t = tnear / 16 for the t bounds (an absolute
 // slack in t, well inside the tnear / 2 by which the interval is widened anyway).  Where |det| <= E_det the computed sign of
-// det cannot be trusted and nothing is rejected.  The far bound's error grows with the ray's own tfar:
+// det cannot be trusted; every bound is then at most Xmax E_det in size, which the K terms include: nothing is rejected there.  The far bound's error grows with the ray's own tfar:
 // tolFar = tolT + tfarHigh (kappa_far det^2 + E_det^2 / (4 kappa_far)), kappa_far = 1e-6 (a light 20 units away is told from
 // an occluder 1e-3 in front of it with 2e-5 of slack).  Triangles that find no partner keep the exact test.
 #pragma once
@@ -202,7 +202,11 @@ inline SmallItemsLayout buildSmallItems(const float *leafTris, int nTris, const 
         const double area = distance(quad.a1, zero) * distance(quad.a2, zero);
         const double eT = 1.01 * (32.0 * unit * area + 8.0 * quad.delta * amax);
         const double eDet = 1.01 * (16.0 * unit * area + 4.0 * quad.delta * amax);
-        const double k2UV = 1.5 * eUV * eUV / (2.0 * kappa), k2T = 1.5 * eT * eT / (2.0 * std::max(kappaT, 1e-300));
+        // ... plus what covers a det too small to trust its sign (|det| <= E_det): there every bound X det is at most
+        // Xmax E_det in size, Xmax = |o - c0| amax (u, v) or |o - c0| |a1||a2| (t), and |o - c0| <= (|o - c0|^2 / amax + amax) / 2:
+        // a second pair of (K2, K0) terms, folded into the first -- no test of |det| in the kernel
+        const double k2UV = 1.5 * (eUV * eUV / (2.0 * kappa) + eDet / 2.0);
+        const double k2T = 1.5 * (eT * eT / (2.0 * std::max(kappaT, 1e-300)) + eDet * area / (2.0 * std::max(amax, 1e-300)));
         const double cD = 1.5 * eDet * eDet / (4.0 * kSmallKappaFar);
         for (int x = 0; x < 3; x++) {
             record[2 * (0 + x) + half] = (float)quad.c0[x];
