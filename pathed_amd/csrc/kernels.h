@@ -2384,9 +2384,10 @@ __global__ __launch_bounds__(kBlock) void k_debug_small_candidates(DScene scene,
 // its six call sites: as a real function it cost 40-60 % (call frames in scratch, records through LDS instead of scalar
 // loads).  Same hits and events as volumeQuery: acceptance and the two nearest events do not depend on the order
 // primitives are met in; an occlusion query that is decided returns no events anybody reads.
-template <typename MaterialTable>
-__device__ __forceinline__ bool volumeQuerySmall(const VolumeContext<MaterialTable> &c, const f2 *pairRecords, int mode, V3 o, V3 d, float tfar,
-                                                 RayHit *hit, VolumeEvents *eventsOut)
+// QUADS: the records are the item records of small_items.h (parallelograms first) and c.geometry.tris their item-ordered copy
+template <bool QUADS = false, typename MaterialTable>
+__device__ __forceinline__ bool volumeQuerySmall(const VolumeContext<MaterialTable> &c, const f2 *pairRecords, int smallQuads, float smallKappaT,
+                                                 int mode, V3 o, V3 d, float tfar, RayHit *hit, VolumeEvents *eventsOut)
 {
     LaneRay ray;
     const bool anyHit = mode == kQueryVolumeOccluded;
@@ -2394,7 +2395,14 @@ __device__ __forceinline__ bool volumeQuerySmall(const VolumeContext<MaterialTab
     VolumeEvents events;
     eventsClear(events);
     unsigned int low = 0u, high = 0u;
-    smallCandidates<true>(pairRecords, c.geometry.nTris, o, d, &low, &high, candidateNear(PATHED_TNEAR), anyHit ? candidateFar(tfar) : 3e38f);
+    if (QUADS) {
+        // the single query as the pair form's second ray (the one that is held to a far bound); the first ray's words are dropped
+        unsigned int unusedLow = 0u, unusedHigh = 0u;
+        smallCandidatesItems<true>(pairRecords, smallQuads, c.geometry.nTris, smallKappaT, o, d, d, &unusedLow, &unusedHigh, &low, &high,
+                                   candidateNear(PATHED_TNEAR), anyHit ? candidateFar(tfar) : 3e38f);
+    } else {
+        smallCandidates<true>(pairRecords, c.geometry.nTris, o, d, &low, &high, candidateNear(PATHED_TNEAR), anyHit ? candidateFar(tfar) : 3e38f);
+    }
     bool decided = false;
     while (__ballot((low | high) != 0u) != 0ull) {
         if ((low | high) != 0u) {
@@ -2431,13 +2439,18 @@ __device__ __forceinline__ bool volumeQuerySmall(const VolumeContext<MaterialTab
 // vertex's BSDF sample -- `modeA` per lane: kQueryVolumeClosest where direct lighting wants it, kQueryRegular where only the
 // path's next segment does -- and the occlusion query of its light sample.  Lanes pass wantA / wantB = false for a ray
 // they do not have.  Candidates are resolved as in volumeQuerySmall, ray by ray: same hits, same events.
-template <typename MaterialTable>
-__device__ __forceinline__ void volumeQueryPairSmall(const VolumeContext<MaterialTable> &c, const f2 *pairRecords, V3 o,
+template <bool QUADS = false, typename MaterialTable>
+__device__ __forceinline__ void volumeQueryPairSmall(const VolumeContext<MaterialTable> &c, const f2 *pairRecords, int smallQuads, float smallKappaT, V3 o,
                                                      bool wantA, int modeA, V3 dA, RayHit *hitA, bool *foundA, VolumeEvents *eventsA,
                                                      bool wantB, V3 dB, float tfarB, bool *occludedB, VolumeEvents *eventsB)
 {
     unsigned int lowA = 0u, highA = 0u, lowB = 0u, highB = 0u;
-    smallCandidatesPair(pairRecords, c.geometry.nTris, o, dA, dB, &lowA, &highA, &lowB, &highB, candidateNear(PATHED_TNEAR), candidateFar(tfarB));
+    if (QUADS) {
+        smallCandidatesItems<true>(pairRecords, smallQuads, c.geometry.nTris, smallKappaT, o, dA, dB, &lowA, &highA, &lowB, &highB,
+                                   candidateNear(PATHED_TNEAR), candidateFar(tfarB));
+    } else {
+        smallCandidatesPair(pairRecords, c.geometry.nTris, o, dA, dB, &lowA, &highA, &lowB, &highB, candidateNear(PATHED_TNEAR), candidateFar(tfarB));
+    }
     if (!wantA) { lowA = 0u; highA = 0u; }
     if (!wantB) { lowB = 0u; highB = 0u; }
     auto resolve = [&](int mode, LaneRay &ray, VolumeEvents &events, unsigned int low, unsigned int high, bool want) {
@@ -2490,7 +2503,7 @@ __device__ __forceinline__ void volumeQueryPairSmall(const VolumeContext<Materia
 #ifndef PATHED_VOLUME_WAVES
 #define PATHED_VOLUME_WAVES 4   // 128 registers per lane + scratch; 3 / 4 / 5 waves: 787 / 845 / 799 (Cornell), 732 / 787 / 707 (cornell-medium), 368 / 388 / 382 (teapot) Msamples/s; uncapped the kernel takes 220-260 registers and runs one or two waves; with one pass per vertex (round 3) 3 / 4 waves: 1 139 / 1 225 (Cornell), 901 / 985 (cornell-medium)
 #endif
-template <bool LDS_MATERIALS, int STACK, bool SMALL, typename TRAITS = TraitsAll>
+template <bool LDS_MATERIALS, int STACK, bool SMALL, typename TRAITS = TraitsAll, bool QUADS = false>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_VOLUME_WAVES, PATHED_VOLUME_WAVES))) void k_path_volume(RenderParams p, SmallTris smallTris)
 {
     extern __shared__ float4 ldsRaw[];
@@ -2563,7 +2576,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_V
 
     // one ray query: the all-triangles intersector (SMALL) or the per-lane walk of the 4-wide tree
     auto query = [&](int mode, V3 origin, V3 direction, float tfar, RayHit *hit, VolumeEvents *events) -> bool {
-        if constexpr (SMALL) { return volumeQuerySmall(context, (const f2 *)smallTris.data, mode, origin, direction, tfar, hit, events); }
+        if constexpr (SMALL) { return volumeQuerySmall<QUADS>(context, (const f2 *)smallTris.data, p.smallQuads, p.smallKappaT, mode, origin, direction, tfar, hit, events); }
         else { return volumeQuery<STACK>(context, mode, origin, direction, tfar, hit, events); }
     };
 
@@ -2664,7 +2677,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_V
             SHADE_REGION(7, wantClosest);   // the closest-hit query of the BSDF sample / next segment
             SHADE_REGION(6, wantShadow);    // the light sample's occlusion query (same pass)
             if (__ballot(wantShadow) != 0ull) {
-                volumeQueryPairSmall(context, (const f2 *)smallTris.data, isect.point,
+                volumeQueryPairSmall<QUADS>(context, (const f2 *)smallTris.data, p.smallQuads, p.smallKappaT, isect.point,
                                      wantClosest, closestMode, bsdfSample.wiWorld, &bounceHit, &found, &skipped,
                                      wantShadow, wiWorld, lightDistance - 1e-3f, &occluded, &events);
             } else if (__ballot(wantClosest) != 0ull) {

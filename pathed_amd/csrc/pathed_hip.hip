@@ -602,7 +602,12 @@ void launchVolume(int stackRows, bool small, bool narrowed, const RenderParams &
                   hipStream_t stream)
 {
     if (small && narrowed && ldsMaterials) {   // the reference's own volume scene kinds (shading.h: TraitsLambertianGlassContainer)
-        hipLaunchKernelGGL((k_path_volume<true, 8, true, TraitsLambertianGlassContainer>), grid, dim3(kBlock), lds, stream, params, smallTris);
+        if (params.smallQuads > 0) { hipLaunchKernelGGL((k_path_volume<true, 8, true, TraitsLambertianGlassContainer, true>), grid, dim3(kBlock), lds, stream, params, smallTris); }
+        else { hipLaunchKernelGGL((k_path_volume<true, 8, true, TraitsLambertianGlassContainer>), grid, dim3(kBlock), lds, stream, params, smallTris); }
+        return;
+    }
+    if (small && ldsMaterials && params.smallQuads > 0) {
+        hipLaunchKernelGGL((k_path_volume<true, 8, true, TraitsAll, true>), grid, dim3(kBlock), lds, stream, params, smallTris);
         return;
     }
     if (small) { launchVolumeStack<8, true>(params, smallTris, grid, lds, ldsMaterials, stream); return; }
@@ -1924,7 +1929,12 @@ static int renderPassVolume(PathedScene *scene, uint64_t seed, uint32_t begin, u
         timed = scene->traceEvents.acquire();
         (void)hipEventRecord(scene->traceEvents.start[timed], stream);
     }
-    launchVolume(scene->stackRows, small, scene->lambertianGlassContainer, params, scene->smallTris, grid, lds, ldsMaterials, stream);
+    // scenes made of quads: phase 1 over the item records (small_items.h), phase 2 over the item-ordered triangles
+    const bool quads = small && ldsMaterials && scene->smallLayout.nQuads > 0;
+    params.smallQuads = quads ? scene->smallLayout.nQuads : 0;
+    params.smallKappaT = scene->smallLayout.kappaT;
+    if (quads) { params.scene.leafTris = scene->itemTris.ptr; }
+    launchVolume(scene->stackRows, small, scene->lambertianGlassContainer, params, quads ? scene->smallItems : scene->smallTris, grid, lds, ldsMaterials, stream);
     if (timed >= 0) { (void)hipEventRecord(scene->traceEvents.stop[timed], stream); }
     scene->traceLaunchesAll++;
     const dim3 pixelGrid((unsigned)((nPixels + kBlock - 1) / kBlock));

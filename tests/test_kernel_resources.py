@@ -45,14 +45,19 @@ def test_vgpr_budgets_of_the_hot_kernels(tmp_path):
     small = [v for k, v in usage.items() if "k_trace_smallILb0" in k]
     assert small and small[0]["VGPRs"] <= 64 and small[0]["ScratchSize"] == 0, small
     # the fused path kernel lives at four waves per SIMD (128 VGPRs; three waves without spills measured 7 % slower):
-    # what it spills stays within a couple of dozen dwords
-    fused = {k: v for k, v in usage.items() if "k_path_smallILb1ELb0" in k}
+    # what it spills stays within a couple of dozen dwords.  Template tail: ..., MFMA, QUADS (kernels.h)
+    fused = {k: v for k, v in usage.items() if re.search(r"k_path_smallILb1ELb0E.*ELb0ELb0EEEv", k)}   # pair-of-triangles phase 1
     assert len(fused) == 3 and all(v["VGPRs"] <= 128 and v["ScratchSize"] <= 96 and v["Occupancy"] == 4 for v in fused.values()), fused
-    # the instantiation narrowed to Cornell-like scenes (Lambertian, triangle lights: shading.h SceneTraits) is what the
-    # headline runs on: the code it does not contain is what used to spill (92 bytes of scratch in the generic one)
+    # the instantiation narrowed to Cornell-like scenes (Lambertian, triangle lights: shading.h SceneTraits): the code it does
+    # not contain is what used to spill (92 bytes of scratch in the generic one)
     narrow = [v for k, v in fused.items() if "SceneTraitsILj1E" in k]
     assert len(narrow) == 1 and narrow[0]["ScratchSize"] <= 16, fused
-
+    # ... and with the parallelogram phase 1 (small_items.h), which is what the headline runs on: the path state that waits
+    # in LDS across the pass (24 KiB per block) keeps the spills of the Cornell instantiation at a handful
+    quads = {k: v for k, v in usage.items() if re.search(r"k_path_smallILb1ELb0E.*ELb0ELb1EEEv", k)}
+    assert len(quads) == 3 and all(v["VGPRs"] <= 128 and v["Occupancy"] == 4 for v in quads.values()), quads
+    narrow_quads = [v for k, v in quads.items() if "SceneTraitsILj1E" in k]
+    assert len(narrow_quads) == 1 and narrow_quads[0]["ScratchSize"] <= 96, quads
 
 @pytest.mark.skipif(not os.environ.get("PATHED_TEST_EXPERIMENTS"), reason="compiles the experiments build (minutes): set PATHED_TEST_EXPERIMENTS=1")
 def test_vgpr_budgets_of_the_experimental_kernels(tmp_path):
