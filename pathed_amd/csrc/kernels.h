@@ -24,6 +24,12 @@
 // State is SoA-of-float4 in HBM so a wave reads 1 KiB contiguous per stream.
 #pragma once
 
+// Phase 2 of k_path_small<QUADS> (A/B builds: tools/ab_resolve.py, profiles/r4_ab_resolve.log): 0 every lane resolves its own
+// candidates; 1 the first candidate of each ray in place, the wave shares the left-overs out; 2 (the product) as 1, with all
+// of the shadow ray's candidates shared out
+#ifndef PATHED_RESOLVE_SHARED
+#define PATHED_RESOLVE_SHARED 2
+#endif
 #ifndef PATHED_EXPERIMENTS
 #define PATHED_EXPERIMENTS 0   // 1: `make experiments` -- the measured-and-rejected kernel organisations (kernels_experiments.h)
 #endif
@@ -1004,6 +1010,146 @@ __device__ __forceinline__ void smallResolve(const TraceGeometry &geometry, Lane
     }
 }
 
+// Phase 2 with the wave's idle lanes lending a hand (k_path_small<QUADS>).  smallResolve runs max-over-lanes turns: 4.6 for the
+// path's ray and 2.3 for the shadow ray on Cornell, at a quarter of the lanes, because a few lanes hold 3-5 candidates while
+// most hold one (profiles/r3_fused_profile.log).  Here every lane tests the FIRST candidate of its path ray itself (one full
+// turn; SHADOW_IN_PLACE: of its shadow ray too), the other candidates of the whole wave are listed in LDS, and lane i tests
+// items i, i + 64, ... whoever they belong to: the ray comes over ds_bpermute from the lane that owns it, an accepted hit goes
+// back as a 64-bit (t, prim, item) key through an LDS atomic min -- the acceptance rule of testLeafTriangle is "smallest t,
+// then smallest primitive id", independent of order -- and an accepted occluder as an atomic or.  u, v of the winner wait in
+// the item's slot.  More than CAPACITY items (rare): the owners finish them in place as before.  Same hits bit for bit: every
+// candidate still goes through intersectTriangle with its own ray and the same acceptance conditions.
+// Measured (profiles/r4_ab_resolve.log): Cornell 1024^2 +5.0 % with the left-overs shared, +6.7 % with the shadow ray's
+// candidates shared as well; Veach -0.4 % (few left-overs: the cost is the registers the exchange takes from the shading code).
+struct ResolveScratch {
+    unsigned long long *best;   // [64]  per lane of the wave: smallest accepted key
+    float2 *uv;                 // [CAPACITY]  per item
+    unsigned short *items;      // [CAPACITY]  owner lane | candidate << 6 | shadow << 12
+    unsigned int *occluded;     // [64]  per lane
+    unsigned int *count;        // [1]
+};
+
+template <int CAPACITY, bool SHADOW_IN_PLACE>
+__device__ __forceinline__ void smallResolveShared(const TraceGeometry &geometry, LaneRay &ray, LaneRay &shadowRay,
+                                                   unsigned int low, unsigned int high, unsigned int shadowLow, unsigned int shadowHigh,
+                                                   const ResolveScratch &scratch)
+{
+    const int lane = threadIdx.x & 63;
+    auto takeFirst = [](unsigned int &lowWord, unsigned int &highWord) -> int {
+        int k;  // triangle k of a word is bit 31 - (k & 31): take the highest set bit first
+        if (lowWord != 0u) { k = __clz((int)lowWord); lowWord &= ~(0x80000000u >> k); }
+        else { k = __clz((int)highWord); highWord &= ~(0x80000000u >> k); k += 32; }
+        return k;
+    };
+    // ---- every lane's first candidate of each ray, in place
+    if (__ballot((low | high) != 0u) != 0ull) {
+        if ((low | high) != 0u) {
+            const int k = takeFirst(low, high);
+            bool terminate = false;
+            testLeafTriangle(ray, geometry.tris[3 * k + 0], geometry.tris[3 * k + 1], geometry.tris[3 * k + 2], &terminate);
+        }
+    }
+    if (SHADOW_IN_PLACE && __ballot((shadowLow | shadowHigh) != 0u) != 0ull) {
+        if ((shadowLow | shadowHigh) != 0u) {
+            const int k = takeFirst(shadowLow, shadowHigh);
+            bool terminate = false;
+            testLeafTriangle(shadowRay, geometry.tris[3 * k + 0], geometry.tris[3 * k + 1], geometry.tris[3 * k + 2], &terminate);
+            if (terminate) { shadowLow = 0u; shadowHigh = 0u; }  // occluded: the other candidates do not matter
+        }
+    }
+    // ---- the left-overs of the wave.  Sharing them out costs about 1.7 turns of the in-place loop (ten ds_bpermute, the
+    // list, the atomics), so it is taken when the loops would run two turns or more: left-overs on both rays, or a lane
+    // with two of one kind.
+    const unsigned int mineRay = (unsigned int)(__popc(low) + __popc(high)), mineShadow = (unsigned int)(__popc(shadowLow) + __popc(shadowHigh));
+    const unsigned int mine = mineRay + mineShadow;
+    const bool anyRay = __ballot(mineRay != 0u) != 0ull, anyShadow = __ballot(mineShadow != 0u) != 0ull;
+    if (!anyRay && !anyShadow) { return; }
+    bool share = (anyRay && anyShadow) || __ballot(mineRay > 1u || mineShadow > 1u) != 0ull;
+    unsigned int base = 0u, total = 0u;
+    if (share) {
+        if (lane == 0) { *scratch.count = 0u; }
+        scratch.best[lane] = ~0ull;
+        scratch.occluded[lane] = 0u;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (mine != 0u) { base = atomicAdd(scratch.count, mine); }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        total = (unsigned int)__builtin_amdgcn_readfirstlane((int)*scratch.count);
+        share = total <= (unsigned int)CAPACITY;     // more than the list holds (rare): as before
+    }
+    if (!share) {
+        while (__ballot((low | high) != 0u) != 0ull) {
+            if ((low | high) != 0u) {
+                const int k = takeFirst(low, high);
+                bool terminate = false;
+                testLeafTriangle(ray, geometry.tris[3 * k + 0], geometry.tris[3 * k + 1], geometry.tris[3 * k + 2], &terminate);
+            }
+        }
+        while (__ballot((shadowLow | shadowHigh) != 0u) != 0ull) {
+            if ((shadowLow | shadowHigh) != 0u) {
+                const int k = takeFirst(shadowLow, shadowHigh);
+                bool terminate = false;
+                testLeafTriangle(shadowRay, geometry.tris[3 * k + 0], geometry.tris[3 * k + 1], geometry.tris[3 * k + 2], &terminate);
+                if (terminate) { shadowLow = 0u; shadowHigh = 0u; }
+            }
+        }
+        return;
+    }
+    // the owners list their items (a short loop: a lane holds a handful at most)
+    {
+        unsigned int at = base;
+        while ((low | high) != 0u) { const int k = takeFirst(low, high); scratch.items[at++] = (unsigned short)((unsigned int)lane | ((unsigned int)k << 6)); }
+        while ((shadowLow | shadowHigh) != 0u) { const int k = takeFirst(shadowLow, shadowHigh); scratch.items[at++] = (unsigned short)((unsigned int)lane | ((unsigned int)k << 6) | 0x1000u); }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // lane i tests item i (+ 64, ...)
+    for (unsigned int chunk = 0u; chunk < total; chunk += 64u) {
+        const unsigned int index = chunk + (unsigned int)lane;
+        const bool helping = index < total;
+        const unsigned int item = helping ? scratch.items[index] : 0u;
+        const int owner = (int)(item & 63u), k = (int)((item >> 6) & 63u);
+        const bool forShadow = (item & 0x1000u) != 0u;
+        // the owner's rays (every lane takes part in the exchange)
+        const float ox = __shfl(ray.o.x, owner), oy = __shfl(ray.o.y, owner), oz = __shfl(ray.o.z, owner);
+        const float ax = __shfl(ray.d.x, owner), ay = __shfl(ray.d.y, owner), az = __shfl(ray.d.z, owner);
+        const float bx = __shfl(shadowRay.d.x, owner), by = __shfl(shadowRay.d.y, owner), bz = __shfl(shadowRay.d.z, owner);
+        const float shadowFar = __shfl(shadowRay.tfar, owner);
+        if (helping) {
+            const float4 t0 = geometry.tris[3 * k + 0], t1 = geometry.tris[3 * k + 1], t2 = geometry.tris[3 * k + 2];
+            const V3 direction = forShadow ? v3(bx, by, bz) : v3(ax, ay, az);
+            float t, u, v;
+            if (intersectTriangle(v3(ox, oy, oz), direction, v3(t0.x, t0.y, t0.z), v3(t1.x, t1.y, t1.z), v3(t2.x, t2.y, t2.z), &t, &u, &v)) {
+                if (t > PATHED_TNEAR) {   // the tnear of both queries (laneRayInit in k_path_small)
+                    if (forShadow) {
+                        if (t <= shadowFar) { atomicOr(&scratch.occluded[owner], 1u); }
+                    } else if (t <= PATHED_TFAR) {
+                        scratch.uv[index] = make_float2(u, v);
+                        const unsigned long long key = ((unsigned long long)__float_as_uint(t) << 32)
+                            | ((unsigned long long)(unsigned int)floatAsInt(t0.w) << 8) | (unsigned long long)index;
+                        atomicMin(&scratch.best[owner], key);
+                    }
+                }
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // the owners take what came back
+    const unsigned long long key = scratch.best[lane];
+    if (key != ~0ull) {
+        const float t = __uint_as_float((unsigned int)(key >> 32));
+        const int prim = (int)((key >> 8) & 0xFFFFFFull);
+        const bool closer = (ray.bestPrim < 0) ? (t <= ray.best) : (t < ray.best || (t == ray.best && prim < ray.bestPrim));
+        if (closer) {
+            const float2 uv = scratch.uv[(int)(key & 255ull)];
+            ray.best = t; ray.bestU = uv.x; ray.bestV = uv.y; ray.bestPrim = prim;
+        }
+    }
+    if (scratch.occluded[lane] != 0u) { shadowRay.occluded = true; }
+}
+
 template <bool COUNT>
 __global__ __launch_bounds__(kBlock) void k_trace_small(RenderParams p, SmallTris smallTris)
 {
@@ -1958,6 +2104,13 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_F
     // lane ([quad][thread]: a wave stores 1 KiB contiguous): the parallelogram test needs two dozen registers more than the
     // pair-of-triangles test, and what the compiler spilled for them went to scratch memory (48 dwords, profiles/r4_ab_quads.log)
     __shared__ float4 stashRows[QUADS ? 6 * kBlock : 1];
+    // ... and phase 2 shares the wave's candidates out (smallResolveShared): 2.25 KiB per wave.  With the stash 33.5 KiB per
+    // block: four blocks per CU as long as the material table stays below 6.5 KiB (pathed_hip.hip pairs triangles up to 64 materials)
+    constexpr int kResolveCapacity = PATHED_RESOLVE_SHARED == 2 ? 128 : 64;   // items per wave
+    __shared__ unsigned long long resolveBest[QUADS ? kBlock : 1];
+    __shared__ float2 resolveUv[QUADS ? kWavesPerBlock * kResolveCapacity : 1];
+    __shared__ unsigned short resolveItems[QUADS ? kWavesPerBlock * kResolveCapacity : 1];
+    __shared__ unsigned int resolveOccluded[QUADS ? kBlock : 1], resolveCount[QUADS ? kWavesPerBlock : 1];
     if (MFMA) {
         for (int i = threadIdx.x; i < kMfmaTableFloats; i += kBlock) { mfmaRows[i] = p.mfmaTable[i]; }
         if (!LDS_MATERIALS) { __syncthreads(); }
@@ -2129,6 +2282,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_F
             if (MFMA) {
                 mfmaResolve(geometry, ray, candidatesLow, candidatesHigh);
                 mfmaResolve(geometry, shadowRay, shadowLow, shadowHigh);
+            } else if (QUADS && PATHED_RESOLVE_SHARED) {
+                ResolveScratch scratch;
+                const int waveBase = (int)(threadIdx.x & ~63u), wave = (int)(threadIdx.x >> 6);
+                scratch.best = resolveBest + waveBase; scratch.uv = resolveUv + wave * kResolveCapacity; scratch.items = resolveItems + wave * kResolveCapacity;
+                scratch.occluded = resolveOccluded + waveBase; scratch.count = resolveCount + wave;
+                smallResolveShared<kResolveCapacity, PATHED_RESOLVE_SHARED != 2>(geometry, ray, shadowRay, candidatesLow, candidatesHigh, shadowLow, shadowHigh, scratch);
             } else {
                 smallResolve(geometry, ray, candidatesLow, candidatesHigh);
                 smallResolve(geometry, shadowRay, shadowLow, shadowHigh);

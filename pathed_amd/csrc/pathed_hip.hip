@@ -1113,8 +1113,11 @@ static hipError_t rebuildSmallItems(PathedScene *scene)
     if (!scene->bruteForce || scene->device.nTris <= 0) { return hipSuccess; }
     std::vector<float> points = scene->smallExtraPoints;
     for (int a = 0; a < 3; a++) { points.push_back(scene->device.camera.origin[a]); }
-    // (the parallelogram instantiations of k_path_small keep the material table in LDS: scenes of more than 96 materials pair nothing)
-    const bool pairQuads = scene->options.generic_kernels == 0 && !getenv("PATHED_NO_QUADS") && scene->device.nMaterials <= kMaxLdsMaterials;
+    // (the parallelogram instantiations of k_path_small keep the material table in LDS beside the path-state stash and the
+    // shared resolve's lists, 33.5 KiB per block: up to 64 materials -- 6 KiB -- four blocks fit a CU's 160 KiB; scenes with more
+    // pair nothing)
+    const int kMaxQuadMaterials = 64;
+    const bool pairQuads = scene->options.generic_kernels == 0 && !getenv("PATHED_NO_QUADS") && scene->device.nMaterials <= kMaxQuadMaterials;
     std::vector<float> ordered;
     scene->smallLayout = buildSmallItems(scene->bvh.leafTris.data(), scene->device.nTris, points.data(), (int)(points.size() / 3), pairQuads, PATHED_TNEAR,
                                          reinterpret_cast<float *>(scene->smallItems.data), &ordered);
