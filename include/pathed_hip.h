@@ -216,7 +216,8 @@ typedef struct PathedStats {
     uint32_t path_kernel;          /* 1 wavefront with the per-slot shade kernel, 2 wavefront with the staged shade kernel,
                                       3 fused path kernel (tiny scenes: one persistent launch per pass, timed as trace_ms),
                                       4 volume path kernel (PATHED_INTEGRATOR_VOLUME_PATH_TRACER),
-                                      5 wavefront with the split shade stage (k_vertex + k_regen over the trace kernel's lists) */
+                                      5 wavefront with the split shade stage (k_vertex + k_regen over the trace kernel's lists),
+                                      6 wave path kernel (BVH scenes, the last render call) */
     uint32_t reserved0;
 } PathedStats;
 
@@ -277,7 +278,10 @@ typedef struct PathedSceneOptions {
     int32_t shade_kernel;       /* 0 automatic; 1 wavefront, k_shade (one lane per slot); 2 wavefront, k_shade_staged (dense,
                                    state-sorted stages per block); 3 k_path_small (fused: whole paths in registers; scenes of
                                    <= 64 triangles only, their default); 4 wavefront, k_vertex + k_regen over the hit / miss
-                                   lists the trace kernel writes (BVH scenes only) */
+                                   lists the trace kernel writes (BVH scenes only); 5 k_path_wave (BVH scenes of <= 96 materials:
+                                   paths in registers, the wave's rays shared through LDS, no path state in HBM) for every call.
+                                   0 on a BVH scene: k_path_wave for calls of fewer than 48 Mi camera samples, whose rate hardly
+                                   depends on the call's size, the wavefront (1) for longer ones; images are identical */
     int32_t stage_slots;        /* slots per block of the staged kernel: 512 or 1024 (0 = automatic)           */
     int32_t unit_order;         /* order work units are handed out in (scheduling only, results identical):
                                  * 0 automatic = 1; 1 chunk stripes, rows; 2 chunk stripes, 32 x 8 tiles; 3 pixel tiles */

@@ -2487,6 +2487,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_F
     }
 }
 
+#include "path_wave.h"
+
 // Test hook behind pathed_hip_debug_small_candidates: for every ray pair (origin, continuation direction, shadow direction,
 // shadow far bound) the candidate sets of the phase-1 forms and the set phase 2 accepts, one bit per ORIGINAL primitive id
 // (the forms index the triangles in different orders).  n is padded to whole waves by the host (the matrix instructions of

@@ -202,6 +202,15 @@ struct PathedScene {
     bool hasContainers = false;   // some surface carries the passthrough material: only the volume integrator renders the scene
     bool spheresInTree = false;   // the host builder put the spheres into leaves (else they are tested one by one after the traversal)
     bool fusedPath = false;   // tiny scenes: k_path_small, whole paths in registers, no wavefront buffers
+    // BVH scenes: k_path_wave (path_wave.h: paths in registers, no state in HBM) instead of the wavefront kernels.  It renders
+    // at a rate that hardly depends on the size of the call, the wavefront needs some 50 M camera samples to fill and drain its
+    // 8 Mi slots and is 9-20 % faster beyond (profiles/r4_ab_wave.log): 0 by the size of the call, 1 never, 2 always
+    int waveMode = 0;
+    bool waveAvailable = false;   // ... and the scene is one it serves
+    bool lastCallWave = false;    // what the last render call ran (PathedStats.path_kernel)
+    unsigned long long waveMaxSamples = 48ull << 20;   // calls of fewer camera samples than this take it (waveMode 0)
+    int waveStragglers = 24;      // its traversal bursts end once fewer rays than this are in flight
+    int waveRefill = kRefillThreshold;   // ... and idle lanes draw from the wave's list once fewer than this many are busy
     bool stagedShade = true;  // k_shade_staged (dense, state-sorted stages inside a block) or k_shade (one lane per slot)
     bool lambertianTriangles = false;   // constant-albedo Lambertian surfaces, triangle lights, no spheres, no environment: k_path_small<.., TraitsLambertianTriangles>
     bool lambertianPlasticSpheres = false;   // the Veach scene's set (shading.h)
@@ -1149,7 +1158,7 @@ int pathed_hip_scene_create_ex(const PathedSceneDesc *desc, const PathedSceneOpt
             return fail(PATHED_E_INVALID, "stack_rows must be 0, 8, 16 or 22");
         }
         if (options.max_slots < 0 || (options.max_slots != 0 && options.max_slots < kBlock)) { return fail(PATHED_E_INVALID, "max_slots must be 0 or >= 256"); }
-        if (options.shade_kernel < 0 || options.shade_kernel > 4) { return fail(PATHED_E_INVALID, "shade_kernel must be 0..4"); }
+        if (options.shade_kernel < 0 || options.shade_kernel > 5) { return fail(PATHED_E_INVALID, "shade_kernel must be 0..5"); }
         if (options.stage_slots != 0 && options.stage_slots != 512 && options.stage_slots != 1024) { return fail(PATHED_E_INVALID, "stage_slots must be 0, 512 or 1024"); }
         if (options.refittable != 0 && options.refittable != 1) { return fail(PATHED_E_INVALID, "refittable must be 0 or 1"); }
         if (options.small_phase1 < 0 || options.small_phase1 > 2) { return fail(PATHED_E_INVALID, "small_phase1 must be 0 (automatic), 1 (VALU) or 2 (matrix pipe)"); }
@@ -1560,6 +1569,7 @@ int pathed_hip_scene_create_ex(const PathedSceneDesc *desc, const PathedSceneOpt
         else if (!strcmp(text, "staged")) { shadeKernel = 2; }
         else if (!strcmp(text, "fused")) { shadeKernel = 3; }
         else if (!strcmp(text, "split")) { shadeKernel = 4; }
+        else if (!strcmp(text, "wave")) { shadeKernel = 5; }
     }
     if (shadeKernel == 3 && !scene->bruteForce) {
         delete scene;
@@ -1611,6 +1621,15 @@ int pathed_hip_scene_create_ex(const PathedSceneDesc *desc, const PathedSceneOpt
     if (const char *text = getenv("PATHED_VERTEX_GRID")) { const int value = atoi(text); if (value >= 1 && value <= 65536) { scene->vertexGrid = value; } }
     if (const char *text = getenv("PATHED_REGEN_GRID")) { const int value = atoi(text); if (value >= 1 && value <= 65536) { scene->regenGrid = value; } }
     scene->fusedPath = scene->bruteForce && (shadeKernel == 0 || shadeKernel == 3);
+    scene->waveMode = shadeKernel == 5 ? 2 : shadeKernel == 0 ? 0 : 1;
+    scene->waveAvailable = !scene->bruteForce && scene->device.nMaterials <= kMaxLdsMaterials && scene->nodeFormat == 0;
+    if (shadeKernel == 5 && !scene->waveAvailable) {
+        delete scene;
+        return fail(PATHED_E_INVALID, "the wave path kernel serves BVH scenes (more than 64 triangles or intersector 1) of at most 96 materials over the float nodes");
+    }
+    if (const char *text = getenv("PATHED_WAVE_MAX_SAMPLES")) { scene->waveMaxSamples = strtoull(text, nullptr, 10); }
+    if (const char *text = getenv("PATHED_WAVE_REFILL")) { const int value = atoi(text); if (value >= 1 && value <= 64) { scene->waveRefill = value; } }
+    if (const char *text = getenv("PATHED_WAVE_STRAGGLERS")) { const int value = atoi(text); if (value >= 0 && value <= 64) { scene->waveStragglers = value; } }
     scene->stagedShade = shadeKernel == 2;
     // more slots per block = fuller last waves of the dense stages, fewer blocks to fill the chip with:
     // the 0.5 Mi-slot pools of the all-triangles scenes take 512, the 2 Mi-slot pools of the BVH scenes 1024
@@ -1950,6 +1969,90 @@ static int renderPassVolume(PathedScene *scene, uint64_t seed, uint32_t begin, u
     return PATHED_OK;
 }
 
+// One internal pass of the path tracer over a BVH with the paths on chip (k_path_wave, path_wave.h): one persistent launch.
+static int renderPassWave(PathedScene *scene, uint64_t seed, uint32_t begin, uint32_t count,
+                          int start_bounce, int last_bounce, float *d_accum, hipStream_t stream)
+{
+    const int nPixels = scene->width * scene->height;
+    const int chunk = scene->samplesPerUnit;
+    const int chunksPerPixel = (int)((count + (uint32_t)chunk - 1) / (uint32_t)chunk);
+    const unsigned long long nUnits64 = (unsigned long long)nPixels * (unsigned long long)chunksPerPixel;
+    if (nUnits64 >= 0xFFFFFFF0ull) { return fail(PATHED_E_INVALID, "too many work units in one pass"); }
+    const unsigned int nUnits = (unsigned int)nUnits64;
+
+    if (scene->chunkCapacity < (size_t)nUnits) {
+        HIP_TRY(scene->chunkBuf.allocate((size_t)nUnits));
+        scene->chunkCapacity = (size_t)nUnits;
+    }
+    if (!scene->counters.ptr) { HIP_TRY(scene->counters.allocate(kMaxPools * kCtrCount)); }
+    if (!scene->stats.ptr) {
+        HIP_TRY(scene->stats.allocate(kStatCount));
+        HIP_TRY(hipMemset(scene->stats.ptr, 0, kStatCount * sizeof(unsigned long long)));
+    }
+
+    const int stackRows = 22;
+    const size_t lds = pathWaveLdsBytes(stackRows, scene->device.nMaterials);
+    unsigned long long blocks = (unsigned long long)scene->computeUnits * PATHED_WAVE_WAVES;
+    const unsigned long long blocksNeeded = (nUnits64 + (unsigned long long)kBlock - 1) / kBlock;
+    if (blocks > blocksNeeded) { blocks = blocksNeeded; }
+    if (blocks < 1) { blocks = 1; }
+    const unsigned int waves = (unsigned int)blocks * kWavesPerBlock;
+    const size_t overflowRows = (size_t)(scene->maxStack > stackRows ? scene->maxStack - stackRows : 0);
+    const size_t overflowInts = (size_t)blocks * kBlock * (overflowRows ? overflowRows : 1);
+    if (scene->volumeOverflow.count < overflowInts) { HIP_TRY(scene->volumeOverflow.allocate(overflowInts)); }
+
+    RenderParams params;
+    std::memset(&params, 0, sizeof params);
+    params.scene = scene->device;
+    params.state.chunkBuf = scene->chunkBuf.ptr;
+    params.counters = scene->counters.ptr;
+    params.stats = scene->stats.ptr;
+    params.stackOverflow = scene->volumeOverflow.ptr;
+    params.maxStack = scene->maxStack;
+    params.suspendLanes = scene->waveStragglers;
+    params.suspendPatience = scene->waveRefill;   // k_path_wave: idle lanes are refilled from the wave's list once fewer than this many are busy
+    params.accum = d_accum;
+    params.nPixels = nPixels;
+    if (!fillUnitOrder(params, scene->unitOrder, scene->width, scene->height, chunksPerPixel, 0, 1,
+                       (int)(waves < (unsigned int)kUnitQueues ? waves : (unsigned int)kUnitQueues))) {
+        return fail(PATHED_E_INVALID, "too many work units in one pass");
+    }
+    {
+        const unsigned int wavesPerQueue = (waves + (unsigned int)params.nQueues - 1) / (unsigned int)params.nQueues;
+        unsigned int grab = (nUnits / (unsigned int)params.nQueues) / (wavesPerQueue * 4u);
+        params.unitGrab = (int)(grab < 1u ? 1u : grab > 64u ? 64u : grab);
+    }
+    params.chunk = chunk;
+    params.chunksPerPixel = chunksPerPixel;
+    params.seedLo = (uint32_t)seed;
+    params.seedHi = (uint32_t)(seed >> 32);
+    params.sppBegin = begin;
+    params.sppEnd = begin + count;
+    params.startBounce = start_bounce;
+    params.lastBounce = last_bounce;
+
+    HIP_TRY(hipMemsetAsync(params.counters, 0, kCtrCount * sizeof(unsigned int), stream));
+    const dim3 grid((unsigned)blocks);
+    int timed = -1;
+    if (scene->timeKernels) {
+        timed = scene->traceEvents.acquire();
+        (void)hipEventRecord(scene->traceEvents.start[timed], stream);
+    }
+    if (scene->envOnly && scene->device.nSpheres == 0 && !scene->hasContainers) { hipLaunchKernelGGL((k_path_wave<true, 22, TraitsEnvironmentOnly, false>), grid, dim3(kBlock), lds, stream, params); }
+    else if (scene->device.nSpheres == 0) { hipLaunchKernelGGL((k_path_wave<true, 22, TraitsAll, false>), grid, dim3(kBlock), lds, stream, params); }
+    else { hipLaunchKernelGGL((k_path_wave<true, 22, TraitsAll, true>), grid, dim3(kBlock), lds, stream, params); }
+    if (timed >= 0) { (void)hipEventRecord(scene->traceEvents.stop[timed], stream); }
+    scene->traceLaunchesAll++;
+    const dim3 pixelGrid((unsigned)((nPixels + kBlock - 1) / kBlock));
+    hipLaunchKernelGGL(k_resolve, pixelGrid, dim3(kBlock), 0, stream, params);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(stream));
+
+    scene->iterations += 1;
+    scene->cameraSamples += (unsigned long long)count * (unsigned long long)nPixels;
+    return PATHED_OK;
+}
+
 // One internal pass: samples [begin, begin+count), count <= chunk * kMaxChunksPerPass.
 // The slot pool is split into `pools` independent halves, each with its own unit range,
 // counters and HIP stream: while one half runs its (ALU-bound) trace kernel the other runs its
@@ -2191,6 +2294,11 @@ int pathed_hip_render_device(PathedScene *scene, uint64_t seed,
         if (value >= 1 && value <= 4096) { chunksPerPass = value; }
     }
     const uint32_t perPass = (uint32_t)scene->samplesPerUnit * (uint32_t)chunksPerPass;
+    // BVH scenes: short calls on the wave path kernel, long ones on the wavefront (the counting instantiations are the wavefront's)
+    const unsigned long long callSamples = (unsigned long long)scene->width * (unsigned long long)scene->height * (unsigned long long)spp_count;
+    const bool wavePath = scene->waveAvailable && !usesVolumeKernel(scene) && !scene->countMode
+        && (scene->waveMode == 2 || (scene->waveMode == 0 && callSamples < scene->waveMaxSamples));
+    scene->lastCallWave = wavePath;
     uint32_t done = 0;
     while (done < spp_count) {
         const uint32_t count = (spp_count - done < perPass) ? (spp_count - done) : perPass;
@@ -2198,6 +2306,8 @@ int pathed_hip_render_device(PathedScene *scene, uint64_t seed,
             ? renderPassVolume(scene, seed, spp_begin + done, count, start_bounce, last_bounce, d_accum_rgb_sum, stream)
             : scene->fusedPath
                 ? renderPassFused(scene, seed, spp_begin + done, count, start_bounce, last_bounce, d_accum_rgb_sum, stream)
+            : wavePath
+                ? renderPassWave(scene, seed, spp_begin + done, count, start_bounce, last_bounce, d_accum_rgb_sum, stream)
                 : renderPass(scene, seed, spp_begin + done, count, start_bounce, last_bounce, d_accum_rgb_sum, stream);
         if (code != PATHED_OK) { return code; }
         done += count;
@@ -2467,7 +2577,7 @@ int pathed_hip_get_stats(PathedScene *scene, PathedStats *out)
     out->bvh_build_ms = scene->bvhBuildMs;
     out->bvh_builder = (uint32_t)scene->bvhBuilder;
     out->trace_launches_all = (uint32_t)scene->traceLaunchesAll;
-    out->path_kernel = usesVolumeKernel(scene) ? 4u : scene->fusedPath ? 3u : scene->splitShade ? 5u : (scene->stagedShade ? 2u : 1u);
+    out->path_kernel = usesVolumeKernel(scene) ? 4u : scene->fusedPath ? 3u : scene->lastCallWave ? 6u : scene->splitShade ? 5u : (scene->stagedShade ? 2u : 1u);
     if (getenv("PATHED_SHADE_PROFILE")) {   // counters exist in -DPATHED_SHADE_PROFILE builds only
         static const char *regions[11] = { "all waves", "active slots", "makeIsect (hit)", "camera-ray vertex", "finish previous MIS term",
                                            "new vertex: BSDF sample", "light sampling", "sample finished", "startSample (regeneration)", "shadow ray pushed",

@@ -36,6 +36,8 @@ typedef SceneTraits<1u << 0, false, true, false, false, true> TraitsLambertianTr
 typedef SceneTraits<(1u << 0) | (1u << 3), false, false, true, false, true> TraitsLambertianPlasticSpheres;
 // the reference's VolumePathTracer scene (scenes/cornell-medium.json): Lambertian walls, a glass sphere, a passthrough container, triangle lights
 typedef SceneTraits<(1u << 0) | (1u << 4) | (1u << 6), false, true, true, false> TraitsLambertianGlassContainer;
+// mesh scenes lit by the environment alone (no emissive material, no sphere): any material, any albedo
+typedef SceneTraits<0x3Fu, true, false, false, true> TraitsEnvironmentOnly;
 
 
 #define PATHED_INV_PI 0.3183098861837907f   /* include/util.h:10 */
