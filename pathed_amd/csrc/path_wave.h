@@ -157,18 +157,27 @@ __device__ __forceinline__ bool pathVertex(const RenderParams &p, const DScene &
 #define PATHED_WAVE_WAVES 3   // blocks per CU = waves per SIMD: what 160 KB of LDS holds of stacks + ray lists (168 VGPRs each)
 #endif
 static const int kWaveListRays = 128;                 // a wave's ray list: at most one continuation + one shadow ray per lane
+static const int kWaveRing = kWavesPerBlock * kWaveListRays;   // BLOCK: the block's ray ring (every path has at most two rays in it)
+static const unsigned int kWaveSpinBound = 1u << 22;  // BLOCK: polls (of ~0.2 us) before a wave gives up on the others: a bug, reported as dropped samples
 static const unsigned int kWaveShadowTag = 0x100u;    // list entry / lane target: owner lane | this bit for a shadow ray
 static const unsigned int kWaveOccludedFlag = 0x100u; // ownerFlags: the low byte counts the owner's finished rays
 
 // dynamic LDS of a block: [STACK + 1][kBlock] stack rows | per wave 128 x 2 float4 of ray list | kBlock float4 hits |
-// kBlock flag words | (LDS_MATERIALS) the material table
+// kBlock flag words | the ring's kWaveRing + 4 words | (LDS_MATERIALS) the material table
 __host__ __device__ inline size_t pathWaveLdsBytes(int stackRows, int nLdsMaterials)
 {
     return (size_t)(stackRows + 1) * kBlock * sizeof(int) + (size_t)kWavesPerBlock * kWaveListRays * 2 * sizeof(float4)
-        + (size_t)kBlock * sizeof(float4) + (size_t)kBlock * sizeof(unsigned int) + (size_t)nLdsMaterials * sizeof(DMaterial);
+        + (size_t)kBlock * sizeof(float4) + (size_t)kBlock * sizeof(unsigned int) + (size_t)(kWaveRing + 4) * sizeof(unsigned int)
+        + (size_t)nLdsMaterials * sizeof(DMaterial);
 }
 
-template <bool LDS_MATERIALS, int STACK, typename TRAITS, bool SPHERES>
+// BLOCK (instantiated in the experiments build only: 13-20 % slower, profiles/r4_ab_wave.log -- with one path per lane there
+// is about one ray per lane in the whole block, shared or not, so the idle lanes find the ring empty and the polling costs):
+// the four waves of a block share ONE ray queue (a ring in LDS, every path has at most two rays in it) and work
+// asynchronously: a wave posts its new rays there, any wave's idle lanes draw from it, and a wave shades when enough of its
+// paths have all their rays back (p.parkMinCardsPerWave of them) or it has nothing to traverse.  A wave's own list holds
+// fewer rays than it has lanes (one continuation ray per path, a shadow ray for a quarter of them): its bursts are all tail.
+template <bool LDS_MATERIALS, int STACK, typename TRAITS, bool SPHERES, bool BLOCK = false>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_WAVE_WAVES, PATHED_WAVE_WAVES))) void k_path_wave(RenderParams p)
 {
     extern __shared__ float4 ldsRaw[];
@@ -178,16 +187,25 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_W
     stack.overflow = p.stackOverflow + ((size_t)blockIdx.x * kBlock + threadIdx.x);
     const int lane = threadIdx.x & 63;
     const int wave = (int)(threadIdx.x >> 6);
-    float4 *listO = ldsRaw + ((STACK + 1) * kBlock) / 4 + wave * (2 * kWaveListRays);   // .w = tfar
-    float4 *listD = listO + kWaveListRays;                                                // .w = owner lane | kWaveShadowTag
-    float4 *hitRows = ldsRaw + ((STACK + 1) * kBlock) / 4 + kWavesPerBlock * 2 * kWaveListRays + wave * 64;
-    unsigned int *ownerFlags = reinterpret_cast<unsigned int *>(ldsRaw + ((STACK + 1) * kBlock) / 4 + kWavesPerBlock * 2 * kWaveListRays + kBlock) + wave * 64;
+    // BLOCK: one ring of kWaveRing records for the block, results and flags indexed by the owner's thread
+    float4 *listO = ldsRaw + ((STACK + 1) * kBlock) / 4 + (BLOCK ? 0 : wave * (2 * kWaveListRays));   // .w = tfar
+    float4 *listD = listO + (BLOCK ? kWaveRing : kWaveListRays);                                        // .w = owner | kWaveShadowTag
+    float4 *hitRows = ldsRaw + ((STACK + 1) * kBlock) / 4 + kWavesPerBlock * 2 * kWaveListRays + (BLOCK ? 0 : wave * 64);
+    unsigned int *ownerFlags = reinterpret_cast<unsigned int *>(ldsRaw + ((STACK + 1) * kBlock) / 4 + kWavesPerBlock * 2 * kWaveListRays + kBlock) + (BLOCK ? 0 : wave * 64);
+    unsigned int *ringFlags = reinterpret_cast<unsigned int *>(ldsRaw + ((STACK + 1) * kBlock) / 4 + kWavesPerBlock * 2 * kWaveListRays + kBlock + kBlock / 4);   // [kWaveRing]: ticket + 1 once the record is written
+    unsigned int *ringHead = ringFlags + kWaveRing, *ringTail = ringHead + 1;
+    const int self = BLOCK ? (int)threadIdx.x : lane;   // this lane's row of hitRows / ownerFlags
+    const unsigned int ownerMask = BLOCK ? 0xFFu : 0x3Fu;
+    if (BLOCK) {
+        for (int i = threadIdx.x; i < kWaveRing + 4; i += kBlock) { ringFlags[i] = 0u; }
+        __syncthreads();
+    }
 
     MaterialAccess<LDS_MATERIALS> materials;
     if (LDS_MATERIALS) {
         const int words = p.scene.nMaterials * (int)(sizeof(DMaterial) / 4);
         const int *source = reinterpret_cast<const int *>(p.scene.materials);
-        int *target = reinterpret_cast<int *>(ldsRaw + ((STACK + 1) * kBlock) / 4 + kWavesPerBlock * 2 * kWaveListRays + kBlock + kBlock / 4);
+        int *target = reinterpret_cast<int *>(ldsRaw + ((STACK + 1) * kBlock) / 4 + kWavesPerBlock * 2 * kWaveListRays + kBlock + kBlock / 4 + (kWaveRing + 4) / 4);
         for (int i = threadIdx.x; i < words; i += kBlock) { target[i] = source[i]; }
         __syncthreads();
         materials.table = reinterpret_cast<const DMaterial *>(target);
@@ -263,6 +281,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_W
     bool active = false;
     unsigned int target = 0;         // owner lane | kWaveShadowTag
 
+#ifdef PATHED_SHADE_PROFILE
+    // (tuning builds, tools/wave_profile.py) where a wave's time goes and how full its bursts are
+    unsigned long long profIterations = 0, profAlive = 0, profSteps = 0, profLaneSteps = 0, profShades = 0, profReady = 0, profPosted = 0, profLeft = 0;
+    unsigned long long profBurstCycles = 0, profShadeCycles = 0, profStart = __builtin_amdgcn_s_memtime(), profStamp = 0;
+#endif
     bool startNext = false;
     {
         unit = takeUnits(true);
@@ -295,11 +318,46 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_W
             fresh = true;
             pendingShadow = false;
         }
-        if (__ballot(alive) == 0ull) { break; }   // (a dead lane's path has no ray in flight: nothing is left behind)
+        // (a wave's own rays are all back when its paths are dead; BLOCK: it may still hold other waves' rays)
+        if (__ballot(alive || (BLOCK && active)) == 0ull) { break; }
 
+#ifdef PATHED_SHADE_PROFILE
+        profIterations++; profAlive += (unsigned long long)__popcll(__ballot(alive));
+#endif
         // ---- post the new rays: continuation rays first, then the shadow rays (which leave the same point)
         unsigned int listCount = 0, listPos = 0;   // wave-uniform
-        {
+        if (BLOCK) {
+            const bool postClosest = alive && fresh;
+            const bool postShadow = postClosest && pendingShadow;
+            const unsigned long long closestMask = __ballot(postClosest), shadowMask = __ballot(postShadow);
+            const unsigned int count = (unsigned int)(__popcll(closestMask) + __popcll(shadowMask));
+            if (count != 0u) {
+                unsigned int base = 0u;
+                if (lane == 0) { base = atomicAdd(ringTail, count); }
+                base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
+                const unsigned int closestTicket = base + __builtin_amdgcn_mbcnt_hi((unsigned int)(closestMask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)closestMask, 0u));
+                const unsigned int shadowTicket = base + (unsigned int)__popcll(closestMask)
+                    + __builtin_amdgcn_mbcnt_hi((unsigned int)(shadowMask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)shadowMask, 0u));
+                if (postClosest) {
+                    ownerFlags[self] = 0u;
+                    waiting = postShadow ? 2u : 1u;
+                    listO[closestTicket % kWaveRing] = make_float4(path.o.x, path.o.y, path.o.z, PATHED_TFAR);
+                    listD[closestTicket % kWaveRing] = make_float4(path.d.x, path.d.y, path.d.z, intAsFloat(self));
+                }
+                if (postShadow) {
+                    listO[shadowTicket % kWaveRing] = make_float4(path.o.x, path.o.y, path.o.z, shadowTfar);
+                    listD[shadowTicket % kWaveRing] = make_float4(shadowDirection.x, shadowDirection.y, shadowDirection.z, intAsFloat(self | (int)kWaveShadowTag));
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (postClosest) { *(volatile unsigned int *)&ringFlags[closestTicket % kWaveRing] = closestTicket + 1u; }
+                if (postShadow) { *(volatile unsigned int *)&ringFlags[shadowTicket % kWaveRing] = shadowTicket + 1u; }
+            }
+            fresh = false;
+            pendingShadow = false;
+#ifdef PATHED_SHADE_PROFILE
+            profPosted += count; profStamp = __builtin_amdgcn_s_memtime();
+#endif
+        } else {
             const bool postClosest = alive && fresh;
             const bool postShadow = postClosest && pendingShadow;
             const unsigned long long closestMask = __ballot(postClosest), shadowMask = __ballot(postShadow);
@@ -319,10 +377,106 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_W
             fresh = false;
             pendingShadow = false;
             listCount = (unsigned int)(__popcll(closestMask) + __popcll(shadowMask));
+#ifdef PATHED_SHADE_PROFILE
+            profPosted += listCount; profStamp = __builtin_amdgcn_s_memtime();
+#endif
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
         }
 
+        // ---- BLOCK: traverse rays of the block's ring until this wave has paths to shade
+        if (BLOCK) {
+            unsigned int spins = 0u;
+            while (true) {
+                // idle lanes claim records of the ring
+                const unsigned long long idleMask = __ballot(!active);
+                bool ringEmpty = false;
+                if (idleMask != 0ull) {
+                    const unsigned int wanted = (unsigned int)__popcll(idleMask);
+                    unsigned int claimedBase = 0u, claimed = 0u;
+                    if (lane == 0) {
+                        unsigned int head = *(volatile unsigned int *)ringHead;
+                        while (true) {
+                            const unsigned int available = *(volatile unsigned int *)ringTail - head;
+                            const unsigned int take = wanted < available ? wanted : available;
+                            if (take == 0u) { break; }
+                            const unsigned int seen = atomicCAS(ringHead, head, head + take);
+                            if (seen == head) { claimedBase = head; claimed = take; break; }
+                            head = seen;
+                        }
+                    }
+                    claimedBase = (unsigned int)__builtin_amdgcn_readfirstlane((int)claimedBase);
+                    claimed = (unsigned int)__builtin_amdgcn_readfirstlane((int)claimed);
+                    ringEmpty = claimed < wanted;
+                    const unsigned int rank = __builtin_amdgcn_mbcnt_hi((unsigned int)(idleMask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)idleMask, 0u));
+                    if (!active && rank < claimed) {
+                        const unsigned int ticket = claimedBase + rank, slot = ticket % kWaveRing;
+                        unsigned int polls = 0u;
+                        while (*(volatile unsigned int *)&ringFlags[slot] != ticket + 1u && polls < kWaveSpinBound) { polls++; }   // (written right after the ticket was drawn)
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                        const float4 first = listO[slot];
+                        const float4 second = listD[slot];
+                        // (a record is overwritten 512 tickets later, when its ray has long been claimed and read; a reader that found
+                        // another ticket's flag would be a bug: reported, not traced)
+                        if (polls >= kWaveSpinBound) {
+                            atomicAdd(&p.stats[kStatDropped], 1ull << 40);
+                        } else {
+                            target = (unsigned int)floatAsInt(second.w);
+                            laneRayInit(ray, v3(first.x, first.y, first.z), v3(second.x, second.y, second.z), PATHED_TNEAR, first.w, (target & kWaveShadowTag) != 0u);
+                            active = true;
+                        }
+                    }
+                }
+                const int inFlight = __popcll(__ballot(active));
+                const bool complete = alive && waiting != 0u && (*(volatile unsigned int *)&ownerFlags[self] & 0xFFu) == waiting;
+                const int nReady = __popcll(__ballot(complete));
+                if (nReady >= p.parkMinCardsPerWave) { break; }
+                if (inFlight == 0) {
+                    if (nReady > 0 || __ballot(alive) == 0ull) { break; }
+                    // this wave's rays are on other waves' lanes
+                    __builtin_amdgcn_s_sleep(8);
+                    if (++spins > kWaveSpinBound) {
+                        if (lane == 0) { atomicAdd(&p.stats[kStatDropped], 1ull << 40); }
+                        alive = false;
+                        break;
+                    }
+                    continue;
+                }
+                if (ringEmpty && inFlight < p.suspendLanes && nReady > 0 && nReady >= 2 * inFlight) { break; }
+                // a few steps, then look again (a full wave keeps going until it has thinned out)
+                for (int step = 0; step < 16; step++) {
+                    const unsigned long long leafMask = __ballot(active && ray.pendingLeaf != 0);
+                    const unsigned long long innerMask = __ballot(active && ray.pendingLeaf == 0);
+                    const bool trianglePhase = __popcll(leafMask) >= kLeafThreshold || innerMask == 0ull;
+#ifdef PATHED_SHADE_PROFILE
+                    profSteps++; profLaneSteps += (unsigned long long)__popcll(trianglePhase ? leafMask : innerMask);
+#endif
+                    bool done = false;
+                    if (trianglePhase) {
+                        if (active && ray.pendingLeaf != 0) { done = leafStep<false, STACK, kBlock, SPHERES>(geometry, stack, ray, nullptr); }
+                    } else {
+                        if (active && ray.pendingLeaf == 0) {
+                            done = (geometry.nNodes == 0) || innerStep<false, STACK, kBlock, false, false>(geometry, stack, p.maxStack, ray, nullptr);
+                        }
+                    }
+                    if (done) {
+                        finishRay<SPHERES>(geometry, ray);
+                        const unsigned int owner = target & ownerMask;
+                        if (ray.anyHit) {
+                            atomicAdd(&ownerFlags[owner], ray.occluded ? (1u + kWaveOccludedFlag) : 1u);
+                        } else {
+                            hitRows[owner] = make_float4(ray.best, ray.bestU, ray.bestV, intAsFloat(ray.bestPrim));
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                            atomicAdd(&ownerFlags[owner], 1u);
+                        }
+                        active = false;
+                    }
+                    const int busy = __popcll(__ballot(active));
+                    if (busy == 0 || (busy < p.suspendPatience && step >= 1)) { break; }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
         // ---- traversal burst (k_trace's loop over the wave's own list)
         // The list is dealt out and few rays are still in flight: the burst ends if the shade burst has something to do --
         // at least twice as many paths with all their rays back as rays in flight (so every burst ends with progress, and the
@@ -333,7 +487,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_W
             const bool complete = alive && waiting != 0u && (*(volatile unsigned int *)&ownerFlags[lane] & 0xFFu) == waiting;
             return __popcll(__ballot(complete)) >= 2 * inFlight;
         };
-        while (true) {
+        while (!BLOCK) {
             // hand rays to the idle lanes
             while (listPos < listCount) {
                 const unsigned long long idleMask = __ballot(!active);
@@ -362,6 +516,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_W
                 const unsigned long long leafMask = __ballot(active && ray.pendingLeaf != 0);
                 const unsigned long long innerMask = __ballot(active && ray.pendingLeaf == 0);
                 const bool trianglePhase = __popcll(leafMask) >= kLeafThreshold || innerMask == 0ull;
+#ifdef PATHED_SHADE_PROFILE
+                profSteps++; profLaneSteps += (unsigned long long)__popcll(trianglePhase ? leafMask : innerMask);
+#endif
                 bool done = false;
                 if (trianglePhase) {
                     if (active && ray.pendingLeaf != 0) { done = leafStep<false, STACK, kBlock, SPHERES>(geometry, stack, ray, nullptr); }
@@ -390,18 +547,26 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_W
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
 
+#ifdef PATHED_SHADE_PROFILE
+        profLeft += (unsigned long long)__popcll(__ballot(active));
+        { const unsigned long long now = __builtin_amdgcn_s_memtime(); profBurstCycles += now - profStamp; profStamp = now; }
+#endif
         // ---- shade burst: the paths whose rays have all come back
         bool ready = false;
         float4 h = make_float4(0.f, 0.f, 0.f, intAsFloat(-1));
         if (alive && waiting != 0u) {
-            const unsigned int flags = *(volatile unsigned int *)&ownerFlags[lane];
+            const unsigned int flags = *(volatile unsigned int *)&ownerFlags[self];
             if ((flags & 0xFFu) == waiting) {
                 ready = true;
-                h = hitRows[lane];
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // the hit was written before the count moved
+                h = hitRows[self];
                 if (flags & kWaveOccludedFlag) { path.pend = rgb(0.f); }
                 waiting = 0u;
             }
         }
+#ifdef PATHED_SHADE_PROFILE
+        { const unsigned long long mask = __ballot(ready); if (mask != 0ull) { profShades++; profReady += (unsigned long long)__popcll(mask); } }
+#endif
         bool finished = false;
         Rgb color = rgb(0.f);
         if (ready) {
@@ -449,5 +614,15 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_W
                 }
             }
         }
+#ifdef PATHED_SHADE_PROFILE
+        profShadeCycles += __builtin_amdgcn_s_memtime() - profStamp;
+#endif
     }
+#ifdef PATHED_SHADE_PROFILE
+    if (lane == 0) {
+        const unsigned long long values[12] = { profIterations, profAlive, profSteps, profLaneSteps, profShades, profReady, profPosted, profLeft,
+                                                __builtin_amdgcn_s_memtime() - profStart, profBurstCycles, profShadeCycles, 1ull };
+        for (int i = 0; i < 12; i++) { atomicAdd(&p.stats[kStatShadeProfile + i], values[i]); }
+    }
+#endif
 }

@@ -210,6 +210,8 @@ struct PathedScene {
     bool lastCallWave = false;    // what the last render call ran (PathedStats.path_kernel)
     unsigned long long waveMaxSamples = 48ull << 20;   // calls of fewer camera samples than this take it (waveMode 0)
     int waveStragglers = 24;      // its traversal bursts end once fewer rays than this are in flight
+    bool waveBlock = false;       // the block's waves share one ray ring (k_path_wave<.., BLOCK>; PATHED_WAVE_BLOCK=1)
+    int waveShadeReady = 40;      // ... and a wave shades once this many of its paths have their rays back
     int waveRefill = kRefillThreshold;   // ... and idle lanes draw from the wave's list once fewer than this many are busy
     bool stagedShade = true;  // k_shade_staged (dense, state-sorted stages inside a block) or k_shade (one lane per slot)
     bool lambertianTriangles = false;   // constant-albedo Lambertian surfaces, triangle lights, no spheres, no environment: k_path_small<.., TraitsLambertianTriangles>
@@ -1628,6 +1630,8 @@ int pathed_hip_scene_create_ex(const PathedSceneDesc *desc, const PathedSceneOpt
         return fail(PATHED_E_INVALID, "the wave path kernel serves BVH scenes (more than 64 triangles or intersector 1) of at most 96 materials over the float nodes");
     }
     if (const char *text = getenv("PATHED_WAVE_MAX_SAMPLES")) { scene->waveMaxSamples = strtoull(text, nullptr, 10); }
+    if (const char *text = getenv("PATHED_WAVE_BLOCK")) { scene->waveBlock = atoi(text) != 0; }
+    if (const char *text = getenv("PATHED_WAVE_SHADE_READY")) { const int value = atoi(text); if (value >= 1 && value <= 64) { scene->waveShadeReady = value; } }
     if (const char *text = getenv("PATHED_WAVE_REFILL")) { const int value = atoi(text); if (value >= 1 && value <= 64) { scene->waveRefill = value; } }
     if (const char *text = getenv("PATHED_WAVE_STRAGGLERS")) { const int value = atoi(text); if (value >= 0 && value <= 64) { scene->waveStragglers = value; } }
     scene->stagedShade = shadeKernel == 2;
@@ -2038,6 +2042,12 @@ static int renderPassWave(PathedScene *scene, uint64_t seed, uint32_t begin, uin
         timed = scene->traceEvents.acquire();
         (void)hipEventRecord(scene->traceEvents.start[timed], stream);
     }
+    params.parkMinCardsPerWave = scene->waveShadeReady;   // k_path_wave<BLOCK>: a wave shades once this many of its paths have their rays back
+#if PATHED_EXPERIMENTS
+    // the block's waves sharing one ray ring: measured 13-20 % slower than a list per wave (profiles/r4_ab_wave.log)
+    if (scene->waveBlock && scene->envOnly && scene->device.nSpheres == 0 && !scene->hasContainers) { hipLaunchKernelGGL((k_path_wave<true, 22, TraitsEnvironmentOnly, false, true>), grid, dim3(kBlock), lds, stream, params); }
+    else
+#endif
     if (scene->envOnly && scene->device.nSpheres == 0 && !scene->hasContainers) { hipLaunchKernelGGL((k_path_wave<true, 22, TraitsEnvironmentOnly, false>), grid, dim3(kBlock), lds, stream, params); }
     else if (scene->device.nSpheres == 0) { hipLaunchKernelGGL((k_path_wave<true, 22, TraitsAll, false>), grid, dim3(kBlock), lds, stream, params); }
     else { hipLaunchKernelGGL((k_path_wave<true, 22, TraitsAll, true>), grid, dim3(kBlock), lds, stream, params); }
@@ -2603,6 +2613,15 @@ int pathed_hip_get_stats(PathedScene *scene, PathedStats *out)
             fprintf(stderr, "[pathed] k_path_small %-44s %.2f turns per iteration, %.2f candidates per turn (of 64 lanes)\n", loops[r],
                     device[kStatShadeProfile] ? (double)turns / (double)device[kStatShadeProfile] : 0.0, turns ? (double)candidates / (double)turns : 0.0);
         }
+    }
+    if (getenv("PATHED_WAVE_PROFILE")) {   // k_path_wave (-DPATHED_SHADE_PROFILE builds, tools/wave_profile.py)
+        const unsigned long long *v = device + kStatShadeProfile;
+        const double iterations = v[0] ? (double)v[0] : 1.0, cycles = v[8] ? (double)v[8] : 1.0;
+        fprintf(stderr, "[pathed] k_path_wave: %llu waves, %.0f iterations each, %.1f live paths per iteration\n", v[11], iterations / (double)(v[11] ? v[11] : 1), (double)v[1] / iterations);
+        fprintf(stderr, "[pathed] k_path_wave traversal: %.1f rays posted per iteration, %.1f steps per iteration at %.1f of 64 lanes, %.1f rays left in flight at the end of a burst\n",
+                (double)v[6] / iterations, (double)v[2] / iterations, v[2] ? (double)v[3] / (double)v[2] : 0.0, (double)v[7] / iterations);
+        fprintf(stderr, "[pathed] k_path_wave shade: %.3f of the iterations shade, %.1f paths each\n", (double)v[4] / iterations, v[4] ? (double)v[5] / (double)v[4] : 0.0);
+        fprintf(stderr, "[pathed] k_path_wave wave cycles: traversal bursts %.3f, shade + post + regeneration %.3f of the waves' lifetimes\n", (double)v[9] / cycles, (double)v[10] / cycles);
     }
     if (getenv("PATHED_VOLUME_PROFILE")) {   // the same counters in k_path_volume (-DPATHED_SHADE_PROFILE builds)
         static const char *regions[9] = { "samples", "camera-ray query", "bounce-loop iterations", "segment query (no direct lighting before)",

@@ -53,6 +53,7 @@ def main():
     parser.add_argument("--dragon", type=int, default=9)
     parser.add_argument("--stragglers", default="24")
     parser.add_argument("--refill", default="48")
+    parser.add_argument("--block", default="", help="shade-ready thresholds of the block-ring variant, e.g. 32,40,48 (variants block/<stragglers>/<ready>)")
     parser.add_argument("--child", default=None)
     args = parser.parse_args()
     if args.child:
@@ -63,6 +64,10 @@ def main():
     for value in args.stragglers.split(","):
         for refill in args.refill.split(","):
             variants["wave/%s/%s" % (value, refill)] = {"PATHED_SHADE_KERNEL": "wave", "PATHED_WAVE_STRAGGLERS": value, "PATHED_WAVE_REFILL": refill}
+    for ready in [v for v in args.block.split(",") if v]:
+        for value in args.stragglers.split(","):
+            variants["block/%s/%s" % (value, ready)] = {"PATHED_SHADE_KERNEL": "wave", "PATHED_WAVE_BLOCK": "1", "PATHED_WAVE_STRAGGLERS": value,
+                                                        "PATHED_WAVE_SHADE_READY": ready}
     for name in args.scenes.split(","):
         rates = {k: [] for k in variants}
         digests = {k: set() for k in variants}
