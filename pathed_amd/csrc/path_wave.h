@@ -163,11 +163,12 @@ static const unsigned int kWaveShadowTag = 0x100u;    // list entry / lane targe
 static const unsigned int kWaveOccludedFlag = 0x100u; // ownerFlags: the low byte counts the owner's finished rays
 
 // dynamic LDS of a block: [STACK + 1][kBlock] stack rows | per wave 128 x 2 float4 of ray list | kBlock float4 hits |
-// kBlock flag words | the ring's kWaveRing + 4 words | (LDS_MATERIALS) the material table
-__host__ __device__ inline size_t pathWaveLdsBytes(int stackRows, int nLdsMaterials)
+// kBlock flag words | (BLOCK) the ring's kWaveRing + 4 words | (LDS_MATERIALS) the material table
+// (22 stack rows, no ring: 44 KiB + the material table, 9 KiB at most: three blocks per CU)
+__host__ __device__ inline size_t pathWaveLdsBytes(int stackRows, int nLdsMaterials, bool blockRing)
 {
     return (size_t)(stackRows + 1) * kBlock * sizeof(int) + (size_t)kWavesPerBlock * kWaveListRays * 2 * sizeof(float4)
-        + (size_t)kBlock * sizeof(float4) + (size_t)kBlock * sizeof(unsigned int) + (size_t)(kWaveRing + 4) * sizeof(unsigned int)
+        + (size_t)kBlock * sizeof(float4) + (size_t)kBlock * sizeof(unsigned int) + (blockRing ? (size_t)(kWaveRing + 4) * sizeof(unsigned int) : 0)
         + (size_t)nLdsMaterials * sizeof(DMaterial);
 }
 
@@ -205,7 +206,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_W
     if (LDS_MATERIALS) {
         const int words = p.scene.nMaterials * (int)(sizeof(DMaterial) / 4);
         const int *source = reinterpret_cast<const int *>(p.scene.materials);
-        int *target = reinterpret_cast<int *>(ldsRaw + ((STACK + 1) * kBlock) / 4 + kWavesPerBlock * 2 * kWaveListRays + kBlock + kBlock / 4 + (kWaveRing + 4) / 4);
+        int *target = reinterpret_cast<int *>(ldsRaw + ((STACK + 1) * kBlock) / 4 + kWavesPerBlock * 2 * kWaveListRays + kBlock + kBlock / 4 + (BLOCK ? (kWaveRing + 4) / 4 : 0));
         for (int i = threadIdx.x; i < words; i += kBlock) { target[i] = source[i]; }
         __syncthreads();
         materials.table = reinterpret_cast<const DMaterial *>(target);

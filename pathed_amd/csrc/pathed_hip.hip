@@ -1995,7 +1995,7 @@ static int renderPassWave(PathedScene *scene, uint64_t seed, uint32_t begin, uin
     }
 
     const int stackRows = 22;
-    const size_t lds = pathWaveLdsBytes(stackRows, scene->device.nMaterials);
+    const size_t lds = pathWaveLdsBytes(stackRows, scene->device.nMaterials, PATHED_EXPERIMENTS && scene->waveBlock);
     unsigned long long blocks = (unsigned long long)scene->computeUnits * PATHED_WAVE_WAVES;
     const unsigned long long blocksNeeded = (nUnits64 + (unsigned long long)kBlock - 1) / kBlock;
     if (blocks > blocksNeeded) { blocks = blocksNeeded; }
