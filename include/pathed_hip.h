@@ -281,7 +281,8 @@ typedef struct PathedSceneOptions {
                                    lists the trace kernel writes (BVH scenes only); 5 k_path_wave (BVH scenes of <= 96 materials:
                                    paths in registers, the wave's rays shared through LDS, no path state in HBM) for every call.
                                    0 on a BVH scene: k_path_wave for calls of fewer than 48 Mi camera samples, whose rate hardly
-                                   depends on the call's size, the wavefront (1) for longer ones; images are identical */
+                                   depends on the call's size, the wavefront (1) for longer ones (trees of up to 36 KB, which the
+                                   wavefront would copy into LDS: k_path_wave at every length); images are identical */
     int32_t stage_slots;        /* slots per block of the staged kernel: 512 or 1024 (0 = automatic)           */
     int32_t unit_order;         /* order work units are handed out in (scheduling only, results identical):
                                  * 0 automatic = 1; 1 chunk stripes, rows; 2 chunk stripes, 32 x 8 tiles; 3 pixel tiles */

@@ -216,6 +216,7 @@ struct PathedScene {
     bool stagedShade = true;  // k_shade_staged (dense, state-sorted stages inside a block) or k_shade (one lane per slot)
     bool lambertianTriangles = false;   // constant-albedo Lambertian surfaces, triangle lights, no spheres, no environment: k_path_small<.., TraitsLambertianTriangles>
     bool lambertianPlasticSpheres = false;   // the Veach scene's set (shading.h)
+    bool triangleLit = false;                // any BSDF, constant albedo, triangle lights only, no spheres, no environment
     bool lambertianGlassContainer = false;   // the reference's volume scene's set
     int nodeFormat = 0;                      // what k_trace walks (trace.h): 0 the 128-byte float nodes, 1 nodeQ, 2 node8
     bool envOnly = false;     // the one light is the environment and no material emits: k_shade<.., ENV_ONLY> (kernels.h)
@@ -1527,6 +1528,12 @@ int pathed_hip_scene_create_ex(const PathedSceneDesc *desc, const PathedSceneOpt
         bool triangleLights = false;
         for (const DLight &light : lights) { triangleLights = triangleLights || light.kind == 0; }
         scene->lambertianPlasticSpheres = lambertianPlastic && desc->env == nullptr && !triangleLights && narrow;
+        bool constantAlbedo = true, noContainer = true;
+        for (uint32_t i = 0; i < desc->n_materials; i++) {
+            constantAlbedo = constantAlbedo && desc->materials[i].albedo_type == PATHED_ALBEDO_CONSTANT;
+            noContainer = noContainer && desc->materials[i].type != PATHED_MAT_PASSTHROUGH;
+        }
+        scene->triangleLit = constantAlbedo && noContainer && desc->env == nullptr && desc->n_spheres == 0 && narrow;
         bool glassContainer = desc->env == nullptr;
         for (uint32_t i = 0; i < desc->n_materials; i++) {
             const int type = desc->materials[i].type;
@@ -1851,6 +1858,8 @@ static int renderPassFused(PathedScene *scene, uint64_t seed, uint32_t begin, ui
         } else if (scene->lambertianPlasticSpheres) {
             if (scene->countMode) { hipLaunchKernelGGL((k_path_small<true, true, TraitsLambertianPlasticSpheres, false, true>), grid, block, lds, stream, params, scene->smallItems); }
             else { hipLaunchKernelGGL((k_path_small<true, false, TraitsLambertianPlasticSpheres, false, true>), grid, block, lds, stream, params, scene->smallItems); }
+        } else if (scene->triangleLit && !scene->countMode) {
+            hipLaunchKernelGGL((k_path_small<true, false, TraitsTriangleLit, false, true>), grid, block, lds, stream, params, scene->smallItems);
         } else {
             if (scene->countMode) { hipLaunchKernelGGL((k_path_small<true, true, TraitsAll, false, true>), grid, block, lds, stream, params, scene->smallItems); }
             else { hipLaunchKernelGGL((k_path_small<true, false, TraitsAll, false, true>), grid, block, lds, stream, params, scene->smallItems); }
@@ -2049,6 +2058,7 @@ static int renderPassWave(PathedScene *scene, uint64_t seed, uint32_t begin, uin
     else
 #endif
     if (scene->envOnly && scene->device.nSpheres == 0 && !scene->hasContainers) { hipLaunchKernelGGL((k_path_wave<true, 22, TraitsEnvironmentOnly, false>), grid, dim3(kBlock), lds, stream, params); }
+    else if (scene->triangleLit) { hipLaunchKernelGGL((k_path_wave<true, 22, TraitsTriangleLit, false>), grid, dim3(kBlock), lds, stream, params); }
     else if (scene->device.nSpheres == 0) { hipLaunchKernelGGL((k_path_wave<true, 22, TraitsAll, false>), grid, dim3(kBlock), lds, stream, params); }
     else { hipLaunchKernelGGL((k_path_wave<true, 22, TraitsAll, true>), grid, dim3(kBlock), lds, stream, params); }
     if (timed >= 0) { (void)hipEventRecord(scene->traceEvents.stop[timed], stream); }
@@ -2307,7 +2317,9 @@ int pathed_hip_render_device(PathedScene *scene, uint64_t seed,
     // BVH scenes: short calls on the wave path kernel, long ones on the wavefront (the counting instantiations are the wavefront's)
     const unsigned long long callSamples = (unsigned long long)scene->width * (unsigned long long)scene->height * (unsigned long long)spp_count;
     const bool wavePath = scene->waveAvailable && !usesVolumeKernel(scene) && !scene->countMode
-        && (scene->waveMode == 2 || (scene->waveMode == 0 && callSamples < scene->waveMaxSamples));
+        && (scene->waveMode == 2 || (scene->waveMode == 0 && (callSamples < scene->waveMaxSamples || scene->sceneInLds)));
+    // (trees small enough for the trace kernel's LDS copy -- the Cornell box with its two meshes: k_path_wave, whose node reads
+    // hit L1 / L2, is level with the wavefront or 11 % ahead at every length, profiles/r4_ab_wave.log)
     scene->lastCallWave = wavePath;
     uint32_t done = 0;
     while (done < spp_count) {

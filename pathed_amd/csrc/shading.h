@@ -36,6 +36,10 @@ typedef SceneTraits<1u << 0, false, true, false, false, true> TraitsLambertianTr
 typedef SceneTraits<(1u << 0) | (1u << 3), false, false, true, false, true> TraitsLambertianPlasticSpheres;
 // the reference's VolumePathTracer scene (scenes/cornell-medium.json): Lambertian walls, a glass sphere, a passthrough container, triangle lights
 typedef SceneTraits<(1u << 0) | (1u << 4) | (1u << 6), false, true, true, false> TraitsLambertianGlassContainer;
+// Cornell-box variants with any BSDF (Oren-Nayar, microfacet, plastic, glass, mirror): triangle lights only, no spheres, no
+// environment, constant albedo -- what the generic instantiation carries beyond that (environment sampling and lookup, sphere
+// lights, checkerboard / texture albedo) is registers the fused kernel does not have (103 spilled dwords)
+typedef SceneTraits<0x3Fu, false, true, false, false, true> TraitsTriangleLit;
 // mesh scenes lit by the environment alone (no emissive material, no sphere): any material, any albedo
 typedef SceneTraits<0x3Fu, true, false, false, true> TraitsEnvironmentOnly;
 

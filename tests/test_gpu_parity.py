@@ -375,6 +375,7 @@ def test_unit_orders_are_bit_identical(libs, scene_path, width, height, spp):
     ("scenes/mis-pbrt.json", 96, 8, 6),             # sphere lights, plastic plates: black-bodied emitters end samples
     ("scenes/teapot.json", 96, 8, 10),              # environment light, glass, checkerboard
     ("scenes/cornell-oren-nayar.json", 64, 6, 3),   # Oren-Nayar + microfacet, short bounce window
+    ("scenes/cornell-ggx.json", 64, 6, 5),          # GGX microfacet: the any-BSDF, triangle-lit instantiation of the fused kernel
     ("test_scenes/environment_map_sampling.json", 64, 8, 4),
 ])
 def test_shade_kernels_are_bit_identical(libs, scene_path, size, spp, last_bounce):

@@ -55,7 +55,8 @@ def test_vgpr_budgets_of_the_hot_kernels(tmp_path):
     # ... and with the parallelogram phase 1 (small_items.h), which is what the headline runs on: the path state that waits
     # in LDS across the pass (24 KiB per block) keeps the spills of the Cornell instantiation at a handful
     quads = {k: v for k, v in usage.items() if re.search(r"k_path_smallILb1ELb0E.*ELb0ELb1EEEv", k)}
-    assert len(quads) == 3 and all(v["VGPRs"] <= 128 and v["Occupancy"] == 4 for v in quads.values()), quads
+    # (Cornell-like, Veach-like, any BSDF under triangle lights, generic)
+    assert len(quads) == 4 and all(v["VGPRs"] <= 128 and v["Occupancy"] == 4 for v in quads.values()), quads
     narrow_quads = [v for k, v in quads.items() if "SceneTraitsILj1E" in k]
     assert len(narrow_quads) == 1 and narrow_quads[0]["ScratchSize"] <= 160, quads
     # static LDS: the stash + the lists of the shared phase 2 (kernels.h smallResolveShared); with the material table of a

@@ -19,6 +19,9 @@ SCENES = {
     "C4s": ("scenes/teapot.json", 256, 256),
     "C5": ("scenes/dragon-standin.json", 1920, 1080),
     "C5s": ("scenes/dragon-standin.json", 320, 180),
+    "GL": ("scenes/cornell-glossy.json", 1024, 1024),
+    "GLASS": ("scenes/cornell-glass.json", 1024, 1024),
+    "BUNNY": ("scenes/cornell-bunny.json", 1024, 1024),
     "C4m": ("scenes/teapot.json", 512, 512),
     "C5m": ("scenes/dragon-standin.json", 960, 540),
 }
