@@ -100,3 +100,30 @@ def test_item_candidates_on_random_scenes_with_quads(seed):
     image = gpu.render(7, 0, 16, 0, 6)
     assert np.array_equal(HipScene(desc, device=0, generic_kernels=1).render(7, 0, 16, 0, 6), image)
     assert np.array_equal(HipScene(desc, device=0, intersector="bvh").render(7, 0, 16, 0, 6), image)
+
+
+@pytest.mark.parametrize("sheets,gap", [(31, 0.02), (12, 0.05), (4, 0.1)])
+def test_stacked_sheets_fill_and_overflow_the_shared_resolve(sheets, gap):
+    """Every camera ray crosses a stack of parallel quads: with 31 sheets each lane holds dozens of phase-2 candidates, so the
+    wave's list of left-overs (kernels.h smallResolveShared, 128 items) overflows and the owners resolve in place; with 12 it
+    takes two helping turns; with 4 one.  Same image as the generic kernels (lone triangles, in-place resolve) and the tree walk."""
+    from pathed_amd import _capi
+    from pathed_amd.integrator import HipScene
+    from scene_builder import BuiltScene
+    built = BuiltScene(48, 48, (0.1, 0.2, 4.0), (0, 0, 0), fov_degrees=40.0)
+    light = built.material(_capi.MAT_LAMBERTIAN, diffuse=(0, 0, 0), emit=(8.0, 8.0, 8.0))
+    for k in range(sheets):
+        z = -gap * k
+        shade = 0.2 + 0.6 * ((k * 7) % 10) / 10.0
+        sheet = built.material(_capi.MAT_LAMBERTIAN, diffuse=(shade, 0.5, 1.0 - shade))
+        built.quad([(-1.0, -1.0, z), (1.0, -1.0, z), (1.0, 1.0, z), (-1.0, 1.0, z)], sheet)
+    built.quad([(-3.0, -3.0, 6.0), (-3.0, 3.0, 6.0), (3.0, 3.0, 6.0), (3.0, -3.0, 6.0)], light)   # behind the camera, facing the stack
+    desc = built.finish()
+    assert desc.contents.n_triangles == 2 * sheets + 2 <= 64
+    gpu = HipScene(desc, device=0)
+    assert gpu.stats()["scene_in_lds"] == 2 and gpu.stats()["path_kernel"] == 3
+    image = gpu.render(11, 0, 24, 0, 5)
+    assert image.any()
+    assert np.array_equal(HipScene(desc, device=0, generic_kernels=1).render(11, 0, 24, 0, 5), image)
+    assert np.array_equal(HipScene(desc, device=0, intersector="bvh", shade_kernel="per-slot").render(11, 0, 24, 0, 5), image)
+    assert np.array_equal(HipScene(desc, device=0, intersector="bvh", shade_kernel="wave").render(11, 0, 24, 0, 5), image)
