@@ -880,17 +880,20 @@ __device__ __forceinline__ void smallCandidatesItems(const f2 *records, int nQua
                                                      unsigned int *lowA, unsigned int *highA, unsigned int *lowB, unsigned int *highB,
                                                      float tnearLow, float tfarHighB)
 {
-    unsigned int aLow = 0, aHigh = 0, bLow = 0, bHigh = 0;
+    // candidate bits of ray A / ray B, appended at the low end of a 64-bit word (two registers: v_alignbit_b32 + v_lshl_or_b32
+    // per append; as one 64-bit integer the compiler spends four more instructions on the upper half of the "or"):
+    // after the last item triangle 0 is bit nTris - 1
+    unsigned int loA = 0u, hiA = 0u, loB = 0u, hiB = 0u;
     const f2 ax = splat2(directionA.x), ay = splat2(directionA.y), az = splat2(directionA.z);
     const f2 bx = splat2(directionB.x), by = splat2(directionB.y), bz = splat2(directionB.z);
     const f2 ox = splat2(origin.x), oy = splat2(origin.y), oz = splat2(origin.z);
     const f2 nearLow = splat2(-tnearLow), farHighB = splat2(fminf(tfarHighB, 1e30f));
     const f2 kappaLength = splat2(kappaT);
-    int done = 0;   // item-order triangles whose bits are in
-    auto append = [&](unsigned int bitsA, unsigned int bitsB, int count) {
-        if (done < 32) { aLow = (aLow << count) | bitsA; bLow = (bLow << count) | bitsB; }
-        else { aHigh = (aHigh << count) | bitsA; bHigh = (bHigh << count) | bitsB; }
-        done += count;
+    auto append = [&](unsigned int bitsA, unsigned int bitsB, int count) {   // count: 2 or 4
+        hiA = __builtin_amdgcn_alignbit(hiA, loA, 32 - count);
+        hiB = __builtin_amdgcn_alignbit(hiB, loB, 32 - count);
+        loA = (loA << count) | bitsA;
+        loB = (loB << count) | bitsB;
     };
 
     // ---- parallelograms, two per packed instruction
@@ -943,8 +946,12 @@ __device__ __forceinline__ void smallCandidatesItems(const f2 *records, int nQua
         __builtin_amdgcn_sched_barrier(0);   // one ray's temporaries at a time: interleaved, the two chains spilled 39 dwords of path state
         unsigned int bitsB = SHADOW ? oneRay(bx, by, bz, true) : 0u;
         __builtin_amdgcn_sched_barrier(0);
-        if (2 * pair + 1 < nQuads) { append(bitsA, bitsB, 4); }
-        else { append(bitsA >> 2, bitsB >> 2, 2); }   // an odd count: the last pair's second half is padding
+        append(bitsA, bitsB, 4);
+    }
+    unsigned long long accA, accB;
+    if (QUADS && (nQuads & 1)) {   // an odd count: the last pair's second half is padding
+        accA = (((unsigned long long)hiA << 32) | loA) >> 2; accB = (((unsigned long long)hiB << 32) | loB) >> 2;
+        loA = (unsigned int)accA; hiA = (unsigned int)(accA >> 32); loB = (unsigned int)accB; hiB = (unsigned int)(accB >> 32);
     }
 
     // ---- triangles without a partner, two per packed instruction: smallCandidatesPair's test, ray by ray
@@ -980,15 +987,16 @@ __device__ __forceinline__ void smallCandidatesItems(const f2 *records, int nQua
         };
         const unsigned int bitsA = oneRay(ax, ay, az, false);
         const unsigned int bitsB = SHADOW ? oneRay(bx, by, bz, true) : 0u;
-        if (2 * pair + 1 < nLone) { append(bitsA, bitsB, 2); }
-        else { append(bitsA >> 1, bitsB >> 1, 1); }
+        append(bitsA, bitsB, 2);
     }
+    accA = ((unsigned long long)hiA << 32) | loA; accB = ((unsigned long long)hiB << 32) | loB;
+    if (LONE && (nLone & 1)) { accA >>= 1; accB >>= 1; }
 
-    // left-align: the last bit shifted into a word sits at bit 0
-    const int lowBits = nTris < 32 ? nTris : 32, highBits = nTris - lowBits;
-    if (lowBits > 0 && lowBits < 32) { aLow <<= 32 - lowBits; bLow <<= 32 - lowBits; }
-    if (highBits > 0 && highBits < 32) { aHigh <<= 32 - highBits; bHigh <<= 32 - highBits; }
-    *lowA = aLow; *highA = aHigh; *lowB = bLow; *highB = bHigh;
+    // left-align: triangle k is bit 31 - (k & 31) of word k >> 5
+    const int shift = 64 - nTris;   // 1 <= nTris <= 64
+    accA <<= shift;
+    accB <<= shift;
+    *lowA = (unsigned int)(accA >> 32); *highA = (unsigned int)accA; *lowB = (unsigned int)(accB >> 32); *highB = (unsigned int)accB;
 }
 
 // Phase 2 (a wave-level loop: call it from wave-uniform control flow, lanes without a ray pass empty masks):
