@@ -868,6 +868,17 @@ __device__ __forceinline__ void smallCandidatesPair(const f2 *pairRecords, int n
     *lowA = aLow; *highA = aHigh; *lowB = bLow; *highB = bHigh;
 }
 
+// word = 2 word + bit in ONE instruction: v_addc_co_u32 with a lane mask as the carry-in (a select, a shift and an or
+// otherwise).  The masks are the compare instructions' own results (ballots of single comparisons fold into the compare;
+// combining them is scalar work), the carry-out is dropped.
+__device__ __forceinline__ unsigned int shiftInBit(unsigned int word, unsigned long long laneMask)
+{
+    unsigned int result;
+    unsigned long long carryOut;
+    asm("v_addc_co_u32_e64 %0, %1, %2, %2, %3" : "=v"(result), "=s"(carryOut) : "v"(word), "s"(laneMask));
+    return result;
+}
+
 // Phase 1 over the ITEM records of the fused kernel (small_items.h): first the parallelograms -- one Moeller-Trumbore
 // evaluation for the two triangles of a quad, every bound with the tolerance derived there -- then the triangles that found
 // no partner, two per packed instruction with the exact test above.  Bits are shifted in in item order (triangle k of a word
@@ -880,21 +891,14 @@ __device__ __forceinline__ void smallCandidatesItems(const f2 *records, int nQua
                                                      unsigned int *lowA, unsigned int *highA, unsigned int *lowB, unsigned int *highB,
                                                      float tnearLow, float tfarHighB)
 {
-    // candidate bits of ray A / ray B, appended at the low end of a 64-bit word (two registers: v_alignbit_b32 + v_lshl_or_b32
-    // per append; as one 64-bit integer the compiler spends four more instructions on the upper half of the "or"):
-    // after the last item triangle 0 is bit nTris - 1
+    // candidate bits of ray A / ray B, appended at the low end of a 64-bit word (two registers: one v_alignbit_b32 for the
+    // upper half, then one v_addc per bit -- shiftInBit -- for the lower): after the last item triangle 0 is bit nTris - 1
     unsigned int loA = 0u, hiA = 0u, loB = 0u, hiB = 0u;
     const f2 ax = splat2(directionA.x), ay = splat2(directionA.y), az = splat2(directionA.z);
     const f2 bx = splat2(directionB.x), by = splat2(directionB.y), bz = splat2(directionB.z);
     const f2 ox = splat2(origin.x), oy = splat2(origin.y), oz = splat2(origin.z);
     const f2 nearLow = splat2(-tnearLow), farHighB = splat2(fminf(tfarHighB, 1e30f));
     const f2 kappaLength = splat2(kappaT);
-    auto append = [&](unsigned int bitsA, unsigned int bitsB, int count) {   // count: 2 or 4
-        hiA = __builtin_amdgcn_alignbit(hiA, loA, 32 - count);
-        hiB = __builtin_amdgcn_alignbit(hiB, loB, 32 - count);
-        loA = (loA << count) | bitsA;
-        loB = (loB << count) | bitsB;
-    };
 
     // ---- parallelograms, two per packed instruction
     const int nQuadPairs = QUADS ? (nQuads + 1) >> 1 : 0;
@@ -903,7 +907,7 @@ __device__ __forceinline__ void smallCandidatesItems(const f2 *records, int nQua
         const f2 c0x = record[0], c0y = record[1], c0z = record[2];
         const f2 a1x = record[3], a1y = record[4], a1z = record[5];
         const f2 a2x = record[6], a2y = record[7], a2z = record[8];
-        const f2 k2UV = record[9], k0UV = record[10], k2T = record[11], k0T = record[12], cD = record[13], kappaUV = record[15];
+        const f2 k2UV = record[9], amaxSquared = record[10], k2T = record[11], cD = record[13], kappaUV = record[15];
         const f2 tx = ox - c0x, ty = oy - c0y, tz = oz - c0z;
         const f2 qx = fma2(ty, a1z, -(tz * a1y));
         const f2 qy = fma2(tz, a1x, -(tx * a1z));
@@ -911,8 +915,9 @@ __device__ __forceinline__ void smallCandidatesItems(const f2 *records, int nQua
         const f2 tScaled = fma2(a2x, qx, fma2(a2y, qy, a2z * qz));
         // the part of the tolerances that grows with the distance of the origin (small_items.h): K2 |o - c0|^2 + K0
         const f2 tt = fma2(tx, tx, fma2(ty, ty, tz * tz));
-        const f2 originUV = fma2(k2UV, tt, k0UV), originT = fma2(k2T, tt, k0T);
-        auto oneRay = [&](f2 dx, f2 dy, f2 dz, bool far) -> unsigned int {
+        const f2 reachSquared = tt + amaxSquared;   // bounds r^2 / 2 (small_items.h)
+        const f2 originUV = k2UV * reachSquared, originT = k2T * reachSquared;
+        auto oneRay = [&](f2 dx, f2 dy, f2 dz, bool far, unsigned int &lo, unsigned int &hi) {
             const f2 px = fma2(dy, a2z, -(dz * a2y));
             const f2 py = fma2(dz, a2x, -(dx * a2z));
             const f2 pz = fma2(dx, a2y, -(dy * a2x));
@@ -928,25 +933,29 @@ __device__ __forceinline__ void smallCandidatesItems(const f2 *records, int nQua
             const f2 reach = half + tolUV;
             const f2 tolT = fma2(kappaLength, dd, originT);
             const f2 nearBound = fma2(nearLow, det, tScaled) * det;     // (t - tnearLow) det^2
-            // "x > bound" rejects: -0, underflow and NaN all keep the candidate
-            bool rejectX = (fmaxf(fabsf(uCentred.x), fabsf(vCentred.x)) > reach.x) || (nearBound.x < -tolT.x);
-            bool rejectY = (fmaxf(fabsf(uCentred.y), fabsf(vCentred.y)) > reach.y) || (nearBound.y < -tolT.y);
+            // "x > bound" rejects: -0, underflow and NaN all keep the candidate.  Lane masks (scalar registers) from here on
+            #define PATHED_LANES(condition) __builtin_amdgcn_ballot_w64(condition)
+            unsigned long long rejectX = PATHED_LANES(fmaxf(fabsf(uCentred.x), fabsf(vCentred.x)) > reach.x) | PATHED_LANES(nearBound.x < -tolT.x);
+            unsigned long long rejectY = PATHED_LANES(fmaxf(fabsf(uCentred.y), fabsf(vCentred.y)) > reach.y) | PATHED_LANES(nearBound.y < -tolT.y);
             if (far) {
                 const f2 farBound = fma2(farHighB, det, -tScaled) * det;   // (tfarHigh - t) det^2
                 const f2 tolFar = fma2(farHighB, fma2(splat2(kSmallKappaFar), dd, cD), tolT);
-                rejectX = rejectX || (farBound.x < -tolFar.x);
-                rejectY = rejectY || (farBound.y < -tolFar.y);
+                rejectX |= PATHED_LANES(farBound.x < -tolFar.x);
+                rejectY |= PATHED_LANES(farBound.y < -tolFar.y);
             }
-            const bool keepX = !rejectX, keepY = !rejectY;   // (a det too small to trust its sign: the tolerances cover it, small_items.h)
-            const float twiceX = 2.f * tolUV.x, twiceY = 2.f * tolUV.y;
-            return ((keepX && !(diagonal.x < -twiceX)) ? 8u : 0u) | ((keepX && !(diagonal.x > twiceX)) ? 4u : 0u)
-                 | ((keepY && !(diagonal.y < -twiceY)) ? 2u : 0u) | ((keepY && !(diagonal.y > twiceY)) ? 1u : 0u);
+            // (a det too small to trust its sign: the tolerances cover it, small_items.h)
+            const f2 twice = tolUV + tolUV;
+            const float twiceX = twice.x, twiceY = twice.y;
+            hi = __builtin_amdgcn_alignbit(hi, lo, 28);
+            lo = shiftInBit(lo, ~(rejectX | PATHED_LANES(diagonal.x < -twiceX)));   // first quad: triangle A, then B
+            lo = shiftInBit(lo, ~(rejectX | PATHED_LANES(diagonal.x > twiceX)));
+            lo = shiftInBit(lo, ~(rejectY | PATHED_LANES(diagonal.y < -twiceY)));   // second quad
+            lo = shiftInBit(lo, ~(rejectY | PATHED_LANES(diagonal.y > twiceY)));
         };
-        unsigned int bitsA = oneRay(ax, ay, az, false);
+        oneRay(ax, ay, az, false, loA, hiA);
         __builtin_amdgcn_sched_barrier(0);   // one ray's temporaries at a time: interleaved, the two chains spilled 39 dwords of path state
-        unsigned int bitsB = SHADOW ? oneRay(bx, by, bz, true) : 0u;
+        if (SHADOW) { oneRay(bx, by, bz, true, loB, hiB); }
         __builtin_amdgcn_sched_barrier(0);
-        append(bitsA, bitsB, 4);
     }
     unsigned long long accA, accB;
     if (QUADS && (nQuads & 1)) {   // an odd count: the last pair's second half is padding
@@ -968,7 +977,7 @@ __device__ __forceinline__ void smallCandidatesItems(const f2 *records, int nQua
         const f2 qy = fma2(tz, e1x, -(tx * e1z));
         const f2 qz = fma2(tx, e1y, -(ty * e1x));
         const f2 tScaled = fma2(e2x, qx, fma2(e2y, qy, e2z * qz));
-        auto oneRay = [&](f2 dx, f2 dy, f2 dz, bool far) -> unsigned int {
+        auto oneRay = [&](f2 dx, f2 dy, f2 dz, bool far, unsigned int &lo, unsigned int &hi) {
             const f2 px = fma2(dy, e2z, -(dz * e2y));
             const f2 py = fma2(dz, e2x, -(dx * e2z));
             const f2 pz = fma2(dx, e2y, -(dy * e2x));
@@ -983,11 +992,13 @@ __device__ __forceinline__ void smallCandidatesItems(const f2 *records, int nQua
                 worstA = fminf(worstA, g.x);
                 worstB = fminf(worstB, g.y);
             }
-            return ((worstA < 0.f) ? 0u : 2u) | ((worstB < 0.f) ? 0u : 1u);
+            hi = __builtin_amdgcn_alignbit(hi, lo, 30);
+            lo = shiftInBit(lo, ~PATHED_LANES(worstA < 0.f));
+            lo = shiftInBit(lo, ~PATHED_LANES(worstB < 0.f));
+            #undef PATHED_LANES
         };
-        const unsigned int bitsA = oneRay(ax, ay, az, false);
-        const unsigned int bitsB = SHADOW ? oneRay(bx, by, bz, true) : 0u;
-        append(bitsA, bitsB, 2);
+        oneRay(ax, ay, az, false, loA, hiA);
+        if (SHADOW) { oneRay(bx, by, bz, true, loB, hiB); }
     }
     accA = ((unsigned long long)hiA << 32) | loA; accB = ((unsigned long long)hiB << 32) | loB;
     if (LONE && (nLone & 1)) { accA >>= 1; accB >>= 1; }

@@ -20,7 +20,7 @@
 // The errors scale with the distance of the ORIGIN, not with the scene: a ray leaving a quad sees that quad (t = 0, to be
 // told from t >= tnear / 2) with the error of a nearby origin, however far away the camera is.  A bound "X sign(det) >= -E" is
 // tested as X det >= -E |det| with E |det| <= kappa det^2 + E^2 / (4 kappa) and r^2 <= 2 (|o - c0|^2 + amax^2), so the kernel
-// compares against   tol = kappa det^2 + K2 |o - c0|^2 + K0,   K2 = (E / r)^2 / (2 kappa),  K0 = K2 amax^2,
+// compares against   tol = kappa det^2 + K2 (|o - c0|^2 + amax^2),   K2 = (E / r)^2 / (2 kappa),
 // kappa = 1e-5 for the barycentric bounds (a relative slack of 1e-5), kappa_t = tnear / 16 for the t bounds (an absolute
 // slack in t, well inside the tnear / 2 by which the interval is widened anyway).  Where |det| <= E_det the computed sign of
 // det cannot be trusted; every bound is then at most Xmax E_det in size, which the K terms include: nothing is rejected there.  The far bound's error grows with the ray's own tfar:
@@ -35,7 +35,7 @@
 
 namespace pathed {
 
-static const int kSmallQuadWords = 16;        // float2 per packed PAIR of parallelograms: c0.xyz, a1.xyz, a2.xyz, K2uv, K0uv, K2t, K0t, cD, Edet, kappaUV
+static const int kSmallQuadWords = 16;        // float2 per packed PAIR of parallelograms: c0.xyz, a1.xyz, a2.xyz, K2uv, amax^2, K2t, -, cD, Edet, kappaUV
 static const int kSmallLoneWords = 9;         // float2 per packed pair of lone triangles: v0.xyz, e1.xyz, e2.xyz (kSmallPairWords)
 static const int kSmallItemFloats = 2 * 9 * 32;   // the kernarg array of SmallTris, in floats
 static const float kSmallKappa = 1e-5f;       // relative slack of the barycentric bounds
@@ -214,9 +214,8 @@ inline SmallItemsLayout buildSmallItems(const float *leafTris, int nTris, const 
             record[2 * (6 + x) + half] = (float)quad.a2[x];
         }
         record[2 * 9 + half] = (float)std::max(k2UV, 1e-37);
-        record[2 * 10 + half] = (float)std::max(k2UV * amax * amax, 1e-37);
+        record[2 * 10 + half] = (float)std::max(amax * amax * 1.000001, 1e-37);   // K0 = K2 amax^2: the kernel multiplies K2 by (|o - c0|^2 + amax^2)
         record[2 * 11 + half] = (float)std::max(k2T, 1e-37);
-        record[2 * 12 + half] = (float)std::max(k2T * amax * amax, 1e-37);
         record[2 * 13 + half] = (float)std::max(cD, 1e-37);
         record[2 * 14 + half] = (float)std::max(eDet, 1e-37);
         record[2 * 15 + half] = (float)(kappa + 1.0001 * quad.excess);   // relative slack of the box test: kappa + how far the quad sticks out
