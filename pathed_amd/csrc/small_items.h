@@ -5,8 +5,8 @@
 // and floor are quads, `"type": "quad"` models are quads (reference src/quad.cpp:27-151, src/obj_parser.cpp's (0,1,2),(0,2,3)
 // split).  Two triangles that share a diagonal and form a parallelogram are ONE Moeller-Trumbore evaluation in phase 1: the
 // parallelogram c0 + alpha a1 + beta a2, alpha, beta in [0, 1], holds both (triangle A: beta <= alpha, triangle B: alpha <=
-// beta), so u det, v det, det and t det are computed once for the two of them -- half the arithmetic of the pass, which is
-// half of k_path_small's instructions.  Phase 1 only has to be CONSERVATIVE (phase 2, trace.h: intersectTriangle +
+// beta), so u det, v det, det and t det are computed once for the two of them -- half the arithmetic of the pass, which is a
+// third of k_path_small's instructions.  Phase 1 only has to be CONSERVATIVE (phase 2, trace.h: intersectTriangle +
 // testLeafTriangle, decides): but here its quantities are no longer the bits phase 2 computes for the triangle (another
 // origin, other edges), so every bound carries a tolerance that covers both evaluations' rounding and the distance delta
 // between the triangles' corners (as the intersector sees them: v0, v0 + e1, v0 + e2) and the parallelogram's.
