@@ -209,6 +209,9 @@ struct RenderParams {
     uint32_t sppBegin, sppEnd;
     int startBounce, lastBounce;
     int smallQuads;           // k_path_small: parallelograms among the phase-1 records (small_items.h), item-order triangles 2 q, 2 q + 1
+    // k_path_small<QUADS>: the scene's spheres, two per packed record (centre x, y, z, radius^2; the odd one out paired with a
+    // sphere of radius -1 that no ray touches): phase 1 of the sphere queries (smallSphereCandidates)
+    float spherePairs[8][4][2];   // [pair][component][half], kBruteForceMaxSpheres / 2 pairs
     float smallKappaT;        // ... and the absolute slack of their t bounds per det^2
     const float *mfmaTable;   // k_path_small<.., MFMA>: the A-side rows of the matrix-pipe phase 1 (mfma_candidates.h), kMfmaTableFloats
     MfmaFrame mfmaFrame;
@@ -1029,6 +1032,44 @@ __device__ __forceinline__ void smallResolve(const TraceGeometry &geometry, Lane
     }
 }
 
+// Phase 1 of the SPHERE queries of k_path_small<QUADS> (scenes with sphere primitives: the Veach scene's lights), two spheres
+// per packed instruction, the path's ray and the shadow ray together (they leave the same point: c0 = centre - o and |c0|^2
+// are shared).  A ray's line misses a sphere iff |c0|^2 |d|^2 - (c0 . d)^2 > r^2 |d|^2; intersectSphere (trace.h) decides that
+// from the perpendicular's length, in other roundings (both within 16 u |c0|^2 |d|^2 of the truth), so the candidate test keeps
+// everything up to 2e-5 |c0|^2 |d|^2 beyond: phase 2 -- intersectSphere + the acceptance rule, on whichever lane is free
+// (smallResolveShared) -- decides.  No interval test: the target of a shadow ray ends 1e-3 before the light it aims at, which
+// only the exact t can tell.  Bit k of a word = sphere k.
+__device__ __forceinline__ void smallSphereCandidates(const RenderParams &p, int nSpheres, V3 origin, V3 directionA, V3 directionB,
+                                                      unsigned int *candidatesA, unsigned int *candidatesB)
+{
+    const f2 ox = splat2(origin.x), oy = splat2(origin.y), oz = splat2(origin.z);
+    const f2 ax = splat2(directionA.x), ay = splat2(directionA.y), az = splat2(directionA.z);
+    const f2 bx = splat2(directionB.x), by = splat2(directionB.y), bz = splat2(directionB.z);
+    const f2 aa = splat2(dot(directionA, directionA)), bb = splat2(dot(directionB, directionB));
+    const f2 slack = splat2(2e-5f);
+    unsigned int bitsA = 0u, bitsB = 0u;   // sphere 2 pair at bit 2 pair (the words are built from the top pair down)
+    const int nPairs = (nSpheres + 1) >> 1;
+    for (int pair = nPairs - 1; pair >= 0; pair--) {
+        const f2 *record = reinterpret_cast<const f2 *>(&p.spherePairs[pair][0][0]);   // uniform index: scalar loads from the kernarg segment
+        const f2 cx = record[0] - ox, cy = record[1] - oy, cz = record[2] - oz, radiusSquared = record[3];
+        const f2 cc = fma2(cx, cx, fma2(cy, cy, cz * cz));
+        auto oneRay = [&](f2 dx, f2 dy, f2 dz, f2 dd, unsigned int &bits) {
+            const f2 cd = fma2(cx, dx, fma2(cy, dy, cz * dz));
+            const f2 scale = cc * dd;
+            const f2 distance = fma2(-cd, cd, scale);            // |perpendicular|^2 |d|^2
+            const f2 bound = fma2(slack, scale, radiusSquared * dd);
+            // "x > bound" rejects: NaN keeps the candidate
+            bits = shiftInBit(bits, ~__builtin_amdgcn_ballot_w64(distance.y > bound.y));   // sphere 2 pair + 1
+            bits = shiftInBit(bits, ~__builtin_amdgcn_ballot_w64(distance.x > bound.x));   // sphere 2 pair
+        };
+        oneRay(ax, ay, az, aa, bitsA);
+        oneRay(bx, by, bz, bb, bitsB);
+    }
+    const unsigned int present = nSpheres >= 32 ? 0xFFFFFFFFu : (1u << nSpheres) - 1u;   // (an odd count's padding sphere)
+    *candidatesA = bitsA & present;
+    *candidatesB = bitsB & present;
+}
+
 // Phase 2 with the wave's idle lanes lending a hand (k_path_small<QUADS>).  smallResolve runs max-over-lanes turns: 4.6 for the
 // path's ray and 2.3 for the shadow ray on Cornell, at a quarter of the lanes, because a few lanes hold 3-5 candidates while
 // most hold one (profiles/r3_fused_profile.log).  Here every lane tests the FIRST candidate of its path ray itself (one full
@@ -1048,11 +1089,17 @@ struct ResolveScratch {
     unsigned int *count;        // [1]
 };
 
-template <int CAPACITY, bool SHADOW_IN_PLACE>
-__device__ __forceinline__ void smallResolveShared(const TraceGeometry &geometry, LaneRay &ray, LaneRay &shadowRay,
+// SPHERES: sphereCandidates / shadowSphereCandidates (smallSphereCandidates: bit k = sphere k) are resolved on the shared
+// list as well -- a shadow ray's own target is always among them, so the exact sphere test would otherwise run for every
+// sphere at a handful of lanes each.  Returns false when the list overflowed and the spheres are still to be tested
+// (finishRay's loop), true otherwise.
+template <int CAPACITY, bool SHADOW_IN_PLACE, bool SPHERES>
+__device__ __forceinline__ bool smallResolveShared(const TraceGeometry &geometry, LaneRay &ray, LaneRay &shadowRay,
                                                    unsigned int low, unsigned int high, unsigned int shadowLow, unsigned int shadowHigh,
+                                                   unsigned int sphereCandidates, unsigned int shadowSphereCandidates,
                                                    const ResolveScratch &scratch)
 {
+    if (!SPHERES) { sphereCandidates = 0u; shadowSphereCandidates = 0u; }
     const int lane = threadIdx.x & 63;
     auto takeFirst = [](unsigned int &lowWord, unsigned int &highWord) -> int {
         int k;  // triangle k of a word is bit 31 - (k & 31): take the highest set bit first
@@ -1079,11 +1126,13 @@ __device__ __forceinline__ void smallResolveShared(const TraceGeometry &geometry
     // ---- the left-overs of the wave.  Sharing them out costs about 1.7 turns of the in-place loop (ten ds_bpermute, the
     // list, the atomics), so it is taken when the loops would run two turns or more: left-overs on both rays, or a lane
     // with two of one kind.
-    const unsigned int mineRay = (unsigned int)(__popc(low) + __popc(high)), mineShadow = (unsigned int)(__popc(shadowLow) + __popc(shadowHigh));
+    const unsigned int mineRay = (unsigned int)(__popc(low) + __popc(high) + (SPHERES ? __popc(sphereCandidates) : 0));
+    const unsigned int mineShadow = (unsigned int)(__popc(shadowLow) + __popc(shadowHigh) + (SPHERES ? __popc(shadowSphereCandidates) : 0));
     const unsigned int mine = mineRay + mineShadow;
     const bool anyRay = __ballot(mineRay != 0u) != 0ull, anyShadow = __ballot(mineShadow != 0u) != 0ull;
-    if (!anyRay && !anyShadow) { return; }
-    bool share = (anyRay && anyShadow) || __ballot(mineRay > 1u || mineShadow > 1u) != 0ull;
+    if (!anyRay && !anyShadow) { return true; }
+    const bool anySphere = SPHERES && __ballot((sphereCandidates | shadowSphereCandidates) != 0u) != 0ull;
+    bool share = anySphere || (anyRay && anyShadow) || __ballot(mineRay > 1u || mineShadow > 1u) != 0ull;
     unsigned int base = 0u, total = 0u;
     if (share) {
         if (lane == 0) { *scratch.count = 0u; }
@@ -1113,13 +1162,23 @@ __device__ __forceinline__ void smallResolveShared(const TraceGeometry &geometry
                 if (terminate) { shadowLow = 0u; shadowHigh = 0u; }
             }
         }
-        return;
+        return !anySphere;
     }
     // the owners list their items (a short loop: a lane holds a handful at most)
     {
         unsigned int at = base;
         while ((low | high) != 0u) { const int k = takeFirst(low, high); scratch.items[at++] = (unsigned short)((unsigned int)lane | ((unsigned int)k << 6)); }
         while ((shadowLow | shadowHigh) != 0u) { const int k = takeFirst(shadowLow, shadowHigh); scratch.items[at++] = (unsigned short)((unsigned int)lane | ((unsigned int)k << 6) | 0x1000u); }
+        if (SPHERES) {   // 0x2000: the candidate is sphere k
+            while (sphereCandidates != 0u) {
+                const int k = __ffs((int)sphereCandidates) - 1; sphereCandidates &= sphereCandidates - 1u;
+                scratch.items[at++] = (unsigned short)((unsigned int)lane | ((unsigned int)k << 6) | 0x2000u);
+            }
+            while (shadowSphereCandidates != 0u) {
+                const int k = __ffs((int)shadowSphereCandidates) - 1; shadowSphereCandidates &= shadowSphereCandidates - 1u;
+                scratch.items[at++] = (unsigned short)((unsigned int)lane | ((unsigned int)k << 6) | 0x3000u);
+            }
+        }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -1135,7 +1194,23 @@ __device__ __forceinline__ void smallResolveShared(const TraceGeometry &geometry
         const float ax = __shfl(ray.d.x, owner), ay = __shfl(ray.d.y, owner), az = __shfl(ray.d.z, owner);
         const float bx = __shfl(shadowRay.d.x, owner), by = __shfl(shadowRay.d.y, owner), bz = __shfl(shadowRay.d.z, owner);
         const float shadowFar = __shfl(shadowRay.tfar, owner);
-        if (helping) {
+        if (SPHERES && helping && (item & 0x2000u) != 0u) {
+            // testSphere (trace.h) for somebody else's ray
+            const DSphere sphere = geometry.spheres[k];
+            const V3 direction = forShadow ? v3(bx, by, bz) : v3(ax, ay, az);
+            float t;
+            if (intersectSphere(v3(ox, oy, oz), direction, v3(sphere.centerWorld[0], sphere.centerWorld[1], sphere.centerWorld[2]), sphere.radius, PATHED_TNEAR, &t)
+                && t > PATHED_TNEAR) {
+                if (forShadow) {
+                    if (t <= shadowFar) { atomicOr(&scratch.occluded[owner], 1u); }
+                } else if (t <= PATHED_TFAR) {
+                    scratch.uv[index] = make_float2(0.f, 0.f);
+                    const unsigned long long key = ((unsigned long long)__float_as_uint(t) << 32)
+                        | ((unsigned long long)(unsigned int)(geometry.nTris + k) << 8) | (unsigned long long)index;
+                    atomicMin(&scratch.best[owner], key);
+                }
+            }
+        } else if (helping) {
             const float4 t0 = geometry.tris[3 * k + 0], t1 = geometry.tris[3 * k + 1], t2 = geometry.tris[3 * k + 2];
             const V3 direction = forShadow ? v3(bx, by, bz) : v3(ax, ay, az);
             float t, u, v;
@@ -1167,6 +1242,7 @@ __device__ __forceinline__ void smallResolveShared(const TraceGeometry &geometry
         }
     }
     if (scratch.occluded[lane] != 0u) { shadowRay.occluded = true; }
+    return true;
 }
 
 template <bool COUNT>
@@ -2296,6 +2372,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_F
                 closestRays++;
                 if (traceShadow) { shadowRays++; }
             }
+            bool spheresDone = false;   // (wave-uniform) the shared phase 2 tested the sphere candidates: no loop over the spheres
             RESOLVE_PROBE(9, candidatesLow, candidatesHigh);   // (profile builds) the resolve loops: iterations, candidates
             RESOLVE_PROBE(10, shadowLow, shadowHigh);
             if (MFMA) {
@@ -2306,14 +2383,21 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_F
                 const int waveBase = (int)(threadIdx.x & ~63u), wave = (int)(threadIdx.x >> 6);
                 scratch.best = resolveBest + waveBase; scratch.uv = resolveUv + wave * kResolveCapacity; scratch.items = resolveItems + wave * kResolveCapacity;
                 scratch.occluded = resolveOccluded + waveBase; scratch.count = resolveCount + wave;
-                smallResolveShared<kResolveCapacity, PATHED_RESOLVE_SHARED != 2>(geometry, ray, shadowRay, candidatesLow, candidatesHigh, shadowLow, shadowHigh, scratch);
+                // spheres (the Veach scene's lights): a packed line-misses-sphere test for both rays, the exact tests on the shared list
+                unsigned int sphereCandidates = 0u, shadowSphereCandidates = 0u;
+                if (TRAITS::spheres && geometry.nSpheres > 0 && alive) {
+                    smallSphereCandidates(p, geometry.nSpheres, o, d, shadowDirection, &sphereCandidates, &shadowSphereCandidates);
+                    if (!traceShadow) { shadowSphereCandidates = 0u; }
+                }
+                spheresDone = smallResolveShared<kResolveCapacity, PATHED_RESOLVE_SHARED != 2, TRAITS::spheres>(
+                    geometry, ray, shadowRay, candidatesLow, candidatesHigh, shadowLow, shadowHigh, sphereCandidates, shadowSphereCandidates, scratch);
             } else {
                 smallResolve(geometry, ray, candidatesLow, candidatesHigh);
                 smallResolve(geometry, shadowRay, shadowLow, shadowHigh);
             }
-            if (alive) { finishRay(geometry, ray); }
+            if (alive && !spheresDone) { finishRay(geometry, ray); }
             if (traceShadow) {
-                finishRay(geometry, shadowRay);
+                if (!spheresDone) { finishRay(geometry, shadowRay); }
                 if (shadowRay.occluded) { pend = rgb(0.f); }
             }
             pendingShadow = false;

@@ -170,6 +170,7 @@ struct PathedScene {
 
     DeviceBuffer<float4> nodes, nodesQ, leafTris, triShade, triCompact, envRgba, texels;
     DeviceBuffer<DSphere> spheres;
+    float spherePairs[8][4][2] = {};   // RenderParams.spherePairs: the spheres two by two for the fused kernel's packed pre-test
     DeviceBuffer<DMaterial> materials;
     DeviceBuffer<DLight> lights;
     DeviceBuffer<float> thetaCdf, phiCdf;
@@ -1239,6 +1240,12 @@ int pathed_hip_scene_create_ex(const PathedSceneDesc *desc, const PathedSceneOpt
         spheres[i].radius = s.radius;
         spheres[i].material = s.material;
     }
+    std::memset(scene->spherePairs, 0, sizeof scene->spherePairs);
+    for (int pair = 0; pair < 8; pair++) { scene->spherePairs[pair][3][0] = -1.f; scene->spherePairs[pair][3][1] = -1.f; }   // radius^2 < 0: nothing touches it
+    for (uint32_t i = 0; i < desc->n_spheres && i < 16u; i++) {
+        for (int k = 0; k < 3; k++) { scene->spherePairs[i / 2][k][i % 2] = spheres[i].centerWorld[k]; }
+        scene->spherePairs[i / 2][3][i % 2] = spheres[i].radius * spheres[i].radius;
+    }
 
     // lights: emissive surfaces in model order, environment light last
     // (reference src/scene_parser.cpp:173-190)
@@ -1835,6 +1842,7 @@ static int renderPassFused(PathedScene *scene, uint64_t seed, uint32_t begin, ui
     params.smallQuads = scene->smallLayout.nQuads;
     params.smallKappaT = scene->smallLayout.kappaT;
     params.scene.leafTris = scene->itemTris.ptr;   // phase 2 indexes the triangles in the order phase 1's bits come in
+    std::memcpy(params.spherePairs, scene->spherePairs, sizeof params.spherePairs);
 #if PATHED_EXPERIMENTS
     if (scene->mfmaPhase1 && ldsMaterials) {
         // phase 1 on the matrix pipe: the same instantiations with MFMA = true
