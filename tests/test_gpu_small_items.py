@@ -127,3 +127,43 @@ def test_stacked_sheets_fill_and_overflow_the_shared_resolve(sheets, gap):
     assert np.array_equal(HipScene(desc, device=0, generic_kernels=1).render(11, 0, 24, 0, 5), image)
     assert np.array_equal(HipScene(desc, device=0, intersector="bvh", shade_kernel="per-slot").render(11, 0, 24, 0, 5), image)
     assert np.array_equal(HipScene(desc, device=0, intersector="bvh", shade_kernel="wave").render(11, 0, 24, 0, 5), image)
+
+
+@pytest.mark.parametrize("seed,n_spheres", [(1, 16), (2, 15), (3, 7), (4, 1)])
+def test_sphere_candidates_of_the_fused_kernel_lose_no_hit(seed, n_spheres):
+    """Spheres of the fused kernel: a packed line-misses-sphere test picks the candidates (kernels.h smallSphereCandidates), the
+    exact tests run on the wave's shared list.  Spheres from a thousandth of the scene to one that holds the camera,
+    overlapping, emissive and not, glass and mirror among them (rays start ON spheres, inside them, graze them): the image of
+    the tree walk, whose leaves go through testSphere alone, bit for bit."""
+    from pathed_amd import _capi
+    from pathed_amd.integrator import HipScene
+    from scene_builder import BuiltScene
+    rng = np.random.default_rng(seed)
+    built = BuiltScene(56, 40, (0.2, 0.8, 5.0), (0, 0.5, 0), fov_degrees=45.0)
+    grey = built.material(_capi.MAT_LAMBERTIAN, diffuse=(0.6, 0.6, 0.6))
+    kinds = [built.material(_capi.MAT_LAMBERTIAN, diffuse=(0.7, 0.3, 0.2)), built.material(_capi.MAT_GLASS, ior=1.5), built.material(_capi.MAT_MIRROR),
+             built.material(_capi.MAT_PLASTIC, diffuse=(0.2, 0.4, 0.6), alpha=0.1),
+             built.material(_capi.MAT_LAMBERTIAN, diffuse=(0, 0, 0), emit=(9.0, 8.0, 6.0))]
+    built.quad([(-4, 0, 4), (4, 0, 4), (4, 0, -4), (-4, 0, -4)], grey)
+    built.quad([(-4, 0, -4), (4, 0, -4), (4, 5, -4), (-4, 5, -4)], grey)
+    built.quad([(-1, 4.5, 1), (-1, 4.5, -1), (1, 4.5, -1), (1, 4.5, 1)], kinds[4])
+    for k in range(n_spheres):
+        if k == 0 and n_spheres > 8:
+            centre, radius, material = (0.2, 0.8, 5.0), 1.5, kinds[1]       # the camera sits inside a glass sphere
+        elif k == 1 and n_spheres > 8:
+            centre, radius, material = (0.0, 1.0, 0.0), 4e-3, kinds[4]      # a speck of light
+        else:
+            centre = tuple(rng.uniform(-2.5, 2.5, 3) * (1.0, 0.5, 1.0) + (0.0, 1.2, 0.0))
+            radius = float(10.0 ** rng.uniform(-1.5, 0.1))
+            material = kinds[int(rng.integers(0, len(kinds)))]
+        built.sphere(centre, radius, material)
+    desc = built.finish()
+    fused = HipScene(desc, device=0)
+    assert fused.stats()["scene_in_lds"] == 2 and fused.stats()["path_kernel"] == 3
+    image = fused.render(3, 0, 24, 0, 8)
+    assert image.any()
+    assert np.array_equal(HipScene(desc, device=0, intersector="bvh", shade_kernel="per-slot").render(3, 0, 24, 0, 8), image)
+    per_slot = HipScene(desc, device=0, shade_kernel="per-slot")
+    assert np.array_equal(per_slot.render(3, 0, 24, 0, 8), image)
+    # (a camera inside glass, a speck of light: some samples are not finite and are dropped -- by every kernel alike)
+    assert fused.stats()["dropped_samples"] == per_slot.stats()["dropped_samples"]
