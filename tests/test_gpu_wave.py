@@ -12,6 +12,7 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("scene_path,width,height,spp,options", [
     ("scenes/teapot.json", 160, 120, 8, {}),                               # environment light only: the narrowed instantiation
+    ("scenes/teapot.json", 17, 5, 3, {}),                                  # ragged: 85 pixels, fewer paths than one block has lanes
     ("assets/dragon-standin-9.json", 128, 72, 8, {}),                      # 5.2 M triangles (tests/conftest.py generates them): a deep tree
     ("scenes/cornell.json", 96, 96, 12, {"intersector": "bvh"}),           # triangle lights, the generic instantiation
     ("scenes/mis-pbrt.json", 96, 96, 12, {"intersector": "bvh"}),          # sphere lights as leaves of the tree
