@@ -66,7 +66,17 @@ def parse_args():
                         help="HIP events around every trace / shade launch instead of every 8th")
     parser.add_argument("--no-kernel-timing", action="store_true",
                         help="no HIP-event timing of kernel launches (the roofline block becomes null)")
+    parser.add_argument("--allow-overrides", action="store_true",
+                        help="run although PATHED_* variables are set in the environment (they are listed in the line either way: "
+                             "PATHED_HIP_LIB selects another library, the experiments build honours tuning variables)")
     return parser.parse_args()
+
+
+def environment_overrides():
+    """Every PATHED_* variable of this process's environment.  The product library reads none that changes a kernel, a slot
+    count or a builder (include/pathed_hip.h: PathedSceneOptions), but PATHED_HIP_LIB swaps the library itself and the
+    experiments build listens to dozens: a bench line must say so, and refuses to be produced silently."""
+    return {name: value for name, value in sorted(os.environ.items()) if name.startswith("PATHED_")}
 
 
 # --------------------------------------------------------------------------- launcher (no GPU call)
@@ -173,53 +183,64 @@ def scene_description(scene, stats):
         desc.n_triangles, desc.n_spheres, ", ".join(kinds[k] for k in used), lights, intersector)
 
 
-def usable_cores():
-    """Host threads this process can really run at once: the scheduler affinity, cut to the cgroup's CPU quota (a GPU
-    box hands a job a share of its cores; os.cpu_count() reports the whole machine, and 256 threads on a 16-core share
-    is what made earlier rounds' baseline scale 10x on "256 threads")."""
+def host_cores():
+    """What this process may run at once, and where each number comes from: the scheduler affinity, the cgroup's CPU quota
+    (a GPU box hands a job a share of its cores; os.cpu_count() reports the whole machine, and 256 threads on a 16-core
+    share is what made earlier rounds' baseline scale 10x on "256 threads"), and the smaller of the two."""
     try:
-        count = len(os.sched_getaffinity(0))
+        affinity = len(os.sched_getaffinity(0))
     except (AttributeError, OSError):
-        count = os.cpu_count() or 1
-    quota = None
+        affinity = os.cpu_count() or 1
+    quota, source = None, None
     try:
         with open("/sys/fs/cgroup/cpu.max") as handle:   # cgroup v2: "<quota|max> <period>"
             first, period = handle.read().split()[:2]
+            source = "/sys/fs/cgroup/cpu.max = %s %s" % (first, period)
             if first != "max":
                 quota = float(first) / float(period)
     except (OSError, ValueError):
         try:
             with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as q, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as p:
-                value = float(q.read())
+                value, period = float(q.read()), float(p.read())
+                source = "cpu.cfs_quota_us / cpu.cfs_period_us = %g / %g" % (value, period)
                 if value > 0:
-                    quota = value / float(p.read())
+                    quota = value / period
         except (OSError, ValueError):
             pass
-    if quota is not None:
-        count = max(1, min(count, int(quota + 0.999)))
-    return count
+    usable = affinity if quota is None else max(1, min(affinity, int(quota + 0.999)))
+    return {"machine_threads": os.cpu_count(), "affinity": affinity, "cgroup_quota_cores": quota, "cgroup_source": source, "usable": usable}
+
+
+def usable_cores():
+    return host_cores()["usable"]
 
 
 def cpu_baseline(scene, args):
-    """Time the CPU oracle on the same workload at reduced spp (rate is spp-independent)."""
+    """Time the CPU oracle on the same workload at reduced spp (rate is spp-independent).  Every thread count tried is
+    reported with its rate; `value` is the fastest, `cores` the threads it ran on."""
     sys.path.insert(0, os.path.join(REPO_ROOT, "tests"))
     import oracle_lib  # the checker; used here only as the reported CPU baseline
 
-    allowed = min(usable_cores(), oracle_lib.host_threads())   # oracle_lib never starts more than that
+    host = host_cores()
+    allowed = min(host["usable"], oracle_lib.host_threads())   # oracle_lib never starts more than that
     oracle = oracle_lib.OracleScene(scene.desc)
-    # the thread count that is fastest HERE: a box may report more hardware threads than the share of it this job runs on
-    one, cores = None, allowed
-    for candidate in sorted({min(count, allowed) for count in (8, 16, 24, 32, allowed)}):
+    pixels = args.width * args.height
+    oracle.render(args.width, args.height, args.seed, 0, 1, 0, args.last_bounce, threads=allowed)   # warm-up: the BVH, the thread pool
+    # the thread count that is fastest HERE: a box may report more hardware threads than the share of it this job runs on.
+    # Two samples per pixel each (a few tenths of a second to a few seconds), sample indices disjoint from the timed ones.
+    tried = []
+    for candidate in sorted({max(1, min(count, allowed)) for count in (allowed // 2, allowed, 8, 16, 24, 32)}):
         t0 = time.perf_counter()
-        oracle.render(args.width, args.height, args.seed, 0, 1, 0, args.last_bounce, threads=candidate)
+        oracle.render(args.width, args.height, args.seed, 1000, 2, 0, args.last_bounce, threads=candidate)
         took = time.perf_counter() - t0
-        if one is None or took < one:
-            one, cores = took, candidate
-    spp = max(1, min(64, int(15.0 / max(one, 1e-3))))
+        tried.append({"threads": candidate, "Msamples_per_s": 2 * pixels / took / 1e6, "spp": 2, "seconds": took})
+    best = max(tried, key=lambda row: row["Msamples_per_s"])
+    cores = best["threads"]
+    spp = max(2, min(64, int(15.0 * best["Msamples_per_s"] * 1e6 / pixels)))
     t0 = time.perf_counter()
     oracle.render(args.width, args.height, args.seed, 1, spp, 0, args.last_bounce, threads=cores)
     elapsed = time.perf_counter() - t0
-    samples = args.width * args.height * spp
+    samples = pixels * spp
     # one thread on a 256 x 256 rendering of the same scene: the scalar rate the reference's per-core code is comparable to
     from pathed_amd.scene import LoadedScene
     small = LoadedScene(args.scene, 256, 256)
@@ -241,13 +262,19 @@ def cpu_baseline(scene, args):
         "unit": "Msamples/s",
         "cores": cores,
         "threads": cores,
-        "machine_threads": os.cpu_count(),
+        "host": host,
+        "oracle_thread_cap": oracle_lib.host_threads(),
+        "thread_counts_tried": tried,
+        "machine_threads": host["machine_threads"],
         "cpu_model": model,
         "single_thread": single_rate,
         "parallel_efficiency": rate / (cores * single_rate),
         "kind": "port",
-        "sample": "%s %dx%d, %d spp, lastBounce %d, OpenMP over rows (dynamic), %d threads (the fastest of 8 / 16 / 24 / 32 on this box), %.1f s" % (
-            args.scene, args.width, args.height, spp, args.last_bounce, cores, elapsed),
+        "sample": "%s %dx%d, %d spp, lastBounce %d, OpenMP over rows (dynamic) on %d threads -- the fastest of %s threads at 2 spp each; "
+                  "the job may use %d cores (affinity %d, cgroup quota %s), the machine has %s hardware threads; %.1f s" % (
+            args.scene, args.width, args.height, spp, args.last_bounce, cores, " / ".join(str(row["threads"]) for row in tried),
+            host["usable"], host["affinity"], "none" if host["cgroup_quota_cores"] is None else "%.1f" % host["cgroup_quota_cores"],
+            host["machine_threads"], elapsed),
     }
 
 
@@ -446,7 +473,7 @@ def run_rank(args):
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         world_size = dist.get_world_size()   # the ranks the backend actually sees
 
-    from pathed_amd import parallel
+    from pathed_amd import _capi, parallel
     from pathed_amd.integrator import HipScene, measure_bandwidth
     from pathed_amd.scene import LoadedScene
 
@@ -670,6 +697,8 @@ def run_rank(args):
             "cpu_baseline": baseline,
             "image_mean_rgb": mean,
             "dropped_samples": timed["dropped_samples"],
+            "environment_overrides": environment_overrides(),
+            "library": {"path": os.path.relpath(_capi.hip_library_path(), REPO_ROOT), "experiments_build": bool(_capi.load_hip().pathed_hip_has_experiments())},
         }
         print(json.dumps(line), flush=True)
 
@@ -680,6 +709,11 @@ def run_rank(args):
 
 def main():
     args = parse_args()
+    overrides = environment_overrides()
+    if overrides and not args.allow_overrides:
+        sys.stderr.write("bench.py: PATHED_* variables are set (%s): unset them, or pass --allow-overrides to run anyway "
+                         "(they are reported in the line's \"environment_overrides\")\n" % ", ".join("%s=%s" % item for item in overrides.items()))
+        return 3
     if "WORLD_SIZE" in os.environ or args.gpus <= 1:
         return run_rank(args)      # a rank of torch.distributed.run / of our own launcher, or the single-GPU run
     return launch_ranks(args)

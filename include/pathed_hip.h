@@ -227,8 +227,7 @@ typedef struct PathedStats {
  * Replaces the reference's rtcNewDevice / rtcNewScene (app/main.cpp:46-52). */
 int pathed_hip_init(int device_id);
 
-/* Which builder stands in for rtcCommitScene (reference src/scene.cpp:39): PathedSceneOptions.bvh_builder
- * (the environment variable PATHED_BVH_BUILDER=sah|lbvh|ploc overrides, for experiments):
+/* Which builder stands in for rtcCommitScene (reference src/scene.cpp:39): PathedSceneOptions.bvh_builder:
  *   PATHED_BVH_SAH_HOST     binned-SAH tree built on the host cores (default: cheapest to traverse)
  *   PATHED_BVH_LBVH_DEVICE  Morton-code linear BVH built on the GPU in milliseconds;
  *                           same node format, so hits and images are bit-identical, traversal costs more.
@@ -260,8 +259,10 @@ int pathed_hip_scene_refit(PathedScene *scene, const float *positions, const flo
  * the device of pathed_hip_init.  The device is part of the scene: every call that takes the
  * PathedScene selects it first (hipSetDevice is per host thread), so a host may drive several
  * scenes on several GPUs from one thread per GPU (reference app/main.cpp:93-98 runs the
- * integrator on its own std::thread).  The PATHED_* environment variables remain as overrides
- * for tuning experiments; tests and hosts use this struct. */
+ * integrator on its own std::thread).  This struct is the ONLY way to tune the product library: it
+ * reads no PATHED_* environment variable that could change a kernel, a slot count or a builder
+ * (the experiments build, `make experiments`, still honours them for A/B scripts; two debug prints,
+ * PATHED_DEBUG_ALLOC and PATHED_DEBUG_STATS, exist in both and change no result). */
 #define PATHED_DEVICE_CURRENT (-1)
 typedef struct PathedSceneOptions {
     uint32_t struct_size;       /* sizeof(PathedSceneOptions)                                  */
@@ -299,6 +300,14 @@ typedef struct PathedSceneOptions {
                                    phase 2 decides either way: hits and images are bit-identical */
     int32_t refittable;         /* 1: keep the triangle soup (positions, normals, uvs, indices: 44 bytes per triangle or so) on the
                                    device so that pathed_hip_scene_refit can move the vertices later; BVH scenes only */
+    int32_t wave_max_ksamples;  /* shade_kernel 0 on a BVH scene: render calls of fewer than this many x 1024 camera samples run
+                                   k_path_wave, longer ones the wavefront (0 = 49 152, i.e. 48 Mi samples) */
+    int32_t wave_stragglers;    /* k_path_wave: a traversal burst ends once the wave's list is dealt and fewer rays than this are
+                                   still in flight, 1..64; -1 = every ray is finished first (0 = 24).  Scheduling only */
+    int32_t wave_refill;        /* k_path_wave: idle lanes draw from the wave's ray list once fewer than this many are busy,
+                                   1..64 (0 = 48).  Scheduling only */
+    int32_t chunks_per_pass;    /* work units per pixel of one internal pass, 1..4096 (0 = 256, fewer at resolutions whose partial
+                                   sums would not fit): longer passes amortise a pass's ramp-up and drain, at 16 bytes per unit */
 } PathedSceneOptions;
 int pathed_hip_scene_create_ex(const PathedSceneDesc *desc, const PathedSceneOptions *options, PathedScene **out);
 int pathed_hip_scene_device(const PathedScene *scene);   /* the HIP device the scene lives on, or a negative error */
@@ -373,8 +382,9 @@ int pathed_hip_debug_small_candidates(PathedScene *scene, const float *rays, siz
 
 /* 1 in libpathed_hip_experiments.so (`make experiments`), 0 in the product library.  The experiments build adds the
  * kernel organisations that were measured and rejected: shade_kernel 2 (staged) and 4 (split),
- * node_format 2 / 3 (compressed nodes), small_phase1 2 (matrix pipe), pathed_hip_measure_valu_clocks and
- * pathed_hip_debug_small_candidates.  The product library answers PATHED_E_UNSUPPORTED to each of them. */
+ * node_format 2 / 3 (compressed nodes), small_phase1 2 (matrix pipe) and pathed_hip_measure_valu_clocks; the product
+ * library answers PATHED_E_UNSUPPORTED to each of them.  (pathed_hip_debug_small_candidates runs in both: the product reports
+ * zero for the matrix-pipe form's two words.)  The experiments build also honours the PATHED_* tuning variables. */
 int pathed_hip_has_experiments(void);
 
 /* Bit 0: the counting variants of the trace kernel (nodes_visited / tris_tested); off by default, the

@@ -156,6 +156,10 @@ class PathedSceneOptions(C.Structure):
         ("node_format", C.c_int32),
         ("small_phase1", C.c_int32),
         ("refittable", C.c_int32),
+        ("wave_max_ksamples", C.c_int32),
+        ("wave_stragglers", C.c_int32),
+        ("wave_refill", C.c_int32),
+        ("chunks_per_pass", C.c_int32),
     ]
 
 

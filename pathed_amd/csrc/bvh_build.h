@@ -63,16 +63,19 @@ struct TempNode {
 };
 
 static const int kBins = 16;
-// leaf size: <= 7 (3-bit count in the traversal's leaf references); PATHED_MAX_LEAF overrides for tuning
+// leaf size: <= 7 (3-bit count in the traversal's leaf references); PATHED_MAX_LEAF overrides for tuning in the experiments
+// build (the product library reads no PATHED_* variable)
 inline uint32_t maxLeafSize()
 {
     static uint32_t value = 0;
     if (value == 0) {
         value = 4;
+#if defined(PATHED_EXPERIMENTS) && PATHED_EXPERIMENTS
         if (const char *text = getenv("PATHED_MAX_LEAF")) {
             const int parsed = atoi(text);
             if (parsed >= 1 && parsed <= 7) { value = (uint32_t)parsed; }
         }
+#endif
     }
     return value;
 }

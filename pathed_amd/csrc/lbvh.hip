@@ -805,16 +805,20 @@ hipError_t buildBvhOnDevice(int builder, const float *positions, const uint32_t 
         if (scratch.status != hipSuccess) { return failed(scratch.status, "scan scratch"); }
 
         int radius = kPlocRadius;
-        if (const char *text = getenv("PATHED_PLOC_RADIUS")) {   // tuning
+#if PATHED_EXPERIMENTS
+        if (const char *text = getenv("PATHED_PLOC_RADIUS")) {   // tuning (experiments build only: the product library reads no PATHED_* variable)
             const int value = atoi(text);
             if (value >= 1 && value <= kPlocMaxRadius) { radius = value; }
         }
+#endif
         hipLaunchKernelGGL(k_ploc_init, dim3(blocksFor(n)), dim3(kLbvhBlock), 0, stream, n, triangleCount, sorted, boxLo, boxHi, a);
         unsigned int topLimit = 1024;   // clusters left to the host's SAH build (0: cluster all the way); 1 024: fewer rounds AND a better top
+#if PATHED_EXPERIMENTS
         if (const char *text = getenv("PATHED_PLOC_TOP")) {
             const int value = atoi(text);
             if (value >= 0 && value <= (1 << 20)) { topLimit = (unsigned int)value; }
         }
+#endif
         unsigned int c = n, nodeBase = 0;
         while (c > 1 && c > topLimit) {
             if (++rounds > 4096) { return failed(hipErrorInvalidValue, "clustering does not converge"); }

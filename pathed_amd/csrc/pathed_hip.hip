@@ -17,6 +17,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -33,6 +34,20 @@ int fail(int code, const std::string &message)
 {
     g_error = message;
     return code;
+}
+
+// Tuning switches read from the environment exist in the EXPERIMENTS build only (`make experiments`): the product library
+// takes every setting from PathedSceneOptions, so a stray PATHED_* variable on a bench box cannot change a kernel, a slot
+// count or a builder behind the caller's back (bench.py also refuses to run with one set).  Two debug PRINTS stay in both
+// builds: PATHED_DEBUG_ALLOC and PATHED_DEBUG_STATS (they change no result and no timing path).
+inline const char *tuningEnv(const char *name)
+{
+#if PATHED_EXPERIMENTS
+    return std::getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
 }
 
 #define HIP_TRY(expr)                                                                      \
@@ -531,7 +546,7 @@ void launchTraceStack(PathedScene *scene, const RenderParams &params, hipStream_
         return;
     }
 #endif
-    if (!scene->sceneInLds && scene->device.nSpheres == 0 && !scene->options.generic_kernels && !getenv("PATHED_NO_SCENE_TRAITS")) {
+    if (!scene->sceneInLds && scene->device.nSpheres == 0 && !scene->options.generic_kernels && !tuningEnv("PATHED_NO_SCENE_TRAITS")) {
         if (scene->countMode) { hipLaunchKernelGGL((k_trace<STACK, false, true, false, false>), grid, block, lds, stream, params); }
         else { hipLaunchKernelGGL((k_trace<STACK, false, false, false, false>), grid, block, lds, stream, params); }
         return;
@@ -639,7 +654,7 @@ void launchVolume(int stackRows, bool small, bool narrowed, const RenderParams &
 // PathedSceneOptions.node_format with the experiments' override: 0 automatic, 1 float nodes, 2 compressed, 3 compressed 8-wide
 int requestedNodeFormat(const PathedSceneOptions &options)
 {
-    if (const char *text = getenv("PATHED_NODE_FORMAT")) {
+    if (const char *text = tuningEnv("PATHED_NODE_FORMAT")) {
         if (!strcmp(text, "wide")) { return 1; }
         if (!strcmp(text, "compressed")) { return 2; }
         if (!strcmp(text, "compressed8")) { return 3; }
@@ -659,7 +674,7 @@ void configureTrace(PathedScene *scene)
     scene->maxStack = mayWalkNode8 ? 7 * scene->bvh.maxDepth + 9 : 3 * scene->bvh.maxDepth + 1;
     scene->stackRows = scene->maxStack <= 8 ? 8 : scene->maxStack <= 16 ? 16 : 22;
     if (options.stack_rows == 8 || options.stack_rows == 16 || options.stack_rows == 22) { scene->stackRows = options.stack_rows; }
-    if (const char *override = getenv("PATHED_STACK_ROWS")) {   // experiments: force the HBM spill path
+    if (const char *override = tuningEnv("PATHED_STACK_ROWS")) {   // experiments: force the HBM spill path
         const int value = atoi(override);
         if (value == 8 || value == 16 || value == 22) { scene->stackRows = value; }
     }
@@ -682,27 +697,27 @@ void configureTrace(PathedScene *scene)
     if (!scene->sceneInLds) { blocksPerCu = scene->pools > 1 ? (blocksPerCu < 2 ? blocksPerCu : 2) : (blocksPerCu < 5 ? blocksPerCu : 5); }
     if (blocksPerCu < 1) { blocksPerCu = 1; }
     if (options.trace_blocks_per_cu >= 1 && options.trace_blocks_per_cu <= 16) { blocksPerCu = options.trace_blocks_per_cu; }
-    if (const char *override = getenv("PATHED_TRACE_BLOCKS_PER_CU")) {
+    if (const char *override = tuningEnv("PATHED_TRACE_BLOCKS_PER_CU")) {
         const int value = atoi(override);
         if (value >= 1 && value <= 16) { blocksPerCu = value; }
     }
     scene->traceGrid = scene->computeUnits * blocksPerCu;
-    if (const char *override = getenv("PATHED_TRACE_GRID")) {   // experiments: the persistent grid in blocks, any number
+    if (const char *override = tuningEnv("PATHED_TRACE_GRID")) {   // experiments: the persistent grid in blocks, any number
         const int value = atoi(override);
         if (value >= 1 && value <= scene->computeUnits * 16) { scene->traceGrid = value; }
     }
     if (options.park_min_cards != 0) { scene->parkMinCards = options.park_min_cards < 0 ? 0 : (options.park_min_cards > 1024 ? 1024 : options.park_min_cards); }
     if (options.suspend_patience != 0) { scene->suspendPatience = options.suspend_patience < 0 ? 0 : (options.suspend_patience > 4096 ? 4096 : options.suspend_patience); }
     if (options.suspend_lanes != 0) { scene->suspendLanes = options.suspend_lanes < 0 ? 0 : (options.suspend_lanes > 64 ? 64 : options.suspend_lanes); }
-    if (const char *override = getenv("PATHED_PARK_MIN_CARDS")) {
+    if (const char *override = tuningEnv("PATHED_PARK_MIN_CARDS")) {
         const int value = atoi(override);
         if (value >= 0 && value <= 1024) { scene->parkMinCards = value; }
     }
-    if (const char *override = getenv("PATHED_SUSPEND_PATIENCE")) {
+    if (const char *override = tuningEnv("PATHED_SUSPEND_PATIENCE")) {
         const int value = atoi(override);
         if (value >= 0 && value <= 4096) { scene->suspendPatience = value; }
     }
-    if (const char *override = getenv("PATHED_SUSPEND_LANES")) {
+    if (const char *override = tuningEnv("PATHED_SUSPEND_LANES")) {
         const int value = atoi(override);
         if (value >= 0 && value <= 64) { scene->suspendLanes = value; }
     }
@@ -1111,7 +1126,7 @@ int pathed_hip_scene_device(const PathedScene *scene)
 
 static int unitOrderFromEnvironment(int fallback)
 {
-    if (const char *text = getenv("PATHED_UNIT_ORDER")) {   // experiments
+    if (const char *text = tuningEnv("PATHED_UNIT_ORDER")) {   // experiments
         if (!strcmp(text, "tiles")) { return kOrderTiles; }
         if (!strcmp(text, "stripes-tiled")) { return kOrderStripesTiled; }
         if (!strcmp(text, "stripes")) { return kOrderStripes; }
@@ -1130,14 +1145,22 @@ static hipError_t rebuildSmallItems(PathedScene *scene)
     // shared resolve's lists, 33.5 KiB per block: up to 64 materials -- 6 KiB -- four blocks fit a CU's 160 KiB; scenes with more
     // pair nothing)
     const int kMaxQuadMaterials = 64;
-    const bool pairQuads = scene->options.generic_kernels == 0 && !getenv("PATHED_NO_QUADS") && scene->device.nMaterials <= kMaxQuadMaterials;
+    const bool pairQuads = scene->options.generic_kernels == 0 && !tuningEnv("PATHED_NO_QUADS") && scene->device.nMaterials <= kMaxQuadMaterials;
     std::vector<float> ordered;
     scene->smallLayout = buildSmallItems(scene->bvh.leafTris.data(), scene->device.nTris, points.data(), (int)(points.size() / 3), pairQuads, PATHED_TNEAR,
                                          reinterpret_cast<float *>(scene->smallItems.data), &ordered);
     std::vector<float4> records(ordered.size() / 4);
     std::memcpy(records.data(), ordered.data(), ordered.size() * sizeof(float));
     scene->itemTrisHost = ordered;
-    return scene->itemTris.upload(records);
+    const hipError_t status = scene->itemTris.upload(records);
+    if (status == hipSuccess && scene->mfmaPhase1) {
+        // (experiments build) the matrix-pipe rows are expressed in a frame centred on the camera: a new camera is a new table,
+        // or phase 1 stops being conservative for rays that start far from the old one
+        std::vector<float> table;
+        buildMfmaTable(scene->itemTrisHost.data(), scene->device.nTris, scene->device.camera.origin, 1, &table, &scene->mfmaFrame);
+        return scene->mfmaTable.upload(table);
+    }
+    return status;
 }
 
 int pathed_hip_scene_create_ex(const PathedSceneDesc *desc, const PathedSceneOptions *optionsIn, PathedScene **out)
@@ -1166,6 +1189,10 @@ int pathed_hip_scene_create_ex(const PathedSceneDesc *desc, const PathedSceneOpt
         if (options.stage_slots != 0 && options.stage_slots != 512 && options.stage_slots != 1024) { return fail(PATHED_E_INVALID, "stage_slots must be 0, 512 or 1024"); }
         if (options.refittable != 0 && options.refittable != 1) { return fail(PATHED_E_INVALID, "refittable must be 0 or 1"); }
         if (options.small_phase1 < 0 || options.small_phase1 > 2) { return fail(PATHED_E_INVALID, "small_phase1 must be 0 (automatic), 1 (VALU) or 2 (matrix pipe)"); }
+        if (options.wave_max_ksamples < 0) { return fail(PATHED_E_INVALID, "wave_max_ksamples must be >= 0"); }
+        if (options.wave_stragglers < -1 || options.wave_stragglers > 64) { return fail(PATHED_E_INVALID, "wave_stragglers must be -1 (none), 0 (default) or 1..64"); }
+        if (options.wave_refill < 0 || options.wave_refill > 64) { return fail(PATHED_E_INVALID, "wave_refill must be 0 (default) or 1..64"); }
+        if (options.chunks_per_pass < 0 || options.chunks_per_pass > 4096) { return fail(PATHED_E_INVALID, "chunks_per_pass must be 0 (default) or 1..4096"); }
     }
     int deviceId = options.device;
     if (deviceId == PATHED_DEVICE_CURRENT) {
@@ -1347,7 +1374,7 @@ int pathed_hip_scene_create_ex(const PathedSceneDesc *desc, const PathedSceneOpt
 
     hipError_t status;
     int builder = options.bvh_builder > 0 ? options.bvh_builder - 1 : PATHED_BVH_SAH_HOST;
-    if (const char *text = getenv("PATHED_BVH_BUILDER")) {
+    if (const char *text = tuningEnv("PATHED_BVH_BUILDER")) {
         if (!strcmp(text, "lbvh")) { builder = PATHED_BVH_LBVH_DEVICE; }
         else if (!strcmp(text, "ploc")) { builder = PATHED_BVH_PLOC_DEVICE; }
         else if (!strcmp(text, "sah")) { builder = PATHED_BVH_SAH_HOST; }
@@ -1416,7 +1443,7 @@ int pathed_hip_scene_create_ex(const PathedSceneDesc *desc, const PathedSceneOpt
         // src/sphere.cpp:16-48) unless the scene is small enough for the all-triangles kernel, which tests them one by one.
         std::vector<float> sphereBounds;
         const bool tiny = desc->n_triangles <= (uint32_t)kBruteForceMaxTris && desc->n_spheres <= (uint32_t)kBruteForceMaxSpheres
-            && scene->options.intersector != 1 && !getenv("PATHED_NO_BRUTE_FORCE");
+            && scene->options.intersector != 1 && !tuningEnv("PATHED_NO_BRUTE_FORCE");
         if (!tiny) {
             for (uint32_t i = 0; i < desc->n_spheres; i++) {
                 for (int a = 0; a < 3; a++) { sphereBounds.push_back(desc->spheres[i].center_world[a]); }
@@ -1520,12 +1547,12 @@ int pathed_hip_scene_create_ex(const PathedSceneDesc *desc, const PathedSceneOpt
     {
         bool emissive = false;
         for (const DMaterial &material : materials) { emissive = emissive || emits(material); }
-        scene->envOnly = desc->env != nullptr && lights.size() == 1 && !emissive && options.generic_kernels == 0 && !getenv("PATHED_NO_ENV_ONLY");
+        scene->envOnly = desc->env != nullptr && lights.size() == 1 && !emissive && options.generic_kernels == 0 && !tuningEnv("PATHED_NO_ENV_ONLY");
         bool plainLambertian = desc->env == nullptr && desc->n_spheres == 0;
         for (uint32_t i = 0; i < desc->n_materials; i++) {
             plainLambertian = plainLambertian && desc->materials[i].type == PATHED_MAT_LAMBERTIAN && desc->materials[i].albedo_type == PATHED_ALBEDO_CONSTANT;
         }
-        const bool narrow = options.generic_kernels == 0 && !getenv("PATHED_NO_SCENE_TRAITS");
+        const bool narrow = options.generic_kernels == 0 && !tuningEnv("PATHED_NO_SCENE_TRAITS");
         scene->lambertianTriangles = plainLambertian && narrow;
         bool lambertianPlastic = true;
         for (uint32_t i = 0; i < desc->n_materials; i++) {
@@ -1562,12 +1589,12 @@ int pathed_hip_scene_create_ex(const PathedSceneDesc *desc, const PathedSceneOpt
     d.env.phiRecords = scene->phiRecords.ptr;
 
     if (options.pools > 0) { scene->pools = options.pools; }
-    if (const char *poolCount = getenv("PATHED_POOLS")) {
+    if (const char *poolCount = tuningEnv("PATHED_POOLS")) {
         const int value = atoi(poolCount);
         scene->pools = value < 1 ? 1 : value > kMaxPools ? kMaxPools : value;
     }
     scene->bruteForce = scene->device.nTris <= kBruteForceMaxTris && scene->device.nSpheres <= kBruteForceMaxSpheres
-        && options.intersector != 1 && !getenv("PATHED_NO_BRUTE_FORCE");
+        && options.intersector != 1 && !tuningEnv("PATHED_NO_BRUTE_FORCE");
     // BVH scenes: more slots = more rays per persistent wave to refill finished lanes from (ray cost is heavy-tailed) and
     // fewer, longer launches: 8 Mi slots (1.3 GB of path state) against 4 Mi: +3.6 % on the teapot, +6.1 % on the 5.2 M-
     // triangle mesh at >= 256 spp per call, 16 Mi +1 % / +7.6 %, 32 Mi less again (tools/slots_sweep.py); short calls want
@@ -1580,7 +1607,7 @@ int pathed_hip_scene_create_ex(const PathedSceneDesc *desc, const PathedSceneOpt
     // shade stage (k_vertex + k_regen over lists the trace kernel writes) are selectable: both issue fewer
     // instructions on fuller waves and both lose to the coalesced per-slot kernel (DESIGN.md has the measurements)
     int shadeKernel = options.shade_kernel;
-    if (const char *text = getenv("PATHED_SHADE_KERNEL")) {   // experiments: "per-slot" | "staged" | "fused" | "split"
+    if (const char *text = tuningEnv("PATHED_SHADE_KERNEL")) {   // experiments: "per-slot" | "staged" | "fused" | "split"
         if (!strcmp(text, "per-slot")) { shadeKernel = 1; }
         else if (!strcmp(text, "staged")) { shadeKernel = 2; }
         else if (!strcmp(text, "fused")) { shadeKernel = 3; }
@@ -1634,8 +1661,8 @@ int pathed_hip_scene_create_ex(const PathedSceneDesc *desc, const PathedSceneOpt
     scene->vertexGrid = scene->computeUnits * PATHED_VERTEX_WAVES;
     scene->regenGrid = scene->computeUnits * PATHED_REGEN_WAVES;
 #endif
-    if (const char *text = getenv("PATHED_VERTEX_GRID")) { const int value = atoi(text); if (value >= 1 && value <= 65536) { scene->vertexGrid = value; } }
-    if (const char *text = getenv("PATHED_REGEN_GRID")) { const int value = atoi(text); if (value >= 1 && value <= 65536) { scene->regenGrid = value; } }
+    if (const char *text = tuningEnv("PATHED_VERTEX_GRID")) { const int value = atoi(text); if (value >= 1 && value <= 65536) { scene->vertexGrid = value; } }
+    if (const char *text = tuningEnv("PATHED_REGEN_GRID")) { const int value = atoi(text); if (value >= 1 && value <= 65536) { scene->regenGrid = value; } }
     scene->fusedPath = scene->bruteForce && (shadeKernel == 0 || shadeKernel == 3);
     scene->waveMode = shadeKernel == 5 ? 2 : shadeKernel == 0 ? 0 : 1;
     scene->waveAvailable = !scene->bruteForce && scene->device.nMaterials <= kMaxLdsMaterials && scene->nodeFormat == 0;
@@ -1643,17 +1670,20 @@ int pathed_hip_scene_create_ex(const PathedSceneDesc *desc, const PathedSceneOpt
         delete scene;
         return fail(PATHED_E_INVALID, "the wave path kernel serves BVH scenes (more than 64 triangles or intersector 1) of at most 96 materials over the float nodes");
     }
-    if (const char *text = getenv("PATHED_WAVE_MAX_SAMPLES")) { scene->waveMaxSamples = strtoull(text, nullptr, 10); }
-    if (const char *text = getenv("PATHED_WAVE_BLOCK")) { scene->waveBlock = atoi(text) != 0; }
-    if (const char *text = getenv("PATHED_WAVE_SHADE_READY")) { const int value = atoi(text); if (value >= 1 && value <= 64) { scene->waveShadeReady = value; } }
-    if (const char *text = getenv("PATHED_WAVE_REFILL")) { const int value = atoi(text); if (value >= 1 && value <= 64) { scene->waveRefill = value; } }
-    if (const char *text = getenv("PATHED_WAVE_STRAGGLERS")) { const int value = atoi(text); if (value >= 0 && value <= 64) { scene->waveStragglers = value; } }
+    if (options.wave_max_ksamples > 0) { scene->waveMaxSamples = (unsigned long long)options.wave_max_ksamples << 10; }
+    if (options.wave_stragglers != 0) { scene->waveStragglers = options.wave_stragglers < 0 ? 0 : options.wave_stragglers; }
+    if (options.wave_refill != 0) { scene->waveRefill = options.wave_refill; }
+    if (const char *text = tuningEnv("PATHED_WAVE_MAX_SAMPLES")) { scene->waveMaxSamples = strtoull(text, nullptr, 10); }
+    if (const char *text = tuningEnv("PATHED_WAVE_BLOCK")) { scene->waveBlock = atoi(text) != 0; }
+    if (const char *text = tuningEnv("PATHED_WAVE_SHADE_READY")) { const int value = atoi(text); if (value >= 1 && value <= 64) { scene->waveShadeReady = value; } }
+    if (const char *text = tuningEnv("PATHED_WAVE_REFILL")) { const int value = atoi(text); if (value >= 1 && value <= 64) { scene->waveRefill = value; } }
+    if (const char *text = tuningEnv("PATHED_WAVE_STRAGGLERS")) { const int value = atoi(text); if (value >= 0 && value <= 64) { scene->waveStragglers = value; } }
     scene->stagedShade = shadeKernel == 2;
     // more slots per block = fuller last waves of the dense stages, fewer blocks to fill the chip with:
     // the 0.5 Mi-slot pools of the all-triangles scenes take 512, the 2 Mi-slot pools of the BVH scenes 1024
     scene->stageRounds = scene->bruteForce ? 2 : 4;
     if (options.stage_slots != 0) { scene->stageRounds = options.stage_slots / kBlock; }
-    if (const char *text = getenv("PATHED_STAGE_SLOTS")) {
+    if (const char *text = tuningEnv("PATHED_STAGE_SLOTS")) {
         const int value = atoi(text);
         if (value == 512 || value == 1024) { scene->stageRounds = value / kBlock; }
     }
@@ -1682,7 +1712,7 @@ int pathed_hip_scene_create_ex(const PathedSceneDesc *desc, const PathedSceneOpt
     std::memset(&scene->mfmaFrame, 0, sizeof scene->mfmaFrame);
     if (scene->bruteForce && scene->fusedPath) {
         int phase1 = options.small_phase1;
-        if (const char *text = getenv("PATHED_SMALL_PHASE1")) {
+        if (const char *text = tuningEnv("PATHED_SMALL_PHASE1")) {
             if (!strcmp(text, "valu")) { phase1 = 1; } else if (!strcmp(text, "mfma")) { phase1 = 2; }
         }
         if (phase1 == 0) { phase1 = kDefaultSmallPhase1; }
@@ -1696,7 +1726,7 @@ int pathed_hip_scene_create_ex(const PathedSceneDesc *desc, const PathedSceneOpt
     }
     scene->unitOrder = unitOrderFromEnvironment(options.unit_order == 2 ? kOrderStripesTiled : options.unit_order == 3 ? kOrderTiles : kOrderStripes);
     if (options.max_slots >= kBlock) { scene->maxSlots = options.max_slots; scene->adaptiveSlots = false; }
-    if (const char *slots = getenv("PATHED_MAX_SLOTS")) {
+    if (const char *slots = tuningEnv("PATHED_MAX_SLOTS")) {
         const long value = atol(slots);
         if (value >= kBlock) { scene->maxSlots = (int)value; scene->adaptiveSlots = false; }
     }
@@ -2317,7 +2347,8 @@ int pathed_hip_render_device(PathedScene *scene, uint64_t seed,
         const unsigned long long cap = (1ull << 30) / (pixels ? pixels : 1ull);   // 2^30 partial sums = 17 GB
         if ((unsigned long long)chunksPerPass > cap) { chunksPerPass = cap >= 1ull ? (int)cap : 1; }
     }
-    if (const char *text = getenv("PATHED_CHUNKS_PER_PASS")) {   // tuning: fewer, longer passes at the cost of a larger partial-sum buffer
+    if (scene->options.chunks_per_pass > 0) { chunksPerPass = scene->options.chunks_per_pass; }
+    if (const char *text = tuningEnv("PATHED_CHUNKS_PER_PASS")) {   // tuning: fewer, longer passes at the cost of a larger partial-sum buffer
         const int value = atoi(text);
         if (value >= 1 && value <= 4096) { chunksPerPass = value; }
     }
@@ -2541,9 +2572,15 @@ int pathed_hip_scene_refit(PathedScene *scene, const float *positions, const flo
     if (status == hipSuccess) { status = hipEventElapsedTime(&ms, start, stop); }
     if (status == hipSuccess) { status = hipMemcpy(&rootReady, scene->refitReady.ptr + (size_t)(passes & 1) * nNodes, 1, hipMemcpyDeviceToHost); }
     while (status == hipSuccess && !rootReady && passes < 4096) {
-        // (a tree deeper than its recorded depth: keep going, four passes per look at the root's flag)
-        runPasses(4);
-        status = hipGetLastError();
+        // (a tree deeper than its recorded depth: keep going, four passes per look at the root's flag; their device time
+        // joins device_ms)
+        float extra = 0.f;
+        status = hipEventRecord(start, nullptr);
+        if (status == hipSuccess) { runPasses(4); status = hipGetLastError(); }
+        if (status == hipSuccess) { status = hipEventRecord(stop, nullptr); }
+        if (status == hipSuccess) { status = hipEventSynchronize(stop); }
+        if (status == hipSuccess) { status = hipEventElapsedTime(&extra, start, stop); }
+        ms += extra;
         if (status == hipSuccess) { status = hipMemcpy(&rootReady, scene->refitReady.ptr + (size_t)(passes & 1) * nNodes, 1, hipMemcpyDeviceToHost); }
     }
     (void)hipEventDestroy(start);
@@ -2608,7 +2645,7 @@ int pathed_hip_get_stats(PathedScene *scene, PathedStats *out)
     out->bvh_builder = (uint32_t)scene->bvhBuilder;
     out->trace_launches_all = (uint32_t)scene->traceLaunchesAll;
     out->path_kernel = usesVolumeKernel(scene) ? 4u : scene->fusedPath ? 3u : scene->lastCallWave ? 6u : scene->splitShade ? 5u : (scene->stagedShade ? 2u : 1u);
-    if (getenv("PATHED_SHADE_PROFILE")) {   // counters exist in -DPATHED_SHADE_PROFILE builds only
+    if (tuningEnv("PATHED_SHADE_PROFILE")) {   // counters exist in -DPATHED_SHADE_PROFILE builds only
         static const char *regions[11] = { "all waves", "active slots", "makeIsect (hit)", "camera-ray vertex", "finish previous MIS term",
                                            "new vertex: BSDF sample", "light sampling", "sample finished", "startSample (regeneration)", "shadow ray pushed",
                                            "BSDF sample with black throughput" };
@@ -2618,7 +2655,7 @@ int pathed_hip_get_stats(PathedScene *scene, PathedStats *out)
                     device[kStatShadeProfile] ? (double)waves / (double)device[kStatShadeProfile] : 0.0, waves ? (double)lanes / (double)waves : 0.0);
         }
     }
-    if (getenv("PATHED_FUSED_PROFILE")) {   // the same counters in k_path_small (-DPATHED_SHADE_PROFILE builds)
+    if (tuningEnv("PATHED_FUSED_PROFILE")) {   // the same counters in k_path_small (-DPATHED_SHADE_PROFILE builds)
         static const char *regions[9] = { "iterations (live lanes)", "camera ray", "passes with shadow rays (lanes with one)", "makeIsect (hit)",
                                           "camera-ray vertex", "BSDF sample met an emitter: lightsPDF", "new vertex: BSDF sample", "light sampling",
                                           "sample finished" };
@@ -2634,7 +2671,7 @@ int pathed_hip_get_stats(PathedScene *scene, PathedStats *out)
                     device[kStatShadeProfile] ? (double)turns / (double)device[kStatShadeProfile] : 0.0, turns ? (double)candidates / (double)turns : 0.0);
         }
     }
-    if (getenv("PATHED_WAVE_PROFILE")) {   // k_path_wave (-DPATHED_SHADE_PROFILE builds, tools/wave_profile.py)
+    if (tuningEnv("PATHED_WAVE_PROFILE")) {   // k_path_wave (-DPATHED_SHADE_PROFILE builds, tools/wave_profile.py)
         const unsigned long long *v = device + kStatShadeProfile;
         const double iterations = v[0] ? (double)v[0] : 1.0, cycles = v[8] ? (double)v[8] : 1.0;
         fprintf(stderr, "[pathed] k_path_wave: %llu waves, %.0f iterations each, %.1f live paths per iteration\n", v[11], iterations / (double)(v[11] ? v[11] : 1), (double)v[1] / iterations);
@@ -2643,7 +2680,7 @@ int pathed_hip_get_stats(PathedScene *scene, PathedStats *out)
         fprintf(stderr, "[pathed] k_path_wave shade: %.3f of the iterations shade, %.1f paths each\n", (double)v[4] / iterations, v[4] ? (double)v[5] / (double)v[4] : 0.0);
         fprintf(stderr, "[pathed] k_path_wave wave cycles: traversal bursts %.3f, shade + post + regeneration %.3f of the waves' lifetimes\n", (double)v[9] / cycles, (double)v[10] / cycles);
     }
-    if (getenv("PATHED_VOLUME_PROFILE")) {   // the same counters in k_path_volume (-DPATHED_SHADE_PROFILE builds)
+    if (tuningEnv("PATHED_VOLUME_PROFILE")) {   // the same counters in k_path_volume (-DPATHED_SHADE_PROFILE builds)
         static const char *regions[9] = { "samples", "camera-ray query", "bounce-loop iterations", "segment query (no direct lighting before)",
                                           "medium event: occlusion query", "direct lighting at a vertex", "light sample: occlusion query",
                                           "BSDF sample: closest query", "seen through a container: query" };

@@ -96,12 +96,51 @@ int pathed_host_parse_mtl(const char *path, char *out, size_t capacity)
 #include "integrator.h"
 #include "job.h"
 
+#include <algorithm>
 #include <chrono>
 #include <fstream>
 #include <iomanip>
 #include <iostream>
 #include <iterator>
 #include <thread>
+
+// FNV-1a over everything of a loaded scene that a radiance sum depends on (the camera's resolution is in the state header)
+static std::string flatSceneDigest(const PathedSceneDesc &desc)
+{
+    unsigned long long hash = 1469598103934665603ull;
+    auto add = [&](const void *data, size_t bytes) {
+        const unsigned char *p = static_cast<const unsigned char *>(data);
+        for (size_t i = 0; i < bytes; i++) { hash = (hash ^ p[i]) * 1099511628211ull; }
+    };
+    add(desc.camera.origin, sizeof desc.camera.origin); add(desc.camera.target, sizeof desc.camera.target); add(desc.camera.up, sizeof desc.camera.up);
+    add(&desc.camera.vertical_fov, sizeof(float)); add(&desc.camera.flip_handedness, sizeof(int32_t));
+    add(desc.positions, sizeof(float) * 3 * desc.n_vertices);
+    add(desc.normals, sizeof(float) * 3 * desc.n_vertices);
+    add(desc.uvs, sizeof(float) * 2 * desc.n_vertices);
+    add(desc.indices, sizeof(uint32_t) * 3 * desc.n_triangles);
+    add(desc.tri_material, sizeof(int32_t) * desc.n_triangles);
+    add(desc.spheres, sizeof(PathedSphere) * desc.n_spheres);
+    add(desc.geoms, sizeof(PathedGeom) * desc.n_geoms);
+    for (uint32_t i = 0; i < desc.n_materials; i++) {   // field by field: a digest must not read padding
+        const PathedMaterial &m = desc.materials[i];
+        add(&m.type, sizeof m.type); add(&m.albedo_type, sizeof m.albedo_type); add(m.diffuse, sizeof m.diffuse); add(m.emit, sizeof m.emit);
+        add(m.checker_on, sizeof m.checker_on); add(m.checker_off, sizeof m.checker_off); add(m.checker_res, sizeof m.checker_res);
+        add(&m.sigma, sizeof m.sigma); add(&m.alpha, sizeof m.alpha); add(&m.ior, sizeof m.ior); add(&m.distribution, sizeof m.distribution); add(&m.texture, sizeof m.texture);
+    }
+    if (desc.env) {
+        add(&desc.env->width, sizeof(int32_t)); add(&desc.env->height, sizeof(int32_t)); add(&desc.env->scale, sizeof(float));
+        add(desc.env->map_to_world, sizeof desc.env->map_to_world);
+        add(desc.env->rgba, sizeof(float) * 4 * (size_t)desc.env->width * (size_t)desc.env->height);
+    }
+    for (uint32_t i = 0; i < desc.n_textures; i++) {
+        add(&desc.textures[i].width, sizeof(int32_t)); add(&desc.textures[i].height, sizeof(int32_t));
+        add(desc.textures[i].rgb, (size_t)3 * desc.textures[i].width * desc.textures[i].height);
+    }
+    add(desc.media, sizeof(PathedMedium) * desc.n_media);
+    char text[32];
+    snprintf(text, sizeof text, "%016llx", hash);
+    return text;
+}
 
 int runJob(const std::string &jobPath, const std::string &assetRootOverride)
 {
@@ -118,8 +157,28 @@ int runJob(const std::string &jobPath, const std::string &assetRootOverride)
         std::string builder = job.bvhBuilder();
         if (builder != "auto" && builder != "sah" && builder != "lbvh" && builder != "ploc") { throw std::runtime_error("job: unknown bvh_builder: " + builder); }
         const std::vector<int> devices = job.devices();
+        const std::string reduce = job.reduceMethod();
+        if (reduce != "rccl" && reduce != "peer-copy") { throw std::runtime_error("job: \"reduce\" must be \"rccl\" or \"peer-copy\""); }
+        // Several DISTINCT devices and "reduce": "rccl" (the default): the communicator is made first, before the scene is
+        // loaded and N trees are built -- a node whose RCCL / xGMI is broken stops the job here, in its first second.
+        // (Replicas that share a device, how the fan-out is rehearsed on a one-GPU box, cannot form one: peer copies, decided
+        // in Integrator::run.)
+        PathedComm *earlyComm = nullptr;
+        {
+            std::vector<int> ids = devices;
+            std::sort(ids.begin(), ids.end());
+            const bool distinct = std::adjacent_find(ids.begin(), ids.end()) == ids.end();
+            if (devices.size() > 1 && distinct && reduce == "rccl") {
+                if (pathed_hip_comm_init((int)devices.size(), devices.data(), &earlyComm) != PATHED_OK) {
+                    throw std::runtime_error("job asks for the RCCL reduce over " + std::to_string(devices.size()) + " distinct GPUs and RCCL is unavailable: "
+                                             + std::string(pathed_hip_last_error()) + " (set \"reduce\": \"peer-copy\" to use peer copies)");
+                }
+            }
+        }
+        struct CommGuard { PathedComm *&comm; ~CommGuard() { if (comm) { pathed_hip_comm_destroy(comm); } } } commGuard{ earlyComm };
         const auto loadBegin = std::chrono::steady_clock::now();
         FlatScene flat = loadScene(job.scene(), width, height, assetRoot);
+        const std::string sceneDigest = flatSceneDigest(flat.desc());
         if (builder == "auto") {
             // several replicas of a large mesh: each GPU builds its own tree in milliseconds (PLOC) instead of N host SAH
             // builds competing for the cores before the first sample (include/pathed_hip.h: PATHED_BVH_*)
@@ -136,18 +195,14 @@ int runJob(const std::string &jobPath, const std::string &assetRootOverride)
         integrator->configure(job.spp(), job.seed(), job.sppPerLaunch(), job.outputDirectory());
         integrator->setStateFile(job.outputDirectory() + "auto.state", job.resume());
         {
-            // what the sums depend on besides resolution, seed and bounce window (those are in the state header): the scene
-            // FILE's bytes (edited in place = another render), where its assets come from, the integrator
-            std::string sceneBytes;
-            for (const std::string &candidate : { assetRoot.empty() ? job.scene() : assetRoot + "/" + job.scene(), job.scene() }) {
-                std::ifstream in(candidate, std::ios::binary);
-                if (in) { sceneBytes.assign(std::istreambuf_iterator<char>(in), std::istreambuf_iterator<char>()); break; }
-            }
-            integrator->setStateIdentity(job.scene() + "|" + job.integratorName() + "|" + assetRoot + "|" + sceneBytes);
+            // what the sums depend on besides resolution, seed and bounce window (those are in the state header): the scene as
+            // LOADED -- every vertex, index, material, sphere, environment texel and texture byte, so a mesh or a map edited in
+            // place is another render -- the integrator, and the BVH builder (hits do not depend on the tree, but "the same job"
+            // should mean the same tree: with "auto" the builder follows the number of GPUs)
+            integrator->setStateIdentity(job.scene() + "|" + job.integratorName() + "|" + assetRoot + "|" + builder + "|" + sceneDigest);
         }
-        const std::string reduce = job.reduceMethod();
-        if (reduce != "rccl" && reduce != "peer-copy") { throw std::runtime_error("job: \"reduce\" must be \"rccl\" or \"peer-copy\""); }
         integrator->setUseRccl(reduce == "rccl");
+        if (earlyComm) { integrator->adoptComm(earlyComm); earlyComm = nullptr; }
         const std::string metricsLevel = job.metricsLevel();
         if (metricsLevel != "full" && metricsLevel != "basic") { throw std::runtime_error("job: \"metrics\" must be \"full\" or \"basic\""); }
 

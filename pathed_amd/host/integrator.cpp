@@ -107,7 +107,7 @@ private:
 // sample" needs no generator state: a resumed run is the straight run, bit for bit, as long as the
 // interruption fell on a batch boundary (it always does: the file is written after a batch).
 struct StateHeader {
-    char magic[8];            // "PATHEDS2"
+    char magic[8];            // "PATHEDS3"
     int32_t width, height;
     int32_t done;             // samples per pixel already in the sums
     int32_t startBounce, lastBounce;
@@ -218,7 +218,8 @@ void Integrator::run(
         if (pathed_hip_accum_alloc(scene.handle(0), floats, &total) != PATHED_OK) { throw std::runtime_error(hipError("pathed_hip_accum_alloc")); }
         // the path's one exchange step as ONE collective (RCCL reduce over xGMI); replicas that share a
         // device, or a machine without librccl, fall back to peer copies + adds on replica 0
-        if (m_useRccl && pathed_hip_comm_init((int)replicas, scene.devices().data(), &comm) != PATHED_OK) {
+        if (m_adoptedComm) { comm = m_adoptedComm; m_adoptedComm = nullptr; }
+        else if (m_useRccl && pathed_hip_comm_init((int)replicas, scene.devices().data(), &comm) != PATHED_OK) {
             comm = nullptr;
             m_metrics.reduceFallback = pathed_hip_last_error();
             // replicas that SHARE a device cannot form a communicator (rehearsals on one GPU): peer copies.  On distinct
@@ -332,7 +333,12 @@ void Integrator::run(
                         radianceLookup[index + 2] / done);
                 }
             }
+            // files: auto.exr + auto-%05dspp.exr at the powers of two, as the reference (src/integrator.cpp:87-92).  The
+            // reference renders ALL primarySamples waves (:42) and its last samples reach no file when the count is not a
+            // power of two; here the end of the run also refreshes auto.exr -- "the latest image" -- so that every sample
+            // rendered is in a file (no numbered checkpoint for it).  python -m pathed_amd.run_job does exactly the same.
             if (checkpoint) { image.saveCheckpoint("auto"); }
+            else if (done == primarySamples) { image.save("auto"); }
             saveState(radianceLookup, width, height, done);
         }
 
@@ -362,7 +368,7 @@ void Integrator::saveState(const std::vector<float> &sums, int width, int height
     if (m_statePath.empty()) { return; }
     StateHeader header;
     std::memset(&header, 0, sizeof header);
-    std::memcpy(header.magic, "PATHEDS2", 8);
+    std::memcpy(header.magic, "PATHEDS3", 8);
     header.width = width;
     header.height = height;
     header.done = done;
@@ -388,7 +394,7 @@ int Integrator::loadState(std::vector<float> &sums, int width, int height) const
     if (!in) { return 0; }   // nothing to resume from: start at sample 0
     StateHeader header;
     in.read(reinterpret_cast<char *>(&header), sizeof header);
-    if (!in || std::memcmp(header.magic, "PATHEDS2", 8) != 0) { throw std::runtime_error("resume: " + m_statePath + " is not a pathed state file (of this version)"); }
+    if (!in || std::memcmp(header.magic, "PATHEDS3", 8) != 0) { throw std::runtime_error("resume: " + m_statePath + " is not a pathed state file (of this version)"); }
     if (header.width != width || header.height != height) { throw std::runtime_error("resume: state file has another resolution"); }
     if (header.seed != m_seed || header.startBounce != stateStartBounce() || header.lastBounce != stateLastBounce()) {
         throw std::runtime_error("resume: state file was rendered with another seed or bounce window");

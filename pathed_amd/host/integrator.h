@@ -95,11 +95,16 @@ public:
     // With resume the run continues from it (a missing file means "start at 0").
     void setStateFile(const std::string &path, bool resume) { m_statePath = path; m_resume = resume; }
     // what the sums depend on besides resolution, seed and bounce window (which the state header carries itself): the
-    // caller passes scene path + integrator name + asset root + the scene file's BYTES; a state file of another identity is refused
+    // caller passes scene path + integrator name + asset root + BVH builder + a digest of the LOADED scene (geometry, materials,
+    // environment map, textures: an asset edited in place is another render); a state file of another identity is refused
     void setStateIdentity(const std::string &identity);
     // job key "reduce": "rccl" (default: ONE ncclReduce; an error when RCCL is unavailable on distinct devices, peer copies only
     // for replicas that share a device) or "peer-copy"
     void setUseRccl(bool use) { m_useRccl = use; }
+    // A communicator over the replicas' devices made BEFORE the scene was loaded and its trees were built (runJob does that, so
+    // that a machine without a usable RCCL stops the job in its first second, not after N BVH builds): run() uses it instead
+    // of making its own, and destroys it when it is done.
+    void adoptComm(PathedComm *comm) { m_adoptedComm = comm; }
     const RenderMetrics &metrics() const { return m_metrics; }
 
 protected:
@@ -118,6 +123,7 @@ protected:
     int m_sppPerLaunch = 1024;
     bool m_resume = false;
     bool m_useRccl = true;
+    PathedComm *m_adoptedComm = nullptr;
     unsigned long long m_stateDigest = 0;
     std::string m_statePath;
     std::string m_logPrefix;

@@ -67,7 +67,8 @@ public:
     int gpu() const { return m_json["gpu"].isNumber() ? m_json["gpu"].asInt() : 0; }
     std::string assetRoot() const { return m_json["asset_root"].isString() ? m_json["asset_root"].asString() : ""; }
     std::string bvhBuilder() const { return m_json["bvh_builder"].isString() ? m_json["bvh_builder"].asString() : "auto"; }
-    // fan-in of several devices' sums: "rccl" (one ncclReduce; falls back to peer copies where RCCL cannot be used) | "peer-copy"
+    // fan-in of several devices' sums: "rccl" (ONE ncclReduce; on distinct devices a missing RCCL is an ERROR, raised before the
+    // scene is loaded; only replicas that share a device use peer copies instead) | "peer-copy" (hipMemcpyPeer + add, on request)
     std::string reduceMethod() const { return m_json["reduce"].isString() ? m_json["reduce"].asString() : "rccl"; }
     // metrics.json: "full" (default) adds rays per sample, Mrays/s, algorithmic bytes and the roofline fraction from a
     // one-sample counting pass after the render; "basic" leaves them out

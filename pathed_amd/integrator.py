@@ -66,7 +66,8 @@ class HipScene:
     """A scene uploaded to one GPU (PathedScene handle).
 
     Keyword options map onto PathedSceneOptions (include/pathed_hip.h): stack_rows, pools,
-    suspend_lanes, suspend_patience, park_min_cards, max_slots, build_threads, generic_kernels, intersector ("auto" | "bvh"),
+    suspend_lanes, suspend_patience, park_min_cards, max_slots, build_threads, generic_kernels, refittable, wave_max_ksamples,
+    wave_stragglers, wave_refill, chunks_per_pass, intersector ("auto" | "bvh"),
     trace_blocks_per_cu, shade_kernel ("auto" | "per-slot" | "staged" | "fused" | "split" | "wave"), stage_slots,
     unit_order ("auto" | "stripes" | "stripes-tiled" | "tiles"), node_format ("auto" | "wide" | "compressed" | "compressed8"), small_phase1 ("auto" | "valu" | "mfma").  `device=None` keeps the device of an earlier pathed_hip_init.
     """
@@ -85,7 +86,8 @@ class HipScene:
         packed.node_format = {"auto": 0, "wide": 1, "compressed": 2, "compressed8": 3}[options.pop("node_format", "auto")]
         packed.unit_order = {"auto": 0, "stripes": 1, "stripes-tiled": 2, "tiles": 3}[options.pop("unit_order", "auto")]
         packed.small_phase1 = {"auto": 0, "valu": 1, "mfma": 2}[options.pop("small_phase1", "auto")]
-        for name in ("stack_rows", "pools", "suspend_lanes", "suspend_patience", "park_min_cards", "max_slots", "trace_blocks_per_cu", "stage_slots", "build_threads", "generic_kernels", "refittable"):
+        for name in ("stack_rows", "pools", "suspend_lanes", "suspend_patience", "park_min_cards", "max_slots", "trace_blocks_per_cu", "stage_slots", "build_threads", "generic_kernels", "refittable",
+                     "wave_max_ksamples", "wave_stragglers", "wave_refill", "chunks_per_pass"):
             if name in options:
                 setattr(packed, name, int(options.pop(name)))
         if options:

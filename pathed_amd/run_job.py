@@ -92,16 +92,11 @@ def main(argv=None):
     stream = torch.cuda.current_stream().cuda_stream
 
     # this rank's sums; they keep growing, and are reduced only when an image is due: at the power-of-two
-    # checkpoints (src/integrator.cpp:87-92).  The union over ranks of what has been rendered is always exactly
-    # the samples [0, done).  The reference's loop runs all `spp` waves and saves at the powers of two only
-    # (src/integrator.cpp:42, :87-92); samples past the last power of two would reach no file here, so the loop
-    # stops at the last power of two <= spp instead of rendering them on every rank for nothing.
-    last_power = 1
-    while last_power * 2 <= spp:
-        last_power *= 2
-    if last_power != spp and rank == 0:
-        print("[%s] spp %d is not a power of two: rendering the %d samples of the last checkpoint" % (out_dir, spp, last_power))
-    spp = last_power
+    # checkpoints (src/integrator.cpp:87-92) and at the end.  The union over ranks of what has been rendered is always
+    # exactly the samples [0, done).  Like the reference (src/integrator.cpp:42) and like the C++ host
+    # (pathed_amd/host/integrator.cpp) the loop renders ALL `spp` samples; numbered files appear at the powers of two only,
+    # and when spp is not one the end of the run refreshes auto.exr with all of them -- the same files, sample counts and
+    # timings whichever launcher ran the job.
     accum = torch.zeros((height, width, 3), dtype=torch.float32, device="cuda")
     total = torch.zeros_like(accum)
     done = 0
@@ -116,16 +111,16 @@ def main(argv=None):
             gpu.render_device(seed, begin, mine, bounces.start_bounce, bounces.last_bounce, accum.data_ptr(), stream)
         done += count
         checkpoint = (done & (done - 1)) == 0
-        if checkpoint:   # images are written at the power-of-two sample counts only (src/integrator.cpp:87-92)
+        if checkpoint or done == spp:   # numbered images at the power-of-two sample counts only (src/integrator.cpp:87-92)
             total.copy_(accum)
             parallel.reduce_to_root(total, root=0)
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         if rank == 0:
-            if checkpoint:
+            if checkpoint or done == spp:
                 mean = (total / float(done)).cpu().numpy()
                 pointer = mean.ctypes.data_as(C.POINTER(C.c_float))
-                for name in ("auto.exr", "auto-%05dspp.exr" % done):
+                for name in (("auto.exr", "auto-%05dspp.exr" % done) if checkpoint else ("auto.exr",)):
                     path = os.path.join(out_dir, name)
                     if host.pathed_host_write_exr_half_bgr(path.encode(), width, height, pointer) != 0:
                         raise RuntimeError(host.pathed_host_last_error().decode())

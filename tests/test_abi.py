@@ -78,3 +78,27 @@ def test_product_never_imports_the_oracle():
                 if re.search(r"oracle_lib|liboracle|oracle/|#include\s+\"oracle", text):
                     offenders.append(os.path.join(root, name))
     assert offenders == []
+
+
+def test_product_library_reads_no_tuning_variable_from_the_environment():
+    """35 getenv("PATHED_*") in the product library let a stray variable on a bench box change kernels, slot counts
+    or the builder silently.  Every setting travels in PathedSceneOptions now; the environment is read by the experiments
+    build only (tuningEnv in pathed_hip.hip), apart from two debug prints that change no result."""
+    import re
+    from pathed_amd import _capi
+    source = open(os.path.join(_capi.REPO_ROOT, "pathed_amd", "csrc", "pathed_hip.hip")).read()
+    assert source.count("getenv(") <= 3
+    blob = open(_capi.hip_library_path(), "rb").read()
+    if b"libpathed_hip_experiments" in os.path.basename(_capi.hip_library_path()).encode():
+        return
+    names = set(re.findall(rb"PATHED_[A-Z0-9_]+", blob))
+    assert names <= {b"PATHED_DEBUG_ALLOC", b"PATHED_DEBUG_STATS"}, names
+
+
+def test_bench_refuses_to_run_with_overrides_in_the_environment():
+    import subprocess
+    import sys
+    from pathed_amd import _capi
+    env = dict(os.environ, PATHED_MAX_SLOTS="4096")
+    result = subprocess.run([sys.executable, os.path.join(_capi.REPO_ROOT, "bench.py"), "--steps", "1"], env=env, capture_output=True, text=True)
+    assert result.returncode == 3 and "PATHED_MAX_SLOTS" in result.stderr and "--allow-overrides" in result.stderr

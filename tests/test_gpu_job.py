@@ -86,6 +86,40 @@ def test_python_job_runner_matches_the_executable(tmp_path):
     assert np.allclose(outputs["cpp"], outputs["py"], rtol=1e-3, atol=1e-4)
 
 
+def test_both_launchers_render_every_sample_of_a_count_that_is_no_power_of_two(tmp_path):
+    """spp = 11: the reference runs all 11 waves and saves numbered files at 1, 2, 4, 8 (src/integrator.cpp:42, :87-92).
+    Both launchers do that, and both refresh auto.exr with all 11 samples at the end: same files, same sample counts."""
+    import sys
+    from pathed_amd import _capi
+
+    job = json.load(open(os.path.join(_capi.REPO_ROOT, "jobs", "cornell-c1.json")))
+    job["width"] = job["height"] = 48
+    job["spp"] = 11
+    final, numbered = {}, {}
+    for name in ("cpp", "py"):
+        out_dir = str(tmp_path / name)
+        job["output_directory"] = out_dir
+        job_path = str(tmp_path / (name + ".json"))
+        json.dump(job, open(job_path, "w"))
+        command = ([os.path.join(_capi.REPO_ROOT, "pathed_amd", "bin", "pathed")] if name == "cpp" else [sys.executable, "-m", "pathed_amd.run_job"]) + [job_path, _capi.REPO_ROOT]
+        result = subprocess.run(command, capture_output=True, text=True, cwd=_capi.REPO_ROOT)
+        assert result.returncode == 0, result.stdout + result.stderr
+        assert "sample: 11/11" in result.stdout
+        assert sorted(f for f in os.listdir(out_dir) if f.endswith("spp.exr")) == ["auto-%05dspp.exr" % n for n in (1, 2, 4, 8)]
+        final[name] = _read_exr(os.path.join(out_dir, "auto.exr"))[..., :3]
+        numbered[name] = _read_exr(os.path.join(out_dir, "auto-00008spp.exr"))[..., :3]
+    assert np.allclose(final["cpp"], final["py"], rtol=1e-3, atol=1e-4)
+    # auto.exr holds 11 samples, not the 8 of the last numbered file
+    assert not np.allclose(final["cpp"], numbered["cpp"], rtol=1e-3, atol=1e-4)
+    # ... namely the mean of samples [0, 11) (HALF precision in the file)
+    from pathed_amd.integrator import HipScene
+    from pathed_amd.scene import LoadedScene
+    scene = LoadedScene(job["scene"], 48, 48)
+    mean = HipScene(scene.desc, device=0).render(job.get("seed", 1), 0, 11, job["startBounce"], job["lastBounce"]) / 11.0
+    half = mean[::-1].astype(np.float16).astype(np.float32)   # Image::set flips: EXR row 0 is the top scanline
+    assert np.allclose(final["cpp"], half, rtol=2e-3, atol=2e-3)
+
+
 def test_bvh_builder_job_key_changes_the_build_not_the_image(tmp_path):
     """job.json "bvh_builder": the on-GPU PLOC / LBVH builds give the checkpoint the host SAH build gives,
     byte for byte (hits do not depend on the tree); an unknown name is an error."""
@@ -114,7 +148,7 @@ def test_bvh_builder_job_key_changes_the_build_not_the_image(tmp_path):
 def _read_state(path):
     """<outdir>/auto.state: 48-byte header (magic, w, h, done, startBounce, lastBounce, pad, seed, job digest) + fp32 sums."""
     blob = open(path, "rb").read()
-    assert blob[:8] == b"PATHEDS2"
+    assert blob[:8] == b"PATHEDS3"
     width, height, done, start, last = np.frombuffer(blob, dtype="<i4", count=5, offset=8)
     sums = np.frombuffer(blob, dtype="<f4", offset=48).reshape(height, width, 3)
     return int(done), sums

@@ -1,0 +1,100 @@
+"""The product's timed C4 / C5 path AT ITS OPERATING SIZE, and oracle parity at the configurations' own resolutions.
+
+A render call of at least 48 Mi camera samples on a BVH scene runs the wavefront -- persistent k_trace + per-slot k_shade over
+8 Mi slots, two pools on two streams, tails parked between launches (DESIGN.md sections 4.2 - 4.5; the stage structure of
+reference src/data_parallel_integrator.cpp:307-371 over the queries of src/scene.cpp:91-223).  That is what bench.py's
+large-BVH leg and every C4 / C5 number time, and every other GPU test of those scenes is far below that size (they run
+k_path_wave, or the wavefront with a few thousand slots forced).  Here it runs as the product runs it:
+
+  * one call of >= 48 Mi samples with default options: path_kernel == 1, nothing dropped, the image the SAME BITS as
+    k_path_wave's on the same call (whose arithmetic is pinned against the oracle at small sizes, tests/test_gpu_wave.py) and,
+    with counting on, rays really were parked between launches and the image still has the same bits;
+  * BASELINE configurations 2 - 5 at THEIR resolutions, 16 spp, against the CPU oracle on every core the job may use
+    (reference src/sample_integrator.cpp:80-113 is what both sides restate): relL2 <= 2e-3 and <= 0.1 % of pixels off by more
+    than 1 % (the glass scene: 1e-2 / 1 %), SURVEY.md section 8d's stated tolerance.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+WAVEFRONT_MIN_SAMPLES = 48 << 20   # include/pathed_hip.h: shade_kernel 0
+
+
+@pytest.mark.parametrize("scene_path,width,height,spp,builder", [
+    ("scenes/teapot.json", 1024, 1024, 64, "sah"),                   # C4: 67.1 M camera samples in one call
+    ("assets/dragon-standin-9.json", 1920, 1080, 32, "ploc"),         # C5 (5.2 M triangles): 66.4 M
+])
+def test_the_wavefront_at_its_operating_size_is_the_wave_kernels_image_bit_for_bit(scene_path, width, height, spp, builder):
+    import torch
+    from pathed_amd.integrator import HipScene
+    from pathed_amd.scene import LoadedScene
+    assert width * height * spp >= WAVEFRONT_MIN_SAMPLES
+    scene = LoadedScene(scene_path, width, height)
+
+    product = HipScene(scene.desc, device=0, bvh_builder=builder)     # default options: what bench.py and a job get
+    image = torch.zeros((height, width, 3), dtype=torch.float32, device="cuda")
+    product.render_device(7, 0, spp, 0, 10, image.data_ptr())
+    torch.cuda.synchronize()
+    stats = product.stats()
+    assert stats["path_kernel"] == 1 and stats["scene_in_lds"] == 0          # the wavefront over a tree in HBM / L2
+    assert stats["dropped_samples"] == 0
+    assert stats["camera_samples"] == width * height * spp
+    # 8 Mi slots: a pass of this size is a few dozen iterations of two pools, not thousands of tiny ones
+    assert 8 <= stats["iterations"] <= 400, stats["iterations"]
+    assert torch.isfinite(image).all() and (image >= 0).all() and float(image.sum()) > 0.0
+
+    on_chip = HipScene(scene.desc, device=0, bvh_builder=builder, shade_kernel="wave")
+    expected = torch.zeros_like(image)
+    on_chip.render_device(7, 0, spp, 0, 10, expected.data_ptr())
+    torch.cuda.synchronize()
+    assert on_chip.stats()["path_kernel"] == 6 and on_chip.stats()["dropped_samples"] == 0
+    assert torch.equal(image, expected)
+
+    # the counting instantiations of the same kernels: rays were parked between launches (tails carried over, with their
+    # stacks) and the image has the same bits
+    product.set_stats_mode(count=True)
+    product.reset_stats()
+    counted = torch.zeros_like(image)
+    product.render_device(7, 0, spp, 0, 10, counted.data_ptr())
+    torch.cuda.synchronize()
+    stats = product.stats()
+    assert stats["path_kernel"] == 1 and stats["parked_rays"] > 0 and stats["dropped_samples"] == 0
+    assert stats["closest_rays"] > width * height * spp and stats["shadow_rays"] > 0
+    assert torch.equal(counted, image)
+
+    # a second batch continues the sums exactly as the on-chip kernel continues them
+    product.set_stats_mode(count=False)
+    product.render_device(7, spp, spp, 0, 10, image.data_ptr())
+    on_chip.render_device(7, spp, spp, 0, 10, expected.data_ptr())
+    torch.cuda.synchronize()
+    assert torch.equal(image, expected)
+
+
+@pytest.mark.parametrize("name,scene_path,width,height,tolerance,bad_pixels", [
+    ("C2", "scenes/cornell.json", 1024, 1024, 2e-3, 1e-3),
+    ("C3", "scenes/mis-pbrt.json", 1024, 1024, 2e-3, 1e-3),
+    ("C4", "scenes/teapot.json", 1024, 1024, 1e-2, 1e-2),
+    ("C5", "assets/dragon-standin-9.json", 1920, 1080, 2e-3, 1e-3),
+])
+def test_oracle_parity_at_the_configurations_own_resolution(name, scene_path, width, height, tolerance, bad_pixels):
+    import oracle_lib
+    from pathed_amd.integrator import HipScene
+    from pathed_amd.scene import LoadedScene
+    spp = 16
+    scene = LoadedScene(scene_path, width, height)
+    builder = "ploc" if scene.n_triangles > 1000000 else "sah"
+    gpu = HipScene(scene.desc, device=0, bvh_builder=builder)
+    image = gpu.render(1, 0, spp, 0, 10)
+    assert gpu.stats()["dropped_samples"] == 0
+    expected, oracle_stats = oracle_lib.OracleScene(scene.desc).render(width, height, 1, 0, spp, 0, 10, threads=oracle_lib.host_threads())
+    assert oracle_stats["camera_samples"] == width * height * spp
+    rel = float(np.linalg.norm(image - expected) / np.linalg.norm(expected))
+    bad = float((np.abs(image - expected) > 1e-2 * np.maximum(np.abs(expected), 1e-3)).any(axis=2).mean())
+    print("%s %dx%d x %d spp: relL2 %.2e, pixels off by > 1 %%: %.2e" % (name, width, height, spp, rel, bad))
+    assert rel <= tolerance and bad <= bad_pixels, (name, rel, bad)
+    if gpu.stats()["path_kernel"] == 6:
+        # a call of this size on a BVH scene runs k_path_wave; the wavefront gives the same bits at this resolution too
+        wavefront = HipScene(scene.desc, device=0, bvh_builder=builder, shade_kernel="per-slot")
+        assert np.array_equal(wavefront.render(1, 0, spp, 0, 10), image)
+        assert wavefront.stats()["path_kernel"] == 1

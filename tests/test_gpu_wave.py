@@ -41,22 +41,27 @@ def test_call_size_picks_the_kernel_and_the_straggler_bound_changes_nothing(monk
     automatic = HipScene(scene.desc, device=0)
     expected = automatic.render(3, 0, 6, 0, 10)
     assert automatic.stats()["path_kernel"] == 6          # 74 k camera samples: far below the 48 Mi where the wavefront takes over
-    monkeypatch.setenv("PATHED_WAVE_MAX_SAMPLES", "1000")
-    long_call = HipScene(scene.desc, device=0)
+    long_call = HipScene(scene.desc, device=0, wave_max_ksamples=1)   # ... unless the scene says 1 024
     assert np.array_equal(long_call.render(3, 0, 6, 0, 10), expected)
     assert long_call.stats()["path_kernel"] == 1
-    monkeypatch.delenv("PATHED_WAVE_MAX_SAMPLES")
+    # the product library reads no tuning variable from the environment (include/pathed_hip.h: PathedSceneOptions)
+    from conftest import has_experiments
+    if not has_experiments():
+        monkeypatch.setenv("PATHED_WAVE_MAX_SAMPLES", "1000")
+        monkeypatch.setenv("PATHED_SHADE_KERNEL", "per-slot")
+        deaf = HipScene(scene.desc, device=0)
+        assert np.array_equal(deaf.render(3, 0, 6, 0, 10), expected) and deaf.stats()["path_kernel"] == 6
+        monkeypatch.delenv("PATHED_WAVE_MAX_SAMPLES")
+        monkeypatch.delenv("PATHED_SHADE_KERNEL")
     # counting is the wavefront kernels': stats mode renders there, with the same image
     counting = HipScene(scene.desc, device=0)
     counting.set_stats_mode(count=True)
     assert np.array_equal(counting.render(3, 0, 6, 0, 10), expected)
     stats = counting.stats()
     assert stats["path_kernel"] == 1 and stats["closest_rays"] > 0
-    for stragglers in ("0", "1", "64"):   # never leave rays in flight / ... / leave whatever is in flight once the list is dealt
-        monkeypatch.setenv("PATHED_WAVE_STRAGGLERS", stragglers)
-        gpu = HipScene(scene.desc, device=0, shade_kernel="wave")
+    for stragglers, refill in ((-1, 0), (1, 16), (64, 64)):   # never leave rays in flight / ... / leave whatever is in flight once the list is dealt
+        gpu = HipScene(scene.desc, device=0, shade_kernel="wave", wave_stragglers=stragglers, wave_refill=refill)
         assert np.array_equal(gpu.render(3, 0, 6, 0, 10), expected), stragglers
-    monkeypatch.delenv("PATHED_WAVE_STRAGGLERS")
 
 
 def test_wave_kernel_is_refused_where_it_does_not_apply():

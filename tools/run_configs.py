@@ -86,7 +86,8 @@ def main():
         rays = counted["closest_rays"] + counted["shadow_rays"]
         alg = 48 * counted["closest_rays"] + 36 * counted["shadow_rays"] + 32 * counted["nodes_visited"] + 48 * counted["tris_tested"]
         alg_total = alg * spp / count_spp
-        fused = counted["path_kernel"] in (3, 4, 6)   # one kernel carries the whole path: there is no separate trace kernel to rate
+        # what the TIMED call ran (count mode never takes k_path_wave; PathedStats.path_kernel is the last render call's)
+        fused = timed["path_kernel"] in (3, 4, 6)   # one kernel carries the whole path: there is no separate trace kernel to rate
         gbs = alg_total / (timed["trace_ms"] * 1e-3) / 1e9 if timed["trace_ms"] and not fused else 0.0
 
         # CPU oracle rate at the same resolution
@@ -124,7 +125,7 @@ def main():
             "trace_Grays_s": round(rays * spp / count_spp / timed["trace_ms"] / 1e6, 2) if timed["trace_ms"] and not fused else None,
             "trace_algorithmic_GBs": round(gbs, 0) if not fused else None, "frac_of_8TBs": round(gbs / 8000.0, 3) if not fused else None,
             "intersector": ["BVH in HBM", "BVH in LDS", "all triangles (scalar loads)"][counted["scene_in_lds"]],
-            "path_kernel": ["", "wavefront: k_trace + k_shade", "wavefront: k_trace + k_shade_staged", "fused: k_path_small", "volume: k_path_volume", "wavefront: k_trace + k_vertex + k_regen", "wave: k_path_wave"][counted["path_kernel"]],
+            "path_kernel": ["", "wavefront: k_trace + k_shade", "wavefront: k_trace + k_shade_staged", "fused: k_path_small", "volume: k_path_volume", "wavefront: k_trace + k_vertex + k_regen", "wave: k_path_wave"][timed["path_kernel"]],
             "cpu_oracle_Msamples_s": round(w * h * cpu_spp / cpu_elapsed / 1e6, 2), "cpu_cores": cores,
             "relL2_vs_oracle_%dx%d_16spp" % (pw, ph): "%.2e" % relative_l2(image, expected),
             "mean_rgb": [round(float(v), 4) for v in (accum / spp).mean(dim=(0, 1)).tolist()],
