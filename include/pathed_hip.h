@@ -217,7 +217,8 @@ typedef struct PathedStats {
                                       3 fused path kernel (tiny scenes: one persistent launch per pass, timed as trace_ms),
                                       4 volume path kernel (PATHED_INTEGRATOR_VOLUME_PATH_TRACER),
                                       5 wavefront with the split shade stage (k_vertex + k_regen over the trace kernel's lists),
-                                      6 wave path kernel (BVH scenes, the last render call) */
+                                      6 wave path kernel (BVH scenes, the last render call),
+                                      7 hybrid path kernel (scenes of 65 .. 4096 triangles, the last render call) */
     uint32_t reserved0;
 } PathedStats;
 
@@ -281,9 +282,13 @@ typedef struct PathedSceneOptions {
                                    <= 64 triangles only, their default); 4 wavefront, k_vertex + k_regen over the hit / miss
                                    lists the trace kernel writes (BVH scenes only); 5 k_path_wave (BVH scenes of <= 96 materials:
                                    paths in registers, the wave's rays shared through LDS, no path state in HBM) for every call.
-                                   0 on a BVH scene: k_path_wave for calls of fewer than 48 Mi camera samples, whose rate hardly
-                                   depends on the call's size, the wavefront (1) for longer ones (trees of up to 36 KB, which the
-                                   wavefront would copy into LDS: k_path_wave at every length); images are identical */
+                                   6 k_path_hybrid (sphere-free scenes of 65 .. 4096 triangles, <= 96 materials: the <= 64 largest
+                                   triangles through the all-items intersector, the rest through a tree of their own, paths in
+                                   registers).
+                                   0 on a BVH scene: k_path_hybrid where it applies; else k_path_wave for calls of fewer than 48 Mi
+                                   camera samples, whose rate hardly depends on the call's size, the wavefront (1) for longer ones
+                                   (trees of up to 36 KB, which the wavefront would copy into LDS: k_path_wave at every length);
+                                   images are identical */
     int32_t stage_slots;        /* slots per block of the staged kernel: 512 or 1024 (0 = automatic)           */
     int32_t unit_order;         /* order work units are handed out in (scheduling only, results identical):
                                  * 0 automatic = 1; 1 chunk stripes, rows; 2 chunk stripes, 32 x 8 tiles; 3 pixel tiles */
@@ -302,10 +307,10 @@ typedef struct PathedSceneOptions {
                                    device so that pathed_hip_scene_refit can move the vertices later; BVH scenes only */
     int32_t wave_max_ksamples;  /* shade_kernel 0 on a BVH scene: render calls of fewer than this many x 1024 camera samples run
                                    k_path_wave, longer ones the wavefront (0 = 49 152, i.e. 48 Mi samples) */
-    int32_t wave_stragglers;    /* k_path_wave: a traversal burst ends once the wave's list is dealt and fewer rays than this are
-                                   still in flight, 1..64; -1 = every ray is finished first (0 = 24).  Scheduling only */
-    int32_t wave_refill;        /* k_path_wave: idle lanes draw from the wave's ray list once fewer than this many are busy,
-                                   1..64 (0 = 48).  Scheduling only */
+    int32_t wave_stragglers;    /* k_path_wave / k_path_hybrid: a traversal burst ends once the wave's list is dealt and fewer rays
+                                   than this are still in flight, 1..64; -1 = every ray is finished first (0 = 24 / 16).  Scheduling only */
+    int32_t wave_refill;        /* k_path_wave / k_path_hybrid: idle lanes draw from the wave's ray list once fewer than this many are
+                                   busy, 1..64 (0 = 48 / 40).  Scheduling only */
     int32_t chunks_per_pass;    /* work units per pixel of one internal pass, 1..4096 (0 = 256, fewer at resolutions whose partial
                                    sums would not fit): longer passes amortise a pass's ramp-up and drain, at 16 bytes per unit */
 } PathedSceneOptions;

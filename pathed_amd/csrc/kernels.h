@@ -215,6 +215,12 @@ struct RenderParams {
     float smallKappaT;        // ... and the absolute slack of their t bounds per det^2
     const float *mfmaTable;   // k_path_small<.., MFMA>: the A-side rows of the matrix-pipe phase 1 (mfma_candidates.h), kMfmaTableFloats
     MfmaFrame mfmaFrame;
+    // k_path_hybrid (path_hybrid.h): scene.leafTris holds the DIRECT set in item order (hybridDirectTris of them), the rest of the
+    // scene has a tree of its own whose bounds (padded) are hybridLo / hybridHi
+    const float4 *hybridNodes, *hybridTris;
+    int hybridNodeCount, hybridTreeTris, hybridDirectTris;
+    float hybridLo[3], hybridHi[3];
+    float hybridSphere[4];   // ... and a bounding sphere of the same triangles: centre, radius^2 (padded)
 };
 
 // BounceController, reference src/bounce_controller.cpp:14-25
@@ -2591,6 +2597,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_F
 }
 
 #include "path_wave.h"
+#include "path_hybrid.h"
+static_assert(sizeof(RenderParams) + sizeof(SmallTris) <= 4096, "the fused kernels' arguments must fit the 4 KB kernarg segment");
 
 // Test hook behind pathed_hip_debug_small_candidates: for every ray pair (origin, continuation direction, shadow direction,
 // shadow far bound) the candidate sets of the phase-1 forms and the set phase 2 accepts, one bit per ORIGINAL primitive id

@@ -224,6 +224,7 @@ struct PathedScene {
     int waveMode = 0;
     bool waveAvailable = false;   // ... and the scene is one it serves
     bool lastCallWave = false;    // what the last render call ran (PathedStats.path_kernel)
+    bool lastCallHybrid = false;
     unsigned long long waveMaxSamples = 48ull << 20;   // calls of fewer camera samples than this take it (waveMode 0)
     int waveStragglers = 24;      // its traversal bursts end once fewer rays than this are in flight
     bool waveBlock = false;       // the block's waves share one ray ring (k_path_wave<.., BLOCK>; PATHED_WAVE_BLOCK=1)
@@ -233,6 +234,8 @@ struct PathedScene {
     bool lambertianTriangles = false;   // constant-albedo Lambertian surfaces, triangle lights, no spheres, no environment: k_path_small<.., TraitsLambertianTriangles>
     bool lambertianPlasticSpheres = false;   // the Veach scene's set (shading.h)
     bool triangleLit = false;                // any BSDF, constant albedo, triangle lights only, no spheres, no environment
+    // [r5] ... narrowed further (shading.h: the ladder): rough BSDFs over one microfacet distribution / Lambertian + glass + mirror
+    bool roughBeckmann = false, roughGgx = false, smoothSet = false;
     bool lambertianGlassContainer = false;   // the reference's volume scene's set
     int nodeFormat = 0;                      // what k_trace walks (trace.h): 0 the 128-byte float nodes, 1 nodeQ, 2 node8
     bool envOnly = false;     // the one light is the environment and no material emits: k_shade<.., ENV_ONLY> (kernels.h)
@@ -263,6 +266,17 @@ struct PathedScene {
     DeviceBuffer<float4> refitLo, refitHi;          // unpadded bounds per node (refit working memory, allocated on first use)
     DeviceBuffer<unsigned char> refitReady;         // two flag arrays
     size_t soupVertices = 0;
+    // [r5] k_path_hybrid (path_hybrid.h): scenes of 65 .. kHybridMaxTris triangles split into a DIRECT set of <= 64 large
+    // triangles (all-items intersector) and a TREE part with a 4-wide BVH of its own
+    bool hybridAvailable = false;  // the split exists
+    bool hybridPath = false;       // ... and render calls take it
+    SmallTris hybridItems;         // phase-1 records of the direct set
+    SmallItemsLayout hybridLayout;
+    std::vector<float> hybridDirectLeaf;   // the direct set as the builder's 12-float records (v0, prim) (e1, -) (e2, -)
+    std::vector<float> hybridBounds;       // corners of the scene's bounding box: where else rays start (buildSmallItems' extra points)
+    DeviceBuffer<float4> hybridItemTris, hybridNodes, hybridTris;
+    int hybridNodeCount = 0, hybridTreeTris = 0, hybridDirectTris = 0, hybridMaxStack = 1;
+    float hybridLo[3] = { 0.f, 0.f, 0.f }, hybridHi[3] = { 0.f, 0.f, 0.f }, hybridSphere[4] = { 0.f, 0.f, 0.f, 0.f };
     bool mfmaPhase1 = false;      // k_path_small<.., MFMA>: phase 1 on the matrix pipe (mfma_candidates.h)
     DeviceBuffer<float> mfmaTable;   // its A-side rows
     MfmaFrame mfmaFrame;
@@ -1163,6 +1177,113 @@ static hipError_t rebuildSmallItems(PathedScene *scene)
     return status;
 }
 
+// [r5] the phase-1 records of the hybrid kernel's direct set (they depend on the camera only through the scene's extent)
+static hipError_t rebuildHybridItems(PathedScene *scene)
+{
+    if (!scene->hybridAvailable || scene->hybridDirectTris <= 0) { return hipSuccess; }
+    std::vector<float> points = scene->hybridBounds;
+    for (int a = 0; a < 3; a++) { points.push_back(scene->device.camera.origin[a]); }
+    std::vector<float> ordered;
+    scene->hybridLayout = buildSmallItems(scene->hybridDirectLeaf.data(), scene->hybridDirectTris, points.data(), (int)(points.size() / 3), true, PATHED_TNEAR,
+                                          reinterpret_cast<float *>(scene->hybridItems.data), &ordered);
+    std::vector<float4> records(ordered.size() / 4);
+    std::memcpy(records.data(), ordered.data(), ordered.size() * sizeof(float));
+    return scene->hybridItemTris.upload(records);
+}
+
+// [r5] Splits a scene of 65 .. kHybridMaxTris triangles for k_path_hybrid: the (up to 64) largest triangles -- each at least
+// 1 / 256 of the scene's surface: walls, floors, boxes, what most rays hit and what no box around it would cull -- are tested
+// directly; everything else gets a tree of its own (the host SAH builder, the node format of the scene's tree).
+static hipError_t buildHybrid(PathedScene *scene, const PathedSceneDesc *desc)
+{
+    const uint32_t n = desc->n_triangles;
+    std::vector<double> area(n);
+    double total = 0.0;
+    double lo[3] = { 1e300, 1e300, 1e300 }, hi[3] = { -1e300, -1e300, -1e300 };
+    for (uint32_t i = 0; i < n; i++) {
+        const float *a = desc->positions + 3 * (size_t)desc->indices[3 * i], *b = desc->positions + 3 * (size_t)desc->indices[3 * i + 1], *c = desc->positions + 3 * (size_t)desc->indices[3 * i + 2];
+        const double e1[3] = { (double)b[0] - a[0], (double)b[1] - a[1], (double)b[2] - a[2] }, e2[3] = { (double)c[0] - a[0], (double)c[1] - a[1], (double)c[2] - a[2] };
+        const double cx = e1[1] * e2[2] - e1[2] * e2[1], cy = e1[2] * e2[0] - e1[0] * e2[2], cz = e1[0] * e2[1] - e1[1] * e2[0];
+        area[i] = 0.5 * std::sqrt(cx * cx + cy * cy + cz * cz);
+        total += area[i];
+        for (const float *v : { a, b, c }) { for (int x = 0; x < 3; x++) { lo[x] = std::min(lo[x], (double)v[x]); hi[x] = std::max(hi[x], (double)v[x]); } }
+    }
+    std::vector<uint32_t> order(n);
+    for (uint32_t i = 0; i < n; i++) { order[i] = i; }
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return area[x] > area[y]; });
+    std::vector<char> isDirect(n, 0);
+    int nDirect = 0;
+    for (uint32_t k = 0; k < n && nDirect < kBruteForceMaxTris; k++) {
+        if (!(area[order[k]] * 256.0 >= total)) { break; }
+        isDirect[order[k]] = 1;
+        nDirect++;
+    }
+    // direct set, in primitive order
+    scene->hybridDirectLeaf.clear();
+    std::vector<uint32_t> treeIndices, treePrim;
+    for (uint32_t i = 0; i < n; i++) {
+        if (!isDirect[i]) {
+            for (int k = 0; k < 3; k++) { treeIndices.push_back(desc->indices[3 * i + k]); }
+            treePrim.push_back(i);
+            continue;
+        }
+        const float *v0 = desc->positions + 3 * (size_t)desc->indices[3 * i], *v1 = desc->positions + 3 * (size_t)desc->indices[3 * i + 1], *v2 = desc->positions + 3 * (size_t)desc->indices[3 * i + 2];
+        float record[12];
+        for (int a = 0; a < 3; a++) { record[a] = v0[a]; record[4 + a] = v1[a] - v0[a]; record[8 + a] = v2[a] - v0[a]; }   // as bvh_build.h writes them
+        bvh_detail::putInt(record + 3, (int)i);
+        record[7] = 0.f; record[11] = 0.f;
+        scene->hybridDirectLeaf.insert(scene->hybridDirectLeaf.end(), record, record + 12);
+    }
+    scene->hybridDirectTris = nDirect;
+    scene->hybridTreeTris = (int)treePrim.size();
+    scene->hybridBounds.clear();
+    for (int corner = 0; corner < 8; corner++) {
+        for (int a = 0; a < 3; a++) { scene->hybridBounds.push_back((float)(((corner >> a) & 1) ? hi[a] : lo[a])); }
+    }
+    scene->hybridNodeCount = 0;
+    scene->hybridMaxStack = 1;
+    hipError_t status = hipSuccess;
+    if (!treePrim.empty()) {
+        FlatBvh tree = buildBvh(desc->positions, treeIndices.data(), (uint32_t)treePrim.size(), nullptr, 0, scene->options.build_threads);
+        // the builder numbered the part's triangles 0 .. : back to the scene's primitive ids (shading records, lights)
+        for (size_t k = 0; k < treePrim.size(); k++) {
+            int sub;
+            std::memcpy(&sub, &tree.leafTris[12 * k + 3], 4);
+            bvh_detail::putInt(&tree.leafTris[12 * k + 3], (int)treePrim[(size_t)sub]);
+        }
+        std::vector<float4> nodes(tree.nodes.size() / 4), tris(tree.leafTris.size() / 4);
+        std::memcpy(nodes.data(), tree.nodes.data(), tree.nodes.size() * sizeof(float));
+        std::memcpy(tris.data(), tree.leafTris.data(), tree.leafTris.size() * sizeof(float));
+        if ((status = scene->hybridNodes.upload(nodes)) != hipSuccess) { return status; }
+        if ((status = scene->hybridTris.upload(tris)) != hipSuccess) { return status; }
+        scene->hybridNodeCount = tree.nodeCount;
+        scene->hybridMaxStack = 3 * tree.maxDepth + 1;
+        double tlo[3] = { 1e300, 1e300, 1e300 }, thi[3] = { -1e300, -1e300, -1e300 };
+        for (uint32_t index : treeIndices) {
+            for (int a = 0; a < 3; a++) { tlo[a] = std::min(tlo[a], (double)desc->positions[3 * (size_t)index + a]); thi[a] = std::max(thi[a], (double)desc->positions[3 * (size_t)index + a]); }
+        }
+        double extent = 0.0;
+        for (int a = 0; a < 3; a++) { extent = std::max(extent, std::max(thi[a] - tlo[a], std::max(std::fabs(tlo[a]), std::fabs(thi[a])))); }
+        for (int a = 0; a < 3; a++) {   // padded: the proxy test is a cull, the walk's own slab tests decide
+            scene->hybridLo[a] = (float)(tlo[a] - 1e-4 * extent - 1e-30);
+            scene->hybridHi[a] = (float)(thi[a] + 1e-4 * extent + 1e-30);
+        }
+        // a bounding sphere about the box's centre (not the smallest one: the vertex farthest from that centre decides)
+        double centre[3], radius2 = 0.0;
+        for (int a = 0; a < 3; a++) { centre[a] = (double)(float)(0.5 * (tlo[a] + thi[a])); }
+        for (uint32_t index : treeIndices) {
+            double d2 = 0.0;
+            for (int a = 0; a < 3; a++) { const double d = (double)desc->positions[3 * (size_t)index + a] - centre[a]; d2 += d * d; }
+            radius2 = std::max(radius2, d2);
+        }
+        const double radius = std::sqrt(radius2) * 1.0001 + 1e-4 * extent + 1e-30;
+        for (int a = 0; a < 3; a++) { scene->hybridSphere[a] = (float)centre[a]; }
+        scene->hybridSphere[3] = (float)(radius * radius * 1.00001);
+    }
+    scene->hybridAvailable = true;
+    return rebuildHybridItems(scene);
+}
+
 int pathed_hip_scene_create_ex(const PathedSceneDesc *desc, const PathedSceneOptions *optionsIn, PathedScene **out)
 {
     if (!out) { return fail(PATHED_E_INVALID, "out pointer is null"); }
@@ -1185,7 +1306,7 @@ int pathed_hip_scene_create_ex(const PathedSceneDesc *desc, const PathedSceneOpt
             return fail(PATHED_E_INVALID, "stack_rows must be 0, 8, 16 or 22");
         }
         if (options.max_slots < 0 || (options.max_slots != 0 && options.max_slots < kBlock)) { return fail(PATHED_E_INVALID, "max_slots must be 0 or >= 256"); }
-        if (options.shade_kernel < 0 || options.shade_kernel > 5) { return fail(PATHED_E_INVALID, "shade_kernel must be 0..5"); }
+        if (options.shade_kernel < 0 || options.shade_kernel > 6) { return fail(PATHED_E_INVALID, "shade_kernel must be 0..6"); }
         if (options.stage_slots != 0 && options.stage_slots != 512 && options.stage_slots != 1024) { return fail(PATHED_E_INVALID, "stage_slots must be 0, 512 or 1024"); }
         if (options.refittable != 0 && options.refittable != 1) { return fail(PATHED_E_INVALID, "refittable must be 0 or 1"); }
         if (options.small_phase1 < 0 || options.small_phase1 > 2) { return fail(PATHED_E_INVALID, "small_phase1 must be 0 (automatic), 1 (VALU) or 2 (matrix pipe)"); }
@@ -1568,6 +1689,19 @@ int pathed_hip_scene_create_ex(const PathedSceneDesc *desc, const PathedSceneOpt
             noContainer = noContainer && desc->materials[i].type != PATHED_MAT_PASSTHROUGH;
         }
         scene->triangleLit = constantAlbedo && noContainer && desc->env == nullptr && desc->n_spheres == 0 && narrow;
+        {
+            unsigned kinds = 0u, distributions = 0u;
+            for (uint32_t i = 0; i < desc->n_materials; i++) {
+                const int type = desc->materials[i].type;
+                kinds |= 1u << type;
+                if (type == PATHED_MAT_MICROFACET || type == PATHED_MAT_PLASTIC) { distributions |= desc->materials[i].distribution == PATHED_DIST_GGX ? 2u : 1u; }
+            }
+            const unsigned rough = (1u << PATHED_MAT_LAMBERTIAN) | (1u << PATHED_MAT_OREN_NAYAR) | (1u << PATHED_MAT_MICROFACET) | (1u << PATHED_MAT_PLASTIC);
+            const unsigned smooth = (1u << PATHED_MAT_LAMBERTIAN) | (1u << PATHED_MAT_GLASS) | (1u << PATHED_MAT_MIRROR);
+            scene->roughBeckmann = scene->triangleLit && (kinds & ~rough) == 0u && (distributions & 2u) == 0u;
+            scene->roughGgx = scene->triangleLit && (kinds & ~rough) == 0u && distributions == 2u;
+            scene->smoothSet = scene->triangleLit && (kinds & ~smooth) == 0u;
+        }
         bool glassContainer = desc->env == nullptr;
         for (uint32_t i = 0; i < desc->n_materials; i++) {
             const int type = desc->materials[i].type;
@@ -1664,8 +1798,22 @@ int pathed_hip_scene_create_ex(const PathedSceneDesc *desc, const PathedSceneOpt
     if (const char *text = tuningEnv("PATHED_VERTEX_GRID")) { const int value = atoi(text); if (value >= 1 && value <= 65536) { scene->vertexGrid = value; } }
     if (const char *text = tuningEnv("PATHED_REGEN_GRID")) { const int value = atoi(text); if (value >= 1 && value <= 65536) { scene->regenGrid = value; } }
     scene->fusedPath = scene->bruteForce && (shadeKernel == 0 || shadeKernel == 3);
-    scene->waveMode = shadeKernel == 5 ? 2 : shadeKernel == 0 ? 0 : 1;
+    scene->waveMode = shadeKernel == 5 ? 2 : (shadeKernel == 0 || shadeKernel == 6) ? 0 : 1;
     scene->waveAvailable = !scene->bruteForce && scene->device.nMaterials <= kMaxLdsMaterials && scene->nodeFormat == 0;
+    {
+        // [r5] k_path_hybrid: BVH scenes small enough that a handful of large triangles carry most of the hits (path_hybrid.h)
+        const bool eligible = !scene->bruteForce && desc->n_triangles <= (uint32_t)kHybridMaxTris && desc->n_spheres == 0
+            && scene->device.nMaterials <= kMaxLdsMaterials && scene->nodeFormat == 0 && options.intersector != 1 && !scene->hasContainers
+            && !options.refittable;   // (a refittable scene keeps ONE tree, the one pathed_hip_scene_refit moves)
+        if (shadeKernel == 6 && !eligible) {
+            delete scene;
+            return fail(PATHED_E_INVALID, "the hybrid path kernel serves sphere-free scenes of 65 .. 4096 triangles and at most 96 materials (intersector 0)");
+        }
+        if (eligible && (shadeKernel == 0 || shadeKernel == 6)) {
+            if ((status = buildHybrid(scene, desc)) != hipSuccess) { return fail_cleanup(status, "build the hybrid kernel's scene split"); }
+            scene->hybridPath = true;
+        }
+    }
     if (shadeKernel == 5 && !scene->waveAvailable) {
         delete scene;
         return fail(PATHED_E_INVALID, "the wave path kernel serves BVH scenes (more than 64 triangles or intersector 1) of at most 96 materials over the float nodes");
@@ -1896,6 +2044,12 @@ static int renderPassFused(PathedScene *scene, uint64_t seed, uint32_t begin, ui
         } else if (scene->lambertianPlasticSpheres) {
             if (scene->countMode) { hipLaunchKernelGGL((k_path_small<true, true, TraitsLambertianPlasticSpheres, false, true>), grid, block, lds, stream, params, scene->smallItems); }
             else { hipLaunchKernelGGL((k_path_small<true, false, TraitsLambertianPlasticSpheres, false, true>), grid, block, lds, stream, params, scene->smallItems); }
+        } else if (scene->roughBeckmann && !scene->countMode) {
+            hipLaunchKernelGGL((k_path_small<true, false, TraitsRoughBeckmann, false, true>), grid, block, lds, stream, params, scene->smallItems);
+        } else if (scene->roughGgx && !scene->countMode) {
+            hipLaunchKernelGGL((k_path_small<true, false, TraitsRoughGgx, false, true>), grid, block, lds, stream, params, scene->smallItems);
+        } else if (scene->smoothSet && !scene->countMode) {
+            hipLaunchKernelGGL((k_path_small<true, false, TraitsSmooth, false, true>), grid, block, lds, stream, params, scene->smallItems);
         } else if (scene->triangleLit && !scene->countMode) {
             hipLaunchKernelGGL((k_path_small<true, false, TraitsTriangleLit, false, true>), grid, block, lds, stream, params, scene->smallItems);
         } else {
@@ -2096,6 +2250,7 @@ static int renderPassWave(PathedScene *scene, uint64_t seed, uint32_t begin, uin
     else
 #endif
     if (scene->envOnly && scene->device.nSpheres == 0 && !scene->hasContainers) { hipLaunchKernelGGL((k_path_wave<true, 22, TraitsEnvironmentOnly, false>), grid, dim3(kBlock), lds, stream, params); }
+    else if (scene->smoothSet) { hipLaunchKernelGGL((k_path_wave<true, 22, TraitsSmooth, false>), grid, dim3(kBlock), lds, stream, params); }
     else if (scene->triangleLit) { hipLaunchKernelGGL((k_path_wave<true, 22, TraitsTriangleLit, false>), grid, dim3(kBlock), lds, stream, params); }
     else if (scene->device.nSpheres == 0) { hipLaunchKernelGGL((k_path_wave<true, 22, TraitsAll, false>), grid, dim3(kBlock), lds, stream, params); }
     else { hipLaunchKernelGGL((k_path_wave<true, 22, TraitsAll, true>), grid, dim3(kBlock), lds, stream, params); }
@@ -2103,6 +2258,101 @@ static int renderPassWave(PathedScene *scene, uint64_t seed, uint32_t begin, uin
     scene->traceLaunchesAll++;
     const dim3 pixelGrid((unsigned)((nPixels + kBlock - 1) / kBlock));
     hipLaunchKernelGGL(k_resolve, pixelGrid, dim3(kBlock), 0, stream, params);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(stream));
+
+    scene->iterations += 1;
+    scene->cameraSamples += (unsigned long long)count * (unsigned long long)nPixels;
+    return PATHED_OK;
+}
+
+// One internal pass of the hybrid path kernel (k_path_hybrid, path_hybrid.h): as renderPassFused, one persistent launch.
+static int renderPassHybrid(PathedScene *scene, uint64_t seed, uint32_t begin, uint32_t count,
+                            int start_bounce, int last_bounce, float *d_accum, hipStream_t stream)
+{
+    const int nPixels = scene->width * scene->height;
+    const int chunk = scene->samplesPerUnit;
+    const int chunksPerPixel = (int)((count + (uint32_t)chunk - 1) / (uint32_t)chunk);
+    const unsigned long long nUnits64 = (unsigned long long)nPixels * (unsigned long long)chunksPerPixel;
+    if (nUnits64 >= 0xFFFFFFF0ull) { return fail(PATHED_E_INVALID, "too many work units in one pass"); }
+    const unsigned int nUnits = (unsigned int)nUnits64;
+
+    if (scene->chunkCapacity < (size_t)nUnits) {
+        HIP_TRY(scene->chunkBuf.allocate((size_t)nUnits));
+        scene->chunkCapacity = (size_t)nUnits;
+    }
+    if (!scene->counters.ptr) { HIP_TRY(scene->counters.allocate(kMaxPools * kCtrCount)); }
+    if (!scene->stats.ptr) {
+        HIP_TRY(scene->stats.allocate(kStatCount));
+        HIP_TRY(hipMemset(scene->stats.ptr, 0, kStatCount * sizeof(unsigned long long)));
+    }
+
+    unsigned long long blocks = (unsigned long long)scene->computeUnits * PATHED_HYBRID_WAVES;
+    const unsigned long long blocksNeeded = (nUnits64 + (unsigned long long)kBlock - 1) / kBlock;
+    if (blocks > blocksNeeded) { blocks = blocksNeeded; }
+    if (blocks < 1) { blocks = 1; }
+    const unsigned int waves = (unsigned int)blocks * kWavesPerBlock;
+    const size_t overflowRows = (size_t)(scene->hybridMaxStack > kHybridStackRows ? scene->hybridMaxStack - kHybridStackRows : 0);
+    const size_t overflowInts = (size_t)blocks * kBlock * (overflowRows ? overflowRows : 1);
+    if (scene->volumeOverflow.count < overflowInts) { HIP_TRY(scene->volumeOverflow.allocate(overflowInts)); }
+
+    RenderParams params;
+    std::memset(&params, 0, sizeof params);
+    params.scene = scene->device;
+    params.state.chunkBuf = scene->chunkBuf.ptr;
+    params.counters = scene->counters.ptr;
+    params.stats = scene->stats.ptr;
+    params.stackOverflow = scene->volumeOverflow.ptr;
+    params.maxStack = scene->hybridMaxStack;
+    params.accum = d_accum;
+    params.nPixels = nPixels;
+    if (!fillUnitOrder(params, scene->unitOrder, scene->width, scene->height, chunksPerPixel, 0, 1,
+                       (int)(waves < (unsigned int)kUnitQueues ? waves : (unsigned int)kUnitQueues))) {
+        return fail(PATHED_E_INVALID, "too many work units in one pass");
+    }
+    {
+        const unsigned int wavesPerQueue = (waves + (unsigned int)params.nQueues - 1) / (unsigned int)params.nQueues;
+        unsigned int grab = (nUnits / (unsigned int)params.nQueues) / (wavesPerQueue * 4u);
+        params.unitGrab = (int)(grab < 1u ? 1u : grab > 64u ? 64u : grab);
+    }
+    params.chunk = chunk;
+    params.chunksPerPixel = chunksPerPixel;
+    params.seedLo = (uint32_t)seed;
+    params.seedHi = (uint32_t)(seed >> 32);
+    params.sppBegin = begin;
+    params.sppEnd = begin + count;
+    params.startBounce = start_bounce;
+    params.lastBounce = last_bounce;
+    params.smallQuads = scene->hybridLayout.nQuads;
+    params.smallKappaT = scene->hybridLayout.kappaT;
+    params.scene.leafTris = scene->hybridItemTris.ptr;   // the direct set in item order
+    params.hybridNodes = scene->hybridNodes.ptr;
+    params.hybridTris = scene->hybridTris.ptr;
+    params.hybridNodeCount = scene->hybridNodeCount;
+    params.hybridTreeTris = scene->hybridTreeTris;
+    params.hybridDirectTris = scene->hybridDirectTris;
+    for (int a = 0; a < 3; a++) { params.hybridLo[a] = scene->hybridLo[a]; params.hybridHi[a] = scene->hybridHi[a]; }
+    for (int a = 0; a < 4; a++) { params.hybridSphere[a] = scene->hybridSphere[a]; }
+    // scheduling of its bursts (PathedSceneOptions.wave_stragglers / wave_refill): results do not depend on them
+    params.suspendLanes = scene->options.wave_stragglers != 0 ? (scene->options.wave_stragglers < 0 ? 0 : scene->options.wave_stragglers) : kHybridStragglers;
+    params.suspendPatience = scene->options.wave_refill != 0 ? scene->options.wave_refill : kHybridRefill;
+
+    HIP_TRY(hipMemsetAsync(params.counters, 0, kCtrCount * sizeof(unsigned int), stream));
+    const dim3 grid((unsigned)blocks), block(kBlock);
+    const size_t lds = (size_t)scene->device.nMaterials * sizeof(DMaterial);
+    int timed = -1;
+    if (scene->timeKernels) {
+        timed = scene->traceEvents.acquire();
+        (void)hipEventRecord(scene->traceEvents.start[timed], stream);
+    }
+    // the narrowest instantiation whose compile-time scene set contains this scene's (shading.h: SceneTraits)
+    if (scene->smoothSet) { hipLaunchKernelGGL((k_path_hybrid<TraitsSmooth>), grid, block, lds, stream, params, scene->hybridItems); }
+    else if (scene->triangleLit) { hipLaunchKernelGGL((k_path_hybrid<TraitsTriangleLit>), grid, block, lds, stream, params, scene->hybridItems); }
+    else { hipLaunchKernelGGL((k_path_hybrid<TraitsAll>), grid, block, lds, stream, params, scene->hybridItems); }
+    if (timed >= 0) { (void)hipEventRecord(scene->traceEvents.stop[timed], stream); }
+    scene->traceLaunchesAll++;
+    const dim3 pixelGrid((unsigned)((nPixels + kBlock - 1) / kBlock));
+    hipLaunchKernelGGL(k_resolve, pixelGrid, block, 0, stream, params);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(stream));
 
@@ -2359,7 +2609,10 @@ int pathed_hip_render_device(PathedScene *scene, uint64_t seed,
         && (scene->waveMode == 2 || (scene->waveMode == 0 && (callSamples < scene->waveMaxSamples || scene->sceneInLds)));
     // (trees small enough for the trace kernel's LDS copy -- the Cornell box with its two meshes: k_path_wave, whose node reads
     // hit L1 / L2, is level with the wavefront or 11 % ahead at every length, profiles/r4_ab_wave.log)
-    scene->lastCallWave = wavePath;
+    // [r5] ... and scenes of 65 .. 4096 triangles on the hybrid kernel at every length (counting is the wavefront's)
+    const bool hybridPath = scene->hybridPath && !usesVolumeKernel(scene) && !scene->countMode;
+    scene->lastCallWave = wavePath && !hybridPath;
+    scene->lastCallHybrid = hybridPath;
     uint32_t done = 0;
     while (done < spp_count) {
         const uint32_t count = (spp_count - done < perPass) ? (spp_count - done) : perPass;
@@ -2367,6 +2620,8 @@ int pathed_hip_render_device(PathedScene *scene, uint64_t seed,
             ? renderPassVolume(scene, seed, spp_begin + done, count, start_bounce, last_bounce, d_accum_rgb_sum, stream)
             : scene->fusedPath
                 ? renderPassFused(scene, seed, spp_begin + done, count, start_bounce, last_bounce, d_accum_rgb_sum, stream)
+            : hybridPath
+                ? renderPassHybrid(scene, seed, spp_begin + done, count, start_bounce, last_bounce, d_accum_rgb_sum, stream)
             : wavePath
                 ? renderPassWave(scene, seed, spp_begin + done, count, start_bounce, last_bounce, d_accum_rgb_sum, stream)
                 : renderPass(scene, seed, spp_begin + done, count, start_bounce, last_bounce, d_accum_rgb_sum, stream);
@@ -2389,6 +2644,7 @@ int pathed_hip_scene_set_camera(PathedScene *scene, const PathedCamera *camera)
     buildCamera(*camera, &scene->device.camera);
     SELECT_DEVICE(scene);
     HIP_TRY(rebuildSmallItems(scene));   // tiny scenes: the phase-1 tolerances depend on how far away a ray may start
+    HIP_TRY(rebuildHybridItems(scene));  // ... and so do the hybrid kernel's direct set's
     return PATHED_OK;
 }
 
@@ -2644,7 +2900,7 @@ int pathed_hip_get_stats(PathedScene *scene, PathedStats *out)
     out->bvh_build_ms = scene->bvhBuildMs;
     out->bvh_builder = (uint32_t)scene->bvhBuilder;
     out->trace_launches_all = (uint32_t)scene->traceLaunchesAll;
-    out->path_kernel = usesVolumeKernel(scene) ? 4u : scene->fusedPath ? 3u : scene->lastCallWave ? 6u : scene->splitShade ? 5u : (scene->stagedShade ? 2u : 1u);
+    out->path_kernel = usesVolumeKernel(scene) ? 4u : scene->fusedPath ? 3u : scene->lastCallHybrid ? 7u : scene->lastCallWave ? 6u : scene->splitShade ? 5u : (scene->stagedShade ? 2u : 1u);
     if (tuningEnv("PATHED_SHADE_PROFILE")) {   // counters exist in -DPATHED_SHADE_PROFILE builds only
         static const char *regions[11] = { "all waves", "active slots", "makeIsect (hit)", "camera-ray vertex", "finish previous MIS term",
                                            "new vertex: BSDF sample", "light sampling", "sample finished", "startSample (regeneration)", "shadow ray pushed",
@@ -2680,6 +2936,18 @@ int pathed_hip_get_stats(PathedScene *scene, PathedStats *out)
         fprintf(stderr, "[pathed] k_path_wave shade: %.3f of the iterations shade, %.1f paths each\n", (double)v[4] / iterations, v[4] ? (double)v[5] / (double)v[4] : 0.0);
         fprintf(stderr, "[pathed] k_path_wave wave cycles: traversal bursts %.3f, shade + post + regeneration %.3f of the waves' lifetimes\n", (double)v[9] / cycles, (double)v[10] / cycles);
     }
+#ifdef PATHED_SHADE_PROFILE
+    if (scene->lastCallHybrid) {   // k_path_hybrid (tools/hybrid_profile.py)
+        const unsigned long long *v = device + kStatShadeProfile;
+        const double iterations = v[0] ? (double)v[0] : 1.0, cycles = v[8] ? (double)v[8] : 1.0, bursts = v[3] ? (double)v[3] : 1.0;
+        fprintf(stderr, "[pathed] k_path_hybrid: %llu waves, %.0f iterations each, %.1f live paths per iteration, %.1f of them at a vertex\n", v[12], iterations / (double)(v[12] ? v[12] : 1),
+                (double)v[1] / iterations, (double)v[13] / iterations);
+        fprintf(stderr, "[pathed] k_path_hybrid tree part: %.3f of the iterations run a burst, %.1f rays posted per burst, %.1f steps per burst (%.1f of them triangle phases) at %.1f of 64 lanes, %.2f refill rounds, %.1f rays parked at its end\n",
+                (double)v[3] / iterations, (double)v[2] / bursts, (double)v[4] / bursts, (double)v[7] / bursts, v[4] ? (double)v[5] / (double)v[4] : 0.0, (double)v[6] / bursts, (double)v[14] / bursts);
+        fprintf(stderr, "[pathed] k_path_hybrid wave cycles: direct pass + resolve %.3f, proxy + burst %.3f, vertex + regeneration %.3f of the waves' lifetimes\n",
+                (double)v[9] / cycles, (double)v[10] / cycles, (double)v[11] / cycles);
+    }
+#endif
     if (tuningEnv("PATHED_VOLUME_PROFILE")) {   // the same counters in k_path_volume (-DPATHED_SHADE_PROFILE builds)
         static const char *regions[9] = { "samples", "camera-ray query", "bounce-loop iterations", "segment query (no direct lighting before)",
                                           "medium event: occlusion query", "direct lighting at a vertex", "light sample: occlusion query",

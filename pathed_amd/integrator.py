@@ -68,7 +68,7 @@ class HipScene:
     Keyword options map onto PathedSceneOptions (include/pathed_hip.h): stack_rows, pools,
     suspend_lanes, suspend_patience, park_min_cards, max_slots, build_threads, generic_kernels, refittable, wave_max_ksamples,
     wave_stragglers, wave_refill, chunks_per_pass, intersector ("auto" | "bvh"),
-    trace_blocks_per_cu, shade_kernel ("auto" | "per-slot" | "staged" | "fused" | "split" | "wave"), stage_slots,
+    trace_blocks_per_cu, shade_kernel ("auto" | "per-slot" | "staged" | "fused" | "split" | "wave" | "hybrid"), stage_slots,
     unit_order ("auto" | "stripes" | "stripes-tiled" | "tiles"), node_format ("auto" | "wide" | "compressed" | "compressed8"), small_phase1 ("auto" | "valu" | "mfma").  `device=None` keeps the device of an earlier pathed_hip_init.
     """
 
@@ -82,7 +82,7 @@ class HipScene:
         packed.bvh_builder = self.BVH_BUILDERS[bvh_builder] + 1
         intersector = options.pop("intersector", "auto")
         packed.intersector = {"auto": 0, "bvh": 1}[intersector]
-        packed.shade_kernel = {"auto": 0, "per-slot": 1, "staged": 2, "fused": 3, "split": 4, "wave": 5}[options.pop("shade_kernel", "auto")]
+        packed.shade_kernel = {"auto": 0, "per-slot": 1, "staged": 2, "fused": 3, "split": 4, "wave": 5, "hybrid": 6}[options.pop("shade_kernel", "auto")]
         packed.node_format = {"auto": 0, "wide": 1, "compressed": 2, "compressed8": 3}[options.pop("node_format", "auto")]
         packed.unit_order = {"auto": 0, "stripes": 1, "stripes-tiled": 2, "tiles": 3}[options.pop("unit_order", "auto")]
         packed.small_phase1 = {"auto": 0, "valu": 1, "mfma": 2}[options.pop("small_phase1", "auto")]

@@ -9,7 +9,8 @@ k_path_wave, or the wavefront with a few thousand slots forced).  Here it runs a
   * one call of >= 48 Mi samples with default options: path_kernel == 1, nothing dropped, the image the SAME BITS as
     k_path_wave's on the same call (whose arithmetic is pinned against the oracle at small sizes, tests/test_gpu_wave.py) and,
     with counting on, rays really were parked between launches and the image still has the same bits;
-  * BASELINE configurations 2 - 5 at THEIR resolutions, 16 spp, against the CPU oracle on every core the job may use
+  * BASELINE configurations 2 - 5 at THEIR resolutions (and the Cornell variants that carry the other BSDFs north_star names, at
+    C2's), 16 spp, against the CPU oracle on every core the job may use
     (reference src/sample_integrator.cpp:80-113 is what both sides restate): relL2 <= 2e-3 and <= 0.1 % of pixels off by more
     than 1 % (the glass scene: 1e-2 / 1 %), SURVEY.md section 8d's stated tolerance.
 """
@@ -76,6 +77,13 @@ def test_the_wavefront_at_its_operating_size_is_the_wave_kernels_image_bit_for_b
     ("C3", "scenes/mis-pbrt.json", 1024, 1024, 2e-3, 1e-3),
     ("C4", "scenes/teapot.json", 1024, 1024, 1e-2, 1e-2),
     ("C5", "assets/dragon-standin-9.json", 1920, 1080, 2e-3, 1e-3),
+    # the other BSDFs north_star names, on the Cornell geometry at C2's resolution.  Oren-Nayar: the kernels evaluate
+    # cos(phi_i - phi_o) sin(alpha) tan(beta) from the local vectors' components (shading.h: orenNayarF), the oracle the
+    # reference's seven libm calls (src/oren_nayar.cpp:20-67, src/coordinate.cpp:7-32): this row is that form's contract
+    ("Oren-Nayar + Beckmann", "scenes/cornell-oren-nayar.json", 1024, 1024, 2e-3, 1e-3),
+    ("GGX microfacet + plastic", "scenes/cornell-ggx.json", 1024, 1024, 2e-3, 1e-3),
+    ("mirror (1 112 triangles)", "scenes/cornell-glossy.json", 1024, 1024, 1e-2, 1e-2),
+    ("glass + mirror (1 112 triangles)", "scenes/cornell-glass.json", 1024, 1024, 1e-2, 1e-2),
 ])
 def test_oracle_parity_at_the_configurations_own_resolution(name, scene_path, width, height, tolerance, bad_pixels):
     import oracle_lib

@@ -337,11 +337,14 @@ def test_result_does_not_depend_on_scheduling_or_intersector_variant(libs):
     few_slots, _ = _render_with_options(libs, {"max_slots": 4096}, "scenes/cornell.json", 160, 11, 12)
     assert np.array_equal(base, few_slots)
     # a BVH scene (1 112 triangles, nodes in HBM/L2), one pool vs two
-    glass_one, stats = _render_with_options(libs, {"pools": 1}, "scenes/cornell-glass.json", 128, 3, 8)
-    assert stats["scene_in_lds"] == 0
+    glass_one, stats = _render_with_options(libs, {"pools": 1, "shade_kernel": "per-slot"}, "scenes/cornell-glass.json", 128, 3, 8)
+    assert stats["scene_in_lds"] == 0 and stats["path_kernel"] == 1
     for pools in (2, 3):
-        glass_several, _ = _render_with_options(libs, {"pools": pools, "max_slots": 20000}, "scenes/cornell-glass.json", 128, 3, 8)
+        glass_several, _ = _render_with_options(libs, {"pools": pools, "max_slots": 20000, "shade_kernel": "per-slot"}, "scenes/cornell-glass.json", 128, 3, 8)
         assert np.array_equal(glass_one, glass_several), pools
+    # ... and what such a scene runs by default since round 5: the hybrid kernel (direct set + a tree of the rest, path_hybrid.h)
+    hybrid, stats = _render_with_options(libs, {}, "scenes/cornell-glass.json", 128, 3, 8)
+    assert stats["path_kernel"] == 7 and np.array_equal(glass_one, hybrid)
 
 
 @pytest.mark.parametrize("scene_path,width,height,spp", [

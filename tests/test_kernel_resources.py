@@ -55,8 +55,12 @@ def test_vgpr_budgets_of_the_hot_kernels(tmp_path):
     # ... and with the parallelogram phase 1 (small_items.h), which is what the headline runs on: the path state that waits
     # in LDS across the pass (24 KiB per block) keeps the spills of the Cornell instantiation at a handful
     quads = {k: v for k, v in usage.items() if re.search(r"k_path_smallILb1ELb0E.*ELb0ELb1EEEv", k)}
-    # (Cornell-like, Veach-like, any BSDF under triangle lights, generic)
-    assert len(quads) == 4 and all(v["VGPRs"] <= 128 and v["Occupancy"] == 4 for v in quads.values()), quads
+    # (Cornell-like, Veach-like, [r5] rough BSDFs over Beckmann / over GGX, Lambertian + glass + mirror, any BSDF under triangle lights, generic)
+    assert len(quads) == 7 and all(v["VGPRs"] <= 128 and v["Occupancy"] == 4 for v in quads.values()), quads
+    # [r5] the ladder's rungs spill no more than the any-BSDF instantiation they stand in for (shading.h: TraitsRough*, TraitsSmooth)
+    any_bsdf = [v for k, v in quads.items() if "SceneTraitsILj63E" in k][0]
+    rungs = [v for k, v in quads.items() if "SceneTraitsILj15E" in k or "SceneTraitsILj49E" in k]
+    assert len(rungs) == 3 and all(v["ScratchSize"] <= any_bsdf["ScratchSize"] for v in rungs), quads
     narrow_quads = [v for k, v in quads.items() if "SceneTraitsILj1E" in k]
     assert len(narrow_quads) == 1 and narrow_quads[0]["ScratchSize"] <= 160, quads
     # static LDS: the stash + the lists of the shared phase 2 (kernels.h smallResolveShared); with the material table of a
