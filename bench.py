@@ -32,6 +32,7 @@ REPO_ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO_ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+PATHED_FUSED_WAVES_PER_SIMD = 4   # k_path_small's occupancy (kernels.h: PATHED_FUSED_WAVES): which row of the VALU probe prices its mix
 STATE_BYTES_PER_VERTEX = 112 + 128   # k_shade's path-state streams: read + written per shaded vertex
 
 
@@ -170,6 +171,32 @@ def pmc_per_sample(workload):
     if entry is not None:
         entry = dict(entry, stale=(entry.get("kernel_sources") != kernel_sources_digest()))
     return entry
+
+
+def static_mix():
+    """The trip-count-weighted static instruction mix of the benchmarked instantiation of the fused kernel
+    (tools/static_mix.py --bench-json profiles/static_mix.json); None when it has not been generated."""
+    path = os.path.join(REPO_ROOT, "profiles", "static_mix.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as handle:
+        entry = json.load(handle)
+    return dict(entry, stale=(entry.get("kernel_sources") != kernel_sources_digest()))
+
+
+def mix_aware_bound(mix, probes_at_occupancy):
+    """The issue rate THIS instruction mix could reach on this box if nothing ever stalled: every class at the rate the
+    box's own probe reaches for it at the kernel's occupancy (pathed_hip_measure_valu_modes: v_fma_f32 on three VGPRs for the
+    plain class, v_pk_fma_f32 for the packed one, the rcp / sqrt rate recovered from the 6 + 2 mix, v_mul_lo_u32 for the wide
+    integer class).  In wave-instructions per second."""
+    fma_scalar_operand, mixed, fma, packed, wide = probes_at_occupancy
+    slow = 8.0 / mixed - 6.0 / fma_scalar_operand          # seconds per (rcp + sqrt) pair per G instructions
+    transcendental = 2.0 / slow if slow > 0 else fma / 4.0
+    rates = {"plain": fma, "packed": packed, "transcendental": transcendental, "wide": wide}
+    classes = mix["classes"]
+    total = float(sum(classes.values()))
+    seconds = sum(classes[name] / rates[name] for name in classes)
+    return total / seconds, {name: rates[name] / 1e9 for name in rates}
 
 
 def scene_description(scene, stats):
@@ -626,6 +653,17 @@ def run_rank(args):
                            "frac": traffic / per_launch_s / 1e9 / HBM_PEAK_GBS, "bytes_per_launch": traffic,
                            "note": "the fused kernel keeps whole paths in registers: HBM sees the partial sums and the scene records only; "
                                    "VALU issue bounds it, not memory"}
+                lanes = pmc.get("valu_lane_utilisation") if pmc else None
+                mix = static_mix()
+                mix_block = None
+                if mix and issued:
+                    bound, class_rates = mix_aware_bound(mix, probes[PATHED_FUSED_WAVES_PER_SIMD])
+                    mix_block = {
+                        "bound": bound / 1e9, "unit": "G wave-instr/s", "frac": issued / kernel_s / bound,
+                        "classes_per_iteration": mix["classes"], "class_rates": class_rates, "waves_per_simd": PATHED_FUSED_WAVES_PER_SIMD,
+                        "source": {"file": "profiles/static_mix.json", "stale": mix["stale"], "method": mix["method"]},
+                        "note": "what this kernel's own instruction mix could issue on this box with no stall at all (every class at the box's probed "
+                                "rate at four waves per SIMD); frac = achieved / bound: what stalls, dependencies and LDS / scalar traffic cost on top of the mix"}
                 roofline = {
                     "bound": "valu",
                     "kernel": "k_path_small (fused: camera ray .. termination in registers, one persistent launch per pass)" if fused
@@ -634,6 +672,12 @@ def run_rank(args):
                     "peak": peak_guide / 1e9,
                     "unit": "G wave-instr/s",
                     "frac": (issued / kernel_s / peak_guide) if issued else None,
+                    # frac counts instructions ISSUED, whatever share of the 64 lanes they worked for: useful_frac = frac x lane
+                    # utilisation (SQ_THREAD_CYCLES_VALU / 64 SQ_ACTIVE_INST_VALU) is the share of the chip's lane-slots that did work
+                    "lane_utilisation": lanes,
+                    "useful_frac": (issued / kernel_s / peak_guide * lanes) if (issued and lanes) else None,
+                    "mix_aware": mix_block,
+                    "valu_wave_instructions_per_sample": pmc["valu_wave_instructions_per_sample"] if pmc else None,
                     "peak_measured": measured / 1e9,
                     "frac_of_measured": (issued / kernel_s / measured) if issued else None,
                     "traffic": traffic,
@@ -645,6 +689,8 @@ def run_rank(args):
                                    "waves_per_simd": {str(waves): [rate / 1e9 for rate in row] for waves, row in probes.items()}},
                     "instructions_source": None if not pmc else {
                         "file": "profiles/pmc_per_sample.json", "valu_wave_instructions_per_sample": pmc["valu_wave_instructions_per_sample"],
+                        "collected": "a committed rocprofv3 --pmc pass over this kernel (tools/pmc_per_sample.sh), NOT counters of this run: "
+                                     "a process cannot read its own PMC counters; `stale` says whether the kernel sources have changed since",
                         "stale": pmc["stale"]},
                     "hbm": hbm,
                 }

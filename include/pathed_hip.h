@@ -313,6 +313,10 @@ typedef struct PathedSceneOptions {
                                    busy, 1..64 (0 = 48 / 40).  Scheduling only */
     int32_t chunks_per_pass;    /* work units per pixel of one internal pass, 1..4096 (0 = 256, fewer at resolutions whose partial
                                    sums would not fit): longer passes amortise a pass's ramp-up and drain, at 16 bytes per unit */
+    int32_t hybrid_batch;       /* k_path_hybrid: a wave walks its tree part once this many of its rays wait or are in flight,
+                                   1..128 (1 = in every iteration; 0 = 24).  Scheduling only */
+    int32_t hybrid_ready;       /* ... or once fewer of its paths than this can go on without a result, 1..64; -1 = only when
+                                   none can (0 = 28).  Scheduling only */
 } PathedSceneOptions;
 int pathed_hip_scene_create_ex(const PathedSceneDesc *desc, const PathedSceneOptions *options, PathedScene **out);
 int pathed_hip_scene_device(const PathedScene *scene);   /* the HIP device the scene lives on, or a negative error */

@@ -160,6 +160,8 @@ class PathedSceneOptions(C.Structure):
         ("wave_stragglers", C.c_int32),
         ("wave_refill", C.c_int32),
         ("chunks_per_pass", C.c_int32),
+        ("hybrid_batch", C.c_int32),
+        ("hybrid_ready", C.c_int32),
     ]
 
 

@@ -221,6 +221,7 @@ struct RenderParams {
     int hybridNodeCount, hybridTreeTris, hybridDirectTris;
     float hybridLo[3], hybridHi[3];
     float hybridSphere[4];   // ... and a bounding sphere of the same triangles: centre, radius^2 (padded)
+    int hybridBatch, hybridReady;   // a burst runs once this many rays wait or are in flight, or fewer paths than hybridReady can proceed
 };
 
 // BounceController, reference src/bounce_controller.cpp:14-25

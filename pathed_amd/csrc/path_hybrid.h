@@ -33,13 +33,19 @@ static const int kHybridResolveItems = 64;     // capacity of the direct pass's 
 #endif
 static const int kHybridRefill = 40;           // default of p.suspendPatience: idle lanes draw from the burst's list once fewer than this many are busy
 static const int kHybridStragglers = 16;       // default of p.suspendLanes: a burst may end once its list is dealt and fewer rays than this are in flight
+// Bursts are BATCHED: a scene's rays mostly never come near the tree part (the reference's dragon scene: 11 of 88 rays per
+// iteration and wave), and a burst over a dozen rays runs as many steps as one over sixty.  Rays wait in the list, their paths
+// with them, while the others carry on; a burst runs once kHybridBatch rays are waiting or in flight, or fewer than
+// kHybridReady paths can still proceed without one.
+static const int kHybridBatch = 24;            // default of p.hybridBatch (profiles/r5_ab_hybrid.log: 24 / 28 on the scenes that take the kernel by default)
+static const int kHybridReady = 28;            // default of p.hybridReady
 
-// per-wave LDS, in 4-byte words: [kHybridStackRows + 1][64] stack rows | 64 x float4 hit rows | 64 owner flags | the direct
-// pass's phase-2 scratch (best 128, uv 128, items 32, occluded 64, count 1), whose first 64 words also hold a burst's ray list
-// (128 ushort entries): the two never live at once.  4.4 KiB per wave; with the stash 38 KiB per block: four blocks per CU
+// per-wave LDS, in 4-byte words: [kHybridStackRows + 1][64] stack rows | 64 x float4 hit rows | 64 owner flags | the list of
+// rays waiting for a burst (128 ushort entries) | the direct pass's phase-2 scratch (best 128, uv 128, items 32, occluded 64,
+// count 1).  4.4 KiB per wave; with the stash 38 KiB per block: four blocks per CU
 static const int kHybridStackWords = (kHybridStackRows + 1) * 64;
 static const int kHybridScratchWords = 128 + 2 * kHybridResolveItems + kHybridResolveItems / 2 + 64 + 1;
-static const int kHybridWaveWords = kHybridStackWords + 64 * 4 + 64 + ((kHybridScratchWords + 3) & ~3);
+static const int kHybridWaveWords = kHybridStackWords + 64 * 4 + 64 + 64 + ((kHybridScratchWords + 3) & ~3);
 static const unsigned int kHybridOccluded = 0x100u;   // owner flags: the low byte counts the owner's finished rays
 
 // conservative "the segment (tnear, tfar] of the ray meets the box": reciprocal by v_rcp_f32 (1 ulp), the box padded by the
@@ -119,8 +125,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_H
     stack.overflow = p.stackOverflow + ((size_t)blockIdx.x * kBlock + threadIdx.x);
     float4 *hitRows = reinterpret_cast<float4 *>(mine + kHybridStackWords);          // per owner lane: the path ray's hit so far
     unsigned int *ownerFlags = mine + kHybridStackWords + 64 * 4;                     // per owner lane: finished rays | kHybridOccluded
-    unsigned int *scratchWords = mine + kHybridStackWords + 64 * 4 + 64;
-    unsigned short *entries = reinterpret_cast<unsigned short *>(scratchWords);       // [128]: owner lane | 0x100 for a shadow ray
+    unsigned short *entries = reinterpret_cast<unsigned short *>(mine + kHybridStackWords + 64 * 4 + 64);   // [128]: owner lane | 0x100 for a shadow ray
+    unsigned int *scratchWords = mine + kHybridStackWords + 64 * 4 + 64 + 64;
     ResolveScratch scratch;
     scratch.best = reinterpret_cast<unsigned long long *>(scratchWords);                                   // 128 words
     scratch.uv = reinterpret_cast<float2 *>(scratchWords + 128);                                           // 2 words per item
@@ -176,6 +182,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_H
     V3 shadowDirection = v3(0.f, 0.f, 1.f);
     float shadowTfar = 0.f;
     unsigned int waiting = 0;        // rays of this lane's path that are in the tree part and not yet back (0, 1 or 2)
+    unsigned int pendingCount = 0;   // (wave-uniform) rays in the list, waiting for the next burst
 
     // ---- the ray a lane walks through the tree part (anybody's); between bursts a straggler is PARKED: these eight words
     bool parked = false;
@@ -272,26 +279,28 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_H
             hitRows[lane] = make_float4(ray.best, ray.bestU, ray.bestV, intAsFloat(ray.bestPrim));
             ownerFlags[lane] = 0u;
         }
-        const float pathFar = ray.best;                    // (PATHED_TFAR without a direct hit)
-        unsigned int listCount = 0u;
+        const float pathFar = ray.best;                    // (PATHED_TFAR without a direct hit; the owner's row holds it for the walk)
         if (tree.nNodes > 0) {
             const bool postPath = ready && hybridProxy(p.hybridLo, p.hybridHi, path.o, path.d, pathFar) && hybridProxySphere(p.hybridSphere, path.o, path.d);
             const bool postShadow = traceShadow && !occluded && hybridProxy(p.hybridLo, p.hybridHi, path.o, shadowDirection, shadowTfar)
                 && hybridProxySphere(p.hybridSphere, path.o, shadowDirection);
             const unsigned long long pathMask = __ballot(postPath), shadowMask = __ballot(postShadow);
-            listCount = (unsigned int)(__popcll(pathMask) + __popcll(shadowMask));
-            if (postPath) { entries[laneRank(pathMask)] = (unsigned short)lane; }
-            if (postShadow) { entries[(unsigned int)__popcll(pathMask) + laneRank(shadowMask)] = (unsigned short)(lane | 0x100); }
+            if (postPath) { entries[pendingCount + laneRank(pathMask)] = (unsigned short)lane; }
+            if (postShadow) { entries[pendingCount + (unsigned int)__popcll(pathMask) + laneRank(shadowMask)] = (unsigned short)(lane | 0x100); }
             if (ready) { waiting = (postPath ? 1u : 0u) + (postShadow ? 1u : 0u); }
+            pendingCount += (unsigned int)(__popcll(pathMask) + __popcll(shadowMask));
         }
         pendingShadow = false;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
 
-        // (a path ray's far bound is read when a ray of the LIST is handed out, i.e. for owners that posted in this iteration;
-        // a parked ray restarts from its own best)
-        const float farForExchange = ready ? pathFar : 0.f;
-        if (__ballot(parked) != 0ull || listCount != 0u) {
+        // ---- a burst, if enough rays have gathered or too few paths can go on without one
+        const int nParked = __popcll(__ballot(parked));
+        const int canProceed = __popcll(__ballot(alive && waiting == 0u));
+        const unsigned int gathered = pendingCount + (unsigned int)nParked;
+        if (gathered != 0u && ((int)gathered >= p.hybridBatch || canProceed < p.hybridReady)) {
+            const unsigned int listCount = pendingCount;
+            pendingCount = 0u;
 #ifdef PATHED_SHADE_PROFILE
             profPosted += listCount; profBursts++;
 #endif
@@ -331,7 +340,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_H
                     const float ox = __shfl(path.o.x, owner), oy = __shfl(path.o.y, owner), oz = __shfl(path.o.z, owner);
                     const float ax = __shfl(path.d.x, owner), ay = __shfl(path.d.y, owner), az = __shfl(path.d.z, owner);
                     const float bx = __shfl(shadowDirection.x, owner), by = __shfl(shadowDirection.y, owner), bz = __shfl(shadowDirection.z, owner);
-                    const float farPath = __shfl(farForExchange, owner), farShadow = __shfl(shadowTfar, owner);
+                    const float farShadow = __shfl(shadowTfar, owner);
+                    const float farPath = hitRows[owner].x;      // the direct set's hit (or PATHED_TFAR): the owner wrote it when it posted
                     if (take) {
                         laneRayInit(walk, v3(ox, oy, oz), forShadow ? v3(bx, by, bz) : v3(ax, ay, az), PATHED_TNEAR, forShadow ? farShadow : farPath, forShadow);
                         target = entry;

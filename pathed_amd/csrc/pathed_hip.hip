@@ -1314,6 +1314,8 @@ int pathed_hip_scene_create_ex(const PathedSceneDesc *desc, const PathedSceneOpt
         if (options.wave_stragglers < -1 || options.wave_stragglers > 64) { return fail(PATHED_E_INVALID, "wave_stragglers must be -1 (none), 0 (default) or 1..64"); }
         if (options.wave_refill < 0 || options.wave_refill > 64) { return fail(PATHED_E_INVALID, "wave_refill must be 0 (default) or 1..64"); }
         if (options.chunks_per_pass < 0 || options.chunks_per_pass > 4096) { return fail(PATHED_E_INVALID, "chunks_per_pass must be 0 (default) or 1..4096"); }
+        if (options.hybrid_batch < 0 || options.hybrid_batch > 128) { return fail(PATHED_E_INVALID, "hybrid_batch must be 0 (default) or 1..128"); }
+        if (options.hybrid_ready < -1 || options.hybrid_ready > 64) { return fail(PATHED_E_INVALID, "hybrid_ready must be -1 (never), 0 (default) or 1..64"); }
     }
     int deviceId = options.device;
     if (deviceId == PATHED_DEVICE_CURRENT) {
@@ -1802,14 +1804,15 @@ int pathed_hip_scene_create_ex(const PathedSceneDesc *desc, const PathedSceneOpt
     scene->waveAvailable = !scene->bruteForce && scene->device.nMaterials <= kMaxLdsMaterials && scene->nodeFormat == 0;
     {
         // [r5] k_path_hybrid: BVH scenes small enough that a handful of large triangles carry most of the hits (path_hybrid.h)
-        const bool eligible = !scene->bruteForce && desc->n_triangles <= (uint32_t)kHybridMaxTris && desc->n_spheres == 0
+        // (shade_kernel 6 asks for it on a larger mesh as well: the walk is the same, the tree just stops being cache-resident)
+        const bool eligible = !scene->bruteForce && desc->n_spheres == 0
             && scene->device.nMaterials <= kMaxLdsMaterials && scene->nodeFormat == 0 && options.intersector != 1 && !scene->hasContainers
             && !options.refittable;   // (a refittable scene keeps ONE tree, the one pathed_hip_scene_refit moves)
         if (shadeKernel == 6 && !eligible) {
             delete scene;
-            return fail(PATHED_E_INVALID, "the hybrid path kernel serves sphere-free scenes of 65 .. 4096 triangles and at most 96 materials (intersector 0)");
+            return fail(PATHED_E_INVALID, "the hybrid path kernel serves sphere-free scenes of more than 64 triangles and at most 96 materials (intersector 0, not refittable)");
         }
-        if (eligible && (shadeKernel == 0 || shadeKernel == 6)) {
+        if (eligible && ((shadeKernel == 0 && desc->n_triangles <= (uint32_t)kHybridMaxTris) || shadeKernel == 6)) {
             if ((status = buildHybrid(scene, desc)) != hipSuccess) { return fail_cleanup(status, "build the hybrid kernel's scene split"); }
             scene->hybridPath = true;
         }
@@ -2336,6 +2339,8 @@ static int renderPassHybrid(PathedScene *scene, uint64_t seed, uint32_t begin, u
     // scheduling of its bursts (PathedSceneOptions.wave_stragglers / wave_refill): results do not depend on them
     params.suspendLanes = scene->options.wave_stragglers != 0 ? (scene->options.wave_stragglers < 0 ? 0 : scene->options.wave_stragglers) : kHybridStragglers;
     params.suspendPatience = scene->options.wave_refill != 0 ? scene->options.wave_refill : kHybridRefill;
+    params.hybridBatch = scene->options.hybrid_batch != 0 ? scene->options.hybrid_batch : kHybridBatch;
+    params.hybridReady = scene->options.hybrid_ready != 0 ? (scene->options.hybrid_ready < 0 ? 1 : scene->options.hybrid_ready) : kHybridReady;
 
     HIP_TRY(hipMemsetAsync(params.counters, 0, kCtrCount * sizeof(unsigned int), stream));
     const dim3 grid((unsigned)blocks), block(kBlock);
@@ -2346,7 +2351,8 @@ static int renderPassHybrid(PathedScene *scene, uint64_t seed, uint32_t begin, u
         (void)hipEventRecord(scene->traceEvents.start[timed], stream);
     }
     // the narrowest instantiation whose compile-time scene set contains this scene's (shading.h: SceneTraits)
-    if (scene->smoothSet) { hipLaunchKernelGGL((k_path_hybrid<TraitsSmooth>), grid, block, lds, stream, params, scene->hybridItems); }
+    if (scene->envOnly && !scene->hasContainers) { hipLaunchKernelGGL((k_path_hybrid<TraitsEnvironmentOnly>), grid, block, lds, stream, params, scene->hybridItems); }
+    else if (scene->smoothSet) { hipLaunchKernelGGL((k_path_hybrid<TraitsSmooth>), grid, block, lds, stream, params, scene->hybridItems); }
     else if (scene->triangleLit) { hipLaunchKernelGGL((k_path_hybrid<TraitsTriangleLit>), grid, block, lds, stream, params, scene->hybridItems); }
     else { hipLaunchKernelGGL((k_path_hybrid<TraitsAll>), grid, block, lds, stream, params, scene->hybridItems); }
     if (timed >= 0) { (void)hipEventRecord(scene->traceEvents.stop[timed], stream); }

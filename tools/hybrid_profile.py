@@ -9,7 +9,7 @@ from pathed_amd.scene import LoadedScene
 path = sys.argv[1] if len(sys.argv) > 1 else "scenes/cornell-glossy.json"
 w, h, spp = (int(v) for v in sys.argv[2:5]) if len(sys.argv) > 4 else (1024, 1024, 32)
 scene = LoadedScene(path, w, h)
-gpu = HipScene(scene.desc, device=0)
+gpu = HipScene(scene.desc, device=0, shade_kernel=os.environ.get("HYBRID_PROFILE_KERNEL", "auto"), bvh_builder="ploc" if scene.n_triangles > 1000000 else "sah")
 gpu.render(1, 0, 2, 0, 10)
 gpu.reset_stats()
 gpu.render(1, 2, spp, 0, 10)

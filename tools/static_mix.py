@@ -96,6 +96,9 @@ def main():
     parser.add_argument("--kernel", default="k_path_small|k_path_hybrid|k_path_wave|k_shade|k_trace<")
     parser.add_argument("--loops", action="store_true")
     parser.add_argument("--json", default="")
+    parser.add_argument("--bench-json", default="", help="write the trip-count-weighted mix of the Cornell instantiation of k_path_small (what bench.py times) here")
+    parser.add_argument("--quad-pairs", type=int, default=9, help="trips of the parallelogram-pair loop per pass (Cornell: 17 parallelograms)")
+    parser.add_argument("--lone-pairs", type=int, default=1, help="trips of the lone-triangle-pair loop per pass (Cornell: 2 triangles)")
     args = parser.parse_args()
     path = args.asm
     if not path:
@@ -135,7 +138,62 @@ def main():
     if args.json:
         with open(args.json, "w") as handle:
             json.dump(out, handle, indent=1)
+    if args.bench_json:
+        write_bench_mix(kernels, pretty, args)
     return 0
+
+
+def sources_digest():
+    import hashlib
+    sha = hashlib.sha1()
+    directory = os.path.join(ROOT, "pathed_amd", "csrc")
+    for name in sorted(os.listdir(directory)):
+        sha.update(open(os.path.join(directory, name), "rb").read())
+    return sha.hexdigest()[:16]
+
+
+def write_bench_mix(kernels, pretty, args):
+    """One iteration of the fused kernel's loop as the compiler laid it out, every block once, the two phase-1 loops times
+    their trip counts on the benchmarked scene: the mix bench.py prices against the box's probed issue rates."""
+    wanted = r"k_path_small<true, false, SceneTraits<1u, false, true, false, false, true, 3u>, false, true>"
+    for name, blocks in kernels.items():
+        shown = pretty[name].replace("pathed::", "").replace("void ", "")
+        if not re.search(wanted, shown):
+            continue
+        total = collections.Counter()
+        for block in blocks.values():
+            total.update(block["ops"])
+        loops = []
+        for label, block in blocks.items():
+            if label in block["targets"] and block["ops"]["valu_packed"] >= 40:
+                loops.append((block["ops"]["valu_packed"], label))
+        loops.sort(reverse=True)
+        weights = {}
+        if len(loops) >= 1:
+            weights[loops[0][1]] = args.quad_pairs
+        if len(loops) >= 2:
+            weights[loops[1][1]] = args.lone_pairs
+        weighted = collections.Counter()
+        for label, block in blocks.items():
+            for key, count in block["ops"].items():
+                weighted[key] += count * weights.get(label, 1)
+        valu = {k: v for k, v in weighted.items() if k.startswith("valu")}
+        result = {
+            "kernel": shown, "kernel_sources": sources_digest(),
+            "method": "compiler assembly (hipcc -S), every basic block once, the parallelogram-pair loop x %d and the lone-pair loop x %d "
+                      "(their trip counts on scenes/cornell.json); v_div_scale / v_div_fmas / v_div_fixup counted with the plain instructions" % (args.quad_pairs, args.lone_pairs),
+            "loops": {label: {"trips": trips, "valu": sum(v for k, v in blocks[label]["ops"].items() if k.startswith("valu")),
+                              "packed": blocks[label]["ops"]["valu_packed"]} for label, trips in weights.items()},
+            "valu_per_iteration": sum(valu.values()),
+            "classes": {"plain": weighted["valu_plain"] + weighted["valu_div_helpers"], "packed": weighted["valu_packed"],
+                        "transcendental": weighted["valu_trans"], "wide": weighted["valu_64"]},
+            "static_valu": sum(v for k, v in total.items() if k.startswith("valu")),
+        }
+        with open(args.bench_json, "w") as handle:
+            json.dump(result, handle, indent=1)
+        print("bench mix: %s" % json.dumps(result["classes"]))
+        return
+    raise SystemExit("static_mix.py: the Cornell instantiation of k_path_small was not found in the assembly")
 
 
 if __name__ == "__main__":
