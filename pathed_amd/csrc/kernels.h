@@ -1834,7 +1834,11 @@ struct MaterialAccess {
 // sample per unit, the `acc` stream: 80 bytes less per regenerated slot -- and SLOWER (teapot 1 731 against 1 762, the mesh
 // filling the frame 1 362 against 1 380 Msamples/s, same box, profiles/r3_ab_shade_trim.log): a store that half the lanes
 // of a wave skip writes partial cache lines, which cost more than the full 1 KiB lines they replace.
-#define PATHED_SHADE_TRIM 0
+// 2 [r5]: ONLY the `acc` stream goes (one sample per unit: the unit's partial sum is 0 + colour, nobody needs the running sum):
+// a stream that only finished lanes touched at all -- 32 of the 240 state bytes per vertex, a line of it fetched and written
+// back whenever one of its eight slots finished.  +1.0 % on the teapot, the 5.2 M-triangle mesh and its close-up, same bits
+// (profiles/r5_ab_acc_trim.log): the pipeline is not bound by its state BYTES.
+#define PATHED_SHADE_TRIM 2
 #endif
 #ifdef PATHED_SHADE_WAVES   // experiments: cap k_shade's registers for this many waves per SIMD
 #define PATHED_SHADE_ATTRIBUTE __attribute__((amdgpu_waves_per_eu(PATHED_SHADE_WAVES, PATHED_SHADE_WAVES)))
@@ -2136,7 +2140,7 @@ __global__ __launch_bounds__(kBlock) PATHED_SHADE_ATTRIBUTE void k_shade(RenderP
         // a slot that starts a camera ray (or retires) keeps its stale mod / thr / pend: the camera ray's vertex reads
         // none of them (rayBounce == 0, no eligible bit) and writes all three for the rays that follow -- 48 bytes less
         // per regenerated slot on streams that bound this kernel
-        if (!finished || !PATHED_SHADE_TRIM) {
+        if (!finished || PATHED_SHADE_TRIM != 1) {   // (PATHED_SHADE_TRIM 2: only the acc stream is trimmed)
             p.state.mod[slot] = outMod;
             p.state.thr[slot] = outThr;
             p.state.pend[slot] = outPend;
