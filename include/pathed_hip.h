@@ -220,6 +220,9 @@ typedef struct PathedStats {
                                       6 wave path kernel (BVH scenes, the last render call),
                                       7 hybrid path kernel (scenes of 65 .. 4096 triangles, the last render call) */
     uint32_t reserved0;
+    uint64_t local_closest_rays;   /* closest-hit queries the shade kernel resolved itself (rays that cannot meet anything but the
+                                      scene's few large triangles, PathedSceneOptions.local_rays) -- stats mode; NOT in closest_rays */
+    uint64_t local_shadow_rays;    /* ... and any-hit queries -- stats mode; NOT in shadow_rays */
 } PathedStats;
 
 /* ---- life cycle ---------------------------------------------------------- */
@@ -313,6 +316,9 @@ typedef struct PathedSceneOptions {
                                    busy, 1..64 (0 = 48 / 40).  Scheduling only */
     int32_t chunks_per_pass;    /* work units per pixel of one internal pass, 1..4096 (0 = 256, fewer at resolutions whose partial
                                    sums would not fit): longer passes amortise a pass's ramp-up and drain, at 16 bytes per unit */
+    int32_t local_rays;         /* the wavefront's local rays: a sphere-free BVH scene with at most 8 LARGE triangles (each >= 1 / 256 of
+                                   its surface: a floor, a backdrop) lets the shade kernel resolve the rays that cannot meet the
+                                   bounds of everything else -- they skip the trace kernel; same hits.  0 automatic (on), 1 off */
     int32_t hybrid_batch;       /* k_path_hybrid: a wave walks its tree part once this many of its rays wait or are in flight,
                                    1..128 (1 = in every iteration; 0 = 24).  Scheduling only */
     int32_t hybrid_ready;       /* ... or once fewer of its paths than this can go on without a result, 1..64; -1 = only when

@@ -132,6 +132,8 @@ class PathedStats(C.Structure):
         ("trace_launches_all", C.c_uint32),
         ("path_kernel", C.c_uint32),
         ("reserved0", C.c_uint32),
+        ("local_closest_rays", C.c_uint64),
+        ("local_shadow_rays", C.c_uint64),
     ]
 
 
@@ -160,6 +162,7 @@ class PathedSceneOptions(C.Structure):
         ("wave_stragglers", C.c_int32),
         ("wave_refill", C.c_int32),
         ("chunks_per_pass", C.c_int32),
+        ("local_rays", C.c_int32),
         ("hybrid_batch", C.c_int32),
         ("hybrid_ready", C.c_int32),
     ]

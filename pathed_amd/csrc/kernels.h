@@ -147,6 +147,8 @@ static const int kStatRefillCycles = 16;   // shader clocks spent refilling lane
 static const int kStatInnerCycles = 17;
 static const int kStatLeafCycles = 18;
 static const int kStatInnerSteps = 19;
+static const int kStatLocalClosest = 20;   // rays k_shade resolved itself (counting mode): closest-hit / occlusion
+static const int kStatLocalShadow = 21;
 static const int kStatShadeProfile = 24;   // PATHED_SHADE_PROFILE builds: (waves, lanes) per k_shade region, 2 words each
 static const int kStatCount = 48;
 
@@ -222,7 +224,14 @@ struct RenderParams {
     float hybridLo[3], hybridHi[3];
     float hybridSphere[4];   // ... and a bounding sphere of the same triangles: centre, radius^2 (padded)
     int hybridBatch, hybridReady;   // a burst runs once this many rays wait or are in flight, or fewer paths than hybridReady can proceed
+    // [r5] LOCAL RAYS of the wavefront (k_shade): the scene's few large triangles (a floor, a backdrop: at most kMaxLocalTris,
+    // records as the tree's leaves hold them) and -- in hybridLo / hybridHi / hybridSphere -- the bounds of everything else.  A
+    // ray that cannot meet those bounds can only hit one of the large triangles: k_shade tests them itself, writes the hit
+    // and marks the slot kStLocal; an occlusion ray of that kind never joins the shadow list.  localCount = 0: off
+    int localCount, localCounting;
+    float4 localTris[3 * 8];
 };
+static const int kMaxLocalTris = 8;
 
 // BounceController, reference src/bounce_controller.cpp:14-25
 __device__ inline bool checkDone(int lastBounce, int bounce)
@@ -472,7 +481,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_T
             if (!stagedShadow) {
                 const float4 rd = p.state.rayD[item];
                 const float4 ro = p.state.rayO[item];
-                valid[r] = !(floatAsInt(rd.w) & (kStDone | kStHold));
+                valid[r] = !(floatAsInt(rd.w) & (kStDone | kStHold | kStLocal));
                 first[r] = ro;
                 second[r] = make_float4(rd.x, rd.y, rd.z, intAsFloat((int)item));  // .w = the slot
             } else {
@@ -1904,6 +1913,9 @@ __global__ __launch_bounds__(kBlock) PATHED_SHADE_ATTRIBUTE void k_shade(RenderP
         }
     }
 
+    st &= ~kStLocal;               // (the hit of such a slot is this kernel's own, written last iteration)
+    rd.w = intAsFloat(st);
+
     ShadowRequest shadow;
     shadow.push = false;
     shadow.origin = v3(0.f, 0.f, 0.f);
@@ -2132,6 +2144,55 @@ __global__ __launch_bounds__(kBlock) PATHED_SHADE_ATTRIBUTE void k_shade(RenderP
     SHADE_REGION(8, startNext);
     SHADE_REGION(9, shadow.push);
     if (startNext) { startSample(p, nextPixel, nextSample, sampleInUnit, &outRayO, &outRayD); }
+
+    // ---- [r5] local rays.  Most rays of "an object on a floor under a sky" never come near the object: 87 % of the queries of
+    // the dragon configuration miss the mesh's bounding box or its bounding sphere (profiles/r5_ab_hybrid_large.log).  Such a
+    // ray can only hit one of the scene's few LARGE triangles (RenderParams::localTris), which this kernel tests itself, with
+    // the tree walk's intersector and acceptance rule (same hit, bit for bit): the slot's ray then skips the trace kernel
+    // (kStLocal), an occlusion ray is decided here and never listed.  Scene::testIntersect / testOcclusion, src/scene.cpp:91-223, 355-381.
+    if (p.localCount > 0) {
+        const bool hasRay = active && !retired;
+        auto meetsRest = [&](V3 origin, V3 direction, float tfar) -> bool {
+            return hybridProxy(p.hybridLo, p.hybridHi, origin, direction, tfar) && hybridProxySphere(p.hybridSphere, origin, direction);
+        };
+        const V3 nextO = v3(outRayO.x, outRayO.y, outRayO.z), nextD = v3(outRayD.x, outRayD.y, outRayD.z);
+        const bool localClosest = hasRay && !meetsRest(nextO, nextD, PATHED_TFAR);
+        const bool localShadow = shadow.push && !meetsRest(shadow.origin, shadow.direction, shadow.tfar);
+        if (__ballot(localClosest || localShadow) != 0ull) {
+            float best = PATHED_TFAR, bestU = 0.f, bestV = 0.f;
+            int bestPrim = -1;
+            bool occluded = false;
+            for (int k = 0; k < p.localCount; k++) {
+                const float4 t0 = p.localTris[3 * k + 0], t1 = p.localTris[3 * k + 1], t2 = p.localTris[3 * k + 2];   // kernel arguments: scalar loads
+                const V3 v0 = v3(t0.x, t0.y, t0.z), e1 = v3(t1.x, t1.y, t1.z), e2 = v3(t2.x, t2.y, t2.z);
+                const int prim = floatAsInt(t0.w);
+                float t, u, v;
+                if (localClosest && intersectTriangle(nextO, nextD, v0, e1, e2, &t, &u, &v) && t > PATHED_TNEAR) {
+                    // testLeafTriangle's rule (trace.h)
+                    const bool closer = (bestPrim < 0) ? (t <= best) : (t < best || (t == best && prim < bestPrim));
+                    if (closer) { best = t; bestU = u; bestV = v; bestPrim = prim; }
+                }
+                if (localShadow && !occluded && intersectTriangle(shadow.origin, shadow.direction, v0, e1, e2, &t, &u, &v) && t > PATHED_TNEAR && t <= shadow.tfar) {
+                    occluded = true;
+                }
+            }
+            if (localClosest) {
+                p.state.hit[slot] = make_float4(best, bestU, bestV, intAsFloat(bestPrim));
+                outRayD.w = intAsFloat(floatAsInt(outRayD.w) | kStLocal);
+            }
+            if (localShadow) {
+                if (occluded) { outPend = make_float4(0.f, 0.f, 0.f, 0.f); }
+                shadow.push = false;
+            }
+            if (p.localCounting) {
+                const unsigned long long closestMask = __ballot(localClosest), shadowMask = __ballot(localShadow);
+                if (lane == 0) {
+                    atomicAdd(&p.stats[kStatLocalClosest], (unsigned long long)__popcll(closestMask));
+                    atomicAdd(&p.stats[kStatLocalShadow], (unsigned long long)__popcll(shadowMask));
+                }
+            }
+        }
+    }
 
     if (active) {
         p.state.rayO[slot] = outRayO;

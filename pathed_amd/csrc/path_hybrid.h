@@ -48,35 +48,7 @@ static const int kHybridScratchWords = 128 + 2 * kHybridResolveItems + kHybridRe
 static const int kHybridWaveWords = kHybridStackWords + 64 * 4 + 64 + 64 + ((kHybridScratchWords + 3) & ~3);
 static const unsigned int kHybridOccluded = 0x100u;   // owner flags: the low byte counts the owner's finished rays
 
-// conservative "the segment (tnear, tfar] of the ray meets the box": reciprocal by v_rcp_f32 (1 ulp), the box padded by the
-// host by 1e-4 of its size, tmax by 1e-5 relative: misses only what innerStep's slab test of the root's children would miss too
-__device__ __forceinline__ bool hybridProxy(const float *lo, const float *hi, V3 o, V3 d, float tfar)
-{
-    const float kHuge = 3e30f;
-    const float ix = fminf(fmaxf(__builtin_amdgcn_rcpf(d.x), -kHuge), kHuge);
-    const float iy = fminf(fmaxf(__builtin_amdgcn_rcpf(d.y), -kHuge), kHuge);
-    const float iz = fminf(fmaxf(__builtin_amdgcn_rcpf(d.z), -kHuge), kHuge);
-    const float tx0 = (lo[0] - o.x) * ix, tx1 = (hi[0] - o.x) * ix;
-    const float ty0 = (lo[1] - o.y) * iy, ty1 = (hi[1] - o.y) * iy;
-    const float tz0 = (lo[2] - o.z) * iz, tz1 = (hi[2] - o.z) * iz;
-    // fminf / fmaxf return the non-NaN operand (0 x inf): what a conservative test wants
-    const float tmin = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), 0.f));
-    const float tmax = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fminf(fmaxf(tz0, tz1), tfar));
-    return tmin <= tmax * 1.00001f + 1e-6f;
-}
-
-// ... and "the ray's LINE comes within the part's bounding sphere, ahead of the origin unless that lies inside": the box's
-// corners are empty space around a round cluster (the reference's ball: half the box).  sphere = centre, radius^2 (padded)
-__device__ __forceinline__ bool hybridProxySphere(const float *sphere, V3 o, V3 d)
-{
-    const V3 c0 = v3(sphere[0] - o.x, sphere[1] - o.y, sphere[2] - o.z);
-    const float cc = dot(c0, c0), cd = dot(c0, d), dd = dot(d, d);
-    const float r2 = sphere[3];
-    if (cc <= r2) { return true; }                       // the origin is inside
-    if (cd <= 0.f) { return false; }                     // outside and heading away (a NaN falls through and keeps the ray)
-    // |perpendicular|^2 |d|^2 = cc dd - cd^2 <= r^2 dd, with 1e-5 of slack for the rounding of the three products
-    return !(cc * dd - cd * cd > r2 * dd + 1e-5f * cc * dd);
-}
+// (hybridProxy / hybridProxySphere, the two conservative "can this ray meet the tree part at all" tests: trace.h)
 
 template <typename TRAITS>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_HYBRID_WAVES, PATHED_HYBRID_WAVES))) void k_path_hybrid(RenderParams p, SmallTris smallTris)

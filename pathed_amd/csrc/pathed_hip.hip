@@ -266,6 +266,10 @@ struct PathedScene {
     DeviceBuffer<float4> refitLo, refitHi;          // unpadded bounds per node (refit working memory, allocated on first use)
     DeviceBuffer<unsigned char> refitReady;         // two flag arrays
     size_t soupVertices = 0;
+    // [r5] local rays of the wavefront (kernels.h: RenderParams::localTris): the scene's few large triangles and the bounds of the rest
+    int localCount = 0;
+    float4 localTris[3 * 8];
+    float localLo[3] = { 0.f, 0.f, 0.f }, localHi[3] = { 0.f, 0.f, 0.f }, localSphere[4] = { 0.f, 0.f, 0.f, 0.f };
     // [r5] k_path_hybrid (path_hybrid.h): scenes of 65 .. kHybridMaxTris triangles split into a DIRECT set of <= 64 large
     // triangles (all-items intersector) and a TREE part with a 4-wide BVH of its own
     bool hybridAvailable = false;  // the split exists
@@ -1191,6 +1195,74 @@ static hipError_t rebuildHybridItems(PathedScene *scene)
     return scene->hybridItemTris.upload(records);
 }
 
+// [r5] The wavefront's local rays: a sphere-free BVH scene with at most kMaxLocalTris LARGE triangles (each at least 1 / 256 of
+// the scene's surface: a floor, a backdrop) keeps their records for k_shade, with the bounds of everything else -- a box and
+// a sphere about its centre, padded: the tests that use them only cull.
+static void buildLocalSet(PathedScene *scene, const PathedSceneDesc *desc)
+{
+    scene->localCount = 0;
+    const uint32_t n = desc->n_triangles;
+    if (n == 0 || desc->n_spheres != 0) { return; }
+    std::vector<double> area(n);
+    double total = 0.0;
+    for (uint32_t i = 0; i < n; i++) {
+        const float *a = desc->positions + 3 * (size_t)desc->indices[3 * i], *b = desc->positions + 3 * (size_t)desc->indices[3 * i + 1], *c = desc->positions + 3 * (size_t)desc->indices[3 * i + 2];
+        const double e1[3] = { (double)b[0] - a[0], (double)b[1] - a[1], (double)b[2] - a[2] }, e2[3] = { (double)c[0] - a[0], (double)c[1] - a[1], (double)c[2] - a[2] };
+        const double cx = e1[1] * e2[2] - e1[2] * e2[1], cy = e1[2] * e2[0] - e1[0] * e2[2], cz = e1[0] * e2[1] - e1[1] * e2[0];
+        area[i] = 0.5 * std::sqrt(cx * cx + cy * cy + cz * cz);
+        total += area[i];
+    }
+    std::vector<uint32_t> large;
+    for (uint32_t i = 0; i < n; i++) {
+        if (area[i] * 256.0 >= total) {
+            large.push_back(i);
+            if (large.size() > (size_t)kMaxLocalTris) { return; }   // a scene of many large faces: no "rest" worth culling against
+        }
+    }
+    if (large.empty() || large.size() == n) { return; }
+    std::vector<char> isLarge(n, 0);
+    for (uint32_t i : large) { isLarge[i] = 1; }
+    double lo[3] = { 1e300, 1e300, 1e300 }, hi[3] = { -1e300, -1e300, -1e300 };
+    for (uint32_t i = 0; i < n; i++) {
+        if (isLarge[i]) { continue; }
+        for (int k = 0; k < 3; k++) {
+            const float *v = desc->positions + 3 * (size_t)desc->indices[3 * i + k];
+            for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], (double)v[a]); hi[a] = std::max(hi[a], (double)v[a]); }
+        }
+    }
+    double extent = 0.0, centre[3], radius2 = 0.0;
+    for (int a = 0; a < 3; a++) { extent = std::max(extent, std::max(hi[a] - lo[a], std::max(std::fabs(lo[a]), std::fabs(hi[a])))); }
+    for (int a = 0; a < 3; a++) { centre[a] = (double)(float)(0.5 * (lo[a] + hi[a])); }
+    for (uint32_t i = 0; i < n; i++) {
+        if (isLarge[i]) { continue; }
+        for (int k = 0; k < 3; k++) {
+            const float *v = desc->positions + 3 * (size_t)desc->indices[3 * i + k];
+            double d2 = 0.0;
+            for (int a = 0; a < 3; a++) { const double d = (double)v[a] - centre[a]; d2 += d * d; }
+            radius2 = std::max(radius2, d2);
+        }
+    }
+    const double radius = std::sqrt(radius2) * 1.0001 + 1e-4 * extent + 1e-30;
+    for (int a = 0; a < 3; a++) {
+        scene->localLo[a] = (float)(lo[a] - 1e-4 * extent - 1e-30);
+        scene->localHi[a] = (float)(hi[a] + 1e-4 * extent + 1e-30);
+        scene->localSphere[a] = (float)centre[a];
+    }
+    scene->localSphere[3] = (float)(radius * radius * 1.00001);
+    for (size_t k = 0; k < large.size(); k++) {
+        const uint32_t i = large[k];
+        const float *v0 = desc->positions + 3 * (size_t)desc->indices[3 * i], *v1 = desc->positions + 3 * (size_t)desc->indices[3 * i + 1], *v2 = desc->positions + 3 * (size_t)desc->indices[3 * i + 2];
+        float prim;
+        const int id = (int)i;
+        std::memcpy(&prim, &id, 4);
+        // the record the tree's leaves hold for the triangle (bvh_build.h): v0, e1 = v1 - v0, e2 = v2 - v0 in fp32
+        scene->localTris[3 * k + 0] = make_float4(v0[0], v0[1], v0[2], prim);
+        scene->localTris[3 * k + 1] = make_float4(v1[0] - v0[0], v1[1] - v0[1], v1[2] - v0[2], 0.f);
+        scene->localTris[3 * k + 2] = make_float4(v2[0] - v0[0], v2[1] - v0[1], v2[2] - v0[2], 0.f);
+    }
+    scene->localCount = (int)large.size();
+}
+
 // [r5] Splits a scene of 65 .. kHybridMaxTris triangles for k_path_hybrid: the (up to 64) largest triangles -- each at least
 // 1 / 256 of the scene's surface: walls, floors, boxes, what most rays hit and what no box around it would cull -- are tested
 // directly; everything else gets a tree of its own (the host SAH builder, the node format of the scene's tree).
@@ -1314,6 +1386,7 @@ int pathed_hip_scene_create_ex(const PathedSceneDesc *desc, const PathedSceneOpt
         if (options.wave_stragglers < -1 || options.wave_stragglers > 64) { return fail(PATHED_E_INVALID, "wave_stragglers must be -1 (none), 0 (default) or 1..64"); }
         if (options.wave_refill < 0 || options.wave_refill > 64) { return fail(PATHED_E_INVALID, "wave_refill must be 0 (default) or 1..64"); }
         if (options.chunks_per_pass < 0 || options.chunks_per_pass > 4096) { return fail(PATHED_E_INVALID, "chunks_per_pass must be 0 (default) or 1..4096"); }
+        if (options.local_rays != 0 && options.local_rays != 1) { return fail(PATHED_E_INVALID, "local_rays must be 0 (automatic) or 1 (off)"); }
         if (options.hybrid_batch < 0 || options.hybrid_batch > 128) { return fail(PATHED_E_INVALID, "hybrid_batch must be 0 (default) or 1..128"); }
         if (options.hybrid_ready < -1 || options.hybrid_ready > 64) { return fail(PATHED_E_INVALID, "hybrid_ready must be -1 (never), 0 (default) or 1..64"); }
     }
@@ -1817,6 +1890,7 @@ int pathed_hip_scene_create_ex(const PathedSceneDesc *desc, const PathedSceneOpt
             scene->hybridPath = true;
         }
     }
+    if (!scene->bruteForce && options.local_rays != 1 && scene->nodeFormat == 0) { buildLocalSet(scene, desc); }
     if (shadeKernel == 5 && !scene->waveAvailable) {
         delete scene;
         return fail(PATHED_E_INVALID, "the wave path kernel serves BVH scenes (more than 64 triangles or intersector 1) of at most 96 materials over the float nodes");
@@ -2469,6 +2543,14 @@ static int renderPass(PathedScene *scene, uint64_t seed, uint32_t begin, uint32_
         q.sppEnd = begin + count;
         q.startBounce = start_bounce;
         q.lastBounce = last_bounce;
+        // local rays (per-slot shade kernel only: the staged and split stages of the experiments build do not know them)
+        q.localCount = (!scene->stagedShade && !scene->splitShade) ? scene->localCount : 0;
+        q.localCounting = scene->countMode ? 1 : 0;
+        if (q.localCount > 0) {
+            std::memcpy(q.localTris, scene->localTris, sizeof q.localTris);
+            for (int a = 0; a < 3; a++) { q.hybridLo[a] = scene->localLo[a]; q.hybridHi[a] = scene->localHi[a]; }
+            for (int a = 0; a < 4; a++) { q.hybridSphere[a] = scene->localSphere[a]; }
+        }
         if (pools > 1) { streams[h] = scene->poolStreams[h]; }
     }
 
@@ -2893,6 +2975,8 @@ int pathed_hip_get_stats(PathedScene *scene, PathedStats *out)
     out->nodes_visited = device[kStatBoxes];
     out->tris_tested = device[kStatTris];
     out->dropped_samples = device[kStatDropped];
+    out->local_closest_rays = device[kStatLocalClosest];
+    out->local_shadow_rays = device[kStatLocalShadow];
     out->iterations = scene->iterations;
     out->trace_ms = scene->traceEvents.totalMs;
     out->shade_ms = scene->shadeEvents.totalMs;

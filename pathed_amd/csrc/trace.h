@@ -484,6 +484,38 @@ __device__ inline void finishRay(const TraceGeometry &g, LaneRay &ray)
     }
 }
 
+// ---- proxies: "can this ray meet a set of primitives at all", from the set's bounds alone (k_path_hybrid's tree part,
+// k_shade's local rays: the bounds of everything but a scene's few large triangles)
+// conservative "the segment (tnear, tfar] of the ray meets the box": reciprocal by v_rcp_f32 (1 ulp), the box padded by the
+// host by 1e-4 of its size, tmax by 1e-5 relative: misses only what innerStep's slab test of the root's children would miss too
+__device__ __forceinline__ bool hybridProxy(const float *lo, const float *hi, V3 o, V3 d, float tfar)
+{
+    const float kHuge = 3e30f;
+    const float ix = fminf(fmaxf(__builtin_amdgcn_rcpf(d.x), -kHuge), kHuge);
+    const float iy = fminf(fmaxf(__builtin_amdgcn_rcpf(d.y), -kHuge), kHuge);
+    const float iz = fminf(fmaxf(__builtin_amdgcn_rcpf(d.z), -kHuge), kHuge);
+    const float tx0 = (lo[0] - o.x) * ix, tx1 = (hi[0] - o.x) * ix;
+    const float ty0 = (lo[1] - o.y) * iy, ty1 = (hi[1] - o.y) * iy;
+    const float tz0 = (lo[2] - o.z) * iz, tz1 = (hi[2] - o.z) * iz;
+    // fminf / fmaxf return the non-NaN operand (0 x inf): what a conservative test wants
+    const float tmin = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), 0.f));
+    const float tmax = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fminf(fmaxf(tz0, tz1), tfar));
+    return tmin <= tmax * 1.00001f + 1e-6f;
+}
+
+// ... and "the ray's LINE comes within the part's bounding sphere, ahead of the origin unless that lies inside": the box's
+// corners are empty space around a round cluster (the reference's ball: half the box).  sphere = centre, radius^2 (padded)
+__device__ __forceinline__ bool hybridProxySphere(const float *sphere, V3 o, V3 d)
+{
+    const V3 c0 = v3(sphere[0] - o.x, sphere[1] - o.y, sphere[2] - o.z);
+    const float cc = dot(c0, c0), cd = dot(c0, d), dd = dot(d, d);
+    const float r2 = sphere[3];
+    if (cc <= r2) { return true; }                       // the origin is inside
+    if (cd <= 0.f) { return false; }                     // outside and heading away (a NaN falls through and keeps the ray)
+    // |perpendicular|^2 |d|^2 = cc dd - cd^2 <= r^2 dd, with 1e-5 of slack for the rounding of the three products
+    return !(cc * dd - cd * cd > r2 * dd + 1e-5f * cc * dd);
+}
+
 // One whole ray on one lane (test hook / simple callers).
 // FORMAT: 0 the 128-byte float nodes, 1 nodeQ, 2 node8
 template <bool COUNT, int ROWS, int STRIDE, int FORMAT = 0>
