@@ -1890,7 +1890,8 @@ int pathed_hip_scene_create_ex(const PathedSceneDesc *desc, const PathedSceneOpt
             scene->hybridPath = true;
         }
     }
-    if (!scene->bruteForce && options.local_rays != 1 && scene->nodeFormat == 0) { buildLocalSet(scene, desc); }
+    // (not for refittable scenes: their vertices move, the large triangles' records and the bounds of the rest would go stale)
+    if (!scene->bruteForce && options.local_rays != 1 && scene->nodeFormat == 0 && !options.refittable) { buildLocalSet(scene, desc); }
     if (shadeKernel == 5 && !scene->waveAvailable) {
         delete scene;
         return fail(PATHED_E_INVALID, "the wave path kernel serves BVH scenes (more than 64 triangles or intersector 1) of at most 96 materials over the float nodes");

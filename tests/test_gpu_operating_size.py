@@ -61,7 +61,10 @@ def test_the_wavefront_at_its_operating_size_is_the_wave_kernels_image_bit_for_b
     torch.cuda.synchronize()
     stats = product.stats()
     assert stats["path_kernel"] == 1 and stats["parked_rays"] > 0 and stats["dropped_samples"] == 0
-    assert stats["closest_rays"] > width * height * spp and stats["shadow_rays"] > 0
+    # (every camera sample asks at least one closest-hit query; the shade kernel answers the ones that cannot meet the mesh
+    # itself -- local rays, tests/test_gpu_local_rays.py -- and counts them apart)
+    assert stats["closest_rays"] + stats["local_closest_rays"] > width * height * spp and stats["shadow_rays"] > 0
+    assert stats["local_closest_rays"] > 0
     assert torch.equal(counted, image)
 
     # a second batch continues the sums exactly as the on-chip kernel continues them
