@@ -319,6 +319,9 @@ typedef struct PathedSceneOptions {
     int32_t local_rays;         /* the wavefront's local rays: a sphere-free BVH scene with at most 8 LARGE triangles (each >= 1 / 256 of
                                    its surface: a floor, a backdrop) lets the shade kernel resolve the rays that cannot meet the
                                    bounds of everything else -- they skip the trace kernel; same hits.  0 automatic (on), 1 off */
+    int32_t shade_launches;     /* ... shade launches per trace launch on such a scene, 1..16 (0 = 1: more were measured and lose): in the further ones the slots
+                                   whose rays were all local advance another vertex, the others wait for the trace kernel, which
+                                   then finds the tree-walking rays of several vertices in one launch.  Scheduling only */
     int32_t hybrid_batch;       /* k_path_hybrid: a wave walks its tree part once this many of its rays wait or are in flight,
                                    1..128 (1 = in every iteration; 0 = 24).  Scheduling only */
     int32_t hybrid_ready;       /* ... or once fewer of its paths than this can go on without a result, 1..64; -1 = only when

@@ -111,6 +111,8 @@ static const int kStBounceMask = 0xFFFF;
 static const int kStEligible = 1 << 16;   // the vertex wants the BSDF-sampling MIS term
 static const int kStDelta = 1 << 17;      // the vertex BSDF is a delta lobe
 static const int kStContinue = 1 << 18;   // the path may continue past this ray
+static const int kStAwait = 1 << 26;      // [r5] the slot waits for the trace kernel (a ray of its own to walk the tree, or an occlusion ray on the list):
+                                          // a shade launch that does not follow a trace launch leaves it alone
 static const int kStLocal = 1 << 27;      // [r5] the slot's ray was resolved by k_shade itself (it cannot meet the mesh part): hit[] is valid, nothing to trace
 static const int kStHold = 1 << 28;       // a ray of the slot is parked in a trace wave: do not re-trace, do not shade
 static const int kStDone = 1 << 30;       // slot has no ray in flight

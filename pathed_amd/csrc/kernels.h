@@ -229,6 +229,8 @@ struct RenderParams {
     // ray that cannot meet those bounds can only hit one of the large triangles: k_shade tests them itself, writes the hit
     // and marks the slot kStLocal; an occlusion ray of that kind never joins the shadow list.  localCount = 0: off
     int localCount, localCounting;
+    int afterTrace;           // k_shade: 1 = this launch follows a trace launch of the pool (every slot's results are in); 0 = a further
+                              // shade launch of the same iteration: only the slots whose rays were all local take part
     float4 localTris[3 * 8];
 };
 static const int kMaxLocalTris = 8;
@@ -1913,7 +1915,10 @@ __global__ __launch_bounds__(kBlock) PATHED_SHADE_ATTRIBUTE void k_shade(RenderP
         }
     }
 
-    st &= ~kStLocal;               // (the hit of such a slot is this kernel's own, written last iteration)
+    // [r5] several shade launches may follow one trace launch (local rays): in the later ones a slot that waits for the
+    // trace kernel sits the launch out, untouched
+    if (!p.afterTrace && (st & kStAwait)) { active = false; }
+    st &= ~(kStLocal | kStAwait);  // (the hit of a local slot is this kernel's own, written by the launch before)
     rd.w = intAsFloat(st);
 
     ShadowRequest shadow;
@@ -2192,6 +2197,8 @@ __global__ __launch_bounds__(kBlock) PATHED_SHADE_ATTRIBUTE void k_shade(RenderP
                 }
             }
         }
+        // whatever is left for the trace kernel makes the slot wait for it (kStAwait: later shade launches of this iteration pass it by)
+        if (hasRay && (!(floatAsInt(outRayD.w) & kStLocal) || shadow.push)) { outRayD.w = intAsFloat(floatAsInt(outRayD.w) | kStAwait); }
     }
 
     if (active) {

@@ -168,6 +168,8 @@ struct EventRing {
 }  // namespace
 
 static const int kMaxPools = 4;
+static const int kDefaultShadeLaunches = 1;   // shade launches per trace launch of a scene with local rays (PathedSceneOptions.shade_launches = 0): more were
+// measured and lose -- the shade kernel is the slower partner, profiles/r5_ab_local_rays.log
 static const int kDefaultSmallPhase1 = 1;   // PathedSceneOptions.small_phase1 = 0: 1 VALU, 2 matrix pipe
 
 
@@ -628,6 +630,8 @@ void launchShade(PathedScene *scene, const RenderParams &params, hipStream_t str
         // (k_shade narrowed further to {Lambertian, plastic, environment} -- 88 VGPRs against 92 -- shortens the shade launches of
         // the 5.2 M-triangle mesh by 13 % and LENGTHENS the other pool's trace launches by 23 %: -4.8 % overall, not adopted,
         // profiles/r3_ab_scene_traits.log)
+        // ([r5] again with local rays, when the trace kernel has a fifth of its rays left: {Lambertian, plastic, environment} 2 312
+        // against 2 456 Msamples/s on the same mesh, the sphere-free environment set +-0: profiles/r5_ab_local_rays.log)
         if (scene->envOnly) { hipLaunchKernelGGL((k_shade<true, true>), grid, block, 0, stream, params); }
         else { hipLaunchKernelGGL((k_shade<true, false>), grid, block, 0, stream, params); }
     } else {
@@ -1386,6 +1390,7 @@ int pathed_hip_scene_create_ex(const PathedSceneDesc *desc, const PathedSceneOpt
         if (options.wave_stragglers < -1 || options.wave_stragglers > 64) { return fail(PATHED_E_INVALID, "wave_stragglers must be -1 (none), 0 (default) or 1..64"); }
         if (options.wave_refill < 0 || options.wave_refill > 64) { return fail(PATHED_E_INVALID, "wave_refill must be 0 (default) or 1..64"); }
         if (options.chunks_per_pass < 0 || options.chunks_per_pass > 4096) { return fail(PATHED_E_INVALID, "chunks_per_pass must be 0 (default) or 1..4096"); }
+        if (options.shade_launches < 0 || options.shade_launches > 16) { return fail(PATHED_E_INVALID, "shade_launches must be 0 (automatic) or 1..16"); }
         if (options.local_rays != 0 && options.local_rays != 1) { return fail(PATHED_E_INVALID, "local_rays must be 0 (automatic) or 1 (off)"); }
         if (options.hybrid_batch < 0 || options.hybrid_batch > 128) { return fail(PATHED_E_INVALID, "hybrid_batch must be 0 (default) or 1..128"); }
         if (options.hybrid_ready < -1 || options.hybrid_ready > 64) { return fail(PATHED_E_INVALID, "hybrid_ready must be -1 (never), 0 (default) or 1..64"); }
@@ -2547,6 +2552,7 @@ static int renderPass(PathedScene *scene, uint64_t seed, uint32_t begin, uint32_
         // local rays (per-slot shade kernel only: the staged and split stages of the experiments build do not know them)
         q.localCount = (!scene->stagedShade && !scene->splitShade) ? scene->localCount : 0;
         q.localCounting = scene->countMode ? 1 : 0;
+        q.afterTrace = 1;
         if (q.localCount > 0) {
             std::memcpy(q.localTris, scene->localTris, sizeof q.localTris);
             for (int a = 0; a < 3; a++) { q.hybridLo[a] = scene->localLo[a]; q.hybridHi[a] = scene->localHi[a]; }
@@ -2594,6 +2600,7 @@ static int renderPass(PathedScene *scene, uint64_t seed, uint32_t begin, uint32_
         HIP_TRY(hipEventCreateWithFlags(&pollEvents[h][0], hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&pollEvents[h][1], hipEventDisableTiming));
     }
+    const int shadeLaunches = params[0].localCount > 0 ? (scene->options.shade_launches > 0 ? scene->options.shade_launches : kDefaultShadeLaunches) : 1;
     unsigned long long iteration = 0;
     int pollIndex = 0;
     bool havePending = false;
@@ -2612,11 +2619,20 @@ static int renderPass(PathedScene *scene, uint64_t seed, uint32_t begin, uint32_
                     (void)hipEventRecord(scene->traceEvents.stop[e], streams[h]);
                     const int s = scene->shadeEvents.acquire();
                     (void)hipEventRecord(scene->shadeEvents.start[s], streams[h]);
-                    launchShade(scene, params[h], streams[h]);
+                    for (int round = 0; round < shadeLaunches; round++) {
+                        params[h].afterTrace = round == 0 ? 1 : 0;
+                        launchShade(scene, params[h], streams[h]);
+                    }
                     (void)hipEventRecord(scene->shadeEvents.stop[s], streams[h]);
                 } else {
                     launchTrace(scene, params[h], streams[h]);
-                    launchShade(scene, params[h], streams[h]);
+                    // with local rays: several shade launches per trace launch -- the slots whose rays were all local advance
+                    // another vertex each time, the others wait; the trace kernel then finds the hard rays of several vertices
+                    // in ONE launch
+                    for (int round = 0; round < shadeLaunches; round++) {
+                        params[h].afterTrace = round == 0 ? 1 : 0;
+                        launchShade(scene, params[h], streams[h]);
+                    }
                 }
             }
             iteration++;

@@ -35,6 +35,10 @@ def test_local_rays_change_no_bit_and_lose_no_query(scene_path, width, height, s
     assert a["closest_rays"] + a["local_closest_rays"] == b["closest_rays"]
     assert a["shadow_rays"] + a["local_shadow_rays"] == b["shadow_rays"]
     assert a["nodes_visited"] < b["nodes_visited"] and a["dropped_samples"] == b["dropped_samples"] == 0
+    # several shade launches per trace launch (the slots whose rays were all local advance, the others wait): scheduling only
+    for launches in (1, 3, 5):
+        other = HipScene(scene.desc, device=0, bvh_builder=builder, shade_kernel="per-slot", shade_launches=launches)
+        assert np.array_equal(other.render(3, 0, spp, 0, 10), expected), launches
     # the wave kernel and the default dispatch agree with both
     assert np.array_equal(HipScene(scene.desc, device=0, bvh_builder=builder).render(3, 0, spp, 0, 10), expected)
 
