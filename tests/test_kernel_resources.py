@@ -67,6 +67,15 @@ def test_vgpr_budgets_of_the_hot_kernels(tmp_path):
     # scene that pairs triangles (<= 64 materials, 6 KiB) four blocks must fit a CU's 160 KiB
     assert all(v["LDS"] + 64 * 96 <= 160 * 1024 // 4 for v in quads.values()), quads
 
+    # [r5] the hybrid kernel (path_hybrid.h: direct set + a tree of the rest) keeps k_path_small's budget: four waves per SIMD at
+    # 128 VGPRs, and its static LDS (the stash + 4.4 KiB per wave) leaves room for four blocks per CU beside a material table
+    hybrid = {k: v for k, v in usage.items() if "k_path_hybrid" in k}
+    assert len(hybrid) == 4 and all(v["VGPRs"] <= 128 and v["Occupancy"] == 4 for v in hybrid.values()), hybrid
+    assert all(v["LDS"] + 16 * 96 <= 160 * 1024 // 4 for v in hybrid.values()), hybrid
+    smooth = [v for k, v in hybrid.items() if "SceneTraitsILj49E" in k]
+    assert len(smooth) == 1 and smooth[0]["ScratchSize"] <= 192, hybrid   # (parked-ray words and the burst state: 164 bytes today)
+
+
 @pytest.mark.skipif(not os.environ.get("PATHED_TEST_EXPERIMENTS"), reason="compiles the experiments build (minutes): set PATHED_TEST_EXPERIMENTS=1")
 def test_vgpr_budgets_of_the_experimental_kernels(tmp_path):
     """The measured-and-rejected organisations (kernels_experiments.h, `make experiments`) keep the budgets they were measured at."""
