@@ -12,7 +12,10 @@ ARCH     ?= gfx950
 # x86-64-v3 (AVX2+FMA) rather than -march=native: the objects are built in one
 # container and run on another host.
 CPUFLAGS  = -std=c++17 -O2 -fPIC -ffp-contract=off -fwrapv -march=x86-64-v3 -Wall -Wextra -Iinclude
-HIPFLAGS  = -std=c++17 -O3 -fPIC -ffp-contract=off --offload-arch=$(ARCH) -Iinclude -Wall -Wno-unused-parameter
+# (-instcombine-max-copied-from-constant-users: the kernels take RenderParams, 1.6 KB, by value; past 300 uses of it in one
+#  kernel the compiler stops reading the fields from the kernel-argument segment and gives every lane a private copy in scratch)
+HIPFLAGS  = -std=c++17 -O3 -fPIC -ffp-contract=off --offload-arch=$(ARCH) -Iinclude -Wall -Wno-unused-parameter \
+            -mllvm -instcombine-max-copied-from-constant-users=4000
 
 LIBDIR    = pathed_amd/lib
 BINDIR    = pathed_amd/bin
@@ -31,7 +34,7 @@ hip: $(LIBDIR)/libpathed_hip.so
 host: $(LIBDIR)/libpathed_host.so $(BINDIR)/pathed
 oracle: oracle/liboracle.so
 
-$(LIBDIR)/libpathed_hip.so: $(HIP_SRC) $(HIP_HDR)
+$(LIBDIR)/libpathed_hip.so: $(HIP_SRC) $(HIP_HDR) Makefile
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(HIP_SRC)
 
@@ -39,7 +42,7 @@ $(LIBDIR)/libpathed_hip.so: $(HIP_SRC) $(HIP_HDR)
 # formats, the matrix-pipe phase 1, the clocked VALU probe) are NOT part of `make all`.  Load the result with
 # PATHED_HIP_LIB=pathed_amd/lib/libpathed_hip_experiments.so (pathed_amd/_capi.py); tests: pytest -m experiments.
 experiments: $(LIBDIR)/libpathed_hip_experiments.so
-$(LIBDIR)/libpathed_hip_experiments.so: $(HIP_SRC) $(HIP_HDR)
+$(LIBDIR)/libpathed_hip_experiments.so: $(HIP_SRC) $(HIP_HDR) Makefile
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -DPATHED_EXPERIMENTS=1 -shared -o $@ $(HIP_SRC)
 

@@ -316,8 +316,11 @@ def kernel_rates(counted, counted_samples, timed, timed_samples):
     trace_avg_ms = timed["trace_ms"] / timed["trace_launches"]
     shade_avg_ms = timed["shade_ms"] / timed["trace_launches"]
     trace_bytes = algorithmic_bytes(counted) * scale / launches
-    # every closest-hit result is one slot visit of k_shade: state in (112 B), state out (128 B)
-    shade_bytes = STATE_BYTES_PER_VERTEX * counted["closest_rays"] * scale / launches
+    # every closest-hit result is one slot visit of k_shade: state in (112 B), state out (128 B) -- whether the trace kernel found
+    # it or, for a ray that cannot meet the mesh, the shade kernel itself (local rays, counted apart)
+    local_closest, local_shadow = counted.get("local_closest_rays", 0), counted.get("local_shadow_rays", 0)
+    vertices = counted["closest_rays"] + local_closest
+    shade_bytes = STATE_BYTES_PER_VERTEX * vertices * scale / launches
     return {
         "launches": launches,
         "timed_launches": timed["trace_launches"],
@@ -325,10 +328,12 @@ def kernel_rates(counted, counted_samples, timed, timed_samples):
                   "achieved": trace_bytes / (trace_avg_ms * 1e-3) / 1e9, "frac": trace_bytes / (trace_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
         "shade": {"algorithmic_bytes_per_launch": shade_bytes, "avg_launch_us": shade_avg_ms * 1e3,
                   "achieved": shade_bytes / (shade_avg_ms * 1e-3) / 1e9, "frac": shade_bytes / (shade_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
-        "rays_per_sample": (counted["closest_rays"] + counted["shadow_rays"]) / float(counted_samples),
-        "vertices_per_sample": counted["closest_rays"] / float(counted_samples),
+        "rays_per_sample": (vertices + counted["shadow_rays"] + local_shadow) / float(counted_samples),
+        "traced_rays_per_sample": (counted["closest_rays"] + counted["shadow_rays"]) / float(counted_samples),
+        "local_rays_per_sample": (local_closest + local_shadow) / float(counted_samples),
+        "vertices_per_sample": vertices / float(counted_samples),
         "algorithmic_bytes_per_sample": {"trace": algorithmic_bytes(counted) / float(counted_samples),
-                                         "shade": STATE_BYTES_PER_VERTEX * counted["closest_rays"] / float(counted_samples)},
+                                         "shade": STATE_BYTES_PER_VERTEX * vertices / float(counted_samples)},
     }
 
 
@@ -410,6 +415,8 @@ def large_bvh_leg(args, torch, stream, measured_copy_gbs=None):
             "k_trace": rates["trace"] if rates else None,
             "k_shade": rates["shade"] if rates else None,
             "rays_per_sample": rates["rays_per_sample"] if rates else None,
+            "traced_rays_per_sample": rates["traced_rays_per_sample"] if rates else None,
+            "local_rays_per_sample": rates["local_rays_per_sample"] if rates else None,
             "vertices_per_sample": rates["vertices_per_sample"] if rates else None,
             "mrays_per_s": (rates["rays_per_sample"] * width * height * timed_spp / elapsed / 1e6) if rates else None,
             "traffic": traffic,
@@ -431,7 +438,9 @@ def large_bvh_leg(args, torch, stream, measured_copy_gbs=None):
         "scene_load_s": loaded_s, "setup_s": setup_s,
         "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "note": "k_trace / k_shade: algorithmic bytes per launch (SURVEY.md 8d) / HIP-event time of the launch AS THE PIPELINE RUNS "
-                "(two pools: a trace launch shares the chip with the other pool's shade launch); one_pool below is a diagnostic",
+                "(two pools: a trace launch shares the chip with the other pool's shade launch); one_pool below is a diagnostic.  "
+                "Since round 5 the shade kernel answers the queries that cannot meet the mesh itself (local_rays_per_sample): k_trace's "
+                "launches carry the tree-walking rays only, fewer and longer ones",
         # headline row = the reference's camera; the same keys as round 2 so the lines stay comparable
         "msamples_per_s": reference_row["msamples_per_s"],
         "k_trace": reference_row["k_trace"], "k_shade": reference_row["k_shade"],

@@ -319,6 +319,9 @@ typedef struct PathedSceneOptions {
     int32_t local_rays;         /* the wavefront's local rays: a sphere-free BVH scene with at most 8 LARGE triangles (each >= 1 / 256 of
                                    its surface: a floor, a backdrop) lets the shade kernel resolve the rays that cannot meet the
                                    bounds of everything else -- they skip the trace kernel; same hits.  0 automatic (on), 1 off */
+    int32_t shade_chain;        /* environment-lit scenes: the shade kernel that ends a sample starts the next one at once and, when its
+                                   camera ray is a local ray that hits a large triangle, shades its first vertex in the same launch
+                                   (k_shade_env).  0 automatic (on), 1 off.  Scheduling only */
     int32_t shade_launches;     /* ... shade launches per trace launch on such a scene, 1..16 (0 = 1: more were measured and lose): in the further ones the slots
                                    whose rays were all local advance another vertex, the others wait for the trace kernel, which
                                    then finds the tree-walking rays of several vertices in one launch.  Scheduling only */

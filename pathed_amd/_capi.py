@@ -163,6 +163,7 @@ class PathedSceneOptions(C.Structure):
         ("wave_refill", C.c_int32),
         ("chunks_per_pass", C.c_int32),
         ("local_rays", C.c_int32),
+        ("shade_chain", C.c_int32),
         ("shade_launches", C.c_int32),
         ("hybrid_batch", C.c_int32),
         ("hybrid_ready", C.c_int32),

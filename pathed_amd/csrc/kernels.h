@@ -1650,7 +1650,9 @@ __device__ inline unsigned int grabUnits(const RenderParams &p, bool want, unsig
             total += count;
         }
         if (total == 0u) { __syncthreads(); break; }   // nobody (left) wants a unit: block-uniform
-        const unsigned int queue = home + attempt < queues ? home + attempt : home + attempt - queues;
+        // (block-uniform; readfirstlane says so to the compiler, which otherwise may index the kernel arguments' queueUnits with
+        // a vector register and, to do that, keep a private copy of all of RenderParams: k_shade_env did, 1.6 KB per lane)
+        const unsigned int queue = (unsigned int)__builtin_amdgcn_readfirstlane((int)(home + attempt < queues ? home + attempt : home + attempt - queues));
         const unsigned int limit = p.queueUnits[queue];
         if (threadIdx.x == 0) {
             unsigned int *cursor = &p.counters[kCtrUnitCursor + queue * kCursorStride];
@@ -2244,6 +2246,419 @@ __global__ __launch_bounds__(kBlock) PATHED_SHADE_ATTRIBUTE void k_shade(RenderP
 
     // slots that ran out of units (only at the tail of a render call)
     const unsigned long long retiredMask = __ballot(retired);
+    if (lane == 0 && retiredMask != 0ull) {
+        atomicSub(&p.counters[kCtrRemaining], (unsigned int)__popcll(retiredMask));
+    }
+}
+
+// the wavefront's local rays (RenderParams::localTris): can a ray meet anything but the scene's large triangles, and its closest
+// hit among those (the tree walk's intersector and acceptance rule)
+__device__ __forceinline__ bool localMeetsRest(const RenderParams &p, V3 origin, V3 direction, float tfar)
+{
+    return hybridProxy(p.hybridLo, p.hybridHi, origin, direction, tfar) && hybridProxySphere(p.hybridSphere, origin, direction);
+}
+// (call it from WAVE-UNIFORM control flow, lanes without a ray pass want = false: inside a divergent branch the compiler takes
+// the loop counter for a per-lane value, cannot index the kernel arguments with it and keeps a private copy of all 1.6 KB)
+__device__ __forceinline__ float4 localClosestHit(const RenderParams &p, bool want, V3 origin, V3 direction)
+{
+    float best = PATHED_TFAR, bestU = 0.f, bestV = 0.f;
+    int bestPrim = -1;
+    if (__ballot(want) == 0ull) { return make_float4(best, bestU, bestV, intAsFloat(bestPrim)); }
+    for (int k = 0; k < p.localCount; k++) {
+        const float4 t0 = p.localTris[3 * k + 0], t1 = p.localTris[3 * k + 1], t2 = p.localTris[3 * k + 2];   // kernel arguments: scalar loads
+        const int prim = floatAsInt(t0.w);
+        float t, u, v;
+        if (want && intersectTriangle(origin, direction, v3(t0.x, t0.y, t0.z), v3(t1.x, t1.y, t1.z), v3(t2.x, t2.y, t2.z), &t, &u, &v) && t > PATHED_TNEAR) {
+            const bool closer = (bestPrim < 0) ? (t <= best) : (t < best || (t == best && prim < bestPrim));   // testLeafTriangle's rule (trace.h)
+            if (closer) { best = t; bestU = u; bestV = v; bestPrim = prim; }
+        }
+    }
+    return make_float4(best, bestU, bestV, intAsFloat(bestPrim));
+}
+__device__ __forceinline__ bool localOccluded(const RenderParams &p, bool want, V3 origin, V3 direction, float tfar)
+{
+    bool occluded = false;
+    if (__ballot(want) == 0ull) { return false; }
+    for (int k = 0; k < p.localCount; k++) {
+        const float4 t0 = p.localTris[3 * k + 0], t1 = p.localTris[3 * k + 1], t2 = p.localTris[3 * k + 2];
+        float t, u, v;
+        if (want && !occluded && intersectTriangle(origin, direction, v3(t0.x, t0.y, t0.z), v3(t1.x, t1.y, t1.z), v3(t2.x, t2.y, t2.z), &t, &u, &v)
+            && t > PATHED_TNEAR && t <= tfar) { occluded = true; }
+    }
+    return occluded;
+}
+
+// k_shade for scenes lit by the ENVIRONMENT alone (no emissive surface: what k_shade<.., ENV_ONLY = true> served), with a CHAIN
+// [r5]: a sample that ends when its ray comes back -- a miss, the last bounce, a black throughput: most samples of "an
+// object on a floor under a sky" -- starts the next sample's camera ray at once, and if that ray is a LOCAL one (it cannot
+// meet the mesh: k_shade's local rays) and hits one of the scene's large triangles, the new sample's first vertex is shaded in
+// this very launch, by the lane that would otherwise sit the vertex code of its wave out.  One slot visit -- 112 bytes read,
+// 128 written, one trace launch waited for -- less per such sample; the dragon configuration's typical sample (floor, sky) is
+// two visits instead of three.  Every operation on a path's values is k_shade's, in k_shade's order: same floats
+// (tests/test_gpu_local_rays.py, test_gpu_operating_size.py).  The finish logic needs no intersection record here (no surface
+// emits), so makeIsect stays ONE inlined copy, in front of the vertex code.
+template <bool LDS_MATERIALS, typename TRAITS = TraitsAll>
+__global__ __launch_bounds__(kBlock) PATHED_SHADE_ATTRIBUTE void k_shade_env(RenderParams p)
+{
+    __shared__ DMaterial ldsMaterials[LDS_MATERIALS ? kMaxLdsMaterials : 1];
+    __shared__ unsigned int scratch[kWavesPerBlock + 1];
+
+    MaterialAccess<LDS_MATERIALS> materials;
+    if (LDS_MATERIALS) {
+        const int words = p.scene.nMaterials * (int)(sizeof(DMaterial) / 4);
+        const int *source = reinterpret_cast<const int *>(p.scene.materials);
+        int *target = reinterpret_cast<int *>(ldsMaterials);
+        for (int i = threadIdx.x; i < words; i += kBlock) { target[i] = source[i]; }
+        __syncthreads();
+        materials.table = ldsMaterials;
+    } else {
+        materials.table = p.scene.materials;
+    }
+
+    const int slot = blockIdx.x * kBlock + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const DScene &scene = p.scene;
+
+    // rewind the card cursors for the pool's next trace launch, empty the shadow list the NEXT shade launch fills (k_shade)
+    if (blockIdx.x == 0 && threadIdx.x < kTraceShards) { p.counters[kCtrTraceCursor + threadIdx.x * kCursorStride] = 0u; }
+    if (blockIdx.x == 0 && threadIdx.x == kTraceShards) { p.counters[kCtrShadowCount + (p.parity ^ 1) * kCursorStride] = 0u; }
+
+    float4 rd = p.state.rayD[slot];
+    float4 h = p.state.hit[slot];
+    const float4 roIn = p.state.rayO[slot];
+    const float4 resIn0 = p.state.res[slot];
+    pinLoaded(rd);
+    pinLoaded(h);
+    pinLoaded(roIn);
+    pinLoaded(resIn0);
+    int st = floatAsInt(rd.w);
+    bool active = !(st & kStDone);
+    float4 pendIn = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (active) {
+        if (st & kStEligible) { pendIn = p.state.pend[slot]; }
+        if (p.suspendLanes > 0) {
+            const bool parked = floatAsInt(h.w) == kPrimSuspended
+                || ((st & kStEligible) && floatAsInt(pendIn.w) == kShadowSuspended);
+            if (parked) {
+                if (!(st & kStHold)) { reinterpret_cast<int *>(p.state.rayD + slot)[3] = st | kStHold; }
+                active = false;
+            }
+            st &= ~kStHold;
+            rd.w = intAsFloat(st);
+        }
+    }
+    if (!p.afterTrace && (st & kStAwait)) { active = false; }
+    st &= ~(kStLocal | kStAwait);
+    rd.w = intAsFloat(st);
+
+    ShadowRequest shadow;
+    shadow.push = false;
+    shadow.origin = v3(0.f, 0.f, 0.f);
+    shadow.direction = v3(0.f, 0.f, 0.f);
+    shadow.tfar = 0.f;
+
+    bool finished = false;        // the sample in flight ended
+    Rgb color = rgb(0.f);
+    unsigned int unit = 0xFFFFFFFFu;
+    int sampleInUnit = 0;
+    float4 outRayO = make_float4(0.f, 0.f, 0.f, 0.f), outRayD = rd;
+    float4 outMod = make_float4(1.f, 1.f, 1.f, 1.f);
+    float4 outThr = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 outPend = make_float4(0.f, 0.f, 0.f, 0.f);
+    Rgb result = rgb(0.f);
+    // the vertex the second half shades: the one the slot's ray reached, or the first of the sample the slot starts
+    V3 o = v3(0.f, 0.f, 0.f), d = v3(0.f, 0.f, 1.f);
+    float4 hitNow = h;
+    int rayBounce = 0, firstEmitMaterial = -1;
+    uint32_t pixel = 0, sample = 0;
+    bool haveVertex = false;
+    bool hitWritten = false;      // outRayD's ray is a local one and its hit is in localHit
+    float4 localHit = make_float4(PATHED_TFAR, 0.f, 0.f, intAsFloat(-1));
+
+    unsigned int countedClosest = 0u, countedShadow = 0u;
+
+    SHADE_REGION(0, true);
+    SHADE_REGION(1, active);
+    // ---- first half: what the ray that came back means for the sample in flight (k_shade's logic without an intersection
+    // record: no surface of such a scene emits, so a hit contributes nothing here)
+    if (active) {
+        const float4 ro = roIn;
+        const float4 resIn = resIn0;
+        outRayO = ro;
+        o = v3(ro.x, ro.y, ro.z);
+        d = v3(rd.x, rd.y, rd.z);
+        rayBounce = st & kStBounceMask;
+        sampleInUnit = (st >> kStSampleShift) & kStSampleMask;
+        const bool miss = floatAsInt(h.w) < 0;
+        unit = (unsigned int)floatAsInt(resIn.w);
+        firstEmitMaterial = floatAsInt(ro.w);
+        uint32_t firstSample, endSample;
+        unitSamples(p, unit, &pixel, &firstSample, &endSample);
+        sample = firstSample + (uint32_t)sampleInUnit;
+        result = rgb(resIn.x, resIn.y, resIn.z);
+        Rgb modulation = rgb(1.f);
+
+        if (rayBounce == 0) {
+            // SampleIntegrator::samplePixel, src/sample_integrator.cpp:18-59
+            if (miss) {
+                color = rgb(0.f) + environmentL<TRAITS>(scene, d);
+                finished = true;
+            } else {
+                firstEmitMaterial = -1;
+                result = rgb(0.f);
+                haveVertex = true;
+            }
+        } else {
+            const float4 modIn = p.state.mod[slot];
+            const float4 thrIn = p.state.thr[slot];
+            modulation = rgb(modIn.x, modIn.y, modIn.z);
+            const float bsdfPdf = modIn.w;
+            const Rgb throughput = rgb(thrIn.x, thrIn.y, thrIn.z);
+            const float cosTheta = thrIn.w;
+            if (st & kStEligible) {
+                // PathTracer::directSampleBSDF, src/path_tracer.cpp:167-216
+                Rgb bsdfTerm = rgb(0.f);
+                if (miss) {
+                    const Rgb environmentLight = environmentL<TRAITS>(scene, d);
+                    if (!isBlack(environmentLight)) {
+                        const float lightPDF = envEmitPDF(scene.env, d) / 1;
+                        const float brdfWeight = (st & kStDelta)
+                            ? 1.f
+                            : (1 * bsdfPdf) / (1 * bsdfPdf + 1 * lightPDF);
+                        bsdfTerm = environmentLight * brdfWeight * throughput * cosTheta / bsdfPdf;
+                    }
+                }
+                const Rgb Ld = rgb(pendIn.x, pendIn.y, pendIn.z) + bsdfTerm;
+                if (rayBounce == 1) { result = Ld; }
+                else { result = result + Ld * modulation; }
+            }
+            // PathTracer::L loop body, src/path_tracer.cpp:41-58
+            if (!(st & kStContinue) || miss) {
+                finished = true;
+            } else {
+                const float invPDF = 1.f / bsdfPdf;
+                modulation = modulation * (throughput * cosTheta * invPDF);
+                if (isBlack(modulation)) { finished = true; }
+                else { haveVertex = true; }
+            }
+            if (finished) {
+                const Rgb first = rgb(0.f);
+                color = first + result;
+            }
+        }
+        outMod = make_float4(modulation.r, modulation.g, modulation.b, 1.f);
+    }
+
+    // ---- end of a sample, next unit, camera ray: used after either half (a macro, not a lambda: a closure that is called twice
+    // takes the address of the kernel's arguments, and the compiler then keeps a private copy of all 1.6 KB of them)
+    bool retiredAny = false;
+#define PATHED_END_OF_SAMPLE(ended, value, startedNext, nextPixel, nextSample)                                                 \
+    {                                                                                                                        \
+        bool needUnit_ = false;                                                                                              \
+        startedNext = false;                                                                                                 \
+        SHADE_REGION(7, ended);                                                                                              \
+        if (ended) {                                                                                                         \
+            const bool singleSample_ = PATHED_SHADE_TRIM && p.chunk == 1;                                                    \
+            float4 partial_ = make_float4(0.f, 0.f, 0.f, 0.f);                                                               \
+            if (!singleSample_) { partial_ = p.state.acc[slot]; }                                                            \
+            const bool finite_ = isfinite((value).r) && isfinite((value).g) && isfinite((value).b);                          \
+            if (finite_) {                                                                                                   \
+                partial_.x += (value).r;                                                                                     \
+                partial_.y += (value).g;                                                                                     \
+                partial_.z += (value).b;                                                                                     \
+            } else {                                                                                                         \
+                atomicAdd(&p.stats[kStatDropped], 1ull);                                                                     \
+            }                                                                                                                \
+            uint32_t unitPixel_, firstSample_, endSample_;                                                                   \
+            unitSamples(p, unit, &unitPixel_, &firstSample_, &endSample_);                                                   \
+            sampleInUnit++;                                                                                                  \
+            result = rgb(0.f);                                                                                               \
+            outMod = make_float4(1.f, 1.f, 1.f, 1.f);                                                                        \
+            outThr = make_float4(0.f, 0.f, 0.f, 0.f);                                                                        \
+            outPend = make_float4(0.f, 0.f, 0.f, 0.f);                                                                       \
+            if (firstSample_ + (uint32_t)sampleInUnit < endSample_) {                                                        \
+                startedNext = true;                                                                                          \
+                nextPixel = unitPixel_;                                                                                      \
+                nextSample = firstSample_ + (uint32_t)sampleInUnit;                                                          \
+                p.state.acc[slot] = partial_;                                                                                \
+            } else {                                                                                                         \
+                p.state.chunkBuf[partialIndex(p, unit)] = partial_;                                                          \
+                if (!singleSample_) { p.state.acc[slot] = make_float4(0.f, 0.f, 0.f, 0.f); }                                 \
+                needUnit_ = true;                                                                                            \
+            }                                                                                                                \
+        }                                                                                                                    \
+        const unsigned int newUnit_ = grabUnits(p, needUnit_, scratch);                                                      \
+        if (needUnit_) {                                                                                                     \
+            unit = newUnit_;                                                                                                 \
+            if (newUnit_ != 0xFFFFFFFFu) {                                                                                   \
+                uint32_t endSample_;                                                                                         \
+                unitSamples(p, newUnit_, &nextPixel, &nextSample, &endSample_);                                              \
+                sampleInUnit = 0;                                                                                            \
+                startedNext = true;                                                                                          \
+            } else {                                                                                                         \
+                outRayD.w = intAsFloat(kStDone);                                                                             \
+                retiredAny = true;                                                                                           \
+            }                                                                                                                \
+        }                                                                                                                    \
+        SHADE_REGION(8, startedNext);                                                                                        \
+        if (startedNext) { startSample(p, nextPixel, nextSample, sampleInUnit, &outRayO, &outRayD); }                        \
+    }
+
+    // ---- the sample ended with the ray that came back: the next one starts HERE, and if its camera ray is a local one that
+    // hits a large triangle, its first vertex is the one the second half shades
+    {
+        bool startedNext;
+        uint32_t nextPixel = 0, nextSample = 0;
+        PATHED_END_OF_SAMPLE(active && finished, color, startedNext, nextPixel, nextSample)
+        if (p.localCount > 0) {
+            const V3 cameraO = v3(outRayO.x, outRayO.y, outRayO.z), cameraD = v3(outRayD.x, outRayD.y, outRayD.z);
+            const bool localCamera = startedNext && !localMeetsRest(p, cameraO, cameraD, PATHED_TFAR);
+            const float4 found = localClosestHit(p, localCamera, cameraO, cameraD);
+            if (localCamera) {
+                countedClosest++;
+                if (floatAsInt(found.w) >= 0) {
+                    o = cameraO; d = cameraD; hitNow = found;
+                    rayBounce = 0; firstEmitMaterial = -1;
+                    pixel = nextPixel; sample = nextSample;
+                    result = rgb(0.f);
+                    haveVertex = true;
+                } else {
+                    // it leaves the scene: the next launch ends that sample (the slot's ray needs no trace)
+                    localHit = found;
+                    hitWritten = true;
+                    outRayD.w = intAsFloat(floatAsInt(outRayD.w) | kStLocal);
+                }
+            }
+        }
+    }
+
+    // ---- second half: the vertex (k_shade's, with makeIsect in front of it)
+    bool finishedLate = false;
+    Rgb colorLate = rgb(0.f);
+    SHADE_REGION(5, haveVertex);
+    if (haveVertex) {
+        const Isect isect = makeIsect<TRAITS>(scene, o, d, hitNow);
+        const int vertex = rayBounce + 1;
+        // PathTracer::L: sample the BSDF, then direct(), src/path_tracer.cpp:30-36, 60-73
+        const DMaterial &material = materials[isect.material];
+        Rng random;
+        makeKey(((uint64_t)p.seedHi << 32) | p.seedLo, pixel, sample, &random.k0, &random.k1);
+        random.dimension = vertexBase(vertex);
+        const BSDFSample bsdfSample = materialSample<TRAITS>(material, isect, random);
+
+        const bool counts = checkCounts(p.startBounce, p.lastBounce, vertex);
+        const bool wantDirect = counts;          // (no surface emits)
+        const bool wantContinue = !checkDone(p.lastBounce, vertex + 1);
+
+        Rgb lightTerm = rgb(0.f);
+        SHADE_REGION(6, wantDirect);
+        if (wantDirect) {
+            random.dimension = vertexBase(vertex) + 3;
+            lightTerm = sampleLightsTerm<true, TRAITS>(scene, materials, isect, material, random, &shadow);
+        }
+        const bool deadEnd = isBlack(bsdfSample.throughput) && bsdfSample.pdf > 0.f && bsdfSample.pdf < 3e38f
+            && !shadow.push && isBlack(lightTerm);
+        if ((!wantDirect && !wantContinue) || deadEnd) {
+            finishedLate = true;
+            const Rgb first = rgb(0.f);
+            colorLate = first + result;
+            shadow.push = false;
+        } else {
+            int nextState = vertex | (sampleInUnit << kStSampleShift);
+            if (wantDirect) { nextState |= kStEligible; }
+            if (isDeltaT<TRAITS>(material)) { nextState |= kStDelta; }
+            if (wantContinue) { nextState |= kStContinue; }
+            outRayO = make_float4(isect.point.x, isect.point.y, isect.point.z, intAsFloat(firstEmitMaterial));
+            outRayD = make_float4(bsdfSample.wiWorld.x, bsdfSample.wiWorld.y, bsdfSample.wiWorld.z, intAsFloat(nextState));
+            if (rayBounce == 0) { outMod = make_float4(1.f, 1.f, 1.f, 1.f); }   // (a camera-ray vertex: the modulation is 1)
+            outMod.w = bsdfSample.pdf;
+            outThr = make_float4(
+                bsdfSample.throughput.r, bsdfSample.throughput.g, bsdfSample.throughput.b,
+                fabsf(dot(isect.shadingNormal, bsdfSample.wiWorld)));
+            outPend = make_float4(lightTerm.r, lightTerm.g, lightTerm.b, 0.f);
+            hitWritten = false;
+        }
+    }
+    {
+        bool startedNext;
+        uint32_t nextPixel = 0, nextSample = 0;
+        PATHED_END_OF_SAMPLE(finishedLate, colorLate, startedNext, nextPixel, nextSample)
+        if (startedNext) { hitWritten = false; }
+    }
+#undef PATHED_END_OF_SAMPLE
+
+    // ---- local rays (k_shade): the ray the slot leaves with, and its vertex's occlusion ray
+    if (p.localCount > 0) {
+        const bool retiredNow = (floatAsInt(outRayD.w) & kStDone) != 0;
+        const bool hasRay = active && !retiredNow;
+        const V3 nextO = v3(outRayO.x, outRayO.y, outRayO.z), nextD = v3(outRayD.x, outRayD.y, outRayD.z);
+        const bool localClosest = hasRay && !hitWritten && !localMeetsRest(p, nextO, nextD, PATHED_TFAR);
+        const bool localShadow = shadow.push && !localMeetsRest(p, shadow.origin, shadow.direction, shadow.tfar);
+        {
+            const float4 found = localClosestHit(p, localClosest, nextO, nextD);
+            if (localClosest) {
+                localHit = found;
+                hitWritten = true;
+                outRayD.w = intAsFloat(floatAsInt(outRayD.w) | kStLocal);
+                countedClosest++;
+            }
+            const bool occluded = localOccluded(p, localShadow, shadow.origin, shadow.direction, shadow.tfar);
+            if (localShadow) {
+                if (occluded) { outPend = make_float4(0.f, 0.f, 0.f, 0.f); }
+                shadow.push = false;
+                countedShadow++;
+            }
+        }
+        if (hasRay && (!(floatAsInt(outRayD.w) & kStLocal) || shadow.push)) { outRayD.w = intAsFloat(floatAsInt(outRayD.w) | kStAwait); }
+        if (p.localCounting) {
+            for (int offset = 32; offset >= 1; offset >>= 1) {
+                countedClosest += (unsigned int)__shfl_xor((int)countedClosest, offset, 64);
+                countedShadow += (unsigned int)__shfl_xor((int)countedShadow, offset, 64);
+            }
+            if (lane == 0 && (countedClosest | countedShadow) != 0u) {
+                atomicAdd(&p.stats[kStatLocalClosest], (unsigned long long)countedClosest);
+                atomicAdd(&p.stats[kStatLocalShadow], (unsigned long long)countedShadow);
+            }
+        }
+    }
+
+    if (active) {
+        p.state.rayO[slot] = outRayO;
+        p.state.rayD[slot] = outRayD;
+        p.state.res[slot] = make_float4(result.r, result.g, result.b, intAsFloat((int)unit));
+        if (hitWritten) { p.state.hit[slot] = localHit; }
+        p.state.mod[slot] = outMod;
+        p.state.thr[slot] = outThr;
+        p.state.pend[slot] = outPend;
+    }
+
+    // ---- shadow-ray list (k_shade)
+    {
+        const unsigned long long mask = __ballot(shadow.push);
+        const unsigned int before = (unsigned int)__popcll(mask & ((1ull << lane) - 1ull));
+        if (lane == 0) { scratch[wave] = (unsigned int)__popcll(mask); }
+        __syncthreads();
+        unsigned int offset = 0, total = 0;
+        #pragma unroll
+        for (int w = 0; w < kWavesPerBlock; w++) {
+            const unsigned int count = scratch[w];
+            if (w < wave) { offset += count; }
+            total += count;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            scratch[kWavesPerBlock] = total ? atomicAdd(&p.counters[kCtrShadowCount + p.parity * kCursorStride], total) : 0u;
+        }
+        __syncthreads();
+        if (shadow.push) {
+            const unsigned int index = scratch[kWavesPerBlock] + offset + before;
+            p.state.shO[index] = make_float4(shadow.origin.x, shadow.origin.y, shadow.origin.z, shadow.tfar);
+            p.state.shD[index] = make_float4(shadow.direction.x, shadow.direction.y, shadow.direction.z, intAsFloat(slot));
+        }
+    }
+
+    const unsigned long long retiredMask = __ballot(retiredAny);
     if (lane == 0 && retiredMask != 0ull) {
         atomicSub(&p.counters[kCtrRemaining], (unsigned int)__popcll(retiredMask));
     }

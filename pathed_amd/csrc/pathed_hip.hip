@@ -632,10 +632,15 @@ void launchShade(PathedScene *scene, const RenderParams &params, hipStream_t str
         // profiles/r3_ab_scene_traits.log)
         // ([r5] again with local rays, when the trace kernel has a fifth of its rays left: {Lambertian, plastic, environment} 2 312
         // against 2 456 Msamples/s on the same mesh, the sphere-free environment set +-0: profiles/r5_ab_local_rays.log)
-        if (scene->envOnly) { hipLaunchKernelGGL((k_shade<true, true>), grid, block, 0, stream, params); }
+        // [r5] environment-only scenes: k_shade_env -- the same vertex code, the next sample's camera ray started (and, if it is a
+        // local ray that hits a large triangle, its first vertex shaded) in the launch that ends a sample; shade_chain = 1: the
+        // plain k_shade<.., ENV_ONLY> (A/B runs, same floats)
+        if (scene->envOnly && scene->options.shade_chain != 1) { hipLaunchKernelGGL((k_shade_env<true>), grid, block, 0, stream, params); }
+        else if (scene->envOnly) { hipLaunchKernelGGL((k_shade<true, true>), grid, block, 0, stream, params); }
         else { hipLaunchKernelGGL((k_shade<true, false>), grid, block, 0, stream, params); }
     } else {
-        if (scene->envOnly) { hipLaunchKernelGGL((k_shade<false, true>), grid, block, 0, stream, params); }
+        if (scene->envOnly && scene->options.shade_chain != 1) { hipLaunchKernelGGL((k_shade_env<false>), grid, block, 0, stream, params); }
+        else if (scene->envOnly) { hipLaunchKernelGGL((k_shade<false, true>), grid, block, 0, stream, params); }
         else { hipLaunchKernelGGL((k_shade<false, false>), grid, block, 0, stream, params); }
     }
 }
@@ -1390,6 +1395,7 @@ int pathed_hip_scene_create_ex(const PathedSceneDesc *desc, const PathedSceneOpt
         if (options.wave_stragglers < -1 || options.wave_stragglers > 64) { return fail(PATHED_E_INVALID, "wave_stragglers must be -1 (none), 0 (default) or 1..64"); }
         if (options.wave_refill < 0 || options.wave_refill > 64) { return fail(PATHED_E_INVALID, "wave_refill must be 0 (default) or 1..64"); }
         if (options.chunks_per_pass < 0 || options.chunks_per_pass > 4096) { return fail(PATHED_E_INVALID, "chunks_per_pass must be 0 (default) or 1..4096"); }
+        if (options.shade_chain != 0 && options.shade_chain != 1) { return fail(PATHED_E_INVALID, "shade_chain must be 0 (automatic) or 1 (off)"); }
         if (options.shade_launches < 0 || options.shade_launches > 16) { return fail(PATHED_E_INVALID, "shade_launches must be 0 (automatic) or 1..16"); }
         if (options.local_rays != 0 && options.local_rays != 1) { return fail(PATHED_E_INVALID, "local_rays must be 0 (automatic) or 1 (off)"); }
         if (options.hybrid_batch < 0 || options.hybrid_batch > 128) { return fail(PATHED_E_INVALID, "hybrid_batch must be 0 (default) or 1..128"); }

@@ -67,7 +67,7 @@ class HipScene:
 
     Keyword options map onto PathedSceneOptions (include/pathed_hip.h): stack_rows, pools,
     suspend_lanes, suspend_patience, park_min_cards, max_slots, build_threads, generic_kernels, refittable, wave_max_ksamples,
-    wave_stragglers, wave_refill, chunks_per_pass, hybrid_batch, hybrid_ready, local_rays, shade_launches, intersector ("auto" | "bvh"),
+    wave_stragglers, wave_refill, chunks_per_pass, hybrid_batch, hybrid_ready, local_rays, shade_launches, shade_chain, intersector ("auto" | "bvh"),
     trace_blocks_per_cu, shade_kernel ("auto" | "per-slot" | "staged" | "fused" | "split" | "wave" | "hybrid"), stage_slots,
     unit_order ("auto" | "stripes" | "stripes-tiled" | "tiles"), node_format ("auto" | "wide" | "compressed" | "compressed8"), small_phase1 ("auto" | "valu" | "mfma").  `device=None` keeps the device of an earlier pathed_hip_init.
     """
@@ -87,7 +87,7 @@ class HipScene:
         packed.unit_order = {"auto": 0, "stripes": 1, "stripes-tiled": 2, "tiles": 3}[options.pop("unit_order", "auto")]
         packed.small_phase1 = {"auto": 0, "valu": 1, "mfma": 2}[options.pop("small_phase1", "auto")]
         for name in ("stack_rows", "pools", "suspend_lanes", "suspend_patience", "park_min_cards", "max_slots", "trace_blocks_per_cu", "stage_slots", "build_threads", "generic_kernels", "refittable",
-                     "wave_max_ksamples", "wave_stragglers", "wave_refill", "chunks_per_pass", "hybrid_batch", "hybrid_ready", "local_rays", "shade_launches"):
+                     "wave_max_ksamples", "wave_stragglers", "wave_refill", "chunks_per_pass", "hybrid_batch", "hybrid_ready", "local_rays", "shade_launches", "shade_chain"):
             if name in options:
                 setattr(packed, name, int(options.pop(name)))
         if options:

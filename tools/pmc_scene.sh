@@ -1,18 +1,18 @@
 #!/bin/bash
-# Counter passes over ONE render call of one scene (run through gpurun):  tools/pmc_scene.sh <tag> <scene.json> [spp] [integrator]
+# Counter passes over ONE render call of one scene (run through gpurun):  tools/pmc_scene.sh <tag> <scene.json> [spp] [integrator] [options]
 # One rocprofv3 --pmc pass per counter group (MI355X_MICROARCH.md: no tracing domains beside --kernel-trace), summed per kernel:
 #   instructions   SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVES  -> VALU wave-instructions per sample, lane utilisation
 #   classes        SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_ADD_F32
 #   waits          SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_SALU
 #   icache         SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES
-TAG=${1:-s1}; SCENE=${2:-scenes/cornell.json}; SPP=${3:-64}; INTEGRATOR=${4:-PathTracer}
+TAG=${1:-s1}; SCENE=${2:-scenes/cornell.json}; SPP=${3:-64}; INTEGRATOR=${4:-PathTracer}; OPTIONS=${5:-}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/pmc_scene_$TAG
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 run() {
   name=$1; shift
-  rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/$name -- python3 $ROOT/tools/render_once.py --scene $SCENE --spp $SPP --integrator $INTEGRATOR > $OUT/$name.log 2>&1 || { echo "pass $name failed"; tail -5 $OUT/$name.log; return 1; }
+  rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/$name -- python3 $ROOT/tools/render_once.py --scene $SCENE --spp $SPP --integrator $INTEGRATOR --options "$OPTIONS" > $OUT/$name.log 2>&1 || { echo "pass $name failed"; tail -5 $OUT/$name.log; return 1; }
   find $OUT/$name -name "*_kernel_trace.csv" -delete
 }
 run instructions SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVES && \

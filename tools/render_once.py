@@ -15,9 +15,14 @@ parser.add_argument("--spp", type=int, default=64)
 parser.add_argument("--width", type=int, default=1024)
 parser.add_argument("--height", type=int, default=1024)
 parser.add_argument("--last-bounce", type=int, default=10)
+parser.add_argument("--options", default="", help="PathedSceneOptions as opt:value+opt:value")
 args = parser.parse_args()
 scene = LoadedScene(args.scene, args.width, args.height)
-gpu = HipScene(scene.desc, device=0)
+options = {}
+for item in filter(None, args.options.split("+")):
+    key, _, value = item.partition(":")
+    options[key] = int(value) if value.lstrip("-").isdigit() else value
+gpu = HipScene(scene.desc, device=0, **options)
 gpu.set_integrator(args.integrator)
 accum = torch.zeros((args.height, args.width, 3), dtype=torch.float32, device="cuda")
 torch.cuda.synchronize(); start = time.perf_counter()

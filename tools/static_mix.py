@@ -103,7 +103,7 @@ def main():
     path = args.asm
     if not path:
         path = "/tmp/pathed_hip.s"
-        subprocess.run(["/opt/rocm/bin/hipcc", "-std=c++17", "-O3", "-fPIC", "-ffp-contract=off", "--offload-arch=gfx950", "-Iinclude",
+        subprocess.run(["/opt/rocm/bin/hipcc", "-std=c++17", "-O3", "-fPIC", "-ffp-contract=off", "--offload-arch=gfx950", "-Iinclude", "-mllvm", "-instcombine-max-copied-from-constant-users=4000",
                         "--offload-device-only", "-S", "-o", path, "pathed_amd/csrc/pathed_hip.hip"], cwd=ROOT, check=True)
     kernels = parse(path)
     pretty = demangle(list(kernels))
