@@ -2297,8 +2297,14 @@ __device__ __forceinline__ bool localOccluded(const RenderParams &p, bool want, 
 // two visits instead of three.  Every operation on a path's values is k_shade's, in k_shade's order: same floats
 // (tests/test_gpu_local_rays.py, test_gpu_operating_size.py).  The finish logic needs no intersection record here (no surface
 // emits), so makeIsect stays ONE inlined copy, in front of the vertex code.
+// Five waves per SIMD (96 VGPRs, 12 bytes of spills) like k_shade: left alone the compiler takes 100 - 104 and four waves, and
+// the teapot / dragon configurations run 1 - 2 % slower (profiles/r5_ab_shade_env_waves.log)
+#ifndef PATHED_SHADE_ENV_WAVES
+#define PATHED_SHADE_ENV_WAVES 5
+#endif
+#define PATHED_SHADE_ENV_ATTRIBUTE __attribute__((amdgpu_waves_per_eu(PATHED_SHADE_ENV_WAVES, PATHED_SHADE_ENV_WAVES)))
 template <bool LDS_MATERIALS, typename TRAITS = TraitsAll>
-__global__ __launch_bounds__(kBlock) PATHED_SHADE_ATTRIBUTE void k_shade_env(RenderParams p)
+__global__ __launch_bounds__(kBlock) PATHED_SHADE_ENV_ATTRIBUTE void k_shade_env(RenderParams p)
 {
     __shared__ DMaterial ldsMaterials[LDS_MATERIALS ? kMaxLdsMaterials : 1];
     __shared__ unsigned int scratch[kWavesPerBlock + 1];

@@ -41,9 +41,9 @@ def test_vgpr_budgets_of_the_hot_kernels(tmp_path):
     shade = [v for k, v in usage.items() if "k_shadeILb1" in k]      # generic and ENV_ONLY instantiations
     assert len(shade) == 2 and all(v["VGPRs"] <= 104 and v["ScratchSize"] == 0 for v in shade), shade
     # [r5] the shade kernel of environment-lit scenes (kernels.h: k_shade_env) reads its 1.6 KB of arguments from the kernel-argument
-    # segment: nothing in scratch (without the Makefile's -instcombine-max-copied-from-constant-users every lane held a copy)
+    # segment: no copy of them in scratch (without the Makefile's -instcombine-max-copied-from-constant-users every lane held a copy)
     env = [v for k, v in usage.items() if "k_shade_env" in k]
-    assert len(env) == 2 and all(v["VGPRs"] <= 128 and v["ScratchSize"] == 0 and v["Occupancy"] >= 4 for v in env), env
+    assert len(env) == 2 and all(v["VGPRs"] <= 96 and v["ScratchSize"] <= 32 and v["Occupancy"] == 5 for v in env), env   # (capped at five waves: 12 bytes of spills)
     traces = [v for k, v in usage.items() if re.search(r"k_traceILi\d+ELb[01]ELb0ELb[01]", k)]   # the non-counting variants (plain, LDS-resident tree, sphere-free)
     assert len(traces) == 9 and all(v["VGPRs"] <= 96 for v in traces), traces
     small = [v for k, v in usage.items() if "k_trace_smallILb0" in k]
