@@ -674,9 +674,52 @@ __device__ inline BSDFSample mirrorSample(const Isect &isect)
     return sample;
 }
 
+// BSDF::f / BSDF::sample dispatch (include/bsdf.h: virtual calls in the reference).  [r5] BY LOBE, not by material type: a
+// wave whose lanes stand on different materials -- any scene with more than one BSDF -- runs a `switch (m.type)` one case after
+// the other, and the cases repeat each other: plastic IS a Lambertian lobe plus a microfacet lobe (src/plastic.cpp:19-66), so
+// a wave with Lambertian, microfacet and plastic lanes went through lambertianF and microfacetF twice in an evaluation and
+// three times in a sample (and through the cosine-hemisphere and half-vector sampling two or three times).  Here every lobe's
+// code occurs ONCE and the lanes of every material that has that lobe run it together:
+//     Lambertian lobe: Lambertian, plastic | Oren-Nayar lobe | microfacet lobe: microfacet, plastic.
+// Per lane the operations and their order are plasticF's / plasticSample's / the single-lobe functions' own (plastic's random
+// number that picks the lobe is drawn first, as there; float addition commutes, so "sampled lobe + other lobe" is one sum):
+// the same bits as the per-type switch, which -DPATHED_MATERIAL_SWITCH=1 still builds for that comparison.
+#ifndef PATHED_MATERIAL_SWITCH
+#define PATHED_MATERIAL_SWITCH 0
+#endif
+template <typename TRAITS>
+struct MaterialLobes {
+    bool lambertian, orenNayar, facets, plastic;
+    __device__ inline MaterialLobes(const DMaterial &m)
+    {
+        const int type = m.type;
+        plastic = TRAITS::has(PATHED_MAT_PLASTIC) && type == PATHED_MAT_PLASTIC;
+        lambertian = (TRAITS::has(PATHED_MAT_LAMBERTIAN) && type == PATHED_MAT_LAMBERTIAN) || plastic;
+        orenNayar = TRAITS::has(PATHED_MAT_OREN_NAYAR) && type == PATHED_MAT_OREN_NAYAR;
+        facets = (TRAITS::has(PATHED_MAT_MICROFACET) && type == PATHED_MAT_MICROFACET) || plastic;
+    }
+};
+
+// the lobes of one material at one direction: f and pdf of the material (plastic: src/plastic.cpp:19-33)
+template <typename TRAITS>
+__device__ inline Rgb lobesF(const MaterialLobes<TRAITS> &lobes, const DMaterial &m, const Isect &isect, V3 wiWorld, float *diffusePdf, float *facetPdf,
+                             Rgb *facetsOut)
+{
+    Rgb diffuse = rgb(0.f);
+    *diffusePdf = 0.f;
+    if (lobes.lambertian) { diffuse = lambertianF<TRAITS::varyingAlbedo>(m, isect, wiWorld, diffusePdf); }
+    if (lobes.orenNayar) { diffuse = orenNayarF(m, isect, wiWorld, diffusePdf); }
+    Rgb facets = rgb(0.f);
+    *facetPdf = 0.f;
+    if (lobes.facets) { facets = microfacetF<TRAITS>(m, isect, wiWorld, facetPdf); }
+    *facetsOut = facets;
+    return diffuse;
+}
+
 template <typename TRAITS = TraitsAll>
 __device__ inline Rgb materialF(const DMaterial &m, const Isect &isect, V3 wiWorld, float *pdf)
 {
+#if PATHED_MATERIAL_SWITCH
     switch (m.type) {
     case PATHED_MAT_LAMBERTIAN: if (TRAITS::has(PATHED_MAT_LAMBERTIAN)) { return lambertianF<TRAITS::varyingAlbedo>(m, isect, wiWorld, pdf); } break;
     case PATHED_MAT_OREN_NAYAR: if (TRAITS::has(PATHED_MAT_OREN_NAYAR)) { return orenNayarF(m, isect, wiWorld, pdf); } break;
@@ -686,11 +729,22 @@ __device__ inline Rgb materialF(const DMaterial &m, const Isect &isect, V3 wiWor
     }
     *pdf = 0.f;
     return rgb(0.f);  // src/glass.cpp:20-28, src/mirror.cpp:11-19
+#else
+    const MaterialLobes<TRAITS> lobes(m);
+    float diffusePdf, facetPdf;
+    Rgb facets;
+    const Rgb diffuse = lobesF<TRAITS>(lobes, m, isect, wiWorld, &diffusePdf, &facetPdf, &facets);
+    if (lobes.plastic) { *pdf = (diffusePdf + facetPdf) / 2.f; return diffuse + facets; }
+    if (lobes.facets) { *pdf = facetPdf; return facets; }
+    *pdf = diffusePdf;   // (glass, mirror: 0 and black, src/glass.cpp:20-28, src/mirror.cpp:11-19)
+    return diffuse;
+#endif
 }
 
 template <typename TRAITS = TraitsAll>
 __device__ inline BSDFSample materialSample(const DMaterial &m, const Isect &isect, Rng &random)
 {
+#if PATHED_MATERIAL_SWITCH
     switch (m.type) {
     case PATHED_MAT_LAMBERTIAN: if (TRAITS::has(PATHED_MAT_LAMBERTIAN)) { return lambertianSample<TRAITS::varyingAlbedo, TRAITS::pairedTrig>(m, isect, random); } break;
     case PATHED_MAT_OREN_NAYAR: if (TRAITS::has(PATHED_MAT_OREN_NAYAR)) { return orenNayarSample<TRAITS::pairedTrig>(m, isect, random); } break;
@@ -699,6 +753,50 @@ __device__ inline BSDFSample materialSample(const DMaterial &m, const Isect &ise
     case PATHED_MAT_GLASS: if (TRAITS::has(PATHED_MAT_GLASS)) { return glassSample(m, isect, random); } break;
     default: break;
     }
+#else
+    const MaterialLobes<TRAITS> lobes(m);
+    if (lobes.lambertian || lobes.orenNayar || lobes.facets) {
+        // which lobe draws the direction (src/plastic.cpp:35-43: xi > 0.5 the Lambertian one)
+        bool fromDiffuse = !lobes.facets, fromFacets = !fromDiffuse;
+        if (lobes.plastic) {
+            const float xi = random.next();
+            fromDiffuse = xi > 0.5f;
+            fromFacets = !fromDiffuse;
+        }
+        V3 wiWorld = isect.wo;
+        float sampledPdf = 1.f;
+        if (fromDiffuse) {
+            // src/lambertian.cpp:42-58, src/oren_nayar.cpp:69-85
+            const V3 localSample = cosineSampleHemisphere<TRAITS::pairedTrig>(random);
+            wiWorld = toWorld(isect.frame, localSample);
+            sampledPdf = cosineHemispherePdf(localSample);
+        }
+        if (fromFacets) {
+            // src/microfacet.cpp:59-78
+            const V3 wo = toLocal(isect.frame, isect.wo);
+            const V3 wh = distributionSampleWh<TRAITS>(m, random);
+            const V3 wi = reflect(wo, wh);
+            wiWorld = toWorld(isect.frame, wi);
+            sampledPdf = distributionPdf<TRAITS>(m, wh) / (4.f * dot(wo, wh));
+        }
+        float diffusePdf, facetPdf;
+        Rgb facets;
+        const Rgb diffuse = lobesF<TRAITS>(lobes, m, isect, wiWorld, &diffusePdf, &facetPdf, &facets);
+        BSDFSample sample;
+        sample.wiWorld = wiWorld;
+        if (lobes.plastic) {
+            // src/plastic.cpp:45-66: the pdfs of the two lobes averaged, their values added
+            const float otherPdf = fromDiffuse ? facetPdf : diffusePdf;
+            sample.pdf = (sampledPdf + otherPdf) / 2.f;
+            sample.throughput = diffuse + facets;
+        } else {
+            sample.pdf = sampledPdf;
+            sample.throughput = lobes.facets ? facets : diffuse;
+        }
+        return sample;
+    }
+    if (TRAITS::has(PATHED_MAT_GLASS) && m.type == PATHED_MAT_GLASS) { return glassSample(m, isect, random); }
+#endif
     // a mirror -- or, in a narrowed instantiation, a material type the scene does not contain (never reached)
     if (TRAITS::has(PATHED_MAT_MIRROR)) { return mirrorSample(isect); }
     BSDFSample none;
