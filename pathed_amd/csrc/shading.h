@@ -344,18 +344,24 @@ __device__ inline Rgb textureLookup(const DMaterial &m, const Isect &isect)
 }
 
 // src/lambertian.cpp:16-40
+// (the *Local forms take  wi = normalized(toLocal(frame, wiWorld))  and  wo = normalized(toLocal(frame, isect.wo))  from the
+//  caller: materialF / materialSample form them once for all lobes, see MaterialLobes)
 template <bool VARYING_ALBEDO = true>
-__device__ inline Rgb lambertianF(const DMaterial &m, const Isect &isect, V3 wiWorld, float *pdf)
+__device__ inline Rgb lambertianFLocal(const DMaterial &m, const Isect &isect, V3 wiWorld, V3 wi, float *pdf)
 {
     if (dot(isect.wo, isect.shadingNormal) < 0.f) { *pdf = 0.f; return rgb(0.f); }
     if (dot(wiWorld, isect.shadingNormal) < 0.f) { *pdf = 0.f; return rgb(0.f); }
 
-    const V3 wi = normalized(toLocal(isect.frame, wiWorld));
     *pdf = cosineHemispherePdf(wi);
 
     if (VARYING_ALBEDO && m.albedoType == PATHED_ALBEDO_CHECKERBOARD) { return checkerboardLookup(m, isect) / PATHED_PI; }
     if (VARYING_ALBEDO && m.albedoType == PATHED_ALBEDO_TEXTURE) { return textureLookup(m, isect) / PATHED_PI; }
     return matDiffuse(m) / PATHED_PI;
+}
+template <bool VARYING_ALBEDO = true>
+__device__ inline Rgb lambertianF(const DMaterial &m, const Isect &isect, V3 wiWorld, float *pdf)
+{
+    return lambertianFLocal<VARYING_ALBEDO>(m, isect, wiWorld, normalized(toLocal(isect.frame, wiWorld)), pdf);
 }
 
 // src/lambertian.cpp:42-58
@@ -386,13 +392,10 @@ __device__ inline BSDFSample lambertianSample(const DMaterial &m, const Isect &i
 #ifndef PATHED_OREN_NAYAR_TRIG
 #define PATHED_OREN_NAYAR_TRIG 0
 #endif
-__device__ inline Rgb orenNayarF(const DMaterial &m, const Isect &isect, V3 wiWorld, float *pdf)
+__device__ inline Rgb orenNayarFLocal(const DMaterial &m, const Isect &isect, V3 localWo, V3 localWi, float *pdf)
 {
     if (dot(isect.normal, isect.wo) < 0.f) { *pdf = 1.f; return rgb(0.f); }
     if (dot(isect.shadingNormal, isect.wo) < 0.f) { *pdf = 1.f; return rgb(0.f); }
-
-    const V3 localWo = normalized(toLocal(isect.frame, isect.wo));
-    const V3 localWi = normalized(toLocal(isect.frame, wiWorld));
 
     if (localWo.y < 0.f) { *pdf = 1.f; return rgb(0.f); }
     if (localWi.y < 0.f) { *pdf = 1.f; return rgb(0.f); }
@@ -414,6 +417,10 @@ __device__ inline Rgb orenNayarF(const DMaterial &m, const Isect &isect, V3 wiWo
     const float throughput = PATHED_INV_PI * (m.orenA + m.orenB * rough);
 
     return matDiffuse(m) * throughput;
+}
+__device__ inline Rgb orenNayarF(const DMaterial &m, const Isect &isect, V3 wiWorld, float *pdf)
+{
+    return orenNayarFLocal(m, isect, normalized(toLocal(isect.frame, isect.wo)), normalized(toLocal(isect.frame, wiWorld)), pdf);
 }
 
 // src/oren_nayar.cpp:69-85
@@ -552,11 +559,8 @@ __device__ inline V3 distributionSampleWh(const DMaterial &m, Rng &random)
 
 // src/microfacet.cpp:12-57 (Fresnel eta hard-coded to 1.5 at :41)
 template <typename TRAITS = TraitsAll>
-__device__ inline Rgb microfacetF(const DMaterial &m, const Isect &isect, V3 wiWorld, float *pdf)
+__device__ inline Rgb microfacetFLocal(const DMaterial &m, const Isect &isect, V3 wiWorld, V3 wo, V3 wi, float *pdf)
 {
-    const V3 wo = normalized(toLocal(isect.frame, isect.wo));
-    const V3 wi = normalized(toLocal(isect.frame, wiWorld));
-
     if (dot(isect.wo, isect.shadingNormal) < 0.f) { *pdf = 0.f; return rgb(0.f); }
     if (dot(wiWorld, isect.shadingNormal) < 0.f) { *pdf = 0.f; return rgb(0.f); }
 
@@ -576,6 +580,11 @@ __device__ inline Rgb microfacetF(const DMaterial &m, const Isect &isect, V3 wiW
     const Rgb albedo = rgb(1.f);
 
     return albedo * distribution * masking * fresnel / (4 * cosThetaI * cosThetaO);
+}
+template <typename TRAITS = TraitsAll>
+__device__ inline Rgb microfacetF(const DMaterial &m, const Isect &isect, V3 wiWorld, float *pdf)
+{
+    return microfacetFLocal<TRAITS>(m, isect, wiWorld, normalized(toLocal(isect.frame, isect.wo)), normalized(toLocal(isect.frame, wiWorld)), pdf);
 }
 
 // src/microfacet.cpp:59-78
@@ -705,13 +714,19 @@ template <typename TRAITS>
 __device__ inline Rgb lobesF(const MaterialLobes<TRAITS> &lobes, const DMaterial &m, const Isect &isect, V3 wiWorld, float *diffusePdf, float *facetPdf,
                              Rgb *facetsOut)
 {
+    // every lobe works on the two directions in the shading frame: formed once (3 dot products, a square root and 3 divisions
+    // each -- more than the Lambertian and Oren-Nayar lobes' own arithmetic), not once per lobe a divergent wave runs
+    // (the Lambertian lobe does not look at wo: a wave of Lambertian lanes skips it)
+    V3 wo = v3(0.f, 1.f, 0.f);
+    if (lobes.orenNayar || lobes.facets) { wo = normalized(toLocal(isect.frame, isect.wo)); }
+    const V3 wi = normalized(toLocal(isect.frame, wiWorld));
     Rgb diffuse = rgb(0.f);
     *diffusePdf = 0.f;
-    if (lobes.lambertian) { diffuse = lambertianF<TRAITS::varyingAlbedo>(m, isect, wiWorld, diffusePdf); }
-    if (lobes.orenNayar) { diffuse = orenNayarF(m, isect, wiWorld, diffusePdf); }
+    if (lobes.lambertian) { diffuse = lambertianFLocal<TRAITS::varyingAlbedo>(m, isect, wiWorld, wi, diffusePdf); }
+    if (lobes.orenNayar) { diffuse = orenNayarFLocal(m, isect, wo, wi, diffusePdf); }
     Rgb facets = rgb(0.f);
     *facetPdf = 0.f;
-    if (lobes.facets) { facets = microfacetF<TRAITS>(m, isect, wiWorld, facetPdf); }
+    if (lobes.facets) { facets = microfacetFLocal<TRAITS>(m, isect, wiWorld, wo, wi, facetPdf); }
     *facetsOut = facets;
     return diffuse;
 }
