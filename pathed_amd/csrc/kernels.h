@@ -1470,6 +1470,7 @@ __device__ inline Isect makeIsect(const DScene &scene, V3 o, V3 d, float4 h)
     isect.material = material;
     isect.prim = prim;
     isect.frame = normalToWorldSpace(isect.shadingNormal, isect.wo);
+    isect.woLocal = v3(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""));   // prepareLobes (shading.h)
     return isect;
 }
 
@@ -2047,6 +2048,7 @@ __global__ __launch_bounds__(kBlock) PATHED_SHADE_ATTRIBUTE void k_shade(RenderP
         if (haveVertex) {
             // PathTracer::L: sample the BSDF, then direct(), src/path_tracer.cpp:30-36, 60-73
             const DMaterial &material = materials[isect.material];
+            prepareLobes<TRAITS>(material, isect);
 
             Rng random;
             makeKey(((uint64_t)p.seedHi << 32) | p.seedLo, pixel, sample, &random.k0, &random.k1);
@@ -2544,10 +2546,11 @@ __global__ __launch_bounds__(kBlock) PATHED_SHADE_ENV_ATTRIBUTE void k_shade_env
     Rgb colorLate = rgb(0.f);
     SHADE_REGION(5, haveVertex);
     if (haveVertex) {
-        const Isect isect = makeIsect<TRAITS>(scene, o, d, hitNow);
+        Isect isect = makeIsect<TRAITS>(scene, o, d, hitNow);
         const int vertex = rayBounce + 1;
         // PathTracer::L: sample the BSDF, then direct(), src/path_tracer.cpp:30-36, 60-73
         const DMaterial &material = materials[isect.material];
+        prepareLobes<TRAITS>(material, isect);
         Rng random;
         makeKey(((uint64_t)p.seedHi << 32) | p.seedLo, pixel, sample, &random.k0, &random.k1);
         random.dimension = vertexBase(vertex);
@@ -2999,6 +3002,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_F
             if (haveVertex) {
                 // PathTracer::L: sample the BSDF, then direct(), src/path_tracer.cpp:30-36, 60-73
                 const DMaterial &material = materials[isect.material];
+                prepareLobes<TRAITS>(material, isect);
 
                 random.dimension = vertexBase(vertex);
                 const BSDFSample bsdfSample = materialSample<TRAITS>(material, isect, random);
@@ -3608,6 +3612,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_V
         // ---- VolumePathTracer::L, src/volume_path_tracer.cpp:14-99
         int medium = -1;
         random.dimension = vertexBase(1);
+        prepareLobes<TRAITS>(materials[last.material], last);
         BSDFSample bsdfSample = volumeMaterialSample<TRAITS>(materials[last.material], last, random);
         Rgb result = rgb(0.f);
         {
@@ -3632,7 +3637,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_V
             } else {
                 break;   // not reached: every vertex whose path goes on has asked for its segment (needSegment)
             }
-            const Isect next = makeIsect<TRAITS>(scene, last.point, bsdfSample.wiWorld, make_float4(hit.t, hit.u, hit.v, intAsFloat(hit.prim)));
+            Isect next = makeIsect<TRAITS>(scene, last.point, bsdfSample.wiWorld, make_float4(hit.t, hit.u, hit.v, intAsFloat(hit.prim)));
             const float invPDF = 1.f / bsdfSample.pdf;
             const float cosTheta = fabsf(dot(last.shadingNormal, bsdfSample.wiWorld));
             modulation = modulation * (bsdfSample.throughput * cosTheta * invPDF);
@@ -3645,6 +3650,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_V
             if (isBlack(modulation)) { break; }
 
             random.dimension = vertexBase(bounce);
+            prepareLobes<TRAITS>(materials[next.material], next);
             bsdfSample = volumeMaterialSample<TRAITS>(materials[next.material], next, random);
             last = next;
             {

@@ -214,7 +214,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_S
             Rgb color = rgb(0.f);
             bool haveVertex = false;
             const int vertex = rayBounce + 1;
-            const Isect isect = makeIsect(scene, o, d, h);
+            Isect isect = makeIsect(scene, o, d, h);
 
             if (rayBounce == 0) {
                 // SampleIntegrator::samplePixel, src/sample_integrator.cpp:18-59
@@ -280,6 +280,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_S
                 Rng random;
                 makeKey(((uint64_t)p.seedHi << 32) | p.seedLo, pixel, sample, &random.k0, &random.k1);
                 random.dimension = vertexBase(vertex);
+                prepareLobes<TraitsAll>(material, isect);
                 const BSDFSample bsdfSample = materialSample(material, isect, random);
 
                 const bool counts = checkCounts(p.startBounce, p.lastBounce, vertex);
@@ -594,7 +595,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_V
                 Rgb color = rgb(0.f);
                 bool haveVertex = false;
                 const int vertex = rayBounce + 1;
-                const Isect isect = makeIsect(scene, o, d, h);
+                Isect isect = makeIsect(scene, o, d, h);
 
                 if (rayBounce == 0) {
                     // SampleIntegrator::samplePixel, src/sample_integrator.cpp:18-59
@@ -659,6 +660,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PATHED_V
                     Rng random;
                     makeKey(((uint64_t)p.seedHi << 32) | p.seedLo, pixel, sample, &random.k0, &random.k1);
                     random.dimension = vertexBase(vertex);
+                    prepareLobes<TraitsAll>(material, isect);
                     const BSDFSample bsdfSample = materialSample(material, isect, random);
 
                     const bool counts = checkCounts(p.startBounce, p.lastBounce, vertex);

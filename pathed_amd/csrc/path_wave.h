@@ -111,6 +111,7 @@ __device__ __forceinline__ bool pathVertex(const RenderParams &p, const DScene &
     if (haveVertex) {
         // PathTracer::L: sample the BSDF, then direct(), src/path_tracer.cpp:30-36, 60-73
         const DMaterial &material = materials[isect.material];
+        prepareLobes<TRAITS>(material, isect);
 
         path.random.dimension = vertexBase(vertex);
         const BSDFSample bsdfSample = materialSample<TRAITS>(material, isect, path.random);

@@ -158,6 +158,9 @@ struct Isect {
     int material;
     int prim;
     Frame frame;
+    // normalized(toLocal(frame, wo)): what the Oren-Nayar and microfacet lobes see of wo, formed once per vertex by prepareLobes
+    // (not by every evaluation at the vertex); NaN until then, so a vertex that skipped it cannot pass a test
+    V3 woLocal;
 };
 
 // ---------------------------------------------------- tangent-frame trigonometry
@@ -709,6 +712,15 @@ struct MaterialLobes {
     }
 };
 
+// once per vertex, before materialF / materialSample: wo in the shading frame for the lobes that look at it (the Lambertian lobe
+// does not: a wave of Lambertian lanes skips the 3 dot products, square root and 3 divisions)
+template <typename TRAITS>
+__device__ inline void prepareLobes(const DMaterial &m, Isect &isect)
+{
+    const MaterialLobes<TRAITS> lobes(m);
+    if (lobes.orenNayar || lobes.facets) { isect.woLocal = normalized(toLocal(isect.frame, isect.wo)); }
+}
+
 // the lobes of one material at one direction: f and pdf of the material (plastic: src/plastic.cpp:19-33)
 template <typename TRAITS>
 __device__ inline Rgb lobesF(const MaterialLobes<TRAITS> &lobes, const DMaterial &m, const Isect &isect, V3 wiWorld, float *diffusePdf, float *facetPdf,
@@ -716,9 +728,7 @@ __device__ inline Rgb lobesF(const MaterialLobes<TRAITS> &lobes, const DMaterial
 {
     // every lobe works on the two directions in the shading frame: formed once (3 dot products, a square root and 3 divisions
     // each -- more than the Lambertian and Oren-Nayar lobes' own arithmetic), not once per lobe a divergent wave runs
-    // (the Lambertian lobe does not look at wo: a wave of Lambertian lanes skips it)
-    V3 wo = v3(0.f, 1.f, 0.f);
-    if (lobes.orenNayar || lobes.facets) { wo = normalized(toLocal(isect.frame, isect.wo)); }
+    const V3 wo = isect.woLocal;   // (prepareLobes: once per vertex)
     const V3 wi = normalized(toLocal(isect.frame, wiWorld));
     Rgb diffuse = rgb(0.f);
     *diffusePdf = 0.f;
