@@ -61,7 +61,7 @@ def main():
         setup = time.perf_counter() - t0
         gpu.set_integrator(integrator)
         accum = torch.zeros((h, w, 3), dtype=torch.float32, device="cuda")
-        gpu.render_device(1, 0, min(spp, 16), 0, 10, accum.data_ptr())  # warm-up
+        gpu.render_device(1, 0, min(spp, 128), 0, 10, accum.data_ptr())  # warm-up (long enough for the clocks: the first call of a process runs 3 - 8 % low)
         accum.zero_()
         gpu.set_stats_mode(count=False, time_sampled=True)   # HIP events around every 8th launch
         gpu.reset_stats()
@@ -87,7 +87,7 @@ def main():
         alg = 48 * counted["closest_rays"] + 36 * counted["shadow_rays"] + 32 * counted["nodes_visited"] + 48 * counted["tris_tested"]
         alg_total = alg * spp / count_spp
         # what the TIMED call ran (count mode never takes k_path_wave; PathedStats.path_kernel is the last render call's)
-        fused = timed["path_kernel"] in (3, 4, 6)   # one kernel carries the whole path: there is no separate trace kernel to rate
+        fused = timed["path_kernel"] in (3, 4, 6, 7)   # one kernel carries the whole path: there is no separate trace kernel to rate
         gbs = alg_total / (timed["trace_ms"] * 1e-3) / 1e9 if timed["trace_ms"] and not fused else 0.0
 
         # CPU oracle rate at the same resolution
@@ -123,9 +123,12 @@ def main():
             "gpu_Msamples_s": round(w * h * spp / elapsed / 1e6, 1),
             "rays_per_sample": round(rays / (w * h * count_spp), 2),
             "trace_Grays_s": round(rays * spp / count_spp / timed["trace_ms"] / 1e6, 2) if timed["trace_ms"] and not fused else None,
-            "trace_algorithmic_GBs": round(gbs, 0) if not fused else None, "frac_of_8TBs": round(gbs / 8000.0, 3) if not fused else None,
-            "intersector": ["BVH in HBM", "BVH in LDS", "all triangles (scalar loads)"][counted["scene_in_lds"]],
-            "path_kernel": ["", "wavefront: k_trace + k_shade", "wavefront: k_trace + k_shade_staged", "fused: k_path_small", "volume: k_path_volume", "wavefront: k_trace + k_vertex + k_regen", "wave: k_path_wave"][timed["path_kernel"]],
+            # (a tree that fits the 4 MiB L2 of an XCD is read from there: its node bytes per second are not an HBM figure)
+            "trace_algorithmic_GBs": round(gbs, 0) if not fused else None,
+            "frac_of_8TBs": round(gbs / 8000.0, 3) if not fused and counted["bvh_bytes"] > (4 << 20) else None,
+            "bvh_bytes": counted["bvh_bytes"],
+            "intersector": ["BVH in HBM" if counted["bvh_bytes"] > (4 << 20) else "BVH in L2 (%.2f MB)" % (counted["bvh_bytes"] / 1e6), "BVH in LDS", "all triangles (scalar loads)"][counted["scene_in_lds"]],
+            "path_kernel": ["", "wavefront: k_trace + k_shade", "wavefront: k_trace + k_shade_staged", "fused: k_path_small", "volume: k_path_volume", "wavefront: k_trace + k_vertex + k_regen", "wave: k_path_wave", "hybrid: k_path_hybrid"][timed["path_kernel"]],
             "cpu_oracle_Msamples_s": round(w * h * cpu_spp / cpu_elapsed / 1e6, 2), "cpu_cores": cores,
             "relL2_vs_oracle_%dx%d_16spp" % (pw, ph): "%.2e" % relative_l2(image, expected),
             "mean_rgb": [round(float(v), 4) for v in (accum / spp).mean(dim=(0, 1)).tolist()],
