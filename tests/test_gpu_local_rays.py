@@ -39,6 +39,22 @@ def test_local_rays_change_no_bit_and_lose_no_query(scene_path, width, height, s
     for launches in (1, 3, 5):
         other = HipScene(scene.desc, device=0, bvh_builder=builder, shade_kernel="per-slot", shade_launches=launches)
         assert np.array_equal(other.render(3, 0, spp, 0, 10), expected), launches
+    # [r5] k_shade_env (environment-lit scenes: a sample that ends starts the next one in the same launch, and a local camera
+    # ray that hits a large triangle has its first vertex shaded there) against k_shade<ENV_ONLY> (shade_chain=1): scheduling
+    # only -- the same bits, the same queries, with few slots (many launches, slots re-used often) and with many
+    for slots in (0, 4096):
+        chained = HipScene(scene.desc, device=0, bvh_builder=builder, shade_kernel="per-slot", max_slots=slots)
+        plain = HipScene(scene.desc, device=0, bvh_builder=builder, shade_kernel="per-slot", max_slots=slots, shade_chain=1)
+        assert np.array_equal(chained.render(3, 0, spp, 0, 10), expected), slots
+        assert np.array_equal(plain.render(3, 0, spp, 0, 10), expected), slots
+        for gpu in (chained, plain):
+            gpu.set_stats_mode(count=True)
+            gpu.reset_stats()
+            assert np.array_equal(gpu.render(3, 0, spp, 0, 10), expected)
+        c, q = chained.stats(), plain.stats()
+        assert c["closest_rays"] + c["local_closest_rays"] == q["closest_rays"] + q["local_closest_rays"] == b["closest_rays"]
+        assert c["shadow_rays"] + c["local_shadow_rays"] == q["shadow_rays"] + q["local_shadow_rays"] == b["shadow_rays"]
+        assert c["iterations"] <= q["iterations"]          # fewer slot visits per sample: never more launches
     # the wave kernel and the default dispatch agree with both
     assert np.array_equal(HipScene(scene.desc, device=0, bvh_builder=builder).render(3, 0, spp, 0, 10), expected)
 
