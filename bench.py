@@ -32,6 +32,7 @@ REPO_ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO_ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+VALU_PEAK_GINSTR = 1228.8  # G wave-instr/s: 1 024 SIMDs x 2.4 GHz / 2 cycles per v_fma_f32 (same guide)
 PATHED_FUSED_WAVES_PER_SIMD = 4   # k_path_small's occupancy (kernels.h: PATHED_FUSED_WAVES): which row of the VALU probe prices its mix
 STATE_BYTES_PER_VERTEX = 112 + 128   # k_shade's path-state streams: read + written per shaded vertex
 
@@ -450,6 +451,21 @@ def large_bvh_leg(args, torch, stream, measured_copy_gbs=None):
         "image_mean_rgb": reference_row["image_mean_rgb"],
         "rows": [reference_row, close_row],
     }
+    # [r5] The same pipeline seen from the instruction issue side: what its two kernels issue per camera sample (a committed
+    # counter pass over ONE 64-spp call of this workload: ramp-up and drain included) x this run's rate.  The HBM fractions above
+    # are the contract's; this says how much of the chip's VALU issue the pipeline takes while it runs.
+    by_class = (pmc or {}).get("valu_by_class")
+    if by_class and "trace" in by_class and "shade" in by_class:
+        per_sample = by_class["trace"]["wave_instructions_per_sample"] + by_class["shade"]["wave_instructions_per_sample"]
+        issued = per_sample * reference_row["msamples_per_s"] * 1e6 / 1e9
+        result["valu"] = {
+            "wave_instructions_per_sample": {k: by_class[k]["wave_instructions_per_sample"] for k in ("trace", "shade")},
+            "lane_utilisation": {k: by_class[k]["lane_utilisation"] for k in ("trace", "shade")},
+            "achieved": issued, "peak": VALU_PEAK_GINSTR, "unit": "G wave-instr/s", "frac": issued / VALU_PEAK_GINSTR,
+            "source": {"file": "profiles/pmc_per_sample.json", "stale": pmc["stale"]},
+            "note": "k_trace + k_shade VALU wave-instructions per camera sample (counter pass, 64-spp call) x the reference-camera row's Msamples/s, "
+                    "against the guide's issue peak: the two kernels overlap on two streams and TOGETHER issue this much",
+        }
     gpu.close()
     # Diagnostic: one pool -- the launches alternate, HIP events around every launch time each kernel on its own
     alone = HipScene(scene.desc, device=torch.cuda.current_device(), bvh_builder=args.bvh_builder, pools=1)

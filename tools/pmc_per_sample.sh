@@ -4,7 +4,7 @@
 # WRITE_SIZE do not fit one pass; no tracing domains mixed in beside --kernel-trace), each over exactly the kernels of
 # the timed path (bench.py --no-kernel-timing: no counting pass, no event pairs, no probes):
 #   cornell_1024   scenes/cornell.json 1024x1024 x 256 spp        SQ_INSTS_VALU | FETCH_SIZE | WRITE_SIZE
-#   large_bvh      scenes/dragon-standin.json (21 M triangles, as bench.py times it) 1920x1080 x 64 spp  FETCH_SIZE | WRITE_SIZE
+#   large_bvh      scenes/dragon-standin.json (21 M triangles, as bench.py times it) 1920x1080 x 64 spp  SQ_INSTS_VALU | FETCH_SIZE | WRITE_SIZE
 # tools/summarize_pmc_per_sample.py <tag> turns them into profiles/pmc_per_sample.json (per camera sample).
 TAG=${1:-r3}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
@@ -23,6 +23,7 @@ run cornell_valu "SQ_INSTS_VALU SQ_WAVES SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VA
 run cornell_fetch FETCH_SIZE --spp-per-step 256 && \
 run cornell_write WRITE_SIZE --spp-per-step 256 && \
 python3 $ROOT/tools/make_assets.py --dragon ${DRAGON:-10} > /dev/null && \
+run dragon_valu "SQ_INSTS_VALU SQ_WAVES SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU" --scene scenes/dragon-standin.json --width 1920 --height 1080 --spp-per-step 64 && \
 run dragon_fetch FETCH_SIZE --scene scenes/dragon-standin.json --width 1920 --height 1080 --spp-per-step 64 && \
 run dragon_write WRITE_SIZE --scene scenes/dragon-standin.json --width 1920 --height 1080 --spp-per-step 64 && \
 python3 $ROOT/tools/summarize_pmc_per_sample.py $TAG

@@ -70,6 +70,15 @@ def workload(prefix, samples, with_valu):
             for kernel, (launches, total) in kernels.items():
                 per_kernel[kernel][counter + "_per_launch"] = total / launches
                 per_kernel[kernel]["launches"] = launches
+        # ... and by kernel class (the wavefront: what its trace and its shade side issue per camera sample, and at what lane utilisation)
+        by_class = collections.defaultdict(lambda: collections.defaultdict(float))
+        for counter, kernels in valu.items():
+            for kernel, (launches, total) in kernels.items():
+                by_class[kernel_class(kernel)][counter] += total
+        entry["valu_by_class"] = {
+            name: {"wave_instructions_per_sample": c["SQ_INSTS_VALU"] / samples,
+                   "lane_utilisation": (c["SQ_THREAD_CYCLES_VALU"] / c["SQ_ACTIVE_INST_VALU"] / 64.0) if c["SQ_ACTIVE_INST_VALU"] > 0 else None}
+            for name, c in sorted(by_class.items()) if name != "setup"}
     fetch = totals(prefix + "_fetch")["FETCH_SIZE"]
     write = totals(prefix + "_write")["WRITE_SIZE"]
     classes = collections.defaultdict(float)
@@ -92,7 +101,7 @@ summary = {
             "(ramp-up and drain of the slot pool included: 61 % of the slot visits carry a ray, a long render does better)",
     "tag": tag,
     "cornell_1024": workload("cornell", 1024 * 1024 * 256, True),
-    "large_bvh": workload("dragon", 1920 * 1080 * 64, False),
+    "large_bvh": workload("dragon", 1920 * 1080 * 64, os.path.isdir(os.path.join(base, "dragon_valu"))),
 }
 out = os.path.join(ROOT, "profiles", "pmc_per_sample.json")
 json.dump(summary, open(out, "w"), indent=1)
