@@ -2542,8 +2542,6 @@ __global__ __launch_bounds__(kBlock) PATHED_SHADE_ENV_ATTRIBUTE void k_shade_env
     }
 
     // ---- second half: the vertex (k_shade's, with makeIsect in front of it)
-    bool finishedLate = false;
-    Rgb colorLate = rgb(0.f);
     SHADE_REGION(5, haveVertex);
     if (haveVertex) {
         Isect isect = makeIsect<TRAITS>(scene, o, d, hitNow);
@@ -2569,9 +2567,17 @@ __global__ __launch_bounds__(kBlock) PATHED_SHADE_ENV_ATTRIBUTE void k_shade_env
         const bool deadEnd = isBlack(bsdfSample.throughput) && bsdfSample.pdf > 0.f && bsdfSample.pdf < 3e38f
             && !shadow.push && isBlack(lightTerm);
         if ((!wantDirect && !wantContinue) || deadEnd) {
-            finishedLate = true;
-            const Rgb first = rgb(0.f);
-            colorLate = first + result;
+            // The sample ends with this vertex (the last bounce outside the window, a dead end: a few lanes in a hundred).  Ending
+            // it here would be a second end-of-sample + regeneration block that nearly every wave runs for one or two lanes:
+            // instead the slot leaves with a ray that is already answered -- a local miss, not eligible, not to be continued --
+            // and the NEXT launch's first half ends the sample: `color = first + result`, these bits.
+            outRayO = make_float4(isect.point.x, isect.point.y, isect.point.z, intAsFloat(firstEmitMaterial));
+            outRayD = make_float4(d.x, d.y, d.z, intAsFloat((vertex | (sampleInUnit << kStSampleShift)) | kStLocal));
+            outMod.w = 1.f;
+            outThr = make_float4(0.f, 0.f, 0.f, 0.f);
+            outPend = make_float4(0.f, 0.f, 0.f, 0.f);
+            localHit = make_float4(PATHED_TFAR, 0.f, 0.f, intAsFloat(-1));
+            hitWritten = true;
             shadow.push = false;
         } else {
             int nextState = vertex | (sampleInUnit << kStSampleShift);
@@ -2588,12 +2594,6 @@ __global__ __launch_bounds__(kBlock) PATHED_SHADE_ENV_ATTRIBUTE void k_shade_env
             outPend = make_float4(lightTerm.r, lightTerm.g, lightTerm.b, 0.f);
             hitWritten = false;
         }
-    }
-    {
-        bool startedNext;
-        uint32_t nextPixel = 0, nextSample = 0;
-        PATHED_END_OF_SAMPLE(finishedLate, colorLate, startedNext, nextPixel, nextSample)
-        if (startedNext) { hitWritten = false; }
     }
 #undef PATHED_END_OF_SAMPLE
 
