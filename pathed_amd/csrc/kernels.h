@@ -2406,11 +2406,16 @@ __global__ __launch_bounds__(kBlock) PATHED_SHADE_ENV_ATTRIBUTE void k_shade_env
         sample = firstSample + (uint32_t)sampleInUnit;
         result = rgb(resIn.x, resIn.y, resIn.z);
         Rgb modulation = rgb(1.f);
+        // what the environment sends along a ray that left the scene: looked up ONCE, for the camera rays and the BSDF samples of
+        // the wave together (the direction-to-texel mapping is an atan2f and an acosf; as two inlined copies a wave with both
+        // kinds of miss -- every wave of "an object under a sky" -- ran it twice)
+        Rgb missLight = rgb(0.f);
+        if (miss && (rayBounce == 0 || (st & kStEligible))) { missLight = environmentL<TRAITS>(scene, d); }
 
         if (rayBounce == 0) {
             // SampleIntegrator::samplePixel, src/sample_integrator.cpp:18-59
             if (miss) {
-                color = rgb(0.f) + environmentL<TRAITS>(scene, d);
+                color = rgb(0.f) + missLight;
                 finished = true;
             } else {
                 firstEmitMaterial = -1;
@@ -2428,7 +2433,7 @@ __global__ __launch_bounds__(kBlock) PATHED_SHADE_ENV_ATTRIBUTE void k_shade_env
                 // PathTracer::directSampleBSDF, src/path_tracer.cpp:167-216
                 Rgb bsdfTerm = rgb(0.f);
                 if (miss) {
-                    const Rgb environmentLight = environmentL<TRAITS>(scene, d);
+                    const Rgb environmentLight = missLight;
                     if (!isBlack(environmentLight)) {
                         const float lightPDF = envEmitPDF(scene.env, d) / 1;
                         const float brdfWeight = (st & kStDelta)
