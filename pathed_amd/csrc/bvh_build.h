@@ -63,13 +63,16 @@ struct TempNode {
 };
 
 static const int kBins = 16;
-// leaf size: <= 7 (3-bit count in the traversal's leaf references); PATHED_MAX_LEAF overrides for tuning in the experiments
-// build (the product library reads no PATHED_* variable)
+// leaf size: <= 7 (3-bit count in the traversal's leaf references).  [r5] 3 for a scene's tree (was 4): the wavefront's
+// traversal kernel runs the teapot 1.6 % and the 5.2 M-triangle mesh 1.2 - 1.9 % faster on leaves of at most 3 (2: +2.5 % / the
+// same, 1.6x the nodes; profiles/r5_ab_leaf_size.log); the hybrid kernel's tree part, walked in short bursts by few lanes,
+// keeps 4 (buildBvh's maxLeaf).  PATHED_MAX_LEAF overrides for tuning in the experiments build (the product library reads no
+// PATHED_* variable)
 inline uint32_t maxLeafSize()
 {
     static uint32_t value = 0;
     if (value == 0) {
-        value = 4;
+        value = 3;
 #if defined(PATHED_EXPERIMENTS) && PATHED_EXPERIMENTS
         if (const char *text = getenv("PATHED_MAX_LEAF")) {
             const int parsed = atoi(text);
@@ -92,6 +95,7 @@ public:
     struct Deferred { int nodeIndex; uint32_t begin, end; int depth; };
     std::vector<Deferred> deferred;
     uint32_t deferThreshold = 0;
+    uint32_t maxLeaf = maxLeafSize();   // triangles per leaf, at most
 
     int build(uint32_t begin, uint32_t end, int depth, int *maxDepth)
     {
@@ -108,11 +112,11 @@ public:
 
         const uint32_t count = end - begin;
         bool spheresInRange = false;
-        if (count <= maxLeafSize()) {
+        if (count <= maxLeaf) {
             for (uint32_t i = begin; i < end; i++) { spheresInRange = spheresInRange || m_prims[i].sphere; }
         }
-        // leaves are homogeneous: up to maxLeafSize() triangles, or exactly one sphere
-        if (count <= maxLeafSize() && (!spheresInRange || count == 1)) {
+        // leaves are homogeneous: up to maxLeaf triangles, or exactly one sphere
+        if (count <= maxLeaf && (!spheresInRange || count == 1)) {
             nodes[(size_t)index].first = begin;
             nodes[(size_t)index].count = count;
             *maxDepth = std::max(*maxDepth, depth);
@@ -220,7 +224,7 @@ inline void putInt(float *slot, int value) { std::memcpy(slot, &value, 4); }
 // Sphere s becomes the leaf reference -(((s + 1) << 3) | 0) - 1: count 0 marks it, trace.h tests it.
 // `buildThreads` > 0 fixes the number of host threads (PathedSceneOptions.build_threads); the tree does not depend on it
 inline FlatBvh buildBvh(const float *positions, const uint32_t *indices, uint32_t triangleCount,
-                        const float *spheres = nullptr, uint32_t sphereCount = 0, int buildThreads = 0)
+                        const float *spheres = nullptr, uint32_t sphereCount = 0, int buildThreads = 0, uint32_t maxLeaf = 0)
 {
     using namespace bvh_detail;
     FlatBvh out;
@@ -257,6 +261,7 @@ inline FlatBvh buildBvh(const float *positions, const uint32_t *indices, uint32_
     }
 
     Builder builder(prims);
+    if (maxLeaf != 0) { builder.maxLeaf = maxLeaf; }
     builder.nodes.reserve((size_t)primCount);
     int maxDepth = 0;
     // large meshes: the top of the tree here, its subtrees on the host's other cores
@@ -272,6 +277,7 @@ inline FlatBvh buildBvh(const float *positions, const uint32_t *indices, uint32_
             for (size_t job = next.fetch_add(1); job < jobs; job = next.fetch_add(1)) {
                 const Builder::Deferred &item = builder.deferred[job];
                 Builder sub(prims);
+                sub.maxLeaf = builder.maxLeaf;
                 sub.nodes.reserve((size_t)(item.end - item.begin));
                 int subDepth = 0;
                 sub.build(item.begin, item.end, item.depth, &subDepth);

@@ -1325,7 +1325,7 @@ static hipError_t buildHybrid(PathedScene *scene, const PathedSceneDesc *desc)
     scene->hybridMaxStack = 1;
     hipError_t status = hipSuccess;
     if (!treePrim.empty()) {
-        FlatBvh tree = buildBvh(desc->positions, treeIndices.data(), (uint32_t)treePrim.size(), nullptr, 0, scene->options.build_threads);
+        FlatBvh tree = buildBvh(desc->positions, treeIndices.data(), (uint32_t)treePrim.size(), nullptr, 0, scene->options.build_threads, 4u);   // (leaves of <= 4: bvh_build.h)
         // the builder numbered the part's triangles 0 .. : back to the scene's primitive ids (shading records, lights)
         for (size_t k = 0; k < treePrim.size(); k++) {
             int sub;

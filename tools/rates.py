@@ -57,7 +57,7 @@ def run(args):
     for key in args.scenes.split(","):
         path, w, h, integrator = SCENES[key]
         scene = LoadedScene(path, w, h)
-        builder = "ploc" if scene.n_triangles > 1000000 else "sah"
+        builder = args.builder or ("ploc" if scene.n_triangles > 1000000 else "sah")
         variants = {}
         for text in args.variants.split(","):
             name, options = parse_variant(text)
@@ -98,10 +98,11 @@ def main():
     parser.add_argument("--repeats", type=int, default=3)
     parser.add_argument("--scenes", default="C2,ON,GGX,GL,GLASS,C3")
     parser.add_argument("--variants", default="default")
+    parser.add_argument("--builder", default="", help="sah / lbvh / ploc (default: ploc beyond a million triangles, else sah)")
     parser.add_argument("--lib", default="", help="also run with PATHED_HIP_LIB=<this library> in a child process and print both")
     args = parser.parse_args()
     if args.lib:
-        base = [sys.executable, os.path.abspath(__file__), "--spp", str(args.spp), "--repeats", str(args.repeats), "--scenes", args.scenes, "--variants", args.variants]
+        base = [sys.executable, os.path.abspath(__file__), "--spp", str(args.spp), "--repeats", str(args.repeats), "--scenes", args.scenes, "--variants", args.variants] + (["--builder", args.builder] if args.builder else [])
         for label, env in (("this", dict(os.environ)), (args.lib, dict(os.environ, PATHED_HIP_LIB=args.lib))):
             print("== library: %s" % label, flush=True)
             subprocess.run(base, env=env, check=False)

@@ -1,0 +1,6 @@
+#!/bin/bash
+cd ${GRAFT_REPO_ROOT:-.}
+python tools/make_assets.py --dragon 9 > /dev/null 2>&1
+timeout -k 10 400 python tools/rates.py --scenes C4,C5,C5close --spp 256 --repeats 2 --variants default,wave=shade_kernel:wave --builder sah --lib pathed_amd/lib/libpathed_hip_prev.so 2>&1 | grep '^{\|^==' || exit 1
+echo "## short calls (16 spp)"
+timeout -k 10 300 python tools/rates.py --scenes C4,C5 --spp 16 --repeats 3 --variants default --builder sah --lib pathed_amd/lib/libpathed_hip_prev.so 2>&1 | grep '^{\|^==' || exit 1
