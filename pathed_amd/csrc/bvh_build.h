@@ -62,7 +62,10 @@ struct TempNode {
     uint32_t first = 0, count = 0;  // leaf range
 };
 
-static const int kBins = 16;
+#ifndef PATHED_SAH_BINS
+#define PATHED_SAH_BINS 16
+#endif
+static const int kBins = PATHED_SAH_BINS;
 // leaf size: <= 7 (3-bit count in the traversal's leaf references).  [r5] 3 for a scene's tree (was 4): the wavefront's
 // traversal kernel runs the teapot 1.6 % and the 5.2 M-triangle mesh 1.2 - 1.9 % faster on leaves of at most 3 (2: +2.5 % / the
 // same, 1.6x the nodes; profiles/r5_ab_leaf_size.log); the hybrid kernel's tree part, walked in short bursts by few lanes,

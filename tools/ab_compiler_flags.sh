@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools/scratch/ab_flags.sh: the same rates through several builds of the library (one process per library)
+# tools/ab_compiler_flags.sh (through gpurun): the same rates through several builds of the library, one process per library (profiles/r5_ab_compiler_flags.log; the variant libraries are built by hand with the extra -mllvm flag)
 cd ${GRAFT_REPO_ROOT:-.}
 python tools/make_assets.py --dragon 9 > /dev/null 2>&1
 for lib in libpathed_hip.so libpathed_hip_fA.so libpathed_hip_fB.so libpathed_hip_fC.so libpathed_hip_fD.so; do

@@ -1,4 +1,5 @@
 #!/bin/bash
+# tools/leaf_size_sweep.sh (through gpurun): triangles per leaf of the host SAH builder, experiments build (profiles/r5_ab_leaf_size.log)
 cd ${GRAFT_REPO_ROOT:-.}
 python tools/make_assets.py --dragon 9 > /dev/null 2>&1
 for leaf in 4 2 3; do
