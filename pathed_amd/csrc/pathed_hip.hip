@@ -597,6 +597,94 @@ void launchTrace(PathedScene *scene, const RenderParams &params, hipStream_t str
     }
 }
 
+#if defined(PATHED_EXPERIMENTS) && PATHED_EXPERIMENTS
+// [r5, experiments build] What would SORTING the ray queue buy the production trace kernel?  (Round 1's answer came from the
+// one-ray-per-thread test kernel.)  With PATHED_SORT_PROBE=<iteration> the wavefront stops before pool 0's trace launch of that
+// iteration, copies the pool's rays, and times k_trace -- this very kernel, cards, refill, LDS stack rows, parking off -- over
+// (a) the copy in slot order and (b) the same rays permuted so that the ones to be traced come first, ordered by (direction octant,
+// 30-bit Morton code of the origin); hits go to a scratch buffer, the render's own state is not touched.  tools/sort_probe.py.
+static void sortProbe(PathedScene *scene, const RenderParams &q, hipStream_t stream)
+{
+    (void)hipDeviceSynchronize();
+    const size_t n = (size_t)q.nSlots;
+    std::vector<float4> rayO(n), rayD(n);
+    if (hipMemcpy(rayO.data(), q.state.rayO, n * sizeof(float4), hipMemcpyDeviceToHost) != hipSuccess
+        || hipMemcpy(rayD.data(), q.state.rayD, n * sizeof(float4), hipMemcpyDeviceToHost) != hipSuccess) { return; }
+    std::vector<uint32_t> traced, rest;
+    float lo[3] = { 3e38f, 3e38f, 3e38f }, hi[3] = { -3e38f, -3e38f, -3e38f };
+    for (size_t i = 0; i < n; i++) {
+        int flags; std::memcpy(&flags, &rayD[i].w, 4);
+        if (flags & (kStDone | kStHold | kStLocal)) { rest.push_back((uint32_t)i); continue; }
+        traced.push_back((uint32_t)i);
+        const float o[3] = { rayO[i].x, rayO[i].y, rayO[i].z };
+        for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], o[a]); hi[a] = std::max(hi[a], o[a]); }
+    }
+    auto spread = [](uint32_t v) { uint64_t x = v & 0x3FFu; x = (x | (x << 16)) & 0x30000FFull; x = (x | (x << 8)) & 0x300F00Full; x = (x | (x << 4)) & 0x30C30C3ull; x = (x | (x << 2)) & 0x9249249ull; return x; };
+    // orders: 0 slot order; 1 by direction octant only (stable: what eight counters in the shade kernel could produce);
+    // 2 by (octant, 24-bit Morton code of the origin, 18-bit Morton code of the direction), stable
+    const int kOrders = 3;
+    std::vector<float4> orderedO[kOrders], orderedD[kOrders];
+    for (int v = 0; v < kOrders; v++) {
+        std::vector<std::pair<uint64_t, uint32_t>> keyed(traced.size());
+        for (size_t k = 0; k < traced.size(); k++) {
+            const uint32_t i = traced[k];
+            const float o[3] = { rayO[i].x, rayO[i].y, rayO[i].z }, d[3] = { rayD[i].x, rayD[i].y, rayD[i].z };
+            uint32_t cell[3], turn[3];
+            for (int a = 0; a < 3; a++) {
+                const float t = hi[a] > lo[a] ? (o[a] - lo[a]) / (hi[a] - lo[a]) : 0.f;
+                cell[a] = (uint32_t)std::min(255.f, std::max(0.f, t * 255.f));
+                turn[a] = (uint32_t)std::min(63.f, std::max(0.f, (d[a] * 0.5f + 0.5f) * 63.f));
+            }
+            const uint64_t octant = (d[0] < 0.f ? 4u : 0u) | (d[1] < 0.f ? 2u : 0u) | (d[2] < 0.f ? 1u : 0u);
+            const uint64_t place = (spread(cell[0]) << 2) | (spread(cell[1]) << 1) | spread(cell[2]);
+            const uint64_t heading = (spread(turn[0]) << 2) | (spread(turn[1]) << 1) | spread(turn[2]);
+            keyed[k] = { v == 0 ? 0ull : v == 1 ? octant : ((octant << 42) | (place << 18) | heading), i };
+        }
+        std::stable_sort(keyed.begin(), keyed.end(), [](const std::pair<uint64_t, uint32_t> &a, const std::pair<uint64_t, uint32_t> &b) { return a.first < b.first; });
+        orderedO[v].resize(n); orderedD[v].resize(n);
+        size_t at = 0;
+        for (const auto &entry : keyed) { orderedO[v][at] = rayO[entry.second]; orderedD[v][at] = rayD[entry.second]; at++; }
+        for (uint32_t i : rest) { orderedO[v][at] = rayO[i]; orderedD[v][at] = rayD[i]; at++; }
+    }
+    float4 *dO[kOrders] = { nullptr, nullptr, nullptr }, *dD[kOrders] = { nullptr, nullptr, nullptr }, *dHit = nullptr;
+    unsigned int *dCounters = nullptr;
+    bool ok = hipMalloc(&dHit, n * sizeof(float4)) == hipSuccess && hipMalloc(&dCounters, kCtrCount * sizeof(unsigned int)) == hipSuccess;
+    for (int v = 0; v < kOrders && ok; v++) {
+        ok = hipMalloc(&dO[v], n * sizeof(float4)) == hipSuccess && hipMalloc(&dD[v], n * sizeof(float4)) == hipSuccess
+            && hipMemcpy(dO[v], orderedO[v].data(), n * sizeof(float4), hipMemcpyHostToDevice) == hipSuccess
+            && hipMemcpy(dD[v], orderedD[v].data(), n * sizeof(float4), hipMemcpyHostToDevice) == hipSuccess;
+    }
+    hipEvent_t start = nullptr, stop = nullptr;
+    ok = ok && hipEventCreate(&start) == hipSuccess && hipEventCreate(&stop) == hipSuccess;
+    if (ok) {
+        fprintf(stderr, "[pathed] sort probe: %zu slots, %zu rays for the trace kernel (%.3f of the slots), shadow list left out\n", n, traced.size(), (double)traced.size() / (double)n);
+        for (int repeat = 0; repeat < 3; repeat++) {
+            for (int v = -1; v < kOrders; v++) {
+                RenderParams probe = q;
+                if (v >= 0) { probe.state.rayO = dO[v]; probe.state.rayD = dD[v]; }   // (-1: the pool's own arrays, rays where their slots are)
+                probe.state.hit = dHit;
+                probe.counters = dCounters;
+                probe.suspendLanes = 0;   // no parking: the whole pool in one launch
+                (void)hipMemsetAsync(dCounters, 0, kCtrCount * sizeof(unsigned int), stream);
+                (void)hipEventRecord(start, stream);
+                launchTrace(scene, probe, stream);
+                (void)hipEventRecord(stop, stream);
+                (void)hipEventSynchronize(stop);
+                float ms = 0.f;
+                (void)hipEventElapsedTime(&ms, start, stop);
+                fprintf(stderr, "[pathed] sort probe: k_trace over the rays %s: %.1f us (%.2f Grays/s)\n",
+                        v < 0 ? "as they lie in the pool" : v == 0 ? "compacted, in slot order" : v == 1 ? "by direction octant" : "by (octant, origin cell, direction cell)", 1e3 * ms, (double)traced.size() / (1e6 * ms));
+            }
+        }
+    }
+    if (start) { (void)hipEventDestroy(start); }
+    if (stop) { (void)hipEventDestroy(stop); }
+    for (int v = 0; v < kOrders; v++) { if (dO[v]) { (void)hipFree(dO[v]); } if (dD[v]) { (void)hipFree(dD[v]); } }
+    if (dHit) { (void)hipFree(dHit); }
+    if (dCounters) { (void)hipFree(dCounters); }
+}
+#endif
+
 void launchShade(PathedScene *scene, const RenderParams &params, hipStream_t stream)
 {
 #if PATHED_EXPERIMENTS
@@ -2618,6 +2706,13 @@ static int renderPass(PathedScene *scene, uint64_t seed, uint32_t begin, uint32_
                 if (poolDone[h]) { continue; }
                 params[h].parity = (int)(iteration & 1ull);
                 scene->traceLaunchesAll++;
+#if defined(PATHED_EXPERIMENTS) && PATHED_EXPERIMENTS
+                if (h == 0) {
+                    if (const char *text = getenv("PATHED_SORT_PROBE")) {
+                        if (iteration == (unsigned long long)atoll(text)) { sortProbe(scene, params[h], streams[h]); }
+                    }
+                }
+#endif
                 if (scene->timeKernels && iteration % (unsigned long long)scene->timeInterval == 0ull) {
                     const int e = scene->traceEvents.acquire();
                     (void)hipEventRecord(scene->traceEvents.start[e], streams[h]);
