@@ -2708,7 +2708,7 @@ static int renderPass(PathedScene *scene, uint64_t seed, uint32_t begin, uint32_
                 scene->traceLaunchesAll++;
 #if defined(PATHED_EXPERIMENTS) && PATHED_EXPERIMENTS
                 if (h == 0) {
-                    if (const char *text = getenv("PATHED_SORT_PROBE")) {
+                    if (const char *text = tuningEnv("PATHED_SORT_PROBE")) {
                         if (iteration == (unsigned long long)atoll(text)) { sortProbe(scene, params[h], streams[h]); }
                     }
                 }
