@@ -299,3 +299,37 @@ def test_bench_rehearses_many_ranks_on_one_gpu():
     single = json.loads(one.stdout.strip().splitlines()[-1])
     for a, b in zip(line["image_mean_rgb"], single["image_mean_rgb"]):
         assert abs(a - b) <= 1e-5 * abs(b), (line["image_mean_rgb"], single["image_mean_rgb"])
+
+
+def test_bench_line_carries_the_contract_fields():
+    """The ONE JSON line of bench.py on the configuration it is quoted on (scenes/cornell.json 1024 x 1024; two short steps here):
+    the driver's keys, a `roofline` for the dominant kernel -- bound, achieved, peak, unit, frac, traffic, and since round 5
+    `useful_frac` (x the lane utilisation of the counter pass) and `mix_aware` (against what the kernel's own instruction mix can
+    issue) -- and a `cpu_baseline` that states its cores, the host's quota and the rate at every thread count it tried."""
+    import sys
+    from pathed_amd import _capi
+    command = [sys.executable, os.path.join(_capi.REPO_ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--spp-per-step", "64", "--no-large-bvh"]
+    result = subprocess.run(command, capture_output=True, text=True, timeout=900)
+    assert result.returncode == 0, result.stdout + result.stderr
+    lines = [text for text in result.stdout.strip().splitlines() if text.startswith("{")]
+    assert len(lines) == 1                                               # ONE line
+    line = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert key in line, key
+    assert line["unit"] == "Msamples/s" and line["n_gpus"] == 1 and line["steps"] == 2 and line["warmup"] == 1
+    assert line["higher_is_better"] is True and line["vs_baseline"] is None and line["dtype"] == "f32"
+    assert "workload" in line["config"] and "model" not in line["config"]
+    assert line["environment_overrides"] == {} and line["library"]["experiments_build"] is False
+    roofline = line["roofline"]
+    assert roofline["bound"] == "valu" and roofline["unit"] == "G wave-instr/s" and roofline["peak"] == 1228.8
+    assert abs(roofline["frac"] - roofline["achieved"] / roofline["peak"]) < 1e-9 and 0.2 < roofline["frac"] < 1.0
+    assert abs(roofline["useful_frac"] - roofline["frac"] * roofline["lane_utilisation"]) < 1e-9
+    assert 0.5 < roofline["mix_aware"]["frac"] <= 1.05 and roofline["mix_aware"]["bound"] < roofline["peak"]
+    assert roofline["traffic"] is None or roofline["traffic"] > 0
+    # (whether the committed counter pass / static mix are of THESE kernel sources is stated in the line, not hidden)
+    assert roofline["instructions_source"]["stale"] in (True, False) and roofline["mix_aware"]["source"]["stale"] in (True, False)
+    cpu = line["cpu_baseline"]
+    assert cpu["kind"] == "port" and cpu["value"] > 0 and cpu["unit"] == "Msamples/s" and cpu["cores"] >= 1 and cpu["sample"]
+    assert cpu["cores"] == cpu["threads"] <= cpu["host"]["usable"] and len(cpu["thread_counts_tried"]) >= 1
+    assert all(entry["spp"] >= 2 for entry in cpu["thread_counts_tried"])
+    assert max(entry["Msamples_per_s"] for entry in cpu["thread_counts_tried"]) > 0
