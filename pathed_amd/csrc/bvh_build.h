@@ -71,6 +71,8 @@ static const int kBins = PATHED_SAH_BINS;
 // same, 1.6x the nodes; profiles/r5_ab_leaf_size.log); the hybrid kernel's tree part, walked in short bursts by few lanes,
 // keeps 4 (buildBvh's maxLeaf).  PATHED_MAX_LEAF overrides for tuning in the experiments build (the product library reads no
 // PATHED_* variable)
+// ... and 2 for trees of fewer than 256 Ki primitives (the teapot: another 0.9 %; 1.6x the nodes of a tree that is small anyway)
+static const uint32_t kSmallTreePrims = 262144u;
 inline uint32_t maxLeafSize()
 {
     static uint32_t value = 0;
@@ -265,6 +267,7 @@ inline FlatBvh buildBvh(const float *positions, const uint32_t *indices, uint32_
 
     Builder builder(prims);
     if (maxLeaf != 0) { builder.maxLeaf = maxLeaf; }
+    else if (primCount < kSmallTreePrims && builder.maxLeaf > 2u) { builder.maxLeaf = 2u; }   // (see maxLeafSize)
     builder.nodes.reserve((size_t)primCount);
     int maxDepth = 0;
     // large meshes: the top of the tree here, its subtrees on the host's other cores
